@@ -1,0 +1,237 @@
+/*
+ * air_hip.h -- C ABI of libair_hip.so, the MI355X (gfx950) implementation of the
+ * Attend-Infer-Repeat hot path (aakhundov/tf-attend-infer-repeat).
+ *
+ * The reference has no FFI: its seam is the TensorFlow graph that
+ * air/air_model.py builds.  Every entry point below replaces a group of TF ops
+ * the reference instantiates per time step; the reference file:line each one
+ * replaces is cited.  INTEGRATION.md shows the binding a maintainer of the
+ * reference would add.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a CALLER-OWNED DEVICE pointer, contiguous row-major fp32
+ *     unless stated; the library never allocates, frees or synchronises
+ *     (hipGraph-capture safe), is stateless and re-entrant;
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*);
+ *   - return value: 0 on success, a positive hipError_t from the launch, or a
+ *     negative AIR_E* argument error; no C++ exception crosses the boundary.
+ */
+#ifndef AIR_HIP_H
+#define AIR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AIR_ABI_VERSION 1
+
+#define AIR_EINVAL   (-1)   /* bad dimension / null pointer            */
+#define AIR_ELIMIT   (-2)   /* size exceeds what the kernel supports    */
+#define AIR_EALIGN   (-3)   /* pointer / leading dimension misaligned   */
+
+int air_abi_version(void);
+const char* air_strerror(int code);
+
+/* ---- dynamic scalars --------------------------------------------------
+ * Kernels read the float hyper-parameters that the reference allows to be
+ * annealed (air_model.py:76-82) from a device array `dyn` so that a captured
+ * hipGraph sees new values without re-capture. */
+enum {
+    AIR_DYN_PRIOR_LOG_ODDS = 0,  /* z_pres_prior_log_odds          air_model.py:50,405 */
+    AIR_DYN_TEMPERATURE    = 1,  /* z_pres_temperature             :51,381             */
+    AIR_DYN_STOP_THRESHOLD = 2,  /* stopping_threshold             :52,274,412         */
+    AIR_DYN_LEARNING_RATE  = 3,  /* learning_rate                  :54,654             */
+    AIR_DYN_CLIP_NORM      = 4,  /* gradient_clipping_norm         :55,673             */
+    AIR_DYN_SCALE_PM = 5, AIR_DYN_SCALE_PV = 6,   /* scale prior mean / variance  :38-39 */
+    AIR_DYN_SHIFT_PM = 7, AIR_DYN_SHIFT_PV = 8,   /* shift prior                  :40-41 */
+    AIR_DYN_VAE_PM   = 9, AIR_DYN_VAE_PV   = 10,  /* vae prior                    :42-43 */
+    AIR_DYN_LIK_STD  = 11,                        /* vae_likelihood_std           :44    */
+    AIR_DYN_GRAD_SCALE = 12,     /* d(loss)/d(per-item loss) = 1/B (reduce_mean, :610) */
+    AIR_DYN_COUNT    = 16
+};
+
+/* int state words (device int32 array `istate`) */
+enum {
+    AIR_IST_GLOBAL_STEP = 0,     /* air/global_step, air_model.py:69 */
+    AIR_IST_COUNT = 4
+};
+
+/* one annealing schedule (air_model.py:94-121), evaluated on device each step */
+typedef struct {
+    int32_t slot;        /* AIR_DYN_* written                               */
+    int32_t flags;       /* bit0 staircase, bit1 has_min, bit2 has_max, bit3 log */
+    float init, iters, factor, vmin, vmax;
+} air_schedule_t;
+
+/* ---- per-step records ---------------------------------------------------
+ * att[t][b][AIR_ATT_STRIDE] -- per-item scalars of one time step. */
+enum {
+    AIR_ATT_S = 0, AIR_ATT_X = 1, AIR_ATT_Y = 2,     /* scale, shift  :301,318      */
+    AIR_ATT_ZPRE = 3,                                /* z_pres_pre_sigmoid :380     */
+    AIR_ATT_Z = 4,                                   /* z_pres (rounded if !train)  */
+    AIR_ATT_ZPROB = 5,                               /* sigmoid(log_odds) :395      */
+    AIR_ATT_KL_Z = 6, AIR_ATT_KL_SCALE = 7, AIR_ATT_KL_SHIFT = 8, AIR_ATT_KL_VAE = 9,
+    AIR_ATT_MASK_PREV = 10,                          /* stopping_sum(old) < thr :412 */
+    AIR_ATT_MASK = 11,                               /* stopping_sum(new) < thr :427 */
+    AIR_ATT_ST_BACK = 12,                            /* 1/s, -x/s, -y/s  :353-356   */
+    AIR_ATT_STRIDE = 16
+};
+/* out7[t][b][8]: scale_mean, scale_lv, shift_mean.x, .y, shift_lv.x, .y, z_log_odds, pad */
+#define AIR_OUT_STRIDE 8
+
+/* ---- GEMM (K1/K2/K5: LSTM, head and VAE MatMul + BiasAdd + activation) --------
+ * C[M,N] (+)= epilogue( op(A)[M,K] . op(B)[K,N] )
+ *   op(A)(m,k) = transA ? A[k*lda+m] : A[m*lda+k];  op(B)(k,n) = transB ? B[n*ldb+k] : B[k*ldb+n]
+ * epilogue, in this order:  v = acc; v += bias[n]; v += addend[m*ldadd+n];
+ *   v = act(v); v *= actgrad(aux[m*ldaux+n]); if (ACCUM) v += C[m*ldc+n].
+ * Replaces tf.matmul + BiasAdd + Relu/Softplus/Sigmoid nodes of
+ * layers.fully_connected (air_model.py:292-316, 374-376; vae.py:13-34), the
+ * BasicLSTMCell MatMul (:286) and their MatMul_grad nodes.
+ * precision: 0 = exact-fp32 MFMA (v_mfma_f32_16x16x4_f32);
+ *            1 = bf16 operands, fp32 accumulate (v_mfma_f32_16x16x32_bf16). */
+enum {
+    AIR_ACT_NONE = 0, AIR_ACT_RELU = 1, AIR_ACT_SOFTPLUS = 2,
+    AIR_ACT_SIGMOID_NOISE = 3   /* sigmoid(v + aux*aux_scale): vae.py:36-41 */
+};
+enum {
+    AIR_GRAD_NONE = 0,
+    AIR_GRAD_RELU = 1,          /* v *= (aux > 0)                        */
+    AIR_GRAD_SOFTPLUS = 2       /* v *= 1 - exp(-aux)  (aux = softplus output) */
+};
+typedef struct {
+    const float* A; const float* B; float* C;
+    int32_t M, N, K, lda, ldb, ldc;
+    int32_t transA, transB;
+    const float* bias;             /* [N] or NULL                        */
+    const float* addend; int32_t ldadd;   /* [M,N] or NULL               */
+    const float* aux;    int32_t ldaux;   /* [M,N] or NULL               */
+    float   aux_scale;
+    int32_t act;                   /* AIR_ACT_*                          */
+    int32_t actgrad;               /* AIR_GRAD_*                         */
+    int32_t accumulate;            /* C += result                        */
+    int32_t precision;             /* 0 fp32, 1 bf16                     */
+} air_gemm_t;
+int air_gemm(const air_gemm_t* g, void* stream);
+
+/* column sums db[n] = sum_r dY[r*ld + n]  (BiasAdd_grad nodes) for `count` problems */
+typedef struct { const float* src; float* dst; int32_t rows, cols, ld, accumulate; } air_colsum_t;
+int air_colsum(const air_colsum_t* probs /*HOST array*/, int count, void* stream);
+
+/* ---- LSTM gates (K1c) -- BasicLSTMCell pointwise part, air_model.py:286 -------
+ * gates_pre [B,4R] = [x,h].kernel + bias, split order i,j,f,o; forget_bias 1.0.
+ * acts [B,4R] receives sigmoid(i), tanh(j), sigmoid(f+1), sigmoid(o). */
+int air_lstm_gates_fwd(const float* gates_pre, const float* c_prev, float* acts,
+                       float* c, float* h, int B, int R, void* stream);
+/* dgates [B,4R] (pre-activation grads), dc_prev [B,R]; dgsum (+)= dgates when given */
+int air_lstm_gates_bwd(const float* dh, const float* dc_in /*nullable*/, const float* acts,
+                       const float* c_prev, const float* c, float* dgates, float* dc_prev,
+                       float* dgsum /*nullable*/, int dgsum_accumulate, int B, int R, void* stream);
+
+/* ---- spatial transformer, generic (transformer.py:18-175) ---------------------
+ * out[B,Ho,Wo] = transformer(U[B,Hi,Wi,1], theta[B,2,3], (Ho,Wo)); literal
+ * 4-product / add_n op order, indices clipped before the weights. */
+int air_transformer_fwd(const float* U, const float* theta, float* out,
+                        int B, int Hi, int Wi, int Ho, int Wo, void* stream);
+
+/* ---- "attend": heads output layer + sampling + KLs + stop logic + ST read -----
+ * air_model.py:288-333 (scale/shift heads, theta, transformer canvas->window) and
+ * :368-427 (z_pres head, Concrete sample, z KL, stopping_sum, running_digits),
+ * :441-477 (scale/shift KL).  One workgroup per image.
+ * hid [B,HT] = ReLU hidden activations of the 5 heads, concatenated in the order
+ * scale/mean, scale/log_variance, shift/mean, shift/log_variance, z_pres/log_odds
+ * with widths Hs,Hs,Hh,Hh,Hz (HT = 2Hs+2Hh+Hz).  wout [7][max(Hs,Hh,Hz)] holds
+ * one row per output unit, bout [7]. */
+typedef struct {
+    const float* hid; const float* wout; const float* bout;
+    const float* canvas;                 /* input_images [B,C*C]            */
+    const float* eps_scale; const float* eps_shift; const float* u;   /* [B,1],[B,2],[B] */
+    const float* dyn;                    /* AIR_DYN_* device array          */
+    float* out7;                         /* [B,8]                           */
+    float* att;                          /* [B,AIR_ATT_STRIDE]              */
+    float* window;                       /* [B,w*w]                         */
+    float* stop_sum; float* run_loss; int32_t* run_digits;   /* [B] in/out  */
+    int32_t B, C, w, Hs, Hh, Hz, wout_ld, train;
+} air_attend_fwd_t;
+int air_attend_fwd(const air_attend_fwd_t* a, void* stream);
+
+typedef struct {
+    const float* hid; const float* wout;
+    const float* canvas; const float* eps_scale; const float* eps_shift;
+    const float* dyn; const float* out7; const float* att;
+    const float* d_window;               /* [B,w*w] grad wrt the glimpse    */
+    const float* d_sxy_write;            /* [B,4]: ds,dx,dy,dz from the write path */
+    float* d_hid;                        /* [B,HT] grad wrt pre-ReLU hidden */
+    float* d_out7;                       /* [B,8]                           */
+    int32_t B, C, w, Hs, Hh, Hz, wout_ld;
+} air_attend_bwd_t;
+int air_attend_bwd(const air_attend_bwd_t* a, void* stream);
+
+/* grads of the 7 output units: dwout[o][j] = sum_{r} d_out7[r][o]*hid[r][seg(o)+j],
+ * dbout[o] = sum_r d_out7[r][o]; rows = N*B */
+int air_heads_out_wgrad(const float* d_out7, const float* hid, float* dwout, float* dbout,
+                        int rows, int Hs, int Hh, int Hz, int wout_ld, void* stream);
+
+/* ---- VAE re-parameterisation (vae.py:22-24) ---------------------------------- */
+int air_reparam_fwd(const float* ml /*[B,2Z] mean|log_var*/, const float* eps_z, float* zs,
+                    int B, int Z, void* stream);
+/* d_ml [B,2Z] from d_zs [B,Z] plus the VAE-KL gradient (air_model.py:481-493) */
+int air_reparam_bwd(const float* d_zs, const float* ml, const float* eps_z, const float* att,
+                    const float* dyn, float* d_ml, int B, int Z, void* stream);
+
+/* ---- "write": ST window->canvas + z_pres scaling + masked accumulate + VAE KL --
+ * air_model.py:351-366 (theta_recon, transformer), :429-439 (running_recon),
+ * :479-493 (VAE KL into running_loss).  One workgroup per image. */
+typedef struct {
+    const float* vrec;                   /* vae reconstruction [B,w*w]      */
+    const float* ml;                     /* [B,2Z]                          */
+    const float* dyn;
+    float* att;                          /* reads s,x,y,z,mask; writes KL_VAE, ST_BACK */
+    float* run_recon;                    /* [B,C*C] in/out                  */
+    float* run_loss;                     /* [B] in/out                      */
+    int32_t B, C, w, Z;
+} air_write_fwd_t;
+int air_write_fwd(const air_write_fwd_t* a, void* stream);
+
+typedef struct {
+    const float* d_recon;                /* [B,C*C] grad wrt running_recon  */
+    const float* vrec; const float* att;
+    float* d_gen_pre;                    /* [B,w*w] grad wrt gen_mean pre-sigmoid input */
+    float* d_sxy_write;                  /* [B,4]: ds,dx,dy (via theta_recon), dz */
+    int32_t B, C, w;
+} air_write_bwd_t;
+int air_write_bwd(const air_write_bwd_t* a, void* stream);
+
+/* ---- reconstruction loss (air_model.py:580-593) + its gradient ---------------- */
+int air_bce_fwd_bwd(const float* images, const float* run_recon, const float* dyn,
+                    float* recon /*clipped [B,D]*/, float* rec_loss /*[B]*/,
+                    float* d_recon /*[B,D] nullable*/, int B, int D, void* stream);
+/* loss = mean(run_loss + rec_loss), accuracy = mean(target == digits)  (:597-611)
+ * scalars[0] = loss, scalars[1] = accuracy */
+int air_finalize(const float* run_loss, const float* rec_loss, const int32_t* targets,
+                 const int32_t* digits, float* loss_per_item, float* scalars, int B, void* stream);
+
+/* ---- step prologue: annealing schedules + Philox noise ------------------------
+ * Evaluates `nsched` schedules at istate[GLOBAL_STEP] into dyn, and fills
+ * normals[n_normal] ~ N(0,1), uniforms[n_uniform] ~ U[0,1) from
+ * Philox4x32-10(key = seed, counter = (index, global_step + call_salt)). */
+int air_step_begin(const air_schedule_t* sched /*device*/, int nsched, float* dyn,
+                   const int32_t* istate, float* normals, int64_t n_normal,
+                   float* uniforms, int64_t n_uniform, uint64_t seed, void* stream);
+
+/* ---- optimizer (air_model.py:651-694): clip_by_global_norm + TF1.3 ApplyAdam --
+ * partials: scratch [>= air_optim_num_partials(n)] floats.
+ * air_grad_sqnorm also increments istate[GLOBAL_STEP] (apply_gradients, :692). */
+int air_optim_num_partials(int64_t n);
+int air_grad_sqnorm(const float* grads, int64_t n, float* partials, int32_t* istate, void* stream);
+int air_adam_clip_step(float* params, const float* grads, float* m, float* v, int64_t n,
+                       const float* partials, const float* dyn, const int32_t* istate,
+                       float grad_prescale /* e.g. 1/world_size */, float beta1, float beta2,
+                       float epsilon, uint16_t* bf16_shadow /*nullable*/, float* gnorm_out /*nullable*/,
+                       void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AIR_HIP_H */

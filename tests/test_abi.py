@@ -1,0 +1,102 @@
+"""CPU-side checks of the C-ABI boundary: the library builds for gfx950, loads,
+exports every symbol include/air_hip.h declares, the ctypes structs match the C
+layout, argument errors are reported without touching a GPU, and the product
+path refuses to run without the HIP library / on CPU tensors (no fallback)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "air_hip.h")
+
+
+@pytest.fixture(scope="module")
+def H():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("air_build", os.path.join(ROOT, "tf-attend-infer-repeat_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.build(verbose=False)
+    from air import _hip
+    _hip.lib()
+    return _hip
+
+
+def _declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(air_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(H):
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    lib = C.CDLL(H.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert sorted(H.EXPORTED_SYMBOLS) == declared
+
+
+def test_abi_version_and_strerror(H):
+    assert H.lib().air_abi_version() == H.ABI_VERSION == 1
+    assert b"invalid argument" in H.lib().air_strerror(-1)
+    assert H.lib().air_strerror(0) == b"success"
+
+
+def test_struct_layout_matches_c(H, tmp_path):
+    """sizeof/offsetof from a C compile of the header == ctypes."""
+    prog = tmp_path / "layout.c"
+    prog.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "air_hip.h"\nint main(){'
+                    'printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(air_gemm_t), offsetof(air_gemm_t, bias),'
+                    'offsetof(air_gemm_t, aux), offsetof(air_gemm_t, precision), sizeof(air_schedule_t),'
+                    'sizeof(air_attend_fwd_t), offsetof(air_attend_fwd_t, B), sizeof(air_attend_bwd_t),'
+                    'sizeof(air_write_fwd_t), sizeof(air_write_bwd_t)); printf("%zu\\n", sizeof(air_colsum_t)); return 0;}')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)]).decode().split()
+    got = [int(x) for x in out]
+    exp = [C.sizeof(H.Gemm), H.Gemm.bias.offset, H.Gemm.aux.offset, H.Gemm.precision.offset,
+           C.sizeof(H.Schedule), C.sizeof(H.AttendFwd), H.AttendFwd.B.offset, C.sizeof(H.AttendBwd),
+           C.sizeof(H.WriteFwd), C.sizeof(H.WriteBwd), C.sizeof(H.Colsum)]
+    assert got == exp, (got, exp)
+
+
+def test_argument_errors_without_gpu(H):
+    lib = H.lib()
+    assert lib.air_gemm(C.byref(H.Gemm()), None) == -1
+    assert lib.air_gemm(None, None) == -1
+    assert lib.air_attend_fwd(C.byref(H.AttendFwd()), None) == -1
+    assert lib.air_write_bwd(C.byref(H.WriteBwd()), None) == -1
+    assert lib.air_lstm_gates_fwd(None, None, None, None, None, 4, 4, None) == -1
+    assert lib.air_grad_sqnorm(None, 10, None, None, None) == -1
+    assert lib.air_colsum(None, 0, None) == -1
+    assert lib.air_optim_num_partials(1000) > 0
+
+
+def test_no_cpu_fallback(H):
+    from air import air_model as am
+    am.reset_default_graph()
+    with pytest.raises(H.AirHipError):
+        am.AIRModel(torch.zeros(4, 2500), torch.zeros(4, dtype=torch.int32), cnn=False)
+    with pytest.raises(H.AirHipError):
+        H.load("/nonexistent/libair_hip.so")
+    from air.transformer import transformer
+    with pytest.raises(H.AirHipError):
+        transformer(torch.zeros(1, 5, 5, 1), torch.zeros(1, 6), (3, 3))
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "tf-attend-infer-repeat_amd")
+    for dp, _, fns in os.walk(pkg):
+        for fn in fns:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dp, fn)).read()
+                assert "oracle" not in txt.replace("no oracle", ""), os.path.join(dp, fn)
+                assert "/root/reference" not in txt or fn.endswith(".py") and "import" not in \
+                    [ln for ln in txt.splitlines() if "/root/reference" in ln][0]

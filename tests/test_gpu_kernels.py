@@ -1,0 +1,253 @@
+"""GPU parity tests of the individual C-ABI entry points (libair_hip.so) against
+the CPU oracle / fp64 references.  All calls go through the C ABI via ctypes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import air_oracle as ao  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def H():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from air import _hip
+    _hip.lib()
+    return _hip
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _bf16_round(x):
+    return torch.as_tensor(x).to(torch.bfloat16).to(torch.float64).numpy()
+
+
+def _run_gemm(H, A, B, M, N, K, ta, tb, prec, bias=None, addend=None, aux=None, act=0, actgrad=0,
+              aux_scale=0.0, accumulate=0, c_init=None):
+    dev = "cuda"
+    At, Bt = torch.tensor(A, device=dev), torch.tensor(B, device=dev)
+    Ct = torch.tensor(c_init, device=dev) if c_init is not None else torch.full((M, N), float("nan"), device=dev)
+    bt = torch.tensor(bias, device=dev) if bias is not None else None
+    adt = torch.tensor(addend, device=dev) if addend is not None else None
+    axt = torch.tensor(aux, device=dev) if aux is not None else None
+    g = H.Gemm(_p(At), _p(Bt), _p(Ct), M, N, K, A.shape[1], B.shape[1], N, ta, tb,
+               _p(bt) if bt is not None else None, _p(adt) if adt is not None else None, N,
+               _p(axt) if axt is not None else None, N, aux_scale, act, actgrad, accumulate, prec)
+    H.check(H.lib().air_gemm(C.byref(g), _stream()), "air_gemm")
+    torch.cuda.synchronize()
+    return Ct.cpu().numpy()
+
+
+def _ref_gemm(A, B, ta, tb, prec, bias=None, addend=None, aux=None, act=0, actgrad=0, aux_scale=0.0,
+              accumulate=0, c_init=None):
+    A64 = _bf16_round(A) if prec else A.astype(np.float64)
+    B64 = _bf16_round(B) if prec else B.astype(np.float64)
+    opA = A64.T if ta else A64
+    opB = B64.T if tb else B64
+    v = opA @ opB
+    if bias is not None:
+        v = v + bias
+    if addend is not None:
+        v = v + addend
+    if act == 1:
+        v = np.maximum(v, 0)
+    elif act == 2:
+        v = np.log1p(np.exp(-np.abs(v))) + np.maximum(v, 0)
+    elif act == 3:
+        v = 1 / (1 + np.exp(-(v + aux * aux_scale)))
+    if actgrad == 1:
+        v = v * (aux > 0)
+    elif actgrad == 2:
+        v = v * (1 - np.exp(-aux.astype(np.float64)))
+    if accumulate:
+        v = v + c_init
+    return v
+
+
+GEMM_CASES = [
+    # M, N, K, ta, tb  (shapes that occur on the AIR path, Cfg-A)
+    (64, 1024, 2500, 0, 0),    # hoisted x.Wx
+    (64, 1024, 256, 0, 0),     # h.Wh
+    (64, 320, 256, 0, 0),      # heads hidden
+    (64, 512, 784, 0, 0),      # vae rec1
+    (64, 100, 256, 0, 0),      # mean|log_var (N not /16)
+    (64, 256, 50, 0, 0),       # gen1 (K not /4)
+    (64, 784, 512, 0, 0),      # gen_mean
+    (64, 512, 784, 0, 1),      # dgrad through gen_mean
+    (64, 50, 256, 0, 1),       # dgrad to z
+    (64, 784, 512, 0, 1),      # dgrad to window
+    (64, 256, 1024, 0, 1),     # dgrad through Wh
+    (784, 512, 192, 1, 0),     # wgrad rec1
+    (2500, 1024, 64, 1, 0),    # wgrad Wx
+    (50, 256, 192, 1, 0),      # wgrad gen1
+    (7, 33, 5, 0, 0),          # ragged
+    (256, 512, 784, 0, 0),     # stress batch
+]
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("M,N,K,ta,tb", GEMM_CASES)
+def test_gemm_plain(H, M, N, K, ta, tb, prec):
+    rng = np.random.RandomState(M + N + K)
+    A = rng.uniform(-1, 1, (K, M) if ta else (M, K)).astype(np.float32)
+    B = rng.uniform(-1, 1, (N, K) if tb else (K, N)).astype(np.float32)
+    got = _run_gemm(H, A, B, M, N, K, ta, tb, prec)
+    ref = _ref_gemm(A, B, ta, tb, prec)
+    assert not np.isnan(got).any()
+    scale = np.sqrt(K)
+    tol = 2e-6 if prec == 0 else 2e-5      # same-rounded operands, fp32 accumulate
+    assert np.abs(got - ref).max() / scale < tol, np.abs(got - ref).max()
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_gemm_epilogues(H, prec):
+    rng = np.random.RandomState(0)
+    M, N, K = 64, 100, 256
+    A = rng.uniform(-1, 1, (M, K)).astype(np.float32)
+    B = (rng.uniform(-1, 1, (K, N)) / 8).astype(np.float32)
+    bias = rng.uniform(-1, 1, N).astype(np.float32)
+    addend = rng.uniform(-1, 1, (M, N)).astype(np.float32)
+    aux = rng.uniform(0.01, 2, (M, N)).astype(np.float32)
+    c0 = rng.uniform(-1, 1, (M, N)).astype(np.float32)
+    tol = 1e-5 if prec == 0 else 2e-4
+    for kw in (dict(bias=bias), dict(bias=bias, act=1), dict(bias=bias, act=2),
+               dict(bias=bias, act=3, aux=aux, aux_scale=0.3), dict(addend=addend),
+               dict(actgrad=1, aux=aux - 1.0), dict(actgrad=2, aux=aux),
+               dict(bias=bias, accumulate=1, c_init=c0)):
+        got = _run_gemm(H, A, B, M, N, K, 0, 0, prec, **kw)
+        ref = _ref_gemm(A, B, 0, 0, prec, **kw)
+        assert np.abs(got - ref).max() < tol, (kw.keys(), np.abs(got - ref).max())
+
+
+def test_gemm_bad_args(H):
+    g = H.Gemm()
+    assert H.lib().air_gemm(C.byref(g), None) == -1
+
+
+def test_transformer_generic_matches_oracle(H):
+    from air.transformer import transformer
+    rng = np.random.RandomState(0)
+    B = 16
+    U = rng.uniform(0, 1, (B, 50, 50)).astype(np.float32)
+    theta = np.zeros((B, 2, 3), np.float32)
+    theta[:, 0, 0] = theta[:, 1, 1] = rng.uniform(0.2, 1.2, B)
+    theta[:, 0, 2] = rng.uniform(-1, 1, B)
+    theta[:, 1, 2] = rng.uniform(-1, 1, B)
+    theta[B // 2:, 0, 1] = rng.uniform(-0.3, 0.3, B - B // 2)      # general affine as well
+    theta[B // 2:, 1, 0] = rng.uniform(-0.3, 0.3, B - B // 2)
+    for (hi, wi), (ho, wo) in (((50, 50), (28, 28)), ((50, 50), (50, 50))):
+        Ui = U[:, :hi, :wi]
+        ref = ao.transformer(np.ascontiguousarray(Ui), theta, (ho, wo))
+        got = transformer(torch.tensor(np.ascontiguousarray(Ui), device="cuda").unsqueeze(3),
+                          torch.tensor(theta, device="cuda"), (ho, wo))[..., 0].cpu().numpy()
+        # same op order, no FMA: identical up to libm-free arithmetic -> expect (near) bit equality
+        assert np.abs(got - ref).max() <= 1e-6, np.abs(got - ref).max()
+        assert (got == ref).mean() > 0.99
+
+
+def test_write_is_adjoint_of_its_backward(H):
+    """<W(v), g> == <v, W^T(g)> for the canvas write and its gather-form adjoint
+    (checked through d_gen_pre with the sigmoid factor divided out)."""
+    dev = "cuda"
+    rng = np.random.RandomState(1)
+    B, Cc, w, Z = 8, 50, 28, 50
+    vrec = torch.tensor(rng.uniform(0.05, 0.95, (B, w * w)).astype(np.float32), device=dev)
+    att = torch.zeros(B, H.ATT_STRIDE, device=dev)
+    att[:, H.ATT_S] = torch.tensor(rng.uniform(0.25, 0.8, B).astype(np.float32))
+    att[:, H.ATT_X] = torch.tensor(rng.uniform(-0.5, 0.5, B).astype(np.float32))
+    att[:, H.ATT_Y] = torch.tensor(rng.uniform(-0.5, 0.5, B).astype(np.float32))
+    att[:, H.ATT_Z] = 0.7
+    att[:, H.ATT_MASK] = 1.0
+    ml = torch.zeros(B, 2 * Z, device=dev)
+    dyn = torch.zeros(H.DYN_COUNT, device=dev)
+    dyn[H.DYN_VAE_PV] = 1.0
+    R = torch.zeros(B, Cc * Cc, device=dev)
+    L = torch.zeros(B, device=dev)
+    wf = H.WriteFwd(_p(vrec), _p(ml), _p(dyn), _p(att), _p(R), _p(L), B, Cc, w, Z)
+    H.check(H.lib().air_write_fwd(C.byref(wf), _stream()))
+    g = torch.tensor(rng.uniform(-1, 1, (B, Cc * Cc)).astype(np.float32), device=dev)
+    dgen = torch.zeros(B, w * w, device=dev)
+    dsx = torch.zeros(B, 4, device=dev)
+    wb = H.WriteBwd(_p(g), _p(vrec), _p(att), _p(dgen), _p(dsx), B, Cc, w)
+    H.check(H.lib().air_write_bwd(C.byref(wb), _stream()))
+    torch.cuda.synchronize()
+    lhs = (R.double() * g.double()).sum(1)                       # <z W v, g>
+    dv = dgen.double() / (vrec.double() * (1 - vrec.double()))   # z W^T g
+    rhs = (dv * vrec.double()).sum(1)
+    assert torch.allclose(lhs, rhs, rtol=1e-4, atol=1e-4), (lhs, rhs)
+    # d z = <W v, g> = lhs / z
+    assert torch.allclose(dsx[:, 3].double(), lhs / 0.7, rtol=1e-4, atol=1e-4)
+    # oracle check of the forward
+    theta = np.zeros((B, 2, 3), np.float32)
+    s, x, y = (att[:, i].cpu().numpy() for i in (H.ATT_S, H.ATT_X, H.ATT_Y))
+    theta[:, 0, 0] = theta[:, 1, 1] = np.float32(1.0) / s
+    theta[:, 0, 2], theta[:, 1, 2] = -x / s, -y / s
+    ref = np.float32(0.7) * ao.transformer(vrec.cpu().numpy().reshape(B, w, w), theta, (Cc, Cc)).reshape(B, -1)
+    assert np.abs(R.cpu().numpy() - ref).max() <= 1e-6
+
+
+def test_adam_and_norm_match_oracle(H):
+    dev = "cuda"
+    rng = np.random.RandomState(2)
+    n = 10007 * 4
+    p = rng.uniform(-1, 1, n).astype(np.float32)
+    g = (rng.standard_normal(n) * 0.05).astype(np.float32)
+    m0 = (rng.standard_normal(n) * 0.01).astype(np.float32)
+    v0 = (rng.uniform(0, 1e-3, n)).astype(np.float32)
+    P, G, M, V = (torch.tensor(a, device=dev) for a in (p, g, m0, v0))
+    ist = torch.tensor([4, 0, 0, 0], dtype=torch.int32, device=dev)
+    dyn = torch.zeros(H.DYN_COUNT, device=dev)
+    dyn[H.DYN_LEARNING_RATE], dyn[H.DYN_CLIP_NORM] = 1e-4, 1.0
+    part = torch.zeros(H.lib().air_optim_num_partials(n), device=dev)
+    gn = torch.zeros(1, device=dev)
+    H.check(H.lib().air_grad_sqnorm(_p(G), n, _p(part), _p(ist), _stream()))
+    H.check(H.lib().air_adam_clip_step(_p(P), _p(G), _p(M), _p(V), n, _p(part), _p(dyn), _p(ist),
+                                       1.0, 0.9, 0.999, 1e-8, None, _p(gn), _stream()))
+    torch.cuda.synchronize()
+    assert int(ist[0]) == 5
+    grads, gnorm = ao.clip_by_global_norm({"w": g}, 1.0)
+    pp, mm, vv = ao.adam_step({"w": p.copy()}, grads, {"w": m0.copy()}, {"w": v0.copy()}, 5, 1e-4)
+    assert abs(float(gn) - float(gnorm)) / float(gnorm) < 1e-5
+    np.testing.assert_allclose(M.cpu().numpy(), mm["w"], rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(V.cpu().numpy(), vv["w"], rtol=1e-5, atol=1e-12)
+    np.testing.assert_allclose(P.cpu().numpy(), pp["w"], rtol=0, atol=2e-7)
+
+
+def test_step_begin_schedule_and_noise(H):
+    dev = "cuda"
+    arr = np.zeros(1, dtype=[("slot", "<i4"), ("flags", "<i4"), ("init", "<f4"), ("iters", "<f4"),
+                             ("factor", "<f4"), ("vmin", "<f4"), ("vmax", "<f4")])
+    arr[0] = (H.DYN_PRIOR_LOG_ODDS, H.SCHED_HAS_MIN | H.SCHED_LOG, 10000.0, 3000.0, 0.1, 1e-9, 0.0)
+    sched = torch.from_numpy(arr.view(np.uint8).copy()).to(dev)
+    dyn = torch.zeros(H.DYN_COUNT, device=dev)
+    nn, nu = 200003, 50001
+    normals, unif = torch.zeros(nn, device=dev), torch.zeros(nu, device=dev)
+    outs = []
+    for step in (0, 3000, 39000):
+        ist = torch.tensor([step, 0, 0, 0], dtype=torch.int32, device=dev)
+        H.check(H.lib().air_step_begin(_p(sched), 1, _p(dyn), _p(ist), _p(normals), nn, _p(unif), nu,
+                                       C.c_uint64(1234), _stream()))
+        torch.cuda.synchronize()
+        ref = ao.annealed_value(ao.TRAINING_ANNEALING["z_pres_prior_log_odds"], step)
+        assert abs(float(dyn[H.DYN_PRIOR_LOG_ODDS]) - float(ref)) < 2e-3, (step, float(dyn[0]), ref)
+        outs.append(normals.clone())
+    x, u = normals.double(), unif.double()
+    assert abs(float(x.mean())) < 0.01 and abs(float(x.std()) - 1.0) < 0.01
+    assert abs(float((x ** 4).mean()) - 3.0) < 0.1
+    assert float(u.min()) >= 0.0 and float(u.max()) < 1.0 and abs(float(u.mean()) - 0.5) < 0.01
+    assert not torch.equal(outs[0], outs[1])         # stream advances with global_step
+    ist = torch.tensor([39000, 0, 0, 0], dtype=torch.int32, device=dev)
+    H.check(H.lib().air_step_begin(_p(sched), 1, _p(dyn), _p(ist), _p(normals), nn, _p(unif), nu,
+                                   C.c_uint64(1234), _stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(normals, outs[2])             # and is reproducible

@@ -1,0 +1,230 @@
+"""GPU parity tests of the whole hot path (AIRModel on libair_hip.so) against the
+CPU oracle: forward outputs, ELBO, all 36 gradients, the clipped Adam update.
+
+Stated tolerances (fp32 kernels vs fp32 oracle, identical injected noise):
+  reconstruction |d| <= 2e-5; per-step KLs rel 1e-4; rec_num_digits exact;
+  BCE given the SAME reconstruction rel 1e-5; ELBO rel 1e-2 in general
+  (out-of-range sampler residues pass through log(r + 1e-9));
+  gradients: per-tensor relative L2 error <= 2e-3.
+bf16-GEMM path: compared with the same oracle at looser, measured tolerances."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import air_oracle as ao  # noqa: E402
+from oracle import air_oracle_torch as at  # noqa: E402
+from oracle.synth import blob_canvases  # noqa: E402
+
+HP = dict(ao.TRAINING_HP)
+REPORT = {}
+
+
+@pytest.fixture(scope="module")
+def am():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from air import air_model
+    return air_model
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _dump_report():
+    yield
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_report.json"), "w") as f:
+        json.dump(REPORT, f, indent=1, sort_keys=True)
+
+
+def _make(am, B, train, seed_img=3, seed_noise=1, prec="fp32", scope=None, lo=-2.0, hp=HP):
+    images, targets = blob_canvases(B, hp["canvas_size"], hp["max_digits"], seed=seed_img)
+    params = ao.init_params(hp, 0)
+    noise = ao.make_noise(hp, B, seed_noise)
+    am.reset_default_graph()
+    model = am.AIRModel(torch.tensor(images, device="cuda"), torch.tensor(targets, device="cuda"),
+                        cnn=False, train=train, scope=scope or "air", gemm_precision=prec, **hp)
+    model.load_state_dict(params)
+    model.set_noise(noise)
+    model.set_dynamic(z_pres_prior_log_odds=lo)
+    return model, images, targets, params, noise
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("B", [4, 64])
+@pytest.mark.parametrize("train", [True, False])
+def test_forward_parity_fp32(am, B, train):
+    model, images, targets, params, noise = _make(am, B, train)
+    model.forward()
+    torch.cuda.synchronize()
+    o = ao.air_forward(params, images, targets, noise, HP, train, -2.0, early_exit=True)
+    T = o["steps_executed"]
+    assert model.steps_executed == T
+    rep = {}
+    rep["recon"] = float(np.abs(_np(model.reconstruction) - o["reconstruction"]).max())
+    assert rep["recon"] <= 2e-5
+    assert np.array_equal(_np(model.rec_num_digits), o["rec_num_digits"])
+    for k in ("rec_scales", "rec_shifts", "rec_windows", "rec_latents", "rec_st_back", "z_pres_probs"):
+        got = _np(getattr(model, k))
+        assert got.shape == o[k].shape, (k, got.shape, o[k].shape)
+        rep[k] = float(np.abs(got - o[k]).max())
+        assert rep[k] <= 5e-5 * max(1.0, np.abs(o[k]).max()), (k, rep[k])
+    for k in ("z_pres_kls", "scale_kls", "shift_kls", "vae_kls"):
+        got = _np(getattr(model, k))
+        rep[k] = float(np.abs(got - o[k]).max() / max(1.0, np.abs(o[k]).max()))
+        assert rep[k] <= 1e-4, (k, rep[k])
+    # BCE on the device's own reconstruction, recomputed in fp64 on the host
+    r = _np(model.reconstruction).astype(np.float64)
+    x = images.astype(np.float64)
+    bce = -np.sum(x * np.log(r + ao.EPS) + (1 - x) * np.log(1 - r + ao.EPS), axis=1)
+    np.testing.assert_allclose(_np(model.reconstruction_loss), bce, rtol=1e-5)
+    rep["elbo_rel"] = abs(float(model.loss) - float(o["loss"])) / abs(float(o["loss"]))
+    assert rep["elbo_rel"] <= 1e-2
+    assert abs(float(model.accuracy) - float(o["accuracy"])) < 1e-6
+    REPORT["forward_fp32_B%d_%s" % (B, "train" if train else "test")] = rep
+
+
+def test_golden_fixture(am, golden_dir):
+    g = np.load(os.path.join(golden_dir, "air_b4.npz"))
+    lo0 = float(ao.annealed_value(ao.TRAINING_ANNEALING["z_pres_prior_log_odds"], 0))
+    for tag, train, lo in (("train_lo9", True, lo0), ("train_lom2", True, -2.0), ("test_lom2", False, -2.0)):
+        model, *_ = _make(am, 4, train, lo=lo)
+        model.forward()
+        assert np.array_equal(_np(model.rec_num_digits), g[tag + "/rec_num_digits"])
+        assert np.abs(_np(model.reconstruction) - g[tag + "/reconstruction"]).max() <= 2e-5
+        T = model.steps_executed
+        for k in ("z_pres_kls", "scale_kls", "shift_kls", "vae_kls"):
+            np.testing.assert_allclose(_np(getattr(model, k)), g[tag + "/" + k][:, :T], rtol=2e-4, atol=2e-4)
+        assert abs(float(model.loss) - float(g[tag + "/loss"])) / abs(float(g[tag + "/loss"])) <= 1e-2
+
+
+def _grad_check(am, B, prec, tol):
+    model, images, targets, params, noise = _make(am, B, True, prec=prec)
+    # run forward+backward only (no optimizer): use the programs directly
+    s = model._stream()
+    model._run_forward(s)
+    for op in model._bwd:
+        op(s)
+    torch.cuda.synchronize()
+    pt = at.to_torch(params, requires_grad=True)
+    _, grads = at.loss_and_grads(pt, torch.tensor(images), torch.tensor(targets), at.to_torch(noise), HP, -2.0)
+    rep = {}
+    worst = 0.0
+    for k, gref in grads.items():
+        got = model.gradients[k].detach().cpu().double()
+        ref = gref.double()
+        err = float((got - ref).norm() / max(ref.norm(), 1e-12))
+        rep[k] = err
+        worst = max(worst, err)
+    REPORT["grads_%s_B%d" % (prec, B)] = rep
+    bad = {k: v for k, v in rep.items() if v > tol}
+    assert not bad, bad
+    return model, grads
+
+
+@pytest.mark.parametrize("B", [4, 64])
+def test_gradients_fp32(am, B):
+    _grad_check(am, B, "fp32", 2e-3)
+
+
+def test_gradients_bf16(am):
+    _grad_check(am, 64, "bf16", 8e-2)
+
+
+def test_forward_parity_bf16(am):
+    model, images, targets, params, noise = _make(am, 64, True, prec="bf16")
+    model.forward()
+    o = ao.air_forward(params, images, targets, noise, HP, True, -2.0)
+    rep = dict(recon=float(np.abs(_np(model.reconstruction) - o["reconstruction"]).max()),
+               elbo_rel=abs(float(model.loss) - float(o["loss"])) / abs(float(o["loss"])),
+               digits_equal=float((_np(model.rec_num_digits) == o["rec_num_digits"]).mean()))
+    REPORT["forward_bf16_B64"] = rep
+    assert rep["recon"] <= 3e-2 and rep["elbo_rel"] <= 3e-2 and rep["digits_equal"] >= 0.95
+
+
+def test_train_step_matches_oracle_update(am):
+    B = 16
+    model, images, targets, params, noise = _make(am, B, True)
+    model.training()
+    torch.cuda.synchronize()
+    assert int(model.global_step) == 1
+    pt = at.to_torch(params, requires_grad=True)
+    out, grads = at.loss_and_grads(pt, torch.tensor(images), torch.tensor(targets), at.to_torch(noise), HP, -2.0)
+    m = {k: torch.zeros_like(p) for k, p in pt.items()}
+    v = {k: torch.zeros_like(p) for k, p in pt.items()}
+    gn = at.clip_and_adam(pt, grads, m, v, 1, HP)
+    assert abs(float(model.store.gnorm) - float(gn)) / float(gn) < 2e-3
+    worst = 0.0
+    for k, p in pt.items():
+        got = model.variables[k].detach().cpu()
+        # first Adam step moves every weight by ~lr: compare the DELTA
+        d_ref = (p.detach() - torch.as_tensor(params[k])).double()
+        d_got = (got - torch.as_tensor(params[k])).double()
+        err = float((d_got - d_ref).norm() / max(d_ref.norm(), 1e-12))
+        worst = max(worst, err)
+        assert err < 5e-2, (k, err)      # sign-like first step: tiny-gradient entries may flip
+    REPORT["adam_delta_worst_rel"] = worst
+    assert abs(float(model.loss) - float(out["loss"])) / abs(float(out["loss"])) < 1e-2
+
+
+def test_determinism_and_graph_replay(am):
+    model, *_ = _make(am, 32, True)
+    sd = model.state_dict()
+    model.training()
+    torch.cuda.synchronize()
+    p1 = model.store.params.clone()
+    l1 = float(model.loss)
+    model.load_state_dict(sd)
+    model.training()
+    torch.cuda.synchronize()
+    assert torch.equal(p1, model.store.params)       # atomics-free: bit-identical
+    assert l1 == float(model.loss)
+
+
+def test_variable_sharing_and_test_model(am):
+    am.reset_default_graph()
+    B = 8
+    images, targets = blob_canvases(B, 50, 2, seed=9)
+    dev = "cuda"
+    tr = am.AIRModel(torch.tensor(images, device=dev), torch.tensor(targets, device=dev), cnn=False,
+                     train=True, scope="air", **HP)
+    te = am.AIRModel(torch.tensor(images, device=dev), torch.tensor(targets, device=dev), cnn=False,
+                     train=False, reuse=True, scope="air", **HP)
+    assert te.store is tr.store
+    with pytest.raises(ValueError):
+        am.AIRModel(torch.tensor(images, device=dev), torch.tensor(targets, device=dev), cnn=False, scope="air", **HP)
+    with pytest.raises(NotImplementedError):
+        am.AIRModel(torch.tensor(images, device=dev), torch.tensor(targets, device=dev), scope="other", **HP)
+    for _ in range(3):
+        tr.training()
+    te.forward()
+    torch.cuda.synchronize()
+    assert int(te.global_step) == 3
+    z = te.att[:, :, 4]
+    assert bool(((z == 0) | (z == 1)).all())          # test mode rounds z_pres (reference :389-390)
+    assert np.isfinite(float(te.loss))
+
+
+def test_annealed_training_runs_and_loss_drops(am):
+    am.reset_default_graph()
+    B = 64
+    images, targets = blob_canvases(B, 50, 2, seed=21)
+    model = am.AIRModel(torch.tensor(images, device="cuda"), torch.tensor(targets, device="cuda"), cnn=False,
+                        train=True, scope="air", annealing_schedules=ao.TRAINING_ANNEALING, **HP)
+    losses = []
+    for i in range(60):
+        model.training()
+        if i % 10 == 0 or i == 59:
+            losses.append(float(model.loss))
+    torch.cuda.synchronize()
+    assert all(np.isfinite(losses)), losses
+    assert losses[-1] < losses[0], losses
+    assert abs(float(model.dyn[0]) - float(ao.annealed_value(ao.TRAINING_ANNEALING["z_pres_prior_log_odds"], 59))) < 2e-3
+    REPORT["train60_losses"] = losses

@@ -1,0 +1,638 @@
+"""AIRModel on MI355X -- host side of the Attend-Infer-Repeat hot path.
+
+Mirrors the constructor and output attributes of the reference class
+(/root/reference/air/air_model.py:11-92, outputs :568-611, train op :651-694)
+but executes the per-timestep loop as hand-written HIP kernels behind the C ABI
+of libair_hip.so (include/air_hip.h).  PyTorch is used for device memory,
+streams and torch.distributed only; there is no torch autograd, no torch math
+and NO CPU fallback on this path.
+
+Differences forced by the runtime (TF1 graph/session -> eager device buffers):
+  * ``input_images`` / ``target_num_digits`` are device tensors that act as the
+    placeholders: the kernels read them in place every time the model runs;
+  * output attributes are device tensors refreshed by ``forward()`` /
+    ``training()`` (``training`` is the callable train op, reference :692);
+  * the loop runs a fixed ``max_steps`` iterations (numerically identical to the
+    reference's early exit); the stacked ``rec_*`` outputs
+    are sliced to the T' <= max_steps iterations the reference would have run;
+  * every RNG op of the reference graph is unseeded; here noise comes from a
+    device Philox stream (``seed``) or is injected with ``set_noise`` (parity).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _hip as H
+
+# "fp32": exact-fp32 MFMA (parity path); "bf16": bf16 operands, fp32 accumulate
+GEMM_PRECISION = os.environ.get("AIR_GEMM_PRECISION", "fp32")
+
+_SCOPES = {}
+
+
+def reset_default_graph():
+    """Drops all variable scopes (the tf.reset_default_graph() of this runtime)."""
+    _SCOPES.clear()
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _align4(n):
+    return (n + 3) & ~3
+
+
+class VariableStore:
+    """All trainable variables of one scope in ONE flat fp32 buffer (+ grads,
+    Adam m/v) so that the optimizer and the data-parallel all-reduce are a
+    single pass / a single collective.  TF variable names (model/air-model.index,
+    SURVEY appendix B) are exposed as views."""
+
+    def __init__(self, hp, device, seed=0):
+        self.hp = hp
+        self.device = device
+        D, d = hp["canvas_size"] ** 2, hp["windows_size"] ** 2
+        R, Z = hp["rnn_units"], hp["vae_latent_dimensions"]
+        Hs, Hh, Hz = hp["scale_hidden_units"], hp["shift_hidden_units"], hp["z_pres_hidden_units"]
+        HT, Hmax = 2 * Hs + 2 * Hh + Hz, max(Hs, Hh, Hz)
+        self.dims = dict(D=D, d=d, R=R, Z=Z, Hs=Hs, Hh=Hh, Hz=Hz, HT=HT, Hmax=Hmax)
+        rec, gen = list(hp["vae_recognition_units"]), list(hp["vae_generative_units"])
+
+        fused = OrderedDict()           # fused device tensors: name -> shape
+        fused["lstm_kernel"] = (D + R, 4 * R)
+        fused["lstm_bias"] = (4 * R,)
+        fused["whid"] = (R, HT)
+        fused["bhid"] = (HT,)
+        fused["wout"] = (7, Hmax)
+        fused["bout"] = (8,)
+        prev = d
+        for i, u in enumerate(rec):
+            fused["rec%d_w" % i] = (prev, u)
+            fused["rec%d_b" % i] = (u,)
+            prev = u
+        fused["ml_w"] = (prev, 2 * Z)
+        fused["ml_b"] = (2 * Z,)
+        prev = Z
+        for i, u in enumerate(gen):
+            fused["gen%d_w" % i] = (prev, u)
+            fused["gen%d_b" % i] = (u,)
+            prev = u
+        fused["out_w"] = (prev, d)
+        fused["out_b"] = (d,)
+
+        self.offsets = OrderedDict()
+        off = 0
+        for k, shp in fused.items():
+            self.offsets[k] = off
+            off += _align4(int(np.prod(shp)))
+        self.n = off                                        # multiple of 4
+        # +4 tail floats: loss / accuracy ride along in the gradient all-reduce
+        self.params = torch.zeros(self.n, dtype=torch.float32, device=device)
+        self.grads = torch.zeros(self.n + 4, dtype=torch.float32, device=device)
+        self.m = torch.zeros(self.n, dtype=torch.float32, device=device)
+        self.v = torch.zeros(self.n, dtype=torch.float32, device=device)
+        self.istate = torch.zeros(H.IST_COUNT, dtype=torch.int32, device=device)
+        self.partials = torch.zeros(H.lib().air_optim_num_partials(self.n), dtype=torch.float32, device=device)
+        self.gnorm = torch.zeros(1, dtype=torch.float32, device=device)
+
+        def views(buf):
+            return OrderedDict((k, buf[self.offsets[k]:self.offsets[k] + int(np.prod(s))].view(*s))
+                               for k, s in fused.items())
+        self.P, self.G = views(self.params), views(self.grads)
+
+        # TF-named views (air-model.index names, relative to scope "<scope>/rnn/")
+        def named(V):
+            o = OrderedDict()
+            o["rnn/kernel"], o["rnn/bias"] = V["lstm_kernel"], V["lstm_bias"]
+            seg = 0
+            rows = (0, 1, (2, 4), (4, 6), 6)
+            for hi, (head, wid, k) in enumerate((("scale/mean", Hs, 1), ("scale/log_variance", Hs, 1),
+                                                 ("shift/mean", Hh, 2), ("shift/log_variance", Hh, 2),
+                                                 ("z_pres/log_odds", Hz, 1))):
+                o[head + "/hidden/weights"] = V["whid"][:, seg:seg + wid]
+                o[head + "/hidden/biases"] = V["bhid"][seg:seg + wid]
+                r = rows[hi]
+                r0, r1 = (r, r + 1) if isinstance(r, int) else r
+                o[head + "/output/weights"] = V["wout"][r0:r1, :wid].t()
+                o[head + "/output/biases"] = V["bout"][r0:r1]
+                seg += wid
+            for i in range(len(rec)):
+                o["vae/recognition_%d/weights" % (i + 1)] = V["rec%d_w" % i]
+                o["vae/recognition_%d/biases" % (i + 1)] = V["rec%d_b" % i]
+            o["vae/rec_mean/weights"], o["vae/rec_mean/biases"] = V["ml_w"][:, :Z], V["ml_b"][:Z]
+            o["vae/rec_log_variance/weights"], o["vae/rec_log_variance/biases"] = V["ml_w"][:, Z:], V["ml_b"][Z:]
+            for i in range(len(gen)):
+                o["vae/generative_%d/weights" % (i + 1)] = V["gen%d_w" % i]
+                o["vae/generative_%d/biases" % (i + 1)] = V["gen%d_b" % i]
+            o["vae/gen_mean/weights"], o["vae/gen_mean/biases"] = V["out_w"], V["out_b"]
+            return o
+        self.variables = named(self.P)
+        self.gradients = named(self.G)
+        self.num_trainable = sum(v.numel() for v in self.variables.values())
+        self.initialize(seed)
+
+    def initialize(self, seed=0):
+        """Xavier/Glorot-uniform weights, zero biases -- TF1.3 defaults of
+        BasicLSTMCell / layers.fully_connected (limits sqrt(6/(in+out)) as in
+        air-model.meta's initializer constants); zero Adam slots, step 0."""
+        rng = np.random.RandomState(seed)
+        self.params.zero_()
+        for name, v in self.variables.items():
+            if v.dim() == 2:
+                limit = math.sqrt(6.0 / (v.shape[0] + v.shape[1]))
+                v.copy_(torch.from_numpy(rng.uniform(-limit, limit, size=tuple(v.shape)).astype(np.float32)))
+        self.m.zero_(); self.v.zero_(); self.grads.zero_(); self.istate.zero_()
+
+    def state_dict(self):
+        sd = OrderedDict((k, v.detach().cpu().contiguous().clone()) for k, v in self.variables.items())
+        sd["global_step"] = self.istate[H.IST_GLOBAL_STEP].cpu().clone()
+        sd["_adam_m"], sd["_adam_v"] = self.m.cpu().clone(), self.v.cpu().clone()
+        return sd
+
+    def load_state_dict(self, sd, strict=True):
+        for k, v in self.variables.items():
+            if k in sd:
+                v.copy_(torch.as_tensor(np.asarray(sd[k])).to(v.dtype).reshape(v.shape))
+            elif strict:
+                raise KeyError("missing variable %s" % k)
+        if "global_step" in sd:
+            self.istate[H.IST_GLOBAL_STEP] = int(sd["global_step"])
+        if "_adam_m" in sd:
+            self.m.copy_(torch.as_tensor(sd["_adam_m"])); self.v.copy_(torch.as_tensor(sd["_adam_v"]))
+
+
+_ANNEALABLE = {
+    "z_pres_prior_log_odds": H.DYN_PRIOR_LOG_ODDS, "z_pres_temperature": H.DYN_TEMPERATURE,
+    "stopping_threshold": H.DYN_STOP_THRESHOLD, "learning_rate": H.DYN_LEARNING_RATE,
+    "gradient_clipping_norm": H.DYN_CLIP_NORM,
+    "scale_prior_mean": H.DYN_SCALE_PM, "scale_prior_variance": H.DYN_SCALE_PV,
+    "shift_prior_mean": H.DYN_SHIFT_PM, "shift_prior_variance": H.DYN_SHIFT_PV,
+    "vae_prior_mean": H.DYN_VAE_PM, "vae_prior_variance": H.DYN_VAE_PV,
+}
+
+
+class AIRModel:
+
+    def __init__(self, input_images, target_num_digits,
+                 max_steps=3, max_digits=2, rnn_units=256, canvas_size=50, windows_size=28,
+                 vae_latent_dimensions=50, vae_recognition_units=(512, 256), vae_generative_units=(256, 512),
+                 scale_prior_mean=-1.0, scale_prior_variance=0.1, shift_prior_mean=0.0, shift_prior_variance=1.0,
+                 vae_prior_mean=0.0, vae_prior_variance=1.0, vae_likelihood_std=0.3,
+                 scale_hidden_units=64, shift_hidden_units=64, z_pres_hidden_units=64,
+                 z_pres_prior_log_odds=-2.0, z_pres_temperature=1.0, stopping_threshold=0.99,
+                 learning_rate=1e-3, gradient_clipping_norm=100.0, cnn=True, cnn_filters=8,
+                 num_summary_images=60, train=False, reuse=False, scope="air",
+                 annealing_schedules=None, seed=0, gemm_precision=None):
+        if cnn:
+            # reference :510-533; every caller passes cnn=False (training.py:108, demo.py:24)
+            raise NotImplementedError("cnn=True front-end is outside the accelerated hot path; pass cnn=False")
+        if not (torch.is_tensor(input_images) and input_images.is_cuda):
+            raise H.AirHipError("input_images must be a CUDA/HIP device tensor: this path has no CPU fallback")
+        self.lib = H.lib()
+        self.input_images = input_images
+        self.target_num_digits = target_num_digits
+        self.batch_size = int(input_images.shape[0])
+
+        self.max_steps = max_steps
+        self.max_digits = max_digits
+        self.rnn_units = rnn_units
+        self.canvas_size = canvas_size
+        self.windows_size = windows_size
+        self.vae_latent_dimensions = vae_latent_dimensions
+        self.vae_recognition_units = tuple(vae_recognition_units)
+        self.vae_generative_units = tuple(vae_generative_units)
+        self.scale_prior_mean = scale_prior_mean
+        self.scale_prior_variance = scale_prior_variance
+        self.shift_prior_mean = shift_prior_mean
+        self.shift_prior_variance = shift_prior_variance
+        self.vae_prior_mean = vae_prior_mean
+        self.vae_prior_variance = vae_prior_variance
+        self.vae_likelihood_std = vae_likelihood_std
+        self.scale_hidden_units = scale_hidden_units
+        self.shift_hidden_units = shift_hidden_units
+        self.z_pres_hidden_units = z_pres_hidden_units
+        self.z_pres_prior_log_odds = z_pres_prior_log_odds
+        self.z_pres_temperature = z_pres_temperature
+        self.stopping_threshold = stopping_threshold
+        self.learning_rate = learning_rate
+        self.gradient_clipping_norm = gradient_clipping_norm
+        self.num_summary_images = num_summary_images
+        self.cnn = cnn
+        self.cnn_filters = cnn_filters
+        self.train = train
+        self.scope = scope
+        self.annealing_schedules = annealing_schedules
+        self.rnn_input = self.input_images            # reference :535
+        self.num_summaries, self.img_summaries, self.var_summaries, self.grad_summaries = [], [], [], []
+        prec = gemm_precision or GEMM_PRECISION
+        if prec not in ("fp32", "bf16"):
+            raise ValueError("gemm_precision must be 'fp32' or 'bf16'")
+        self.gemm_precision = prec
+        self._prec = 1 if prec == "bf16" else 0
+
+        dev = input_images.device
+        if tuple(input_images.shape) != (self.batch_size, canvas_size * canvas_size) or \
+                input_images.dtype != torch.float32 or not input_images.is_contiguous():
+            raise ValueError("input_images must be contiguous float32 [B, canvas_size**2]")
+        if target_num_digits is None:
+            self.target_num_digits = torch.zeros(self.batch_size, dtype=torch.int32, device=dev)
+        if self.target_num_digits.dtype != torch.int32 or tuple(self.target_num_digits.shape) != (self.batch_size,):
+            raise ValueError("target_num_digits must be int32 [B]")
+
+        hp = dict(canvas_size=canvas_size, windows_size=windows_size, rnn_units=rnn_units,
+                  vae_latent_dimensions=vae_latent_dimensions,
+                  vae_recognition_units=self.vae_recognition_units, vae_generative_units=self.vae_generative_units,
+                  scale_hidden_units=scale_hidden_units, shift_hidden_units=shift_hidden_units,
+                  z_pres_hidden_units=z_pres_hidden_units)
+        # tf.variable_scope(scope, reuse=reuse), reference :68
+        if reuse:
+            if scope not in _SCOPES:
+                raise ValueError("reuse=True but variable scope %r does not exist" % scope)
+            self.store = _SCOPES[scope]
+            if self.store.hp != hp:
+                raise ValueError("variable scope %r was created with different shapes" % scope)
+        else:
+            if scope in _SCOPES:
+                raise ValueError("variable scope %r already exists; pass reuse=True" % scope)
+            self.store = _SCOPES[scope] = VariableStore(hp, dev, seed)
+        self.variables = self.store.variables
+        self.gradients = self.store.gradients
+
+        self._seed = seed + (0 if train else 7919)
+        self._injected_noise = False
+        self._graph = None
+        self._dirty = True
+        self._steps_executed = None
+        self._alloc()
+        self._build_programs()
+
+    # ------------------------------------------------------------------ buffers
+    def _alloc(self):
+        st, dv = self.store, self.input_images.device
+        dm = st.dims
+        B, N = self.batch_size, self.max_steps
+        D, d, R, Z, HT = dm["D"], dm["d"], dm["R"], dm["Z"], dm["HT"]
+        f = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dv)  # noqa: E731
+
+        # dynamic scalars + annealing table (reference :76-82, 94-121)
+        dyn = np.zeros(H.DYN_COUNT, np.float32)
+        dyn[H.DYN_PRIOR_LOG_ODDS] = self.z_pres_prior_log_odds if not isinstance(self.z_pres_prior_log_odds, dict) else 0
+        dyn[H.DYN_TEMPERATURE] = self.z_pres_temperature
+        dyn[H.DYN_STOP_THRESHOLD] = self.stopping_threshold
+        dyn[H.DYN_LEARNING_RATE] = self.learning_rate
+        dyn[H.DYN_CLIP_NORM] = self.gradient_clipping_norm if self.gradient_clipping_norm is not None else 0.0
+        dyn[H.DYN_SCALE_PM], dyn[H.DYN_SCALE_PV] = self.scale_prior_mean, self.scale_prior_variance
+        dyn[H.DYN_SHIFT_PM], dyn[H.DYN_SHIFT_PV] = self.shift_prior_mean, self.shift_prior_variance
+        dyn[H.DYN_VAE_PM], dyn[H.DYN_VAE_PV] = self.vae_prior_mean, self.vae_prior_variance
+        dyn[H.DYN_LIK_STD] = self.vae_likelihood_std
+        dyn[H.DYN_GRAD_SCALE] = 1.0 / B
+        self.dyn = torch.from_numpy(dyn).to(dv)
+        sched = []
+        for param, s in (self.annealing_schedules or {}).items():
+            if param not in _ANNEALABLE:
+                raise NotImplementedError("annealing of %r is not supported on the HIP path" % param)
+            flags = (H.SCHED_STAIRCASE if s.get("staircase", False) else 0) | \
+                    (H.SCHED_HAS_MIN if "min" in s else 0) | (H.SCHED_HAS_MAX if "max" in s else 0) | \
+                    (H.SCHED_LOG if s.get("log", False) else 0)
+            sched.append((_ANNEALABLE[param], flags, s["init"], s["iters"], s["factor"],
+                          s.get("min", 0.0), s.get("max", 0.0)))
+        self._nsched = len(sched)
+        arr = np.zeros(max(1, len(sched)), dtype=[("slot", "<i4"), ("flags", "<i4"), ("init", "<f4"),
+                                                 ("iters", "<f4"), ("factor", "<f4"), ("vmin", "<f4"), ("vmax", "<f4")])
+        for i, srow in enumerate(sched):
+            arr[i] = srow
+        self.sched = torch.from_numpy(arr.view(np.uint8).copy()).to(dv)
+
+        # noise: normals then uniforms, one contiguous buffer each (one Philox launch)
+        n_norm = N * B * (1 + 2 + Z + d)
+        self.normals = f(n_norm)
+        self.uniforms = f(N * B)
+        o = 0
+        self.eps_scale = self.normals[o:o + N * B].view(N, B, 1); o += N * B
+        self.eps_shift = self.normals[o:o + 2 * N * B].view(N, B, 2); o += 2 * N * B
+        self.eps_z = self.normals[o:o + N * B * Z].view(N, B, Z); o += N * B * Z
+        self.eps_x = self.normals[o:o + N * B * d].view(N, B, d)
+        self.u = self.uniforms.view(N, B)
+
+        # running state zeroed with ONE memset at the start of every forward
+        n_state = B * D + 3 * B + 2 * B * R
+        self.state = f(_align4(n_state))
+        o = 0
+        self.run_recon = self.state[o:o + B * D].view(B, D); o += B * D
+        self.stop_sum = self.state[o:o + B]; o += B
+        self.run_loss = self.state[o:o + B]; o += B
+        self.run_digits = self.state[o:o + B].view(torch.int32); o += B
+        self.c = f(N + 1, B, R); self.h = f(N + 1, B, R)         # [0] stays zero (zero_state :540)
+
+        self.xw = f(B, 4 * R)
+        self.gates_pre = f(B, 4 * R)
+        self.acts = f(N, B, 4 * R)
+        self.hid = f(N, B, HT)
+        self.out7 = f(N, B, H.OUT_STRIDE)
+        self.att = f(N, B, H.ATT_STRIDE)
+        self.window = f(N, B, d)
+        self.rec_act = [f(N, B, u) for u in self.vae_recognition_units]
+        self.ml = f(N, B, 2 * Z)
+        self.zs = f(N, B, Z)
+        self.gen_act = [f(N, B, u) for u in self.vae_generative_units]
+        self.vrec = f(N, B, d)
+        self._recon = f(B, D)
+        self._rec_loss = f(B)
+        self._loss_item = f(B)
+        self.scalars = self.store.grads[self.store.n:self.store.n + 4] if self.train else f(4)
+
+        if self.train:
+            self.d_recon = f(B, D)
+            self.d_genpre = f(N, B, d)
+            self.d_gen = [f(N, B, u) for u in self.vae_generative_units]
+            self.d_zs = f(B, Z)
+            self.d_ml = f(N, B, 2 * Z)
+            self.d_rec = [f(N, B, u) for u in self.vae_recognition_units]
+            self.d_window = f(B, d)
+            self.d_sxyw = f(B, 4)
+            self.d_hid = f(N, B, HT)
+            self.d_out7 = f(N, B, H.OUT_STRIDE)
+            self.dh_cur, self.dh_rec = f(B, R), f(B, R)
+            self.dc = [f(B, R), f(B, R)]
+            self.dgates = f(N, B, 4 * R)
+            self.dgsum = f(B, 4 * R)
+
+    # ------------------------------------------------------------- launch lists
+    def _gemm(self, A, Bm, Cm, M, N, K, lda, ldb, ldc, ta=0, tb=0, bias=None, addend=None, ldadd=0,
+              aux=None, ldaux=0, aux_scale=0.0, act=H.ACT_NONE, actgrad=H.GRAD_NONE, accumulate=0):
+        g = H.Gemm(_ptr(A), _ptr(Bm), _ptr(Cm), M, N, K, lda, ldb, ldc, ta, tb, _ptr(bias), _ptr(addend), ldadd,
+                   _ptr(aux), ldaux, aux_scale, act, actgrad, accumulate, self._prec)
+        fn = self.lib.air_gemm
+        return lambda s, g=g, fn=fn: H.check(fn(C.byref(g), s), "air_gemm")
+
+    def _call(self, name, *args):
+        fn = getattr(self.lib, name)
+        return lambda s, fn=fn, args=args, name=name: H.check(fn(*args, s), name)
+
+    def _build_programs(self):
+        st, P, G = self.store, self.store.P, self.store.G
+        dm = st.dims
+        B, N = self.batch_size, self.max_steps
+        D, d, R, Z, HT = dm["D"], dm["d"], dm["R"], dm["Z"], dm["HT"]
+        Hs, Hh, Hz, Hmax = dm["Hs"], dm["Hh"], dm["Hz"], dm["Hmax"]
+        Cc, w = self.canvas_size, self.windows_size
+        rec_u, gen_u = list(self.vae_recognition_units), list(self.vae_generative_units)
+        Wx, Wh = P["lstm_kernel"][:D], P["lstm_kernel"][D:]
+        imgs = self.input_images
+        keep = self._keep = []          # ctypes structs referenced by the closures
+
+        fwd = []
+        # hoisted x.W_x + b (the reference recomputes it every step, :286)
+        fwd.append(self._gemm(imgs, Wx, self.xw, B, 4 * R, D, D, 4 * R, 4 * R, bias=P["lstm_bias"]))
+        for t in range(N):
+            fwd.append(self._gemm(self.h[t], Wh, self.gates_pre, B, 4 * R, R, R, 4 * R, 4 * R,
+                                  addend=self.xw, ldadd=4 * R))
+            fwd.append(self._call("air_lstm_gates_fwd", _ptr(self.gates_pre), _ptr(self.c[t]), _ptr(self.acts[t]),
+                                  _ptr(self.c[t + 1]), _ptr(self.h[t + 1]), B, R))
+            fwd.append(self._gemm(self.h[t + 1], P["whid"], self.hid[t], B, HT, R, R, HT, HT,
+                                  bias=P["bhid"], act=H.ACT_RELU))
+            a = H.AttendFwd(_ptr(self.hid[t]), _ptr(P["wout"]), _ptr(P["bout"]), _ptr(imgs),
+                            _ptr(self.eps_scale[t]), _ptr(self.eps_shift[t]), _ptr(self.u[t]), _ptr(self.dyn),
+                            _ptr(self.out7[t]), _ptr(self.att[t]), _ptr(self.window[t]),
+                            _ptr(self.stop_sum), _ptr(self.run_loss), _ptr(self.run_digits),
+                            B, Cc, w, Hs, Hh, Hz, Hmax, 1 if self.train else 0)
+            keep.append(a)
+            fwd.append(self._call("air_attend_fwd", C.byref(a)))
+            x, k = self.window[t], d
+            for i, u in enumerate(rec_u):
+                fwd.append(self._gemm(x, P["rec%d_w" % i], self.rec_act[i][t], B, u, k, k, u, u,
+                                      bias=P["rec%d_b" % i], act=H.ACT_SOFTPLUS))
+                x, k = self.rec_act[i][t], u
+            fwd.append(self._gemm(x, P["ml_w"], self.ml[t], B, 2 * Z, k, k, 2 * Z, 2 * Z, bias=P["ml_b"]))
+            fwd.append(self._call("air_reparam_fwd", _ptr(self.ml[t]), _ptr(self.eps_z[t]), _ptr(self.zs[t]), B, Z))
+            x, k = self.zs[t], Z
+            for i, u in enumerate(gen_u):
+                fwd.append(self._gemm(x, P["gen%d_w" % i], self.gen_act[i][t], B, u, k, k, u, u,
+                                      bias=P["gen%d_b" % i], act=H.ACT_SOFTPLUS))
+                x, k = self.gen_act[i][t], u
+            fwd.append(self._gemm(x, P["out_w"], self.vrec[t], B, d, k, k, d, d, bias=P["out_b"],
+                                  act=H.ACT_SIGMOID_NOISE, aux=self.eps_x[t], ldaux=d,
+                                  aux_scale=float(self.vae_likelihood_std)))
+            wf = H.WriteFwd(_ptr(self.vrec[t]), _ptr(self.ml[t]), _ptr(self.dyn), _ptr(self.att[t]),
+                            _ptr(self.run_recon), _ptr(self.run_loss), B, Cc, w, Z)
+            keep.append(wf)
+            fwd.append(self._call("air_write_fwd", C.byref(wf)))
+        fwd.append(self._call("air_bce_fwd_bwd", _ptr(imgs), _ptr(self.run_recon), _ptr(self.dyn),
+                              _ptr(self._recon), _ptr(self._rec_loss),
+                              _ptr(self.d_recon if self.train else None), B, D))
+        fwd.append(self._call("air_finalize", _ptr(self.run_loss), _ptr(self._rec_loss),
+                              _ptr(self.target_num_digits), _ptr(self.run_digits), _ptr(self._loss_item),
+                              _ptr(self.scalars), B))
+        self._fwd = fwd
+        self._begin = self._call(
+            "air_step_begin", _ptr(self.sched), self._nsched, _ptr(self.dyn), _ptr(st.istate),
+            _ptr(self.normals), self.normals.numel(), _ptr(self.uniforms), self.uniforms.numel(),
+            C.c_uint64(self._seed))
+        self._begin_sched_only = self._call(
+            "air_step_begin", _ptr(self.sched), self._nsched, _ptr(self.dyn), _ptr(st.istate),
+            None, 0, None, 0, C.c_uint64(self._seed))
+        if not self.train:
+            self._bwd, self._opt = [], []
+            return
+
+        bwd = []
+        for t in reversed(range(N)):
+            wb = H.WriteBwd(_ptr(self.d_recon), _ptr(self.vrec[t]), _ptr(self.att[t]), _ptr(self.d_genpre[t]),
+                            _ptr(self.d_sxyw), B, Cc, w)
+            keep.append(wb)
+            bwd.append(self._call("air_write_bwd", C.byref(wb)))
+            # decoder data-grads: dX = dY . W^T, times softplus'(saved activation)
+            dy, n_out = self.d_genpre[t], d
+            wname = "out_w"
+            for i in reversed(range(len(gen_u))):
+                u = gen_u[i]
+                bwd.append(self._gemm(dy, P[wname], self.d_gen[i][t], B, u, n_out, n_out, n_out, u, tb=1,
+                                      aux=self.gen_act[i][t], ldaux=u, actgrad=H.GRAD_SOFTPLUS))
+                dy, n_out, wname = self.d_gen[i][t], u, "gen%d_w" % i
+            bwd.append(self._gemm(dy, P[wname], self.d_zs, B, Z, n_out, n_out, n_out, Z, tb=1))
+            bwd.append(self._call("air_reparam_bwd", _ptr(self.d_zs), _ptr(self.ml[t]), _ptr(self.eps_z[t]),
+                                  _ptr(self.att[t]), _ptr(self.dyn), _ptr(self.d_ml[t]), B, Z))
+            dy, n_out, wname = self.d_ml[t], 2 * Z, "ml_w"
+            for i in reversed(range(len(rec_u))):
+                u = rec_u[i]
+                bwd.append(self._gemm(dy, P[wname], self.d_rec[i][t], B, u, n_out, n_out, n_out, u, tb=1,
+                                      aux=self.rec_act[i][t], ldaux=u, actgrad=H.GRAD_SOFTPLUS))
+                dy, n_out, wname = self.d_rec[i][t], u, "rec%d_w" % i
+            bwd.append(self._gemm(dy, P[wname], self.d_window, B, d, n_out, n_out, n_out, d, tb=1))
+            ab = H.AttendBwd(_ptr(self.hid[t]), _ptr(P["wout"]), _ptr(imgs), _ptr(self.eps_scale[t]),
+                             _ptr(self.eps_shift[t]), _ptr(self.dyn), _ptr(self.out7[t]), _ptr(self.att[t]),
+                             _ptr(self.d_window), _ptr(self.d_sxyw), _ptr(self.d_hid[t]), _ptr(self.d_out7[t]),
+                             B, Cc, w, Hs, Hh, Hz, Hmax)
+            keep.append(ab)
+            bwd.append(self._call("air_attend_bwd", C.byref(ab)))
+            last = (t == N - 1)
+            dc_cur, dc_nxt = self.dc[t % 2], self.dc[(t + 1) % 2]
+            # grad wrt h[t+1]: heads of step t (d_hid . Whid^T) + LSTM of step t+1 (dh_rec)
+            bwd.append(self._gemm(self.d_hid[t], P["whid"], self.dh_cur, B, R, HT, HT, HT, R, tb=1,
+                                  addend=None if last else self.dh_rec, ldadd=R))
+            bwd.append(self._call("air_lstm_gates_bwd", _ptr(self.dh_cur), _ptr(None if last else dc_nxt),
+                                  _ptr(self.acts[t]), _ptr(self.c[t]), _ptr(self.c[t + 1]), _ptr(self.dgates[t]),
+                                  _ptr(dc_cur), _ptr(self.dgsum), 0 if last else 1, B, R))
+            if t > 0:
+                # grad wrt h[t] through the recurrent matmul of step t (h[0] is the constant zero state)
+                bwd.append(self._gemm(self.dgates[t], Wh, self.dh_rec, B, R, 4 * R, 4 * R, 4 * R, R, tb=1))
+        self._bwd = bwd
+
+        # weight grads: ONE GEMM per matrix over all N*B rows (weights are shared across time steps)
+        NB = N * B
+        wg = []
+        Gx, Gh = G["lstm_kernel"][:D], G["lstm_kernel"][D:]
+        wg.append(self._gemm(imgs, self.dgsum, Gx, D, 4 * R, B, D, 4 * R, 4 * R, ta=1))
+        wg.append(self._gemm(self.h[0], self.dgates, Gh, R, 4 * R, NB, R, 4 * R, 4 * R, ta=1))
+        wg.append(self._gemm(self.h[1], self.d_hid, G["whid"], R, HT, NB, R, HT, HT, ta=1))
+        wg.append(self._call("air_heads_out_wgrad", _ptr(self.d_out7), _ptr(self.hid), _ptr(G["wout"]),
+                             _ptr(G["bout"]), NB, Hs, Hh, Hz, Hmax))
+        x, k = self.window, d
+        for i, u in enumerate(rec_u):
+            wg.append(self._gemm(x, self.d_rec[i], G["rec%d_w" % i], k, u, NB, k, u, u, ta=1))
+            x, k = self.rec_act[i], u
+        wg.append(self._gemm(x, self.d_ml, G["ml_w"], k, 2 * Z, NB, k, 2 * Z, 2 * Z, ta=1))
+        x, k = self.zs, Z
+        for i, u in enumerate(gen_u):
+            wg.append(self._gemm(x, self.d_gen[i], G["gen%d_w" % i], k, u, NB, k, u, u, ta=1))
+            x, k = self.gen_act[i], u
+        wg.append(self._gemm(x, self.d_genpre, G["out_w"], k, d, NB, k, d, d, ta=1))
+        cs = [(self.dgsum, G["lstm_bias"], B, 4 * R), (self.d_hid, G["bhid"], NB, HT)]
+        cs += [(self.d_rec[i], G["rec%d_b" % i], NB, u) for i, u in enumerate(rec_u)]
+        cs += [(self.d_ml, G["ml_b"], NB, 2 * Z)]
+        cs += [(self.d_gen[i], G["gen%d_b" % i], NB, u) for i, u in enumerate(gen_u)]
+        cs += [(self.d_genpre, G["out_b"], NB, d)]
+        for i0 in range(0, len(cs), 16):
+            chunk = cs[i0:i0 + 16]
+            arr = (H.Colsum * len(chunk))(*[H.Colsum(_ptr(s), _ptr(dst), r, c, c, 0) for s, dst, r, c in chunk])
+            keep.append(arr)
+            wg.append(self._call("air_colsum", arr, len(chunk)))
+        self._bwd += wg
+
+        self._opt = [
+            self._call("air_grad_sqnorm", _ptr(st.grads), st.n, _ptr(st.partials), _ptr(st.istate)),
+        ]
+
+    # ------------------------------------------------------------------ running
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.input_images.device).cuda_stream)
+
+    def set_noise(self, noise):
+        """Inject the noise tensors of one pass (parity tests): dict with eps_scale
+        [N,B,1], eps_shift [N,B,2], eps_z [N,B,Z], eps_x [N,B,d], u [N,B]."""
+        for k in ("eps_scale", "eps_shift", "eps_z", "eps_x", "u"):
+            getattr(self, k).copy_(torch.as_tensor(np.asarray(noise[k]), dtype=torch.float32).reshape(getattr(self, k).shape))
+        self._injected_noise = True
+        self._dirty = True
+
+    def use_device_rng(self, seed=None):
+        if seed is not None:
+            self._seed = seed
+            self._build_programs()
+        self._injected_noise = False
+
+    def set_dynamic(self, **kw):
+        """Overrides dynamic scalars (e.g. z_pres_prior_log_odds=-2.0) -- only meaningful
+        for parameters without an annealing schedule."""
+        for k, v in kw.items():
+            self.dyn[_ANNEALABLE[k]] = float(v)
+        self._dirty = True
+
+    def _run_forward(self, s):
+        (self._begin_sched_only if self._injected_noise else self._begin)(s)
+        self.state.zero_()
+        for op in self._fwd:
+            op(s)
+
+    def forward(self):
+        """Evaluates the model on the current contents of the input buffers."""
+        self._run_forward(self._stream())
+        self._dirty = False
+        self._steps_executed = None
+        return self
+
+    def training(self):
+        """The train op (reference :692): forward, loss, backward, clip, Adam, global_step += 1."""
+        if not self.train:
+            raise RuntimeError("model was built with train=False")
+        st = self.store
+        s = self._stream()
+        self._run_forward(s)
+        for op in self._bwd:
+            op(s)
+        world = 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            world = torch.distributed.get_world_size()
+            if world > 1:
+                torch.distributed.all_reduce(st.grads)            # ONE collective: grads + loss/accuracy tail
+        for op in self._opt:
+            op(s)
+        H.check(self.lib.air_adam_clip_step(
+            _ptr(st.params), _ptr(st.grads), _ptr(st.m), _ptr(st.v), st.n, _ptr(st.partials), _ptr(self.dyn),
+            _ptr(st.istate), 1.0 / world, 0.9, 0.999, 1e-8, None, _ptr(st.gnorm), s), "air_adam_clip_step")
+        if world > 1:
+            self.scalars[:2].mul_(1.0 / world)
+        self._dirty = False
+        self._steps_executed = None
+
+    __call__ = forward
+
+    # ------------------------------------------------------------------ outputs
+    def _ensure(self):
+        if self._dirty:
+            self.forward()
+
+    @property
+    def steps_executed(self):
+        """T' of the reference's while_loop (cond :271-275) for the last pass."""
+        self._ensure()
+        if self._steps_executed is None:
+            alive = (self.att[:, :, H.ATT_MASK] > 0).any(dim=1).cpu().tolist()
+            tprime = 1
+            for t in range(self.max_steps - 1):
+                if alive[t]:
+                    tprime += 1
+                else:
+                    break
+            self._steps_executed = tprime
+        return self._steps_executed
+
+    def _stack(self, x):
+        return x[:self.steps_executed].transpose(0, 1)
+
+    loss = property(lambda self: (self._ensure(), self.scalars[0])[1])
+    accuracy = property(lambda self: (self._ensure(), self.scalars[1])[1])
+    global_step = property(lambda self: self.store.istate[H.IST_GLOBAL_STEP])
+    reconstruction = property(lambda self: (self._ensure(), self._recon)[1])
+    reconstruction_loss = property(lambda self: (self._ensure(), self._rec_loss)[1])
+    rec_num_digits = property(lambda self: (self._ensure(), self.run_digits)[1])
+    rec_scales = property(lambda self: self._stack(self.att[:, :, H.ATT_S:H.ATT_S + 1]))
+    rec_shifts = property(lambda self: self._stack(self.att[:, :, H.ATT_X:H.ATT_Y + 1]))
+    rec_windows = property(lambda self: self._stack(self.vrec))
+    rec_latents = property(lambda self: self._stack(self.ml[:, :, :self.vae_latent_dimensions]))
+    z_pres_probs = property(lambda self: self._stack(self.att[:, :, H.ATT_ZPROB]))
+    z_pres_kls = property(lambda self: self._stack(self.att[:, :, H.ATT_KL_Z]))
+    scale_kls = property(lambda self: self._stack(self.att[:, :, H.ATT_KL_SCALE]))
+    shift_kls = property(lambda self: self._stack(self.att[:, :, H.ATT_KL_SHIFT]))
+    vae_kls = property(lambda self: self._stack(self.att[:, :, H.ATT_KL_VAE]))
+
+    @property
+    def rec_st_back(self):
+        a = self._stack(self.att[:, :, H.ATT_ST_BACK:H.ATT_ST_BACK + 3])        # [B,T',3] = 1/s, -x/s, -y/s
+        z = torch.zeros_like(a[..., 0])
+        return torch.stack([torch.stack([a[..., 0], z, a[..., 1]], -1),
+                            torch.stack([z, a[..., 0], a[..., 2]], -1)], -2)
+
+    def state_dict(self):
+        return self.store.state_dict()
+
+    def load_state_dict(self, sd, strict=True):
+        self.store.load_state_dict(sd, strict)
+        self._dirty = True

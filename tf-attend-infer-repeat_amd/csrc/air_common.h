@@ -1,0 +1,50 @@
+// Shared device helpers for libair_hip.so (gfx950 only).
+// The translation units are built with -ffp-contract=off: every fp32 op rounds
+// once, in source order, so the sampler / loss kernels reproduce the op order of
+// the reference graph.  FMAs are written explicitly
+// (__builtin_fmaf) where fusion is wanted.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "air_hip.h"
+
+#define AIR_EPS 1e-9f   // the sources' 10e-10 (air_model.py:95,587; concrete.py:20,33)
+
+#define AIR_CHECK_LAUNCH()                              \
+    do {                                                \
+        hipError_t e__ = hipGetLastError();             \
+        if (e__ != hipSuccess) return (int)e__;         \
+    } while (0)
+
+static inline hipStream_t air_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+__device__ __forceinline__ float air_sigmoid(float x) {
+    // tf.nn.sigmoid: 1 / (1 + exp(-x))
+    return 1.0f / (1.0f + expf(-x));
+}
+
+__device__ __forceinline__ float air_softplus(float x) {
+    // TF 1.3 softplus_op.h: threshold = log(eps)+2 = -13.9424
+    const float thr = -13.942384719848633f;
+    if (x > -thr) return x;
+    if (x < thr) return expf(x);
+    return logf(expf(x) + 1.0f);
+}
+
+// wave64 butterfly sum: every lane ends with the total
+__device__ __forceinline__ float air_wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// block-wide sum for blockDim.x == 256 (4 waves); `red` is >= 4 floats of LDS.
+// Deterministic: fixed butterfly + fixed wave order.  All threads get the total.
+__device__ __forceinline__ float air_block_sum_256(float v, float* red) {
+    v = air_wave_sum(v);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[wave] = v;
+    __syncthreads();
+    return ((red[0] + red[1]) + red[2]) + red[3];
+}

@@ -1,0 +1,202 @@
+// Step prologue (annealing schedules + Philox noise) and the optimizer
+// (clip_by_global_norm + TF-1.3 ApplyAdam) over ONE flat parameter buffer.
+// Both are pure HBM streams: float4 accesses, grid sized to fill 256 CUs,
+// deterministic two-level reduction for the global norm.
+#include "air_common.h"
+
+namespace {
+
+constexpr int THREADS = 256;
+constexpr int NORM_BLOCKS = 1024;      // partial sums; reduced again inside the Adam kernel
+
+// ---- Philox4x32-10 ---------------------------------------------------------
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+    const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+    const uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+__device__ __forceinline__ float u01_open_low(uint32_t x) { return ((float)(x >> 8) + 1.0f) * 5.9604644775390625e-8f; }  // (0,1]
+__device__ __forceinline__ float u01_half_open(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-8f; }          // [0,1)
+
+// air_model.py:94-121: exponential_decay(init, step, iters, factor, staircase) -> max(min) -> min(max) -> log(.+eps)
+__device__ float eval_schedule(const air_schedule_t& s, int step) {
+    float p = (float)step / s.iters;
+    if (s.flags & 1) p = floorf(p);
+    float v = s.init * powf(s.factor, p);
+    if (s.flags & 2) v = fmaxf(v, s.vmin);
+    if (s.flags & 4) v = fminf(v, s.vmax);
+    if (s.flags & 8) v = logf(v + AIR_EPS);
+    return v;
+}
+
+__global__ __launch_bounds__(THREADS) void step_begin_kernel(
+    const air_schedule_t* __restrict__ sched, int nsched, float* __restrict__ dyn,
+    const int32_t* __restrict__ istate, float* __restrict__ normals, long n_normal,
+    float* __restrict__ uniforms, long n_uniform, uint32_t seed_lo, uint32_t seed_hi)
+{
+    const int step = istate[AIR_IST_GLOBAL_STEP];
+    if (blockIdx.x == 0 && threadIdx.x < nsched) {
+        const air_schedule_t s = sched[threadIdx.x];
+        dyn[s.slot] = eval_schedule(s, step);
+    }
+    const long quads_n = (n_normal + 3) / 4, quads_u = (n_uniform + 3) / 4;
+    for (long q = (long)blockIdx.x * THREADS + threadIdx.x; q < quads_n + quads_u; q += (long)gridDim.x * THREADS) {
+        uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)step, 0x41495221u};
+        philox4x32_10(c, seed_lo, seed_hi);
+        float v[4];
+        if (q < quads_n) {
+            // Box-Muller on two pairs
+            const float r0 = sqrtf(-2.0f * logf(u01_open_low(c[0]))), a0 = 6.283185307179586f * u01_half_open(c[1]);
+            const float r1 = sqrtf(-2.0f * logf(u01_open_low(c[2]))), a1 = 6.283185307179586f * u01_half_open(c[3]);
+            v[0] = r0 * cosf(a0); v[1] = r0 * sinf(a0); v[2] = r1 * cosf(a1); v[3] = r1 * sinf(a1);
+            const long base = q * 4;
+            for (int k = 0; k < 4; ++k) if (base + k < n_normal) normals[base + k] = v[k];
+        } else {
+            const long base = (q - quads_n) * 4;
+            for (int k = 0; k < 4; ++k) if (base + k < n_uniform) uniforms[base + k] = u01_half_open(c[k]);
+        }
+    }
+}
+
+// sum of squares, NORM_BLOCKS partials (tf.clip_by_global_norm's 2*l2_loss terms)
+__global__ __launch_bounds__(THREADS) void grad_sqnorm_kernel(
+    const float* __restrict__ g, long n, float* __restrict__ partials, int32_t* __restrict__ istate)
+{
+    __shared__ float red[4];
+    float acc = 0.0f;
+    const long n4 = n / 4;
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    for (long i = (long)blockIdx.x * THREADS + threadIdx.x; i < n4; i += (long)gridDim.x * THREADS) {
+        const float4 v = g4[i];
+        acc += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - n4 * 4)) { const float v = g[n4 * 4 + threadIdx.x]; acc += v * v; }
+    acc = air_block_sum_256(acc, red);
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x] = acc;
+        if (blockIdx.x == 0) istate[AIR_IST_GLOBAL_STEP] += 1;   // apply_gradients(global_step=...) :692-694
+    }
+}
+
+// ApplyAdam (TF 1.3 training_ops): lr_t = lr*sqrt(1-b2^t)/(1-b1^t);
+// m += (g-m)(1-b1); v += (g^2-v)(1-b2); var -= lr_t*m/(sqrt(v)+eps)
+__global__ __launch_bounds__(THREADS) void adam_clip_kernel(
+    float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
+    const float* __restrict__ partials, const float* __restrict__ dyn, const int32_t* __restrict__ istate,
+    float prescale, float b1, float b2, float eps, uint16_t* __restrict__ shadow, float* __restrict__ gnorm_out)
+{
+    __shared__ float red[4];
+    // every workgroup re-reduces the partials in the same fixed order: identical scale everywhere
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < NORM_BLOCKS; i += THREADS) s += partials[i];
+    s = air_block_sum_256(s, red);
+    const float gn = sqrtf(s) * prescale;              // norm of the (pre-scaled, e.g. averaged) gradient
+    const float clip = dyn[AIR_DYN_CLIP_NORM];
+    // t * clip_norm * min(1/global_norm, 1/clip_norm); clip <= 0 disables clipping
+    const float scale = prescale * (clip > 0.0f ? clip * fminf(1.0f / gn, 1.0f / clip) : 1.0f);
+    const float t = (float)istate[AIR_IST_GLOBAL_STEP];     // already incremented by grad_sqnorm
+    const float lr_t = dyn[AIR_DYN_LEARNING_RATE] * sqrtf(1.0f - powf(b2, t)) / (1.0f - powf(b1, t));
+    if (gnorm_out && blockIdx.x == 0 && threadIdx.x == 0) *gnorm_out = gn;
+    const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+
+    const long n4 = n / 4;
+    float4* p4 = reinterpret_cast<float4*>(p);
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    float4* m4 = reinterpret_cast<float4*>(m);
+    float4* v4 = reinterpret_cast<float4*>(v);
+    for (long i = (long)blockIdx.x * THREADS + threadIdx.x; i < n4; i += (long)gridDim.x * THREADS) {
+        float4 pp = p4[i], mm = m4[i], vv = v4[i];
+        const float4 gg = g4[i];
+        float* pa = &pp.x; float* ma = &mm.x; float* va = &vv.x; const float* ga = &gg.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gk = ga[k] * scale;
+            ma[k] = ma[k] + (gk - ma[k]) * omb1;
+            va[k] = va[k] + (gk * gk - va[k]) * omb2;
+            pa[k] = pa[k] - (ma[k] * lr_t) / (sqrtf(va[k]) + eps);
+        }
+        p4[i] = pp; m4[i] = mm; v4[i] = vv;
+        if (shadow) {
+            for (int k = 0; k < 4; ++k) {
+                uint32_t u = __float_as_uint(pa[k]);
+                u += 0x7fffu + ((u >> 16) & 1u);
+                shadow[i * 4 + k] = (uint16_t)(u >> 16);
+            }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - n4 * 4)) {
+        const long i = n4 * 4 + threadIdx.x;
+        const float gk = g[i] * scale;
+        const float mk = m[i] + (gk - m[i]) * omb1;
+        const float vk = v[i] + (gk * gk - v[i]) * omb2;
+        m[i] = mk; v[i] = vk;
+        p[i] = p[i] - (mk * lr_t) / (sqrtf(vk) + eps);
+        if (shadow) { uint32_t u = __float_as_uint(p[i]); u += 0x7fffu + ((u >> 16) & 1u); shadow[i] = (uint16_t)(u >> 16); }
+    }
+}
+
+}  // namespace
+
+extern "C" int air_abi_version(void) { return AIR_ABI_VERSION; }
+
+extern "C" const char* air_strerror(int code) {
+    switch (code) {
+        case 0: return "success";
+        case AIR_EINVAL: return "air: invalid argument (null pointer or non-positive dimension)";
+        case AIR_ELIMIT: return "air: size exceeds kernel limit";
+        case AIR_EALIGN: return "air: pointer or leading dimension misaligned";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "air: unknown error";
+    }
+}
+
+extern "C" int air_step_begin(const air_schedule_t* sched, int nsched, float* dyn, const int32_t* istate,
+                              float* normals, int64_t n_normal, float* uniforms, int64_t n_uniform,
+                              uint64_t seed, void* stream) {
+    if (!dyn || !istate || nsched < 0 || nsched > THREADS || (nsched > 0 && !sched)) return AIR_EINVAL;
+    if (n_normal < 0 || n_uniform < 0 || (n_normal > 0 && !normals) || (n_uniform > 0 && !uniforms)) return AIR_EINVAL;
+    const long quads = (n_normal + 3) / 4 + (n_uniform + 3) / 4;
+    long blocks = (quads + THREADS - 1) / THREADS;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(step_begin_kernel, dim3((int)blocks), dim3(THREADS), 0, air_stream(stream),
+                       sched, nsched, dyn, istate, normals, (long)n_normal, uniforms, (long)n_uniform,
+                       (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32));
+    AIR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int air_optim_num_partials(int64_t n) { (void)n; return NORM_BLOCKS; }
+
+extern "C" int air_grad_sqnorm(const float* grads, int64_t n, float* partials, int32_t* istate, void* stream) {
+    if (!grads || !partials || !istate || n <= 0) return AIR_EINVAL;
+    if (((uintptr_t)grads & 15) != 0) return AIR_EALIGN;
+    hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(NORM_BLOCKS), dim3(THREADS), 0, air_stream(stream),
+                       grads, (long)n, partials, istate);
+    AIR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int air_adam_clip_step(float* params, const float* grads, float* m, float* v, int64_t n,
+                                  const float* partials, const float* dyn, const int32_t* istate,
+                                  float grad_prescale, float beta1, float beta2, float epsilon,
+                                  uint16_t* bf16_shadow, float* gnorm_out, void* stream) {
+    if (!params || !grads || !m || !v || !partials || !dyn || !istate || n <= 0) return AIR_EINVAL;
+    if ((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)m | (uintptr_t)v) & 15) != 0) return AIR_EALIGN;
+    long blocks = (n / 4 + THREADS - 1) / THREADS;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(adam_clip_kernel, dim3((int)blocks), dim3(THREADS), 0, air_stream(stream),
+                       params, grads, m, v, (long)n, partials, dyn, istate, grad_prescale, beta1, beta2,
+                       epsilon, bf16_shadow, gnorm_out);
+    AIR_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,571 @@
+// Spatial-transformer kernels of the AIR loop: glimpse read (canvas -> window),
+// canvas write (window -> canvas), their gradients, fused with the per-item
+// head / sampling / KL / stop logic that surrounds them in the reference body
+// (air_model.py:288-333, 351-439, 441-496).
+//
+// Geometry: theta is axis-aligned on this path (air_model.py:324-327, 353-356:
+// the off-diagonals are zeros_like(s)), so source coordinates are separable:
+// X depends only on the output column, Y only on the output row.  Each
+// workgroup (one image) builds two small per-axis tap tables in LDS and then
+// evaluates the reference's literal 4-product / add_n expression per pixel
+// (transformer.py:108-116) -- same op order, no FMA contraction -- so that the
+// out-of-range residues that later pass through log(r + 1e-9) match the
+// reference arithmetic.  The backward of the write uses
+// the exact adjoint in separable form (R_y^T g R_x) as a deterministic gather:
+// no atomics anywhere.
+#include "air_common.h"
+
+namespace {
+
+constexpr int THREADS = 256;
+
+struct Tap { float w0, w1; int i0, i1; };   // w0 = (x1_f - x), w1 = (x - x0_f)
+
+// transformer.py:75-87,108-115 for one output coordinate of one axis
+__device__ __forceinline__ Tap axis_tap(int j, int n_out, int n_in, float a, float b, float* t_out = nullptr) {
+    const float step = 2.0f / (float)(n_out - 1);
+    const float t = (n_out > 1) ? (-1.0f + step * (float)j) : -1.0f;   // tf.linspace(-1, 1, n)
+    const float xs = a * t + b;                                         // theta . (x_t, y_t, 1)
+    const float X = ((xs + 1.0f) * ((float)n_in - 1.001f)) / 2.0f;
+    const float f0 = floorf(X);
+    const float lim = (float)(n_in - 1);
+    const float c0 = fminf(fmaxf(f0, 0.0f), lim);          // clip AFTER floor / +1
+    const float c1 = fminf(fmaxf(f0 + 1.0f, 0.0f), lim);
+    Tap tp;
+    tp.i0 = (int)c0; tp.i1 = (int)c1;
+    tp.w0 = c1 - X;
+    tp.w1 = X - c0;
+    if (t_out) *t_out = t;
+    return tp;
+}
+
+// literal transformer.py:108-116: wa*Ia + wb*Ib + wc*Ic + wd*Id, add_n left to right
+__device__ __forceinline__ float bilinear4(const Tap& tx, const Tap& ty,
+                                           float Ia, float Ib, float Ic, float Id) {
+    const float wa = tx.w0 * ty.w0;
+    const float wb = tx.w0 * ty.w1;
+    const float wc = tx.w1 * ty.w0;
+    const float wd = tx.w1 * ty.w1;
+    return ((wa * Ia + wb * Ib) + wc * Ic) + wd * Id;
+}
+
+// ---------------------------------------------------------------------------
+// generic transformer (any theta): one thread per output pixel
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(THREADS) void transformer_fwd_kernel(
+    const float* __restrict__ U, const float* __restrict__ theta, float* __restrict__ out,
+    int B, int Hi, int Wi, int Ho, int Wo)
+{
+    const long total = (long)B * Ho * Wo;
+    for (long p = (long)blockIdx.x * THREADS + threadIdx.x; p < total; p += (long)gridDim.x * THREADS) {
+        const int b = (int)(p / (Ho * Wo));
+        const int r = (int)(p % (Ho * Wo));
+        const int i = r / Wo, j = r % Wo;
+        const float* th = theta + (size_t)b * 6;
+        const float xt = (Wo > 1) ? (-1.0f + (2.0f / (float)(Wo - 1)) * (float)j) : -1.0f;
+        const float yt = (Ho > 1) ? (-1.0f + (2.0f / (float)(Ho - 1)) * (float)i) : -1.0f;
+        const float xs = (th[0] * xt + th[1] * yt) + th[2] * 1.0f;
+        const float ys = (th[3] * xt + th[4] * yt) + th[5] * 1.0f;
+        const float X = ((xs + 1.0f) * ((float)Wi - 1.001f)) / 2.0f;
+        const float Y = ((ys + 1.0f) * ((float)Hi - 1.001f)) / 2.0f;
+        const float fx = floorf(X), fy = floorf(Y);
+        const float x0 = fminf(fmaxf(fx, 0.f), (float)(Wi - 1)), x1 = fminf(fmaxf(fx + 1.f, 0.f), (float)(Wi - 1));
+        const float y0 = fminf(fmaxf(fy, 0.f), (float)(Hi - 1)), y1 = fminf(fmaxf(fy + 1.f, 0.f), (float)(Hi - 1));
+        const float* img = U + (size_t)b * Hi * Wi;
+        const float Ia = img[(int)y0 * Wi + (int)x0], Ib = img[(int)y1 * Wi + (int)x0];
+        const float Ic = img[(int)y0 * Wi + (int)x1], Id = img[(int)y1 * Wi + (int)x1];
+        Tap tx{x1 - X, X - x0, 0, 0}, ty{y1 - Y, Y - y0, 0, 0};
+        out[p] = bilinear4(tx, ty, Ia, Ib, Ic, Id);
+    }
+}
+
+// head index -> (offset, width) inside the concatenated hidden vector
+struct HeadSeg { int off[5]; int wid[5]; };
+__device__ __forceinline__ HeadSeg head_segments(int Hs, int Hh, int Hz) {
+    HeadSeg h;
+    h.wid[0] = Hs; h.wid[1] = Hs; h.wid[2] = Hh; h.wid[3] = Hh; h.wid[4] = Hz;
+    h.off[0] = 0;
+    for (int i = 1; i < 5; ++i) h.off[i] = h.off[i - 1] + h.wid[i - 1];
+    return h;
+}
+__device__ __constant__ int kOutHead[7] = {0, 1, 2, 2, 3, 3, 4};
+
+// air_model.py:443-447 for one element
+__device__ __forceinline__ float gauss_kl_term(float plv, float lv, float var, float pv, float mean, float pm) {
+    const float d = mean - pm;
+    return (((plv - lv) - 1.0f) + var / pv) + (d * d) / pv;
+}
+
+// ---------------------------------------------------------------------------
+// attend forward: one workgroup per image
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(THREADS) void attend_fwd_kernel(air_attend_fwd_t a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int C = a.C, w = a.w;
+    const HeadSeg hs = head_segments(a.Hs, a.Hh, a.Hz);
+    const int HT = hs.off[4] + hs.wid[4];
+
+    float* sh_out = smem;                       // [8]
+    float* sh_sc = smem + 8;                    // [8]: s, x, y
+    Tap* sh_tx = reinterpret_cast<Tap*>(smem + 16);      // [w]
+    Tap* sh_ty = sh_tx + w;                              // [w]
+    int* sh_box = reinterpret_cast<int*>(sh_ty + w);     // [4]: x_lo, x_hi, y_lo, y_hi
+    float* sh_hid = reinterpret_cast<float*>(sh_box + 4);   // [HT]
+    float* sh_img = sh_hid + ((HT + 3) & ~3);               // [<= C*C] bounding box of the glimpse
+
+    for (int j = tid; j < HT; j += THREADS) sh_hid[j] = a.hid[(size_t)b * HT + j];
+    __syncthreads();
+
+    // 7 output units (air_model.py:294,299,311,316,376): x.W + b
+    for (int o = wave; o < 7; o += 4) {
+        const int h = kOutHead[o];
+        float p = 0.0f;
+        for (int j = lane; j < hs.wid[h]; j += 64) p += sh_hid[hs.off[h] + j] * a.wout[o * a.wout_ld + j];
+        p = air_wave_sum(p);
+        if (lane == 0) sh_out[o] = p + a.bout[o];
+    }
+    __syncthreads();
+
+    if (tid == 0) {
+        const float* dyn = a.dyn;
+        const float T = dyn[AIR_DYN_TEMPERATURE], thr = dyn[AIR_DYN_STOP_THRESHOLD];
+        const float mu_s = sh_out[0], lv_s = sh_out[1];
+        const float mu_x = sh_out[2], mu_y = sh_out[3], lv_x = sh_out[4], lv_y = sh_out[5];
+        const float z_lo = sh_out[6];
+        // scale :300-303, shift :317-320   (_sample_from_mvn :123-128)
+        const float var_s = expf(lv_s);
+        const float s = air_sigmoid(mu_s + a.eps_scale[b] * sqrtf(var_s));
+        const float var_x = expf(lv_x), var_y = expf(lv_y);
+        const float x = tanhf(mu_x + a.eps_shift[2 * b] * sqrtf(var_x));
+        const float y = tanhf(mu_y + a.eps_shift[2 * b + 1] * sqrtf(var_y));
+        // concrete.py:20-27
+        const float u = a.u[b];
+        const float noise = logf(u + AIR_EPS) - logf((1.0f - u) + AIR_EPS);
+        const float ypre = (z_lo + noise) / T;
+        float z = air_sigmoid(ypre);
+        if (!a.train) z = rintf(z);                       // tf.round (half-to-even) :389-390
+        const float zprob = air_sigmoid(z_lo);
+        // concrete.py:30-43 (prior and posterior temperatures are both T :403-407)
+        const float plo = dyn[AIR_DYN_PRIOR_LOG_ODDS];
+        const float yT = ypre * T;
+        const float log_prior = ((logf(T + AIR_EPS) - yT) + plo) - 2.0f * logf((1.0f + expf(-yT + plo)) + AIR_EPS);
+        const float log_post = ((logf(T + AIR_EPS) - yT) + z_lo) - 2.0f * logf((1.0f + expf(-yT + z_lo)) + AIR_EPS);
+        const float kl_z = log_post - log_prior;
+        // stop logic :409-427
+        float S = a.stop_sum[b], L = a.run_loss[b];
+        const bool mask_prev = S < thr;
+        L = L + (mask_prev ? kl_z : 0.0f);
+        S = S + (1.0f - z);
+        const bool mask = S < thr;
+        a.stop_sum[b] = S;
+        a.run_digits[b] += mask ? 1 : 0;
+        // scale / shift KL :441-477
+        const float pv_s = dyn[AIR_DYN_SCALE_PV], pv_h = dyn[AIR_DYN_SHIFT_PV];
+        const float kl_s = 0.5f * gauss_kl_term(logf(pv_s), lv_s, var_s, pv_s, mu_s, dyn[AIR_DYN_SCALE_PM]);
+        L = L + (mask ? kl_s : 0.0f);
+        const float plv_h = logf(pv_h), pm_h = dyn[AIR_DYN_SHIFT_PM];
+        const float kl_h = 0.5f * (gauss_kl_term(plv_h, lv_x, var_x, pv_h, mu_x, pm_h) +
+                                   gauss_kl_term(plv_h, lv_y, var_y, pv_h, mu_y, pm_h));
+        L = L + (mask ? kl_h : 0.0f);
+        a.run_loss[b] = L;
+
+        float* o7 = a.out7 + (size_t)b * AIR_OUT_STRIDE;
+        for (int o = 0; o < 7; ++o) o7[o] = sh_out[o];
+        o7[7] = 0.0f;
+        float* at = a.att + (size_t)b * AIR_ATT_STRIDE;
+        at[AIR_ATT_S] = s; at[AIR_ATT_X] = x; at[AIR_ATT_Y] = y;
+        at[AIR_ATT_ZPRE] = ypre; at[AIR_ATT_Z] = z; at[AIR_ATT_ZPROB] = zprob;
+        at[AIR_ATT_KL_Z] = kl_z; at[AIR_ATT_KL_SCALE] = kl_s; at[AIR_ATT_KL_SHIFT] = kl_h;
+        at[AIR_ATT_KL_VAE] = 0.0f;
+        at[AIR_ATT_MASK_PREV] = mask_prev ? 1.0f : 0.0f;
+        at[AIR_ATT_MASK] = mask ? 1.0f : 0.0f;
+        // theta_recon :353-356
+        at[AIR_ATT_ST_BACK + 0] = 1.0f / s;
+        at[AIR_ATT_ST_BACK + 1] = (-x) / s;
+        at[AIR_ATT_ST_BACK + 2] = (-y) / s;
+        at[AIR_ATT_ST_BACK + 3] = 0.0f;
+        sh_sc[0] = s; sh_sc[1] = x; sh_sc[2] = y;
+    }
+    __syncthreads();
+
+    // ST read :322-333 -- theta = [[s,0,x],[0,s,y]]
+    const float s = sh_sc[0], sx = sh_sc[1], sy = sh_sc[2];
+    if (tid < w) sh_tx[tid] = axis_tap(tid, w, C, s, sx);
+    else if (tid >= 64 && tid < 64 + w) sh_ty[tid - 64] = axis_tap(tid - 64, w, C, s, sy);
+    __syncthreads();
+    if (tid == 0) {
+        // taps are monotone in the output index (s > 0): the bounding box is set by the ends
+        sh_box[0] = min(sh_tx[0].i0, sh_tx[w - 1].i0); sh_box[1] = max(sh_tx[0].i1, sh_tx[w - 1].i1);
+        sh_box[2] = min(sh_ty[0].i0, sh_ty[w - 1].i0); sh_box[3] = max(sh_ty[0].i1, sh_ty[w - 1].i1);
+    }
+    __syncthreads();
+    const int xlo = sh_box[0], bw = sh_box[1] - sh_box[0] + 1;
+    const int ylo = sh_box[2], bh = sh_box[3] - sh_box[2] + 1;
+    const float* img = a.canvas + (size_t)b * C * C;
+    for (int p = tid; p < bw * bh; p += THREADS) {
+        const int r = p / bw, c = p % bw;
+        sh_img[p] = img[(ylo + r) * C + xlo + c];     // rows of the box: coalesced segments
+    }
+    __syncthreads();
+    float* win = a.window + (size_t)b * w * w;
+    for (int p = tid; p < w * w; p += THREADS) {
+        const int i = p / w, j = p % w;
+        const Tap tx = sh_tx[j], ty = sh_ty[i];
+        const int r0 = (ty.i0 - ylo) * bw, r1 = (ty.i1 - ylo) * bw;
+        const int c0 = tx.i0 - xlo, c1 = tx.i1 - xlo;
+        win[p] = bilinear4(tx, ty, sh_img[r0 + c0], sh_img[r1 + c0], sh_img[r0 + c1], sh_img[r1 + c1]);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// attend backward: ST-read gradient wrt (s,x,y) + sampling / KL / head-output
+// gradients.  One workgroup per image.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(THREADS) void attend_bwd_kernel(air_attend_bwd_t a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int C = a.C, w = a.w;
+    const HeadSeg hs = head_segments(a.Hs, a.Hh, a.Hz);
+    const int HT = hs.off[4] + hs.wid[4];
+
+    float* sh_red = smem;                                // [4]
+    float* sh_d = smem + 4;                              // [8] d_out7
+    Tap* sh_tx = reinterpret_cast<Tap*>(smem + 12);
+    Tap* sh_ty = sh_tx + w;
+    float* sh_t = reinterpret_cast<float*>(sh_ty + w);   // [w] linspace values
+    int* sh_box = reinterpret_cast<int*>(sh_t + w);
+    float* sh_img = reinterpret_cast<float*>(sh_box + 4);
+
+    const float* at = a.att + (size_t)b * AIR_ATT_STRIDE;
+    const float s = at[AIR_ATT_S], sx = at[AIR_ATT_X], sy = at[AIR_ATT_Y];
+    if (tid < w) { float t; sh_tx[tid] = axis_tap(tid, w, C, s, sx, &t); sh_t[tid] = t; }
+    else if (tid >= 64 && tid < 64 + w) sh_ty[tid - 64] = axis_tap(tid - 64, w, C, s, sy);
+    __syncthreads();
+    if (tid == 0) {
+        sh_box[0] = min(sh_tx[0].i0, sh_tx[w - 1].i0); sh_box[1] = max(sh_tx[0].i1, sh_tx[w - 1].i1);
+        sh_box[2] = min(sh_ty[0].i0, sh_ty[w - 1].i0); sh_box[3] = max(sh_ty[0].i1, sh_ty[w - 1].i1);
+    }
+    __syncthreads();
+    const int xlo = sh_box[0], bw = sh_box[1] - sh_box[0] + 1;
+    const int ylo = sh_box[2], bh = sh_box[3] - sh_box[2] + 1;
+    const float* img = a.canvas + (size_t)b * C * C;
+    for (int p = tid; p < bw * bh; p += THREADS) sh_img[p] = img[(ylo + p / bw) * C + xlo + p % bw];
+    __syncthreads();
+
+    // d out / dX = (Ic-Ia)(y1-Y) + (Id-Ib)(Y-y0);  d out / dY = (Ib-Ia)(x1-X) + (Id-Ic)(X-x0)
+    const float half_c = ((float)C - 1.001f) / 2.0f;     // dX/dx_s
+    float ds = 0.f, dx = 0.f, dy = 0.f;
+    const float* g = a.d_window + (size_t)b * w * w;
+    for (int p = tid; p < w * w; p += THREADS) {
+        const int i = p / w, j = p % w;
+        const Tap tx = sh_tx[j], ty = sh_ty[i];
+        const int r0 = (ty.i0 - ylo) * bw, r1 = (ty.i1 - ylo) * bw;
+        const int c0 = tx.i0 - xlo, c1 = tx.i1 - xlo;
+        const float Ia = sh_img[r0 + c0], Ib = sh_img[r1 + c0], Ic = sh_img[r0 + c1], Id = sh_img[r1 + c1];
+        const float gv = g[p];
+        const float gX = gv * ((Ic - Ia) * ty.w0 + (Id - Ib) * ty.w1) * half_c;
+        const float gY = gv * ((Ib - Ia) * tx.w0 + (Id - Ic) * tx.w1) * half_c;
+        ds += gX * sh_t[j] + gY * sh_t[i];
+        dx += gX;
+        dy += gY;
+    }
+    ds = air_block_sum_256(ds, sh_red);
+    dx = air_block_sum_256(dx, sh_red);
+    dy = air_block_sum_256(dy, sh_red);
+
+    if (tid == 0) {
+        const float* dyn = a.dyn;
+        const float gsc = dyn[AIR_DYN_GRAD_SCALE];               // d loss / d per-item loss
+        const float T = dyn[AIR_DYN_TEMPERATURE];
+        const float* o7 = a.out7 + (size_t)b * AIR_OUT_STRIDE;
+        const float* dw = a.d_sxy_write + (size_t)b * 4;
+        const float mask = at[AIR_ATT_MASK], mask_prev = at[AIR_ATT_MASK_PREV];
+        const float d_s = ds + dw[0], d_x = dx + dw[1], d_y = dy + dw[2], d_z = dw[3];
+        const float lv_s = o7[1], lv_x = o7[4], lv_y = o7[5];
+        const float sd_s = sqrtf(expf(lv_s)), sd_x = sqrtf(expf(lv_x)), sd_y = sqrtf(expf(lv_y));
+        const float pv_s = dyn[AIR_DYN_SCALE_PV], pm_s = dyn[AIR_DYN_SCALE_PM];
+        const float pv_h = dyn[AIR_DYN_SHIFT_PV], pm_h = dyn[AIR_DYN_SHIFT_PM];
+        const float klg = mask * gsc;
+        // s = sigmoid(mu + eps*sd), (x,y) = tanh(mu + eps*sd), sd = sqrt(exp(lv))
+        const float da_s = d_s * s * (1.0f - s);
+        const float da_x = d_x * (1.0f - sx * sx), da_y = d_y * (1.0f - sy * sy);
+        const float e_s = a.eps_scale[b], e_x = a.eps_shift[2 * b], e_y = a.eps_shift[2 * b + 1];
+        sh_d[0] = da_s + klg * (o7[0] - pm_s) / pv_s;
+        sh_d[1] = da_s * e_s * 0.5f * sd_s + klg * 0.5f * (sd_s * sd_s / pv_s - 1.0f);
+        sh_d[2] = da_x + klg * (o7[2] - pm_h) / pv_h;
+        sh_d[3] = da_y + klg * (o7[3] - pm_h) / pv_h;
+        sh_d[4] = da_x * e_x * 0.5f * sd_x + klg * 0.5f * (sd_x * sd_x / pv_h - 1.0f);
+        sh_d[5] = da_y * e_y * 0.5f * sd_y + klg * 0.5f * (sd_y * sd_y / pv_h - 1.0f);
+        // z = sigmoid(ypre), ypre = (lo + noise)/T; kl_z = log q(ypre; lo) - log p(ypre; plo)
+        const float z = at[AIR_ATT_Z], ypre = at[AIR_ATT_ZPRE], z_lo = o7[6];
+        const float plo = dyn[AIR_DYN_PRIOR_LOG_ODDS];
+        const float eq = expf(-ypre * T + z_lo), ep = expf(-ypre * T + plo);
+        const float rq = eq / ((1.0f + eq) + AIR_EPS), rp = ep / ((1.0f + ep) + AIR_EPS);
+        const float dkl = mask_prev * gsc;
+        // d logq/dy = -T + 2T rq ; d logp/dy = -T + 2T rp ; d logq/dlo = 1 - 2 rq
+        const float d_ypre = d_z * z * (1.0f - z) + dkl * (2.0f * T * (rq - rp));
+        sh_d[6] = d_ypre / T + dkl * (1.0f - 2.0f * rq);
+        sh_d[7] = 0.0f;
+        float* d7 = a.d_out7 + (size_t)b * AIR_OUT_STRIDE;
+        for (int o = 0; o < 8; ++o) d7[o] = sh_d[o];
+    }
+    __syncthreads();
+    // back through the 7 output units and the hidden ReLU
+    for (int j = tid; j < HT; j += THREADS) {
+        int h = 0;
+        while (h < 4 && j >= hs.off[h + 1]) ++h;
+        const int jj = j - hs.off[h];
+        float v = 0.0f;
+        for (int o = 0; o < 7; ++o)
+            if (kOutHead[o] == h) v += sh_d[o] * a.wout[o * a.wout_ld + jj];
+        a.d_hid[(size_t)b * HT + j] = (a.hid[(size_t)b * HT + j] > 0.0f) ? v : 0.0f;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// write forward: window -> canvas, scaled by z_pres, masked, accumulated
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(THREADS) void write_fwd_kernel(air_write_fwd_t a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int C = a.C, w = a.w, Z = a.Z;
+    float* sh_red = smem;                                  // [4]
+    Tap* sh_tx = reinterpret_cast<Tap*>(smem + 4);         // [C]
+    Tap* sh_ty = sh_tx + C;                                // [C]
+    float* sh_win = reinterpret_cast<float*>(sh_ty + C);   // [w*w]
+
+    float* at = a.att + (size_t)b * AIR_ATT_STRIDE;
+    const float s = at[AIR_ATT_S], x = at[AIR_ATT_X], y = at[AIR_ATT_Y];
+    const float z = at[AIR_ATT_Z];
+    const bool mask = at[AIR_ATT_MASK] != 0.0f;
+    const float* dyn = a.dyn;
+
+    // VAE KL :479-493 (needed whether or not the item is still active: it is a public output)
+    float klt = 0.0f;
+    if (tid < Z) {
+        const float* ml = a.ml + (size_t)b * 2 * Z;
+        const float pv = dyn[AIR_DYN_VAE_PV];
+        const float lv = ml[Z + tid];
+        klt = gauss_kl_term(logf(pv), lv, expf(lv), pv, ml[tid], dyn[AIR_DYN_VAE_PM]);
+    }
+    for (int j = tid + THREADS; j < Z; j += THREADS) {   // Z > 256 (not on the default path)
+        const float* ml = a.ml + (size_t)b * 2 * Z;
+        const float pv = dyn[AIR_DYN_VAE_PV];
+        const float lv = ml[Z + j];
+        klt += gauss_kl_term(logf(pv), lv, expf(lv), pv, ml[j], dyn[AIR_DYN_VAE_PM]);
+    }
+    const float kl = 0.5f * air_block_sum_256(klt, sh_red);
+    if (tid == 0) {
+        at[AIR_ATT_KL_VAE] = kl;
+        a.run_loss[b] = a.run_loss[b] + (mask ? kl : 0.0f);
+    }
+    if (!mask) return;                                     // running_recon += 0
+
+    // theta_recon :353-356
+    const float ia = 1.0f / s, bx = (-x) / s, by = (-y) / s;
+    for (int j = tid; j < C; j += THREADS) { sh_tx[j] = axis_tap(j, C, w, ia, bx); sh_ty[j] = axis_tap(j, C, w, ia, by); }
+    const float* v = a.vrec + (size_t)b * w * w;
+    for (int p = tid; p < w * w; p += THREADS) sh_win[p] = v[p];
+    __syncthreads();
+    float* R = a.run_recon + (size_t)b * C * C;
+    for (int p = tid; p < C * C; p += THREADS) {
+        const int i = p / C, j = p % C;
+        const Tap tx = sh_tx[j], ty = sh_ty[i];
+        const float wr = bilinear4(tx, ty, sh_win[ty.i0 * w + tx.i0], sh_win[ty.i1 * w + tx.i0],
+                                   sh_win[ty.i0 * w + tx.i1], sh_win[ty.i1 * w + tx.i1]);
+        R[p] = R[p] + z * wr;                              // :433-439
+    }
+}
+
+// ---------------------------------------------------------------------------
+// write backward: gradient wrt the window (exact separable adjoint, gather
+// form), wrt theta_recon -> (s,x,y), and wrt z_pres.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(THREADS) void write_bwd_kernel(air_write_bwd_t a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int C = a.C, w = a.w;
+    float* sh_red = smem;                                  // [4]
+    Tap* sh_tx = reinterpret_cast<Tap*>(smem + 4);         // [C]
+    Tap* sh_ty = sh_tx + C;                                // [C]
+    float* sh_t = reinterpret_cast<float*>(sh_ty + C);     // [C] linspace
+    int* sh_rng = reinterpret_cast<int*>(sh_t + C);        // [4*w]: Jlo,Jhi per q ; Ilo,Ihi per p
+    float* sh_win = reinterpret_cast<float*>(sh_rng + 4 * w);   // [w*w]
+    float* sh_T = sh_win + w * w;                          // [C*w]
+
+    const float* at = a.att + (size_t)b * AIR_ATT_STRIDE;
+    float* dgen = a.d_gen_pre + (size_t)b * w * w;
+    float* dsx = a.d_sxy_write + (size_t)b * 4;
+    if (at[AIR_ATT_MASK] == 0.0f) {                        // where(active, ., 0): no gradient
+        for (int p = tid; p < w * w; p += THREADS) dgen[p] = 0.0f;
+        if (tid < 4) dsx[tid] = 0.0f;
+        return;
+    }
+    const float s = at[AIR_ATT_S], x = at[AIR_ATT_X], y = at[AIR_ATT_Y], z = at[AIR_ATT_Z];
+    const float ia = 1.0f / s, bx = (-x) / s, by = (-y) / s;
+    for (int j = tid; j < C; j += THREADS) {
+        float t;
+        sh_tx[j] = axis_tap(j, C, w, ia, bx, &t);
+        sh_ty[j] = axis_tap(j, C, w, ia, by);
+        sh_t[j] = t;
+    }
+    const float* v = a.vrec + (size_t)b * w * w;
+    for (int p = tid; p < w * w; p += THREADS) sh_win[p] = v[p];
+    __syncthreads();
+    // source-index q is touched by a contiguous range of output coordinates (taps are monotone)
+    if (tid < 2 * w) {
+        const Tap* tp = (tid < w) ? sh_tx : sh_ty;
+        const int q = (tid < w) ? tid : tid - w;
+        int lo = C, hi = -1;
+        for (int j = 0; j < C; ++j) {
+            const Tap t = tp[j];
+            if (t.i0 != t.i1 && (t.i0 == q || t.i1 == q)) { lo = min(lo, j); hi = max(hi, j); }
+        }
+        sh_rng[(tid < w ? 0 : 2 * w) + 2 * q] = lo;
+        sh_rng[(tid < w ? 0 : 2 * w) + 2 * q + 1] = hi;
+    }
+    __syncthreads();
+
+    const float* g = a.d_recon + (size_t)b * C * C;
+    // stage 1: T[I][q] = sum_J g[I][J] * Rx[J][q]
+    for (int it = tid; it < C * w; it += THREADS) {
+        const int I = it / w, q = it % w;
+        float acc = 0.0f;
+        for (int J = sh_rng[2 * q]; J <= sh_rng[2 * q + 1]; ++J) {
+            const Tap t = sh_tx[J];
+            const float wq = (t.i0 != t.i1) ? ((t.i0 == q ? t.w0 : 0.0f) + (t.i1 == q ? t.w1 : 0.0f)) : 0.0f;
+            acc += g[I * C + J] * wq;
+        }
+        sh_T[it] = acc;
+    }
+    // theta / z gradients, per canvas pixel (independent of stage 1)
+    const float half_w = ((float)w - 1.001f) / 2.0f;
+    float da = 0.f, dbx = 0.f, dby = 0.f, dz = 0.f;
+    for (int p = tid; p < C * C; p += THREADS) {
+        const int i = p / C, j = p % C;
+        const Tap tx = sh_tx[j], ty = sh_ty[i];
+        const float Ia = sh_win[ty.i0 * w + tx.i0], Ib = sh_win[ty.i1 * w + tx.i0];
+        const float Ic = sh_win[ty.i0 * w + tx.i1], Id = sh_win[ty.i1 * w + tx.i1];
+        const float gv = g[p];
+        dz += gv * bilinear4(tx, ty, Ia, Ib, Ic, Id);
+        const float gz = gv * z;
+        const float gX = gz * ((Ic - Ia) * ty.w0 + (Id - Ib) * ty.w1) * half_w;
+        const float gY = gz * ((Ib - Ia) * tx.w0 + (Id - Ic) * tx.w1) * half_w;
+        da += gX * sh_t[j] + gY * sh_t[i];
+        dbx += gX;
+        dby += gY;
+    }
+    da = air_block_sum_256(da, sh_red);     // contains the __syncthreads() that publishes sh_T
+    dbx = air_block_sum_256(dbx, sh_red);
+    dby = air_block_sum_256(dby, sh_red);
+    dz = air_block_sum_256(dz, sh_red);
+    if (tid == 0) {
+        // a = 1/s, bx = -x/s, by = -y/s
+        const float is2 = 1.0f / (s * s);
+        dsx[0] = (-da + dbx * x + dby * y) * is2;
+        dsx[1] = -dbx / s;
+        dsx[2] = -dby / s;
+        dsx[3] = dz;
+    }
+    // stage 2: dU[p][q] = z * sum_I Ry[I][p] * T[I][q]; fold the sigmoid of vae.py:39-41
+    for (int it = tid; it < w * w; it += THREADS) {
+        const int p = it / w, q = it % w;
+        float acc = 0.0f;
+        for (int I = sh_rng[2 * w + 2 * p]; I <= sh_rng[2 * w + 2 * p + 1]; ++I) {
+            const Tap t = sh_ty[I];
+            const float wp = (t.i0 != t.i1) ? ((t.i0 == p ? t.w0 : 0.0f) + (t.i1 == p ? t.w1 : 0.0f)) : 0.0f;
+            acc += sh_T[I * w + q] * wp;
+        }
+        const float r = sh_win[it];
+        dgen[it] = (z * acc) * (r * (1.0f - r));
+    }
+}
+
+size_t attend_smem(int C, int w, int HT) {
+    return (16 + 8 * w + 4 + ((HT + 3) & ~3) + (size_t)C * C) * sizeof(float);
+}
+size_t attend_bwd_smem(int C, int w) {
+    return (12 + 8 * w + w + 4 + (size_t)C * C) * sizeof(float);
+}
+size_t write_smem(int C, int w) { return (4 + 8 * C + (size_t)w * w) * sizeof(float); }
+size_t write_bwd_smem(int C, int w) { return (4 + 8 * C + C + 4 * w + (size_t)w * w + (size_t)C * w) * sizeof(float); }
+
+template <typename K>
+int ensure_lds(K kernel, size_t bytes) {
+    if (bytes > 160 * 1024) return AIR_ELIMIT;
+    if (bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int air_transformer_fwd(const float* U, const float* theta, float* out,
+                                   int B, int Hi, int Wi, int Ho, int Wo, void* stream) {
+    if (!U || !theta || !out || B <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return AIR_EINVAL;
+    const long total = (long)B * Ho * Wo;
+    const int blocks = (int)((total + THREADS - 1) / THREADS < 2048 ? (total + THREADS - 1) / THREADS : 2048);
+    hipLaunchKernelGGL(transformer_fwd_kernel, dim3(blocks), dim3(THREADS), 0, air_stream(stream),
+                       U, theta, out, B, Hi, Wi, Ho, Wo);
+    AIR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int air_attend_fwd(const air_attend_fwd_t* a, void* stream) {
+    if (!a || !a->hid || !a->wout || !a->bout || !a->canvas || !a->eps_scale || !a->eps_shift || !a->u ||
+        !a->dyn || !a->out7 || !a->att || !a->window || !a->stop_sum || !a->run_loss || !a->run_digits)
+        return AIR_EINVAL;
+    if (a->B <= 0 || a->C < 2 || a->w < 2 || a->Hs <= 0 || a->Hh <= 0 || a->Hz <= 0) return AIR_EINVAL;
+    if (a->w > 64) return AIR_ELIMIT;
+    const size_t lds = attend_smem(a->C, a->w, 2 * a->Hs + 2 * a->Hh + a->Hz);
+    int rc = ensure_lds(attend_fwd_kernel, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(attend_fwd_kernel, dim3(a->B), dim3(THREADS), lds, air_stream(stream), *a);
+    AIR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int air_attend_bwd(const air_attend_bwd_t* a, void* stream) {
+    if (!a || !a->hid || !a->wout || !a->canvas || !a->eps_scale || !a->eps_shift || !a->dyn || !a->out7 ||
+        !a->att || !a->d_window || !a->d_sxy_write || !a->d_hid || !a->d_out7)
+        return AIR_EINVAL;
+    if (a->B <= 0 || a->C < 2 || a->w < 2 || a->Hs <= 0 || a->Hh <= 0 || a->Hz <= 0) return AIR_EINVAL;
+    if (a->w > 64) return AIR_ELIMIT;
+    const size_t lds = attend_bwd_smem(a->C, a->w);
+    int rc = ensure_lds(attend_bwd_kernel, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(attend_bwd_kernel, dim3(a->B), dim3(THREADS), lds, air_stream(stream), *a);
+    AIR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int air_write_fwd(const air_write_fwd_t* a, void* stream) {
+    if (!a || !a->vrec || !a->ml || !a->dyn || !a->att || !a->run_recon || !a->run_loss) return AIR_EINVAL;
+    if (a->B <= 0 || a->C < 2 || a->w < 2 || a->Z <= 0) return AIR_EINVAL;
+    const size_t lds = write_smem(a->C, a->w);
+    int rc = ensure_lds(write_fwd_kernel, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(write_fwd_kernel, dim3(a->B), dim3(THREADS), lds, air_stream(stream), *a);
+    AIR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int air_write_bwd(const air_write_bwd_t* a, void* stream) {
+    if (!a || !a->d_recon || !a->vrec || !a->att || !a->d_gen_pre || !a->d_sxy_write) return AIR_EINVAL;
+    if (a->B <= 0 || a->C < 2 || a->w < 2) return AIR_EINVAL;
+    if (2 * a->w > THREADS) return AIR_ELIMIT;
+    const size_t lds = write_bwd_smem(a->C, a->w);
+    int rc = ensure_lds(write_bwd_kernel, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(write_bwd_kernel, dim3(a->B), dim3(THREADS), lds, air_stream(stream), *a);
+    AIR_CHECK_LAUNCH();
+    return 0;
+}
