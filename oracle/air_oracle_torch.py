@@ -20,8 +20,34 @@ import torch
 EPS = 10e-10
 
 
+class _Bf16MatMul(torch.autograd.Function):
+    """Emulates the device's bf16-operand / fp32-accumulate GEMMs: forward AND both
+    gradient GEMMs round their two operands to bf16 (air_gemm precision = 1)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return _r(a) @ _r(b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        return _r(g) @ _r(b).t(), _r(a).t() @ _r(g)
+
+
+def _r(x):
+    return x.to(torch.bfloat16).to(x.dtype)
+
+
+MATMUL_MODE = "exact"      # "bf16": emulate the device's bf16 GEMM path (tests only)
+
+
+def _mm(a, b):
+    return _Bf16MatMul.apply(a, b) if MATMUL_MODE == "bf16" else a @ b
+
+
 def _fc(x, W, b, act=None):
-    y = x @ W + b
+    y = _mm(x, W) + b
     if act == "relu":
         return torch.relu(y)
     if act == "softplus":
@@ -111,7 +137,7 @@ def air_forward(params, images, targets, noise, hp, train=True, z_pres_prior_log
         return _fc(hid, params[name + "/output/weights"], params[name + "/output/biases"])
 
     for t in range(N):
-        g = torch.cat([images, h], dim=1) @ params["rnn/kernel"] + params["rnn/bias"]
+        g = _mm(torch.cat([images, h], dim=1), params["rnn/kernel"]) + params["rnn/bias"]
         gi, gj, gf, go = torch.split(g, R_units, dim=1)
         c = c * torch.sigmoid(gf + 1.0) + torch.sigmoid(gi) * torch.tanh(gj)
         h = torch.tanh(c) * torch.sigmoid(go)

@@ -452,7 +452,10 @@ __global__ __launch_bounds__(THREADS) void write_bwd_kernel(air_write_bwd_t a)
         const float Ia = sh_win[ty.i0 * w + tx.i0], Ib = sh_win[ty.i1 * w + tx.i0];
         const float Ic = sh_win[ty.i0 * w + tx.i1], Id = sh_win[ty.i1 * w + tx.i1];
         const float gv = g[p];
-        dz += gv * bilinear4(tx, ty, Ia, Ib, Ic, Id);
+        // a degenerate axis (both taps clipped to one index) is exactly 0 in real arithmetic;
+        // the fp32 residue the forward keeps there (~1e-7) would be multiplied by g ~ 1e9/B
+        // (d log(r + 1e-9) at r ~ 0) and drown d z_pres in rounding noise.
+        if (tx.i0 != tx.i1 && ty.i0 != ty.i1) dz += gv * bilinear4(tx, ty, Ia, Ib, Ic, Id);
         const float gz = gv * z;
         const float gX = gz * ((Ic - Ia) * ty.w0 + (Id - Ib) * ty.w1) * half_w;
         const float gY = gz * ((Ib - Ia) * tx.w0 + (Id - Ic) * tx.w1) * half_w;

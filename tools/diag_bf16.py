@@ -1,0 +1,30 @@
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tf-attend-infer-repeat_amd"))
+import numpy as np, torch
+from air import air_model as am
+from oracle import air_oracle as ao
+from oracle.synth import blob_canvases
+HP = dict(ao.TRAINING_HP)
+B = 64
+images, targets = blob_canvases(B, 50, 2, seed=3)
+images = np.zeros_like(images)
+params = ao.init_params(HP, 0); noise = ao.make_noise(HP, B, 1)
+outs = {}
+for prec in ("fp32", "bf16"):
+    am.reset_default_graph()
+    m = am.AIRModel(torch.tensor(images, device="cuda"), torch.tensor(targets, device="cuda"), cnn=False, train=True, gemm_precision=prec, **HP)
+    m.load_state_dict(params); m.set_noise(noise); m.set_dynamic(z_pres_prior_log_odds=-2.0)
+    s = m._stream(); m._run_forward(s)
+    for op in m._bwd: op(s)
+    torch.cuda.synchronize()
+    outs[prec] = {k: getattr(m, k).clone() for k in ("vrec", "att", "d_recon", "d_genpre", "d_ml", "d_zs", "run_recon", "ml", "zs", "window")}
+    outs[prec]["d_gen0"] = m.d_gen[0].clone(); outs[prec]["d_gen1"] = m.d_gen[1].clone()
+    outs[prec]["g_out_b"] = m.store.G["out_b"].clone(); outs[prec]["g_out_w"] = m.store.G["out_w"].clone()
+    outs[prec]["gen1"] = m.gen_act[1].clone()
+for k in outs["fp32"]:
+    a, b = outs["fp32"][k].double(), outs["bf16"][k].double()
+    print(f"{k:10s} |fp32| {float(a.norm()):.4e} |bf16| {float(b.norm()):.4e} rel {float((a-b).norm()/max(a.norm(),1e-30)):.3e}")
+a, b = outs["fp32"]["d_genpre"], outs["bf16"]["d_genpre"]
+for t in range(3):
+    print("t", t, float(a[t].norm()), float(b[t].norm()), float((a[t]-b[t]).norm()))
