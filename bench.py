@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- AIR train-step throughput on MI355X (the BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W [--precision bf16|fp32] [--no-graph]
+  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+
+A "step" = one full AIR train step on one batch of synthetic 50x50 multi-object
+canvases resident in HBM: Philox noise + annealing, hoisted x.Wx, 3 x (LSTM,
+heads, glimpse read, VAE, canvas write), ELBO, full backward, weight grads,
+[all-reduce], global-norm clip, TF-style Adam.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tf-attend-infer-repeat_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+# training.py:100-122 (the benchmark configuration)
+HP = dict(max_steps=3, max_digits=2, rnn_units=256, canvas_size=50, windows_size=28,
+          vae_latent_dimensions=50, vae_recognition_units=(512, 256), vae_generative_units=(256, 512),
+          scale_prior_mean=-1.0, scale_prior_variance=0.05, shift_prior_mean=0.0, shift_prior_variance=1.0,
+          vae_prior_mean=0.0, vae_prior_variance=1.0, vae_likelihood_std=0.3,
+          scale_hidden_units=64, shift_hidden_units=64, z_pres_hidden_units=64,
+          z_pres_prior_log_odds=-0.01, z_pres_temperature=1.0, stopping_threshold=0.99,
+          learning_rate=1e-4, gradient_clipping_norm=1.0)
+ANNEAL = {"z_pres_prior_log_odds": {"init": 10000.0, "min": 0.000000001, "factor": 0.1, "iters": 3000,
+                                    "staircase": False, "log": True}}
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+MFMA_PEAK_TF = {"bf16": 2500.0, "fp32": 157.3}
+
+
+def synthetic_canvases(batch, canvas, max_digits, seed):
+    """0..max_digits ring-shaped ink blobs (14..20 px) without overlap -- a stand-in for
+    multi-MNIST canvases of the same sparsity."""
+    rng = np.random.RandomState(seed)
+    imgs = np.zeros((batch, canvas, canvas), np.float32)
+    counts = rng.randint(0, max_digits + 1, size=batch).astype(np.int32)
+    for b in range(batch):
+        placed, tries = 0, 0
+        while placed < counts[b] and tries < 200:
+            tries += 1
+            h, w = rng.randint(14, 21, size=2)
+            y, x = rng.randint(0, canvas - h + 1), rng.randint(0, canvas - w + 1)
+            if imgs[b, y:y + h, x:x + w].max() > 0:
+                continue
+            yy, xx = np.mgrid[0:h, 0:w]
+            r = np.hypot((yy - h / 2 + 0.5) / (h / 2), (xx - w / 2 + 0.5) / (w / 2))
+            imgs[b, y:y + h, x:x + w] = ((np.abs(r - 0.6) < 0.22) * rng.uniform(0.5, 1.0, size=(h, w))).astype(np.float32)
+            placed += 1
+        counts[b] = placed
+    return imgs.reshape(batch, canvas * canvas), counts
+
+
+def per_kernel_times(model, iters):
+    """HIP-event pair around every kernel launch of the train step, on the stream the
+    kernels are launched on (eager pass, same buffers as the timed region)."""
+    ops = [("step_begin", model._begin)] + [(o.name, o) for o in model._fwd + model._bwd + model._optimizer_ops()]
+    acc = [0.0] * len(ops)
+    s = model._stream()
+    for _ in range(iters):
+        evs = []
+        for i, (name, op) in enumerate(ops):
+            if i == 1:
+                model.state.zero_()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            op(s)
+            e1.record()
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        for i, (e0, e1) in enumerate(evs):
+            acc[i] += e0.elapsed_time(e1) * 1e3           # us
+    out = {}
+    for (name, op), t in zip(ops, acc):
+        d = out.setdefault(name, dict(us=0.0, launches=0, nbytes=getattr(op, "nbytes", 0), flops=getattr(op, "flops", 0)))
+        d["us"] += t / iters
+        d["launches"] += 1
+    return out
+
+
+def cpu_baseline(batch, seconds=15.0):
+    """The oracle's un-fused torch-CPU port of the reference op sequence, timed on this box's
+    host cores on a bounded sample of the same workload (same config, synthetic canvases)."""
+    from oracle import air_oracle as ao
+    from oracle import air_oracle_torch as at
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    hp = dict(ao.TRAINING_HP)
+    images, targets = synthetic_canvases(batch, hp["canvas_size"], hp["max_digits"], 0)
+    tr = at.CpuTrainer(ao.init_params(hp, 0), hp)
+    im, tg = torch.tensor(images), torch.tensor(targets)
+    for _ in range(2):
+        tr.step(im, tg, 9.21)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds and n < 200:
+        tr.step(im, tg, 9.21)
+        n += 1
+    dt = time.perf_counter() - t0
+    return dict(value=round(batch * n / dt, 1), unit="images/sec", cores=threads, kind="port",
+                sample="%d train steps of batch %d (%.1f s) of oracle/air_oracle_torch.CpuTrainer, %d torch threads"
+                       % (n, batch, dt, threads))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--precision", default=os.environ.get("AIR_GEMM_PRECISION", "bf16"), choices=["bf16", "fp32"])
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE: 64)")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    from air import air_model as am
+    B = args.batch
+    images, targets = synthetic_canvases(B, HP["canvas_size"], HP["max_digits"], seed=1000 + rank)
+    model = am.AIRModel(torch.tensor(images, device=dev), torch.tensor(targets, device=dev), cnn=False,
+                        train=True, scope="air", annealing_schedules=ANNEAL, seed=rank,
+                        gemm_precision=args.precision, **HP)
+    if not args.no_graph:
+        model.capture_graph()
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        model.training()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model.training()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    loss = float(model.loss)
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = world * B * args.steps / dt
+        line = {
+            "metric": "images/sec AIR train step, 50x50 multi-MNIST b=64 N=3",
+            "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.precision + ("-gemm/fp32-accumulate" if args.precision == "bf16" else ""),
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: AIR train step, 50x50 canvas, 0-2 objects, batch 64/GPU, 3 steps, "
+                                   "256 LSTM, z=50 (training.py:100-122)", "global_batch": world * B,
+                       "hipgraph": not args.no_graph, "parallelism": "dp%d" % world},
+            "per_gpu_images_per_sec": round(value / world, 1), "final_loss": round(loss, 3),
+        }
+        if not args.no_roofline and world == 1:
+            model.release_graph()
+            kt = per_kernel_times(model, 20)
+            total_us = sum(d["us"] for d in kt.values())
+            # dominant kernel = the launch class with the largest share of the step
+            name, d = max(kt.items(), key=lambda kv: kv[1]["us"])
+            avg_us = d["us"] / d["launches"]
+            gbs = d["nbytes"] / avg_us * 1e-3 if avg_us > 0 else 0.0
+            line["roofline"] = {"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                                "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                                "avg_us": round(avg_us, 2), "algorithmic_bytes": d["nbytes"]}
+            step_bytes = 40 * model.store.num_trainable + 4 * B * model.store.dims["D"]
+            line["step_roofline"] = {"algorithmic_bytes": step_bytes,
+                                     "achieved_GBs": round(step_bytes / (ms * 1e-3) * 1e-9, 1),
+                                     "frac_of_hbm_peak": round(step_bytes / (ms * 1e-3) * 1e-9 / HBM_PEAK_GBS, 4),
+                                     "sum_kernel_us": round(total_us, 1), "launches": sum(x["launches"] for x in kt.values()),
+                                     "mfma_flops": sum(x["flops"] for x in kt.values()),
+                                     "mfma_frac_of_peak": round(sum(x["flops"] for x in kt.values()) / (ms * 1e-3) * 1e-12
+                                                                / MFMA_PEAK_TF[args.precision], 5)}
+            top = sorted(kt.items(), key=lambda kv: -kv[1]["us"])[:8]
+            line["kernels"] = {k: {"us_per_step": round(v["us"], 2), "launches": v["launches"]} for k, v in top}
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(B)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

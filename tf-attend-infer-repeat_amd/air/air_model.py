@@ -178,6 +178,17 @@ _ANNEALABLE = {
 }
 
 
+class _Op:
+    """One enqueued C-ABI call: callable(stream) + algorithmic bytes/flops for rooflines."""
+    __slots__ = ("name", "fn", "nbytes", "flops")
+
+    def __init__(self, name, fn, nbytes=0, flops=0):
+        self.name, self.fn, self.nbytes, self.flops = name, fn, nbytes, flops
+
+    def __call__(self, stream):
+        self.fn(stream)
+
+
 class AIRModel:
 
     def __init__(self, input_images, target_num_digits,
@@ -366,15 +377,20 @@ class AIRModel:
 
     # ------------------------------------------------------------- launch lists
     def _gemm(self, A, Bm, Cm, M, N, K, lda, ldb, ldc, ta=0, tb=0, bias=None, addend=None, ldadd=0,
-              aux=None, ldaux=0, aux_scale=0.0, act=H.ACT_NONE, actgrad=H.GRAD_NONE, accumulate=0):
+              aux=None, ldaux=0, aux_scale=0.0, act=H.ACT_NONE, actgrad=H.GRAD_NONE, accumulate=0, tag="gemm"):
         g = H.Gemm(_ptr(A), _ptr(Bm), _ptr(Cm), M, N, K, lda, ldb, ldc, ta, tb, _ptr(bias), _ptr(addend), ldadd,
                    _ptr(aux), ldaux, aux_scale, act, actgrad, accumulate, self._prec)
         fn = self.lib.air_gemm
-        return lambda s, g=g, fn=fn: H.check(fn(C.byref(g), s), "air_gemm")
+        extra = (addend is not None) + (aux is not None) + (1 if accumulate else 0)
+        return _Op("%s[%dx%dx%d%s]" % (tag, M, N, K, "t" if ta else ("n" + ("t" if tb else "n"))),
+                   lambda s, g=g, fn=fn: H.check(fn(C.byref(g), s), "air_gemm"),
+                   nbytes=4 * (M * K + K * N + M * N * (1 + extra)) + (4 * N if bias is not None else 0),
+                   flops=2 * M * N * K)
 
-    def _call(self, name, *args):
+    def _call(self, name, *args, nbytes=0, flops=0, tag=None):
         fn = getattr(self.lib, name)
-        return lambda s, fn=fn, args=args, name=name: H.check(fn(*args, s), name)
+        return _Op(tag or name, lambda s, fn=fn, args=args, name=name: H.check(fn(*args, s), name),
+                   nbytes=nbytes, flops=flops)
 
     def _build_programs(self):
         st, P, G = self.store, self.store.P, self.store.G
@@ -404,7 +420,7 @@ class AIRModel:
                             _ptr(self.stop_sum), _ptr(self.run_loss), _ptr(self.run_digits),
                             B, Cc, w, Hs, Hh, Hz, Hmax, 1 if self.train else 0)
             keep.append(a)
-            fwd.append(self._call("air_attend_fwd", C.byref(a)))
+            fwd.append(self._call("air_attend_fwd", C.byref(a), nbytes=B * ((D + d + HT) * 4 + 12), tag="attend_fwd"))
             x, k = self.window[t], d
             for i, u in enumerate(rec_u):
                 fwd.append(self._gemm(x, P["rec%d_w" % i], self.rec_act[i][t], B, u, k, k, u, u,
@@ -423,10 +439,11 @@ class AIRModel:
             wf = H.WriteFwd(_ptr(self.vrec[t]), _ptr(self.ml[t]), _ptr(self.dyn), _ptr(self.att[t]),
                             _ptr(self.run_recon), _ptr(self.run_loss), B, Cc, w, Z)
             keep.append(wf)
-            fwd.append(self._call("air_write_fwd", C.byref(wf)))
+            fwd.append(self._call("air_write_fwd", C.byref(wf), nbytes=B * ((d + D) * 4 + 16 + 2 * D * 4), tag="write_fwd"))
         fwd.append(self._call("air_bce_fwd_bwd", _ptr(imgs), _ptr(self.run_recon), _ptr(self.dyn),
                               _ptr(self._recon), _ptr(self._rec_loss),
-                              _ptr(self.d_recon if self.train else None), B, D))
+                              _ptr(self.d_recon if self.train else None), B, D,
+                              nbytes=B * D * 4 * (4 if self.train else 3), tag="bce"))
         fwd.append(self._call("air_finalize", _ptr(self.run_loss), _ptr(self._rec_loss),
                               _ptr(self.target_num_digits), _ptr(self.run_digits), _ptr(self._loss_item),
                               _ptr(self.scalars), B))
@@ -447,7 +464,7 @@ class AIRModel:
             wb = H.WriteBwd(_ptr(self.d_recon), _ptr(self.vrec[t]), _ptr(self.att[t]), _ptr(self.d_genpre[t]),
                             _ptr(self.d_sxyw), B, Cc, w)
             keep.append(wb)
-            bwd.append(self._call("air_write_bwd", C.byref(wb)))
+            bwd.append(self._call("air_write_bwd", C.byref(wb), nbytes=B * ((D + 2 * d) * 4 + 32), tag="write_bwd"))
             # decoder data-grads: dX = dY . W^T, times softplus'(saved activation)
             dy, n_out = self.d_genpre[t], d
             wname = "out_w"
@@ -471,7 +488,7 @@ class AIRModel:
                              _ptr(self.d_window), _ptr(self.d_sxyw), _ptr(self.d_hid[t]), _ptr(self.d_out7[t]),
                              B, Cc, w, Hs, Hh, Hz, Hmax)
             keep.append(ab)
-            bwd.append(self._call("air_attend_bwd", C.byref(ab)))
+            bwd.append(self._call("air_attend_bwd", C.byref(ab), nbytes=B * ((D + d + 2 * HT) * 4 + 64), tag="attend_bwd"))
             last = (t == N - 1)
             dc_cur, dc_nxt = self.dc[t % 2], self.dc[(t + 1) % 2]
             # grad wrt h[t+1]: heads of step t (d_hid . Whid^T) + LSTM of step t+1 (dh_rec)
@@ -517,8 +534,10 @@ class AIRModel:
         self._bwd += wg
 
         self._opt = [
-            self._call("air_grad_sqnorm", _ptr(st.grads), st.n, _ptr(st.partials), _ptr(st.istate)),
+            self._call("air_grad_sqnorm", _ptr(st.grads), st.n, _ptr(st.partials), _ptr(st.istate),
+                       nbytes=4 * st.n, tag="grad_sqnorm"),
         ]
+        self._opt_world = None
 
     # ------------------------------------------------------------------ running
     def _stream(self):
@@ -558,25 +577,85 @@ class AIRModel:
         self._steps_executed = None
         return self
 
+    def _world(self):
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            return torch.distributed.get_world_size()
+        return 1
+
+    def _optimizer_ops(self):
+        world = self._world()
+        if self._opt_world != world:
+            st = self.store
+            adam = self._call("air_adam_clip_step", _ptr(st.params), _ptr(st.grads), _ptr(st.m), _ptr(st.v),
+                              st.n, _ptr(st.partials), _ptr(self.dyn), _ptr(st.istate), 1.0 / world,
+                              0.9, 0.999, 1e-8, None, _ptr(st.gnorm), nbytes=28 * st.n, tag="adam_clip")
+            self._opt = [self._opt[0], adam]
+            self._opt_world = world
+        return self._opt
+
+    def _train_phase_a(self, s):
+        """step prologue + forward + loss + backward (+ weight grads) into the flat grad buffer"""
+        self._run_forward(s)
+        for op in self._bwd:
+            op(s)
+
+    def _train_phase_b(self, s):
+        """global-norm clip + TF-style Adam + global_step += 1 (after the all-reduce)"""
+        for op in self._optimizer_ops():
+            op(s)
+
+    def capture_graph(self):
+        """Captures the train step into hipGraphs (fixed N, no host sync, no allocation inside):
+        one graph for world_size 1; [fwd+bwd] | RCCL all-reduce | [clip+Adam] for data parallel."""
+        if not self.train:
+            raise RuntimeError("capture_graph() is for train=True models")
+        self._optimizer_ops()
+        world = self._world()
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):            # warm-up outside capture (lazy module loads, LDS attributes)
+            s = self._stream()
+            self._run_forward(s)
+            for op in self._bwd:
+                op(s)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        ga = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga):
+            s = self._stream()
+            self._train_phase_a(s)
+            if world == 1:
+                self._train_phase_b(s)
+        gb = None
+        if world > 1:
+            gb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gb):
+                self._train_phase_b(self._stream())
+        self._graph = (ga, gb)
+        return self
+
+    def release_graph(self):
+        self._graph = None
+
     def training(self):
         """The train op (reference :692): forward, loss, backward, clip, Adam, global_step += 1."""
         if not self.train:
             raise RuntimeError("model was built with train=False")
         st = self.store
-        s = self._stream()
-        self._run_forward(s)
-        for op in self._bwd:
-            op(s)
-        world = 1
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            world = torch.distributed.get_world_size()
+        world = self._world()
+        if self._graph is not None:
+            ga, gb = self._graph
+            ga.replay()
+            if world > 1:
+                torch.distributed.all_reduce(st.grads)
+                gb.replay()
+        else:
+            s = self._stream()
+            self._train_phase_a(s)
             if world > 1:
                 torch.distributed.all_reduce(st.grads)            # ONE collective: grads + loss/accuracy tail
-        for op in self._opt:
-            op(s)
-        H.check(self.lib.air_adam_clip_step(
-            _ptr(st.params), _ptr(st.grads), _ptr(st.m), _ptr(st.v), st.n, _ptr(st.partials), _ptr(self.dyn),
-            _ptr(st.istate), 1.0 / world, 0.9, 0.999, 1e-8, None, _ptr(st.gnorm), s), "air_adam_clip_step")
+            self._train_phase_b(s)
         if world > 1:
             self.scalars[:2].mul_(1.0 / world)
         self._dirty = False
