@@ -100,6 +100,23 @@ enum {
     AIR_GRAD_RELU = 1,          /* v *= (aux > 0)                        */
     AIR_GRAD_SOFTPLUS = 2       /* v *= 1 - exp(-aux)  (aux = softplus output) */
 };
+/* fused epilogues (the pointwise ops the reference runs right after the MatMul) */
+enum {
+    AIR_EPI_GENERIC = 0,
+    /* BasicLSTMCell pointwise part (air_model.py:286): N = 4R gate columns i,j,f,o (groups of R);
+     * pre-activation = acc + sum(addend slabs) + bias.  p0 = c_prev [M,R];
+     * q0 = acts [M,4R] (sigmoid i, tanh j, sigmoid(f+1), sigmoid o), q1 = c [M,R], q2 = h [M,R]. */
+    AIR_EPI_LSTM_FWD = 1,
+    /* vae.py:16-24: N = 2Z (mean | log_var); C = ml [M,2Z]; p0 = eps [M,Z]; q0 = sample [M,Z]. */
+    AIR_EPI_REPARAM_FWD = 2,
+    /* LSTM backward: acc (+ addend) = d loss/d h' [M,R]; p0 = acts, p1 = c_prev, p2 = c,
+     * p3 = d c' from the next step (nullable); q0 = dgates [M,4R], q1 = d c_prev [M,R],
+     * q2 = running sum of dgates (nullable), i0 = accumulate into q2. */
+    AIR_EPI_LSTM_BWD = 3,
+    /* re-parameterisation backward + VAE-KL gradient (air_model.py:481-493): acc = d loss/d z;
+     * p0 = ml [M,2Z], p1 = eps [M,Z], p2 = att, p3 = dyn; C = d_ml [M,2Z]. */
+    AIR_EPI_REPARAM_BWD = 4
+};
 typedef struct {
     const float* A; const float* B; float* C;
     int32_t M, N, K, lda, ldb, ldc;
@@ -112,7 +129,17 @@ typedef struct {
     int32_t actgrad;               /* AIR_GRAD_*                         */
     int32_t accumulate;            /* C += result                        */
     int32_t precision;             /* 0 fp32, 1 bf16                     */
+    int32_t epi;                   /* AIR_EPI_*                          */
+    int32_t tile_m, tile_n;        /* output tile in units of 16 (0 = auto): (1,1)(1,2)(1,4)(2,2)(2,4)(4,1)(4,2) */
+    int32_t ksplit;                /* > 1: split K over grid.z; C receives `air_gemm_slabs()` slabs of
+                                      [M,ldc] (plain stores, generic epilogue skipped)            */
+    int32_t addend_slabs;          /* addend is that many [M,ldadd] slabs (0/1 = one)            */
+    int32_t i0;
+    const float* p0; const float* p1; const float* p2; const float* p3;
+    float* q0; float* q1; float* q2;
 } air_gemm_t;
+/* number of K-slabs a ksplit request produces for contraction depth K */
+int air_gemm_slabs(int K, int ksplit);
 int air_gemm(const air_gemm_t* g, void* stream);
 
 /* column sums db[n] = sum_r dY[r*ld + n]  (BiasAdd_grad nodes) for `count` problems */
@@ -137,22 +164,24 @@ int air_transformer_fwd(const float* U, const float* theta, float* out,
 
 /* ---- "attend": heads output layer + sampling + KLs + stop logic + ST read -----
  * air_model.py:288-333 (scale/shift heads, theta, transformer canvas->window) and
- * :368-427 (z_pres head, Concrete sample, z KL, stopping_sum, running_digits),
- * :441-477 (scale/shift KL).  One workgroup per image.
- * hid [B,HT] = ReLU hidden activations of the 5 heads, concatenated in the order
+ * :368-427 (z_pres head, Concrete sample, z KL, stopping_sum masks), :441-477
+ * (scale/shift KL) for ALL N time steps at once: one workgroup per (image, step).
+ * The LSTM input is the same image every step (:286, :535), so h' of every step
+ * exists before the heads run; the stopping sum is re-derived per block in step
+ * order (bitwise equal to the sequential loop).
+ * hid [N,B,HT] = ReLU hidden activations of the 5 heads, concatenated in the order
  * scale/mean, scale/log_variance, shift/mean, shift/log_variance, z_pres/log_odds
- * with widths Hs,Hs,Hh,Hh,Hz (HT = 2Hs+2Hh+Hz).  wout [7][max(Hs,Hh,Hz)] holds
- * one row per output unit, bout [7]. */
+ * with widths Hs,Hs,Hh,Hh,Hz (HT = 2Hs+2Hh+Hz).  wout [7][wout_ld] holds one row
+ * per output unit, bout [7]. */
 typedef struct {
     const float* hid; const float* wout; const float* bout;
     const float* canvas;                 /* input_images [B,C*C]            */
-    const float* eps_scale; const float* eps_shift; const float* u;   /* [B,1],[B,2],[B] */
+    const float* eps_scale; const float* eps_shift; const float* u;   /* [N,B,1],[N,B,2],[N,B] */
     const float* dyn;                    /* AIR_DYN_* device array          */
-    float* out7;                         /* [B,8]                           */
-    float* att;                          /* [B,AIR_ATT_STRIDE]              */
-    float* window;                       /* [B,w*w]                         */
-    float* stop_sum; float* run_loss; int32_t* run_digits;   /* [B] in/out  */
-    int32_t B, C, w, Hs, Hh, Hz, wout_ld, train;
+    float* out7;                         /* [N,B,8]                         */
+    float* att;                          /* [N,B,AIR_ATT_STRIDE]            */
+    float* window;                       /* [N,B,w*w]                       */
+    int32_t B, N, C, w, Hs, Hh, Hz, wout_ld, train;
 } air_attend_fwd_t;
 int air_attend_fwd(const air_attend_fwd_t* a, void* stream);
 
@@ -160,11 +189,11 @@ typedef struct {
     const float* hid; const float* wout;
     const float* canvas; const float* eps_scale; const float* eps_shift;
     const float* dyn; const float* out7; const float* att;
-    const float* d_window;               /* [B,w*w] grad wrt the glimpse    */
-    const float* d_sxy_write;            /* [B,4]: ds,dx,dy,dz from the write path */
-    float* d_hid;                        /* [B,HT] grad wrt pre-ReLU hidden */
-    float* d_out7;                       /* [B,8]                           */
-    int32_t B, C, w, Hs, Hh, Hz, wout_ld;
+    const float* d_window;               /* [N,B,w*w] grad wrt the glimpse  */
+    const float* d_sxy_write;            /* [N,B,4]: ds,dx,dy,dz from the write path */
+    float* d_hid;                        /* [N,B,HT] grad wrt pre-ReLU hidden */
+    float* d_out7;                       /* [N,B,8]                         */
+    int32_t B, N, C, w, Hs, Hh, Hz, wout_ld;
 } air_attend_bwd_t;
 int air_attend_bwd(const air_attend_bwd_t* a, void* stream);
 
@@ -180,26 +209,34 @@ int air_reparam_fwd(const float* ml /*[B,2Z] mean|log_var*/, const float* eps_z,
 int air_reparam_bwd(const float* d_zs, const float* ml, const float* eps_z, const float* att,
                     const float* dyn, float* d_ml, int B, int Z, void* stream);
 
-/* ---- "write": ST window->canvas + z_pres scaling + masked accumulate + VAE KL --
- * air_model.py:351-366 (theta_recon, transformer), :429-439 (running_recon),
- * :479-493 (VAE KL into running_loss).  One workgroup per image. */
+/* ---- "write"/compose: ST window->canvas for all N steps + z_pres scaling + masked
+ * accumulate (in step order, in registers) + VAE KL + running loss + digit count +
+ * reconstruction loss and its gradient.  air_model.py:351-366 (theta_recon,
+ * transformer), :409-439 (masks, running_recon), :479-496 (VAE KL), :580-593 (loss).
+ * One workgroup per image. */
 typedef struct {
-    const float* vrec;                   /* vae reconstruction [B,w*w]      */
-    const float* ml;                     /* [B,2Z]                          */
+    const float* vrec;                   /* vae reconstructions [N,B,w*w]   */
+    const float* ml;                     /* [N,B,2Z] mean | log_var         */
+    const float* images;                 /* [B,C*C]                         */
     const float* dyn;
-    float* att;                          /* reads s,x,y,z,mask; writes KL_VAE, ST_BACK */
-    float* run_recon;                    /* [B,C*C] in/out                  */
-    float* run_loss;                     /* [B] in/out                      */
-    int32_t B, C, w, Z;
+    float* att;                          /* [N,B,16]: reads s,x,y,z,masks,KLs; writes KL_VAE */
+    float* recon;                        /* [B,C*C] clipped reconstruction  */
+    float* rec_loss;                     /* [B]                             */
+    float* d_recon;                      /* [B,C*C] d loss/d running_recon, nullable */
+    float* run_loss;                     /* [B] sum of masked KLs (running_loss) */
+    int32_t* run_digits;                 /* [B] rec_num_digits              */
+    float* loss_item;                    /* [B] run_loss + rec_loss         */
+    int32_t B, N, C, w, Z;
 } air_write_fwd_t;
 int air_write_fwd(const air_write_fwd_t* a, void* stream);
 
+/* one workgroup per (image, step): all steps see the same d loss / d canvas */
 typedef struct {
-    const float* d_recon;                /* [B,C*C] grad wrt running_recon  */
-    const float* vrec; const float* att;
-    float* d_gen_pre;                    /* [B,w*w] grad wrt gen_mean pre-sigmoid input */
-    float* d_sxy_write;                  /* [B,4]: ds,dx,dy (via theta_recon), dz */
-    int32_t B, C, w;
+    const float* d_recon;                /* [B,C*C]                         */
+    const float* vrec; const float* att; /* [N,B,w*w], [N,B,16]             */
+    float* d_gen_pre;                    /* [N,B,w*w] grad wrt gen_mean pre-sigmoid input */
+    float* d_sxy_write;                  /* [N,B,4]: ds,dx,dy (via theta_recon), dz */
+    int32_t B, N, C, w;
 } air_write_bwd_t;
 int air_write_bwd(const air_write_bwd_t* a, void* stream);
 

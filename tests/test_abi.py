@@ -53,15 +53,15 @@ def test_struct_layout_matches_c(H, tmp_path):
     """sizeof/offsetof from a C compile of the header == ctypes."""
     prog = tmp_path / "layout.c"
     prog.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "air_hip.h"\nint main(){'
-                    'printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(air_gemm_t), offsetof(air_gemm_t, bias),'
-                    'offsetof(air_gemm_t, aux), offsetof(air_gemm_t, precision), sizeof(air_schedule_t),'
+                    'printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(air_gemm_t), offsetof(air_gemm_t, bias),'
+                    'offsetof(air_gemm_t, aux), offsetof(air_gemm_t, precision), offsetof(air_gemm_t, p0), offsetof(air_gemm_t, q2), sizeof(air_schedule_t),'
                     'sizeof(air_attend_fwd_t), offsetof(air_attend_fwd_t, B), sizeof(air_attend_bwd_t),'
                     'sizeof(air_write_fwd_t), sizeof(air_write_bwd_t)); printf("%zu\\n", sizeof(air_colsum_t)); return 0;}')
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
     out = subprocess.check_output([str(exe)]).decode().split()
     got = [int(x) for x in out]
-    exp = [C.sizeof(H.Gemm), H.Gemm.bias.offset, H.Gemm.aux.offset, H.Gemm.precision.offset,
+    exp = [C.sizeof(H.Gemm), H.Gemm.bias.offset, H.Gemm.aux.offset, H.Gemm.precision.offset, H.Gemm.p0.offset, H.Gemm.q2.offset,
            C.sizeof(H.Schedule), C.sizeof(H.AttendFwd), H.AttendFwd.B.offset, C.sizeof(H.AttendBwd),
            C.sizeof(H.WriteFwd), C.sizeof(H.WriteBwd), C.sizeof(H.Colsum)]
     assert got == exp, (got, exp)

@@ -171,29 +171,40 @@ def test_write_is_adjoint_of_its_backward(H):
     ml = torch.zeros(B, 2 * Z, device=dev)
     dyn = torch.zeros(H.DYN_COUNT, device=dev)
     dyn[H.DYN_VAE_PV] = 1.0
-    R = torch.zeros(B, Cc * Cc, device=dev)
-    L = torch.zeros(B, device=dev)
-    wf = H.WriteFwd(_p(vrec), _p(ml), _p(dyn), _p(att), _p(R), _p(L), B, Cc, w, Z)
+    dyn[H.DYN_GRAD_SCALE] = 1.0 / B
+    images = torch.tensor(rng.uniform(0, 1, (B, Cc * Cc)).astype(np.float32), device=dev)
+    R = torch.zeros(B, Cc * Cc, device=dev)          # clipped canvas (0 <= z*w*v < 1 here: clip is a no-op)
+    rec_loss, L, loss_item = (torch.zeros(B, device=dev) for _ in range(3))
+    digits = torch.zeros(B, dtype=torch.int32, device=dev)
+    dR = torch.zeros(B, Cc * Cc, device=dev)
+    wf = H.WriteFwd(_p(vrec), _p(ml), _p(images), _p(dyn), _p(att), _p(R), _p(rec_loss), _p(dR), _p(L),
+                    _p(digits), _p(loss_item), B, 1, Cc, w, Z)
     H.check(H.lib().air_write_fwd(C.byref(wf), _stream()))
     g = torch.tensor(rng.uniform(-1, 1, (B, Cc * Cc)).astype(np.float32), device=dev)
     dgen = torch.zeros(B, w * w, device=dev)
     dsx = torch.zeros(B, 4, device=dev)
-    wb = H.WriteBwd(_p(g), _p(vrec), _p(att), _p(dgen), _p(dsx), B, Cc, w)
+    wb = H.WriteBwd(_p(g), _p(vrec), _p(att), _p(dgen), _p(dsx), B, 1, Cc, w)
     H.check(H.lib().air_write_bwd(C.byref(wb), _stream()))
     torch.cuda.synchronize()
+    assert bool((digits == 1).all())
     lhs = (R.double() * g.double()).sum(1)                       # <z W v, g>
     dv = dgen.double() / (vrec.double() * (1 - vrec.double()))   # z W^T g
     rhs = (dv * vrec.double()).sum(1)
     assert torch.allclose(lhs, rhs, rtol=1e-4, atol=1e-4), (lhs, rhs)
     # d z = <W v, g> = lhs / z
     assert torch.allclose(dsx[:, 3].double(), lhs / 0.7, rtol=1e-4, atol=1e-4)
-    # oracle check of the forward
+    # oracle check of the forward (literal op order -> bit-level agreement) and of the fused BCE
     theta = np.zeros((B, 2, 3), np.float32)
     s, x, y = (att[:, i].cpu().numpy() for i in (H.ATT_S, H.ATT_X, H.ATT_Y))
     theta[:, 0, 0] = theta[:, 1, 1] = np.float32(1.0) / s
     theta[:, 0, 2], theta[:, 1, 2] = -x / s, -y / s
     ref = np.float32(0.7) * ao.transformer(vrec.cpu().numpy().reshape(B, w, w), theta, (Cc, Cc)).reshape(B, -1)
+    ref = np.clip(ref, 0, 1)
     assert np.abs(R.cpu().numpy() - ref).max() <= 1e-6
+    r64, x64 = R.double().cpu().numpy(), images.double().cpu().numpy()
+    bce = -np.sum(x64 * np.log(r64 + ao.EPS) + (1 - x64) * np.log(1 - r64 + ao.EPS), axis=1)
+    np.testing.assert_allclose(rec_loss.cpu().numpy(), bce, rtol=1e-5)
+    np.testing.assert_allclose(loss_item.cpu().numpy(), bce, rtol=1e-5)     # all KLs are 0 here
 
 
 def test_adam_and_norm_match_oracle(H):
@@ -251,3 +262,121 @@ def test_step_begin_schedule_and_noise(H):
                                    C.c_uint64(1234), _stream()))
     torch.cuda.synchronize()
     assert torch.equal(normals, outs[2])             # and is reproducible
+
+
+# ---- GEMM: explicit tiles, split-K slabs, fused epilogues ---------------------------------
+
+def _gemm_struct(H, A, B, Cc, M, N, K, lda, ldb, ldc, prec, **kw):
+    g = H.Gemm()
+    g.A, g.B, g.C = A.data_ptr(), B.data_ptr(), Cc.data_ptr()
+    g.M, g.N, g.K, g.lda, g.ldb, g.ldc = M, N, K, lda, ldb, ldc
+    g.precision = prec
+    for k, v in kw.items():
+        setattr(g, k, v.data_ptr() if torch.is_tensor(v) else v)
+    return g
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("tile", [(1, 1), (1, 2), (1, 4), (2, 2), (2, 4), (4, 1), (4, 2)])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0)])
+def test_gemm_explicit_tiles(H, tile, ta, tb, prec):
+    rng = np.random.RandomState(7)
+    M, N, K = 70, 150, 333
+    A = rng.uniform(-1, 1, (K, M) if ta else (M, K)).astype(np.float32)
+    B = rng.uniform(-1, 1, (N, K) if tb else (K, N)).astype(np.float32)
+    At, Bt = torch.tensor(A, device="cuda"), torch.tensor(B, device="cuda")
+    Ct = torch.full((M, N), float("nan"), device="cuda")
+    g = _gemm_struct(H, At, Bt, Ct, M, N, K, A.shape[1], B.shape[1], N, prec, transA=ta, transB=tb,
+                     tile_m=tile[0], tile_n=tile[1])
+    H.check(H.lib().air_gemm(C.byref(g), _stream()))
+    torch.cuda.synchronize()
+    ref = _ref_gemm(A, B, ta, tb, prec)
+    assert np.abs(Ct.cpu().numpy() - ref).max() / np.sqrt(K) < (2e-6 if prec == 0 else 2e-5)
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_gemm_split_k_slabs(H, prec):
+    rng = np.random.RandomState(8)
+    M, N, K = 64, 1024, 2500
+    A = rng.uniform(-1, 1, (M, K)).astype(np.float32)
+    B = rng.uniform(-1, 1, (K, N)).astype(np.float32)
+    At, Bt = torch.tensor(A, device="cuda"), torch.tensor(B, device="cuda")
+    for ks, tile in ((8, (2, 2)), (4, (1, 1)), (6, (4, 1)), (3, (0, 0))):
+        S = H.lib().air_gemm_slabs(K, ks)
+        Ct = torch.full((S, M, N), float("nan"), device="cuda")
+        g = _gemm_struct(H, At, Bt, Ct, M, N, K, K, N, N, prec, ksplit=ks, tile_m=tile[0], tile_n=tile[1])
+        H.check(H.lib().air_gemm(C.byref(g), _stream()))
+        torch.cuda.synchronize()
+        got = Ct.double().sum(0).cpu().numpy()
+        ref = _ref_gemm(A, B, 0, 0, prec)
+        assert np.abs(got - ref).max() / np.sqrt(K) < (2e-6 if prec == 0 else 2e-5), (ks, tile)
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_gemm_fused_lstm_and_reparam_match_unfused(H, prec):
+    dev = "cuda"
+    rng = np.random.RandomState(9)
+    lib = H.lib()
+    Bn, R, Z, HT = 64, 256, 50, 320
+    f = lambda *s: torch.tensor(rng.uniform(-1, 1, s).astype(np.float32), device=dev)  # noqa: E731
+    # ---- LSTM forward: fused vs gemm + air_lstm_gates_fwd
+    h, Wh, bias, c_prev = f(Bn, R), f(R, 4 * R) * 0.1, f(4 * R) * 0.1, f(Bn, R)
+    slabs = f(3, Bn, 4 * R) * 0.3
+    pre = torch.zeros(Bn, 4 * R, device=dev)
+    g = _gemm_struct(H, h, Wh, pre, Bn, 4 * R, R, R, 4 * R, 4 * R, prec, bias=bias, addend=slabs.sum(0).contiguous(),
+                     ldadd=4 * R)
+    H.check(lib.air_gemm(C.byref(g), _stream()))
+    acts0, c0, h0 = torch.zeros(Bn, 4 * R, device=dev), torch.zeros(Bn, R, device=dev), torch.zeros(Bn, R, device=dev)
+    H.check(lib.air_lstm_gates_fwd(_p(pre), _p(c_prev), _p(acts0), _p(c0), _p(h0), Bn, R, _stream()))
+    acts1, c1, h1 = torch.zeros_like(acts0), torch.zeros_like(c0), torch.zeros_like(h0)
+    dummy = torch.zeros(Bn, 4 * R, device=dev)
+    g = _gemm_struct(H, h, Wh, dummy, Bn, 4 * R, R, R, 4 * R, 4 * R, prec, bias=bias, addend=slabs, ldadd=4 * R,
+                     addend_slabs=3, epi=H.EPI_LSTM_FWD, p0=c_prev, q0=acts1, q1=c1, q2=h1)
+    H.check(lib.air_gemm(C.byref(g), _stream()))
+    torch.cuda.synchronize()
+    for a0, a1 in ((acts0, acts1), (c0, c1), (h0, h1)):
+        assert float((a0 - a1).abs().max()) < 2e-5
+    # ---- LSTM backward: fused vs gemm + air_lstm_gates_bwd
+    d_hid, Whid, dh_rec, dc_in = f(Bn, HT), f(R, HT) * 0.1, f(Bn, R), f(Bn, R)
+    dh = torch.zeros(Bn, R, device=dev)
+    g = _gemm_struct(H, d_hid, Whid, dh, Bn, R, HT, HT, HT, R, prec, transB=1, addend=dh_rec, ldadd=R)
+    H.check(lib.air_gemm(C.byref(g), _stream()))
+    dg0, dcp0, ds0 = torch.zeros(Bn, 4 * R, device=dev), torch.zeros(Bn, R, device=dev), f(Bn, 4 * R)
+    ds1 = ds0.clone()
+    H.check(lib.air_lstm_gates_bwd(_p(dh), _p(dc_in), _p(acts0), _p(c_prev), _p(c0), _p(dg0), _p(dcp0), _p(ds0), 1,
+                                   Bn, R, _stream()))
+    dg1, dcp1 = torch.zeros_like(dg0), torch.zeros_like(dcp0)
+    g = _gemm_struct(H, d_hid, Whid, dh, Bn, R, HT, HT, HT, R, prec, transB=1, addend=dh_rec, ldadd=R,
+                     epi=H.EPI_LSTM_BWD, p0=acts0, p1=c_prev, p2=c0, p3=dc_in, q0=dg1, q1=dcp1, q2=ds1, i0=1)
+    H.check(lib.air_gemm(C.byref(g), _stream()))
+    torch.cuda.synchronize()
+    for a0, a1 in ((dg0, dg1), (dcp0, dcp1), (ds0, ds1)):
+        assert float((a0 - a1).abs().max()) < 2e-5
+    # ---- re-parameterisation forward / backward
+    e2, Wml, bml, eps = f(Bn, 256), f(256, 2 * Z) * 0.1, f(2 * Z) * 0.1, f(Bn, Z)
+    ml0, zs0 = torch.zeros(Bn, 2 * Z, device=dev), torch.zeros(Bn, Z, device=dev)
+    g = _gemm_struct(H, e2, Wml, ml0, Bn, 2 * Z, 256, 256, 2 * Z, 2 * Z, prec, bias=bml)
+    H.check(lib.air_gemm(C.byref(g), _stream()))
+    H.check(lib.air_reparam_fwd(_p(ml0), _p(eps), _p(zs0), Bn, Z, _stream()))
+    ml1, zs1 = torch.zeros_like(ml0), torch.zeros_like(zs0)
+    g = _gemm_struct(H, e2, Wml, ml1, Bn, 2 * Z, 256, 256, 2 * Z, 2 * Z, prec, bias=bml, epi=H.EPI_REPARAM_FWD,
+                     p0=eps, q0=zs1)
+    H.check(lib.air_gemm(C.byref(g), _stream()))
+    torch.cuda.synchronize()
+    assert float((ml0 - ml1).abs().max()) < 2e-5 and float((zs0 - zs1).abs().max()) < 2e-5
+    dg1_, G1 = f(Bn, 256), f(Z, 256) * 0.1
+    att = torch.zeros(Bn, H.ATT_STRIDE, device=dev)
+    att[:, H.ATT_MASK] = torch.tensor((rng.uniform(0, 1, Bn) > 0.3).astype(np.float32))
+    dyn = torch.zeros(H.DYN_COUNT, device=dev)
+    dyn[H.DYN_VAE_PV], dyn[H.DYN_VAE_PM], dyn[H.DYN_GRAD_SCALE] = 0.9, 0.1, 1.0 / Bn
+    dzs = torch.zeros(Bn, Z, device=dev)
+    g = _gemm_struct(H, dg1_, G1, dzs, Bn, Z, 256, 256, 256, Z, prec, transB=1)
+    H.check(lib.air_gemm(C.byref(g), _stream()))
+    dml0 = torch.zeros(Bn, 2 * Z, device=dev)
+    H.check(lib.air_reparam_bwd(_p(dzs), _p(ml0), _p(eps), _p(att), _p(dyn), _p(dml0), Bn, Z, _stream()))
+    dml1 = torch.zeros_like(dml0)
+    g = _gemm_struct(H, dg1_, G1, dml1, Bn, Z, 256, 256, 256, 2 * Z, prec, transB=1, epi=H.EPI_REPARAM_BWD,
+                     p0=ml0, p1=eps, p2=att, p3=dyn)
+    H.check(lib.air_gemm(C.byref(g), _stream()))
+    torch.cuda.synchronize()
+    assert float((dml0 - dml1).abs().max()) < 2e-5

@@ -24,6 +24,7 @@ ATT_KL_Z, ATT_KL_SCALE, ATT_KL_SHIFT, ATT_KL_VAE, ATT_MASK_PREV, ATT_MASK, ATT_S
 ATT_STRIDE, OUT_STRIDE = 16, 8
 ACT_NONE, ACT_RELU, ACT_SOFTPLUS, ACT_SIGMOID_NOISE = 0, 1, 2, 3
 GRAD_NONE, GRAD_RELU, GRAD_SOFTPLUS = 0, 1, 2
+EPI_GENERIC, EPI_LSTM_FWD, EPI_REPARAM_FWD, EPI_LSTM_BWD, EPI_REPARAM_BWD = 0, 1, 2, 3, 4
 SCHED_STAIRCASE, SCHED_HAS_MIN, SCHED_HAS_MAX, SCHED_LOG = 1, 2, 4, 8
 
 _p = C.c_void_p
@@ -41,7 +42,9 @@ class Gemm(C.Structure):
                 ("M", _i), ("N", _i), ("K", _i), ("lda", _i), ("ldb", _i), ("ldc", _i),
                 ("transA", _i), ("transB", _i),
                 ("bias", _p), ("addend", _p), ("ldadd", _i), ("aux", _p), ("ldaux", _i),
-                ("aux_scale", _f), ("act", _i), ("actgrad", _i), ("accumulate", _i), ("precision", _i)]
+                ("aux_scale", _f), ("act", _i), ("actgrad", _i), ("accumulate", _i), ("precision", _i),
+                ("epi", _i), ("tile_m", _i), ("tile_n", _i), ("ksplit", _i), ("addend_slabs", _i), ("i0", _i),
+                ("p0", _p), ("p1", _p), ("p2", _p), ("p3", _p), ("q0", _p), ("q1", _p), ("q2", _p)]
 
 
 class Colsum(C.Structure):
@@ -52,8 +55,7 @@ class AttendFwd(C.Structure):
     _fields_ = [("hid", _p), ("wout", _p), ("bout", _p), ("canvas", _p),
                 ("eps_scale", _p), ("eps_shift", _p), ("u", _p), ("dyn", _p),
                 ("out7", _p), ("att", _p), ("window", _p),
-                ("stop_sum", _p), ("run_loss", _p), ("run_digits", _p),
-                ("B", _i), ("C", _i), ("w", _i), ("Hs", _i), ("Hh", _i), ("Hz", _i),
+                ("B", _i), ("N", _i), ("C", _i), ("w", _i), ("Hs", _i), ("Hh", _i), ("Hz", _i),
                 ("wout_ld", _i), ("train", _i)]
 
 
@@ -61,23 +63,25 @@ class AttendBwd(C.Structure):
     _fields_ = [("hid", _p), ("wout", _p), ("canvas", _p), ("eps_scale", _p), ("eps_shift", _p),
                 ("dyn", _p), ("out7", _p), ("att", _p), ("d_window", _p), ("d_sxy_write", _p),
                 ("d_hid", _p), ("d_out7", _p),
-                ("B", _i), ("C", _i), ("w", _i), ("Hs", _i), ("Hh", _i), ("Hz", _i), ("wout_ld", _i)]
+                ("B", _i), ("N", _i), ("C", _i), ("w", _i), ("Hs", _i), ("Hh", _i), ("Hz", _i), ("wout_ld", _i)]
 
 
 class WriteFwd(C.Structure):
-    _fields_ = [("vrec", _p), ("ml", _p), ("dyn", _p), ("att", _p), ("run_recon", _p), ("run_loss", _p),
-                ("B", _i), ("C", _i), ("w", _i), ("Z", _i)]
+    _fields_ = [("vrec", _p), ("ml", _p), ("images", _p), ("dyn", _p), ("att", _p), ("recon", _p),
+                ("rec_loss", _p), ("d_recon", _p), ("run_loss", _p), ("run_digits", _p), ("loss_item", _p),
+                ("B", _i), ("N", _i), ("C", _i), ("w", _i), ("Z", _i)]
 
 
 class WriteBwd(C.Structure):
     _fields_ = [("d_recon", _p), ("vrec", _p), ("att", _p), ("d_gen_pre", _p), ("d_sxy_write", _p),
-                ("B", _i), ("C", _i), ("w", _i)]
+                ("B", _i), ("N", _i), ("C", _i), ("w", _i)]
 
 
 _SIGNATURES = {
     "air_abi_version": (C.c_int, []),
     "air_strerror": (C.c_char_p, [C.c_int]),
     "air_gemm": (C.c_int, [C.POINTER(Gemm), _p]),
+    "air_gemm_slabs": (C.c_int, [C.c_int, C.c_int]),
     "air_colsum": (C.c_int, [C.POINTER(Colsum), C.c_int, _p]),
     "air_lstm_gates_fwd": (C.c_int, [_p, _p, _p, _p, _p, C.c_int, C.c_int, _p]),
     "air_lstm_gates_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, C.c_int, C.c_int, C.c_int, _p]),

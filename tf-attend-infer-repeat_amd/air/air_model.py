@@ -332,17 +332,14 @@ class AIRModel:
         self.eps_x = self.normals[o:o + N * B * d].view(N, B, d)
         self.u = self.uniforms.view(N, B)
 
-        # running state zeroed with ONE memset at the start of every forward
-        n_state = B * D + 3 * B + 2 * B * R
-        self.state = f(_align4(n_state))
-        o = 0
-        self.run_recon = self.state[o:o + B * D].view(B, D); o += B * D
-        self.stop_sum = self.state[o:o + B]; o += B
-        self.run_loss = self.state[o:o + B]; o += B
-        self.run_digits = self.state[o:o + B].view(torch.int32); o += B
+        # per-image results of the compose kernel (no running state lives across kernels any more)
+        self.run_loss = f(B)
+        self.run_digits = torch.zeros(B, dtype=torch.int32, device=dv)
         self.c = f(N + 1, B, R); self.h = f(N + 1, B, R)         # [0] stays zero (zero_state :540)
 
-        self.xw = f(B, 4 * R)
+        self._xw_ksplit, self._xw_tile = 8, (2, 2)
+        self._xw_slabs = self.lib.air_gemm_slabs(D, self._xw_ksplit)
+        self.xw = f(self._xw_slabs, B, 4 * R)            # split-K slabs of the hoisted x.Wx
         self.gates_pre = f(B, 4 * R)
         self.acts = f(N, B, 4 * R)
         self.hid = f(N, B, HT)
@@ -363,28 +360,33 @@ class AIRModel:
             self.d_recon = f(B, D)
             self.d_genpre = f(N, B, d)
             self.d_gen = [f(N, B, u) for u in self.vae_generative_units]
-            self.d_zs = f(B, Z)
             self.d_ml = f(N, B, 2 * Z)
             self.d_rec = [f(N, B, u) for u in self.vae_recognition_units]
-            self.d_window = f(B, d)
-            self.d_sxyw = f(B, 4)
+            self.d_window = f(N, B, d)
+            self.d_sxyw = f(N, B, 4)
+            self.dh_heads = f(N, B, R)
             self.d_hid = f(N, B, HT)
             self.d_out7 = f(N, B, H.OUT_STRIDE)
-            self.dh_cur, self.dh_rec = f(B, R), f(B, R)
+            self.dh_cur = f(B, R)                       # scratch C of the fused LSTM-backward GEMM
             self.dc = [f(B, R), f(B, R)]
             self.dgates = f(N, B, 4 * R)
             self.dgsum = f(B, 4 * R)
 
     # ------------------------------------------------------------- launch lists
     def _gemm(self, A, Bm, Cm, M, N, K, lda, ldb, ldc, ta=0, tb=0, bias=None, addend=None, ldadd=0,
-              aux=None, ldaux=0, aux_scale=0.0, act=H.ACT_NONE, actgrad=H.GRAD_NONE, accumulate=0, tag="gemm"):
+              aux=None, ldaux=0, aux_scale=0.0, act=H.ACT_NONE, actgrad=H.GRAD_NONE, accumulate=0, tag="gemm",
+              epi=H.EPI_GENERIC, tile=(0, 0), ksplit=0, addend_slabs=0, i0=0, p=(), q=(), extra_bytes=0):
+        p = list(p) + [None] * (4 - len(p))
+        q = list(q) + [None] * (3 - len(q))
         g = H.Gemm(_ptr(A), _ptr(Bm), _ptr(Cm), M, N, K, lda, ldb, ldc, ta, tb, _ptr(bias), _ptr(addend), ldadd,
-                   _ptr(aux), ldaux, aux_scale, act, actgrad, accumulate, self._prec)
+                   _ptr(aux), ldaux, aux_scale, act, actgrad, accumulate, self._prec,
+                   epi, tile[0], tile[1], ksplit, addend_slabs, i0,
+                   _ptr(p[0]), _ptr(p[1]), _ptr(p[2]), _ptr(p[3]), _ptr(q[0]), _ptr(q[1]), _ptr(q[2]))
         fn = self.lib.air_gemm
-        extra = (addend is not None) + (aux is not None) + (1 if accumulate else 0)
+        extra = (addend is not None) * max(1, addend_slabs) + (aux is not None) + (1 if accumulate else 0)
         return _Op("%s[%dx%dx%d%s]" % (tag, M, N, K, "t" if ta else ("n" + ("t" if tb else "n"))),
                    lambda s, g=g, fn=fn: H.check(fn(C.byref(g), s), "air_gemm"),
-                   nbytes=4 * (M * K + K * N + M * N * (1 + extra)) + (4 * N if bias is not None else 0),
+                   nbytes=4 * (M * K + K * N + M * N * (1 + extra)) + (4 * N if bias is not None else 0) + extra_bytes,
                    flops=2 * M * N * K)
 
     def _call(self, name, *args, nbytes=0, flops=0, tag=None):
@@ -404,46 +406,49 @@ class AIRModel:
         imgs = self.input_images
         keep = self._keep = []          # ctypes structs referenced by the closures
 
+        NB = N * B
         fwd = []
-        # hoisted x.W_x + b (the reference recomputes it every step, :286)
-        fwd.append(self._gemm(imgs, Wx, self.xw, B, 4 * R, D, D, 4 * R, 4 * R, bias=P["lstm_bias"]))
+        # hoisted x.W_x (the reference recomputes it every step, :286); split-K slabs
+        fwd.append(self._gemm(imgs, Wx, self.xw, B, 4 * R, D, D, 4 * R, 4 * R, ksplit=self._xw_ksplit,
+                              tile=self._xw_tile, tag="xWx"))
+        # the recurrence: N chained LSTM steps (the only sequential part of the loop -- the LSTM
+        # sees the same image every step and nothing downstream feeds back into it, :286/:535)
         for t in range(N):
             fwd.append(self._gemm(self.h[t], Wh, self.gates_pre, B, 4 * R, R, R, 4 * R, 4 * R,
-                                  addend=self.xw, ldadd=4 * R))
-            fwd.append(self._call("air_lstm_gates_fwd", _ptr(self.gates_pre), _ptr(self.c[t]), _ptr(self.acts[t]),
-                                  _ptr(self.c[t + 1]), _ptr(self.h[t + 1]), B, R))
-            fwd.append(self._gemm(self.h[t + 1], P["whid"], self.hid[t], B, HT, R, R, HT, HT,
-                                  bias=P["bhid"], act=H.ACT_RELU))
-            a = H.AttendFwd(_ptr(self.hid[t]), _ptr(P["wout"]), _ptr(P["bout"]), _ptr(imgs),
-                            _ptr(self.eps_scale[t]), _ptr(self.eps_shift[t]), _ptr(self.u[t]), _ptr(self.dyn),
-                            _ptr(self.out7[t]), _ptr(self.att[t]), _ptr(self.window[t]),
-                            _ptr(self.stop_sum), _ptr(self.run_loss), _ptr(self.run_digits),
-                            B, Cc, w, Hs, Hh, Hz, Hmax, 1 if self.train else 0)
-            keep.append(a)
-            fwd.append(self._call("air_attend_fwd", C.byref(a), nbytes=B * ((D + d + HT) * 4 + 12), tag="attend_fwd"))
-            x, k = self.window[t], d
-            for i, u in enumerate(rec_u):
-                fwd.append(self._gemm(x, P["rec%d_w" % i], self.rec_act[i][t], B, u, k, k, u, u,
-                                      bias=P["rec%d_b" % i], act=H.ACT_SOFTPLUS))
-                x, k = self.rec_act[i][t], u
-            fwd.append(self._gemm(x, P["ml_w"], self.ml[t], B, 2 * Z, k, k, 2 * Z, 2 * Z, bias=P["ml_b"]))
-            fwd.append(self._call("air_reparam_fwd", _ptr(self.ml[t]), _ptr(self.eps_z[t]), _ptr(self.zs[t]), B, Z))
-            x, k = self.zs[t], Z
-            for i, u in enumerate(gen_u):
-                fwd.append(self._gemm(x, P["gen%d_w" % i], self.gen_act[i][t], B, u, k, k, u, u,
-                                      bias=P["gen%d_b" % i], act=H.ACT_SOFTPLUS))
-                x, k = self.gen_act[i][t], u
-            fwd.append(self._gemm(x, P["out_w"], self.vrec[t], B, d, k, k, d, d, bias=P["out_b"],
-                                  act=H.ACT_SIGMOID_NOISE, aux=self.eps_x[t], ldaux=d,
-                                  aux_scale=float(self.vae_likelihood_std)))
-            wf = H.WriteFwd(_ptr(self.vrec[t]), _ptr(self.ml[t]), _ptr(self.dyn), _ptr(self.att[t]),
-                            _ptr(self.run_recon), _ptr(self.run_loss), B, Cc, w, Z)
-            keep.append(wf)
-            fwd.append(self._call("air_write_fwd", C.byref(wf), nbytes=B * ((d + D) * 4 + 16 + 2 * D * 4), tag="write_fwd"))
-        fwd.append(self._call("air_bce_fwd_bwd", _ptr(imgs), _ptr(self.run_recon), _ptr(self.dyn),
-                              _ptr(self._recon), _ptr(self._rec_loss),
-                              _ptr(self.d_recon if self.train else None), B, D,
-                              nbytes=B * D * 4 * (4 if self.train else 3), tag="bce"))
+                                  bias=P["lstm_bias"], addend=self.xw, ldadd=4 * R, addend_slabs=self._xw_slabs,
+                                  epi=H.EPI_LSTM_FWD, p=(self.c[t],), q=(self.acts[t], self.c[t + 1], self.h[t + 1]),
+                                  extra_bytes=4 * B * R * 7, tag="lstm_fwd"))
+        # everything else runs ONCE over all N*B (step, image) rows
+        fwd.append(self._gemm(self.h[1], P["whid"], self.hid, NB, HT, R, R, HT, HT, bias=P["bhid"],
+                              act=H.ACT_RELU, tag="heads_hid"))
+        a = H.AttendFwd(_ptr(self.hid), _ptr(P["wout"]), _ptr(P["bout"]), _ptr(imgs),
+                        _ptr(self.eps_scale), _ptr(self.eps_shift), _ptr(self.u), _ptr(self.dyn),
+                        _ptr(self.out7), _ptr(self.att), _ptr(self.window),
+                        B, N, Cc, w, Hs, Hh, Hz, Hmax, 1 if self.train else 0)
+        keep.append(a)
+        fwd.append(self._call("air_attend_fwd", C.byref(a), nbytes=NB * ((D + d + HT) * 4 + 12), tag="attend_fwd"))
+        x, k = self.window, d
+        for i, u in enumerate(rec_u):
+            fwd.append(self._gemm(x, P["rec%d_w" % i], self.rec_act[i], NB, u, k, k, u, u,
+                                  bias=P["rec%d_b" % i], act=H.ACT_SOFTPLUS, tag="vae_rec"))
+            x, k = self.rec_act[i], u
+        fwd.append(self._gemm(x, P["ml_w"], self.ml, NB, 2 * Z, k, k, 2 * Z, 2 * Z, bias=P["ml_b"],
+                              epi=H.EPI_REPARAM_FWD, p=(self.eps_z,), q=(self.zs,),
+                              extra_bytes=8 * NB * Z, tag="ml_reparam"))
+        x, k = self.zs, Z
+        for i, u in enumerate(gen_u):
+            fwd.append(self._gemm(x, P["gen%d_w" % i], self.gen_act[i], NB, u, k, k, u, u,
+                                  bias=P["gen%d_b" % i], act=H.ACT_SOFTPLUS, tag="vae_gen"))
+            x, k = self.gen_act[i], u
+        fwd.append(self._gemm(x, P["out_w"], self.vrec, NB, d, k, k, d, d, bias=P["out_b"],
+                              act=H.ACT_SIGMOID_NOISE, aux=self.eps_x, ldaux=d,
+                              aux_scale=float(self.vae_likelihood_std), tag="vae_out"))
+        wf = H.WriteFwd(_ptr(self.vrec), _ptr(self.ml), _ptr(imgs), _ptr(self.dyn), _ptr(self.att),
+                        _ptr(self._recon), _ptr(self._rec_loss), _ptr(self.d_recon if self.train else None),
+                        _ptr(self.run_loss), _ptr(self.run_digits), _ptr(self._loss_item), B, N, Cc, w, Z)
+        keep.append(wf)
+        fwd.append(self._call("air_write_fwd", C.byref(wf),
+                              nbytes=NB * (d + 2 * Z) * 4 + B * D * 4 * (3 if self.train else 2), tag="compose_fwd"))
         fwd.append(self._call("air_finalize", _ptr(self.run_loss), _ptr(self._rec_loss),
                               _ptr(self.target_num_digits), _ptr(self.run_digits), _ptr(self._loss_item),
                               _ptr(self.scalars), B))
@@ -456,71 +461,76 @@ class AIRModel:
             "air_step_begin", _ptr(self.sched), self._nsched, _ptr(self.dyn), _ptr(st.istate),
             None, 0, None, 0, C.c_uint64(self._seed))
         if not self.train:
-            self._bwd, self._opt = [], []
+            self._bwd, self._opt, self._wgrad_branches = [], [], [[]]
             return
 
         bwd = []
+        wb = H.WriteBwd(_ptr(self.d_recon), _ptr(self.vrec), _ptr(self.att), _ptr(self.d_genpre),
+                        _ptr(self.d_sxyw), B, N, Cc, w)
+        keep.append(wb)
+        bwd.append(self._call("air_write_bwd", C.byref(wb), nbytes=NB * ((D + 2 * d) * 4 + 32), tag="write_bwd"))
+        # decoder data-grads over all N*B rows: dX = dY . W^T, times softplus'(saved activation)
+        dy, n_out, wname = self.d_genpre, d, "out_w"
+        for i in reversed(range(len(gen_u))):
+            u = gen_u[i]
+            bwd.append(self._gemm(dy, P[wname], self.d_gen[i], NB, u, n_out, n_out, n_out, u, tb=1,
+                                  aux=self.gen_act[i], ldaux=u, actgrad=H.GRAD_SOFTPLUS, tag="dgrad_gen"))
+            dy, n_out, wname = self.d_gen[i], u, "gen%d_w" % i
+        bwd.append(self._gemm(dy, P[wname], self.d_ml, NB, Z, n_out, n_out, n_out, 2 * Z, tb=1,
+                              epi=H.EPI_REPARAM_BWD, p=(self.ml, self.eps_z, self.att, self.dyn),
+                              extra_bytes=16 * NB * Z, tag="dz_reparam"))
+        dy, n_out, wname = self.d_ml, 2 * Z, "ml_w"
+        for i in reversed(range(len(rec_u))):
+            u = rec_u[i]
+            bwd.append(self._gemm(dy, P[wname], self.d_rec[i], NB, u, n_out, n_out, n_out, u, tb=1,
+                                  aux=self.rec_act[i], ldaux=u, actgrad=H.GRAD_SOFTPLUS, tag="dgrad_rec"))
+            dy, n_out, wname = self.d_rec[i], u, "rec%d_w" % i
+        bwd.append(self._gemm(dy, P[wname], self.d_window, NB, d, n_out, n_out, n_out, d, tb=1, tag="dgrad_win"))
+        ab = H.AttendBwd(_ptr(self.hid), _ptr(P["wout"]), _ptr(imgs), _ptr(self.eps_scale),
+                         _ptr(self.eps_shift), _ptr(self.dyn), _ptr(self.out7), _ptr(self.att),
+                         _ptr(self.d_window), _ptr(self.d_sxyw), _ptr(self.d_hid), _ptr(self.d_out7),
+                         B, N, Cc, w, Hs, Hh, Hz, Hmax)
+        keep.append(ab)
+        bwd.append(self._call("air_attend_bwd", C.byref(ab), nbytes=NB * ((D + d + 2 * HT) * 4 + 64), tag="attend_bwd"))
+        # heads' contribution to d loss / d h'[t] for every step
+        bwd.append(self._gemm(self.d_hid, P["whid"], self.dh_heads, NB, R, HT, HT, HT, R, tb=1, tag="dh_heads"))
+        # back-propagation through time: the only sequential part of the backward
         for t in reversed(range(N)):
-            wb = H.WriteBwd(_ptr(self.d_recon), _ptr(self.vrec[t]), _ptr(self.att[t]), _ptr(self.d_genpre[t]),
-                            _ptr(self.d_sxyw), B, Cc, w)
-            keep.append(wb)
-            bwd.append(self._call("air_write_bwd", C.byref(wb), nbytes=B * ((D + 2 * d) * 4 + 32), tag="write_bwd"))
-            # decoder data-grads: dX = dY . W^T, times softplus'(saved activation)
-            dy, n_out = self.d_genpre[t], d
-            wname = "out_w"
-            for i in reversed(range(len(gen_u))):
-                u = gen_u[i]
-                bwd.append(self._gemm(dy, P[wname], self.d_gen[i][t], B, u, n_out, n_out, n_out, u, tb=1,
-                                      aux=self.gen_act[i][t], ldaux=u, actgrad=H.GRAD_SOFTPLUS))
-                dy, n_out, wname = self.d_gen[i][t], u, "gen%d_w" % i
-            bwd.append(self._gemm(dy, P[wname], self.d_zs, B, Z, n_out, n_out, n_out, Z, tb=1))
-            bwd.append(self._call("air_reparam_bwd", _ptr(self.d_zs), _ptr(self.ml[t]), _ptr(self.eps_z[t]),
-                                  _ptr(self.att[t]), _ptr(self.dyn), _ptr(self.d_ml[t]), B, Z))
-            dy, n_out, wname = self.d_ml[t], 2 * Z, "ml_w"
-            for i in reversed(range(len(rec_u))):
-                u = rec_u[i]
-                bwd.append(self._gemm(dy, P[wname], self.d_rec[i][t], B, u, n_out, n_out, n_out, u, tb=1,
-                                      aux=self.rec_act[i][t], ldaux=u, actgrad=H.GRAD_SOFTPLUS))
-                dy, n_out, wname = self.d_rec[i][t], u, "rec%d_w" % i
-            bwd.append(self._gemm(dy, P[wname], self.d_window, B, d, n_out, n_out, n_out, d, tb=1))
-            ab = H.AttendBwd(_ptr(self.hid[t]), _ptr(P["wout"]), _ptr(imgs), _ptr(self.eps_scale[t]),
-                             _ptr(self.eps_shift[t]), _ptr(self.dyn), _ptr(self.out7[t]), _ptr(self.att[t]),
-                             _ptr(self.d_window), _ptr(self.d_sxyw), _ptr(self.d_hid[t]), _ptr(self.d_out7[t]),
-                             B, Cc, w, Hs, Hh, Hz, Hmax)
-            keep.append(ab)
-            bwd.append(self._call("air_attend_bwd", C.byref(ab), nbytes=B * ((D + d + 2 * HT) * 4 + 64), tag="attend_bwd"))
             last = (t == N - 1)
             dc_cur, dc_nxt = self.dc[t % 2], self.dc[(t + 1) % 2]
-            # grad wrt h[t+1]: heads of step t (d_hid . Whid^T) + LSTM of step t+1 (dh_rec)
-            bwd.append(self._gemm(self.d_hid[t], P["whid"], self.dh_cur, B, R, HT, HT, HT, R, tb=1,
-                                  addend=None if last else self.dh_rec, ldadd=R))
-            bwd.append(self._call("air_lstm_gates_bwd", _ptr(self.dh_cur), _ptr(None if last else dc_nxt),
-                                  _ptr(self.acts[t]), _ptr(self.c[t]), _ptr(self.c[t + 1]), _ptr(self.dgates[t]),
-                                  _ptr(dc_cur), _ptr(self.dgsum), 0 if last else 1, B, R))
-            if t > 0:
-                # grad wrt h[t] through the recurrent matmul of step t (h[0] is the constant zero state)
-                bwd.append(self._gemm(self.dgates[t], Wh, self.dh_rec, B, R, 4 * R, 4 * R, 4 * R, R, tb=1))
+            if last:
+                bwd.append(self._call("air_lstm_gates_bwd", _ptr(self.dh_heads[t]), _ptr(None), _ptr(self.acts[t]),
+                                      _ptr(self.c[t]), _ptr(self.c[t + 1]), _ptr(self.dgates[t]), _ptr(dc_cur),
+                                      _ptr(self.dgsum), 0, B, R, nbytes=4 * B * R * 15, tag="lstm_bwd_last"))
+            else:
+                # d h'[t] = heads[t] + dgates[t+1] . Wh^T, LSTM pointwise backward fused in the epilogue
+                bwd.append(self._gemm(self.dgates[t + 1], Wh, self.dh_cur, B, R, 4 * R, 4 * R, 4 * R, R, tb=1,
+                                      addend=self.dh_heads[t], ldadd=R, epi=H.EPI_LSTM_BWD,
+                                      p=(self.acts[t], self.c[t], self.c[t + 1], dc_nxt),
+                                      q=(self.dgates[t], dc_cur, self.dgsum), i0=1,
+                                      extra_bytes=4 * B * R * 15, tag="bptt_lstm_bwd"))
         self._bwd = bwd
 
-        # weight grads: ONE GEMM per matrix over all N*B rows (weights are shared across time steps)
-        NB = N * B
-        wg = []
+        # weight grads: ONE GEMM per matrix over all N*B rows (weights are shared across time steps).
+        # They are mutually independent, so they are issued on forked side streams (parallel
+        # branches of the hipGraph) while the main stream is idle: the chip is otherwise empty.
+        br = [[], [], [], []]
         Gx, Gh = G["lstm_kernel"][:D], G["lstm_kernel"][D:]
-        wg.append(self._gemm(imgs, self.dgsum, Gx, D, 4 * R, B, D, 4 * R, 4 * R, ta=1))
-        wg.append(self._gemm(self.h[0], self.dgates, Gh, R, 4 * R, NB, R, 4 * R, 4 * R, ta=1))
-        wg.append(self._gemm(self.h[1], self.d_hid, G["whid"], R, HT, NB, R, HT, HT, ta=1))
-        wg.append(self._call("air_heads_out_wgrad", _ptr(self.d_out7), _ptr(self.hid), _ptr(G["wout"]),
-                             _ptr(G["bout"]), NB, Hs, Hh, Hz, Hmax))
+        br[0].append(self._gemm(imgs, self.dgsum, Gx, D, 4 * R, B, D, 4 * R, 4 * R, ta=1, tag="wgrad"))
+        br[1].append(self._gemm(self.h[0], self.dgates, Gh, R, 4 * R, NB, R, 4 * R, 4 * R, ta=1, tag="wgrad"))
+        br[1].append(self._gemm(self.h[1], self.d_hid, G["whid"], R, HT, NB, R, HT, HT, ta=1, tag="wgrad"))
+        br[1].append(self._call("air_heads_out_wgrad", _ptr(self.d_out7), _ptr(self.hid), _ptr(G["wout"]),
+                                _ptr(G["bout"]), NB, Hs, Hh, Hz, Hmax))
         x, k = self.window, d
         for i, u in enumerate(rec_u):
-            wg.append(self._gemm(x, self.d_rec[i], G["rec%d_w" % i], k, u, NB, k, u, u, ta=1))
+            br[2].append(self._gemm(x, self.d_rec[i], G["rec%d_w" % i], k, u, NB, k, u, u, ta=1, tag="wgrad"))
             x, k = self.rec_act[i], u
-        wg.append(self._gemm(x, self.d_ml, G["ml_w"], k, 2 * Z, NB, k, 2 * Z, 2 * Z, ta=1))
+        br[2].append(self._gemm(x, self.d_ml, G["ml_w"], k, 2 * Z, NB, k, 2 * Z, 2 * Z, ta=1, tag="wgrad"))
         x, k = self.zs, Z
         for i, u in enumerate(gen_u):
-            wg.append(self._gemm(x, self.d_gen[i], G["gen%d_w" % i], k, u, NB, k, u, u, ta=1))
+            br[3].append(self._gemm(x, self.d_gen[i], G["gen%d_w" % i], k, u, NB, k, u, u, ta=1, tag="wgrad"))
             x, k = self.gen_act[i], u
-        wg.append(self._gemm(x, self.d_genpre, G["out_w"], k, d, NB, k, d, d, ta=1))
+        br[3].append(self._gemm(x, self.d_genpre, G["out_w"], k, d, NB, k, d, d, ta=1, tag="wgrad"))
         cs = [(self.dgsum, G["lstm_bias"], B, 4 * R), (self.d_hid, G["bhid"], NB, HT)]
         cs += [(self.d_rec[i], G["rec%d_b" % i], NB, u) for i, u in enumerate(rec_u)]
         cs += [(self.d_ml, G["ml_b"], NB, 2 * Z)]
@@ -530,8 +540,9 @@ class AIRModel:
             chunk = cs[i0:i0 + 16]
             arr = (H.Colsum * len(chunk))(*[H.Colsum(_ptr(s), _ptr(dst), r, c, c, 0) for s, dst, r, c in chunk])
             keep.append(arr)
-            wg.append(self._call("air_colsum", arr, len(chunk)))
-        self._bwd += wg
+            br[2].append(self._call("air_colsum", arr, len(chunk)))
+        self._wgrad_branches = br
+        self._side_streams = None
 
         self._opt = [
             self._call("air_grad_sqnorm", _ptr(st.grads), st.n, _ptr(st.partials), _ptr(st.istate),
@@ -566,7 +577,6 @@ class AIRModel:
 
     def _run_forward(self, s):
         (self._begin_sched_only if self._injected_noise else self._begin)(s)
-        self.state.zero_()
         for op in self._fwd:
             op(s)
 
@@ -593,11 +603,32 @@ class AIRModel:
             self._opt_world = world
         return self._opt
 
+    def _run_backward(self, s):
+        for op in self._bwd:
+            op(s)
+        # fork: independent weight-grad branches on side streams; join before the optimizer
+        if os.environ.get("AIR_SIDE_STREAMS", "0") != "1":
+            for ops in self._wgrad_branches:
+                for op in ops:
+                    op(s)
+            return
+        if self._side_streams is None:
+            self._side_streams = [torch.cuda.Stream(self.input_images.device) for _ in self._wgrad_branches[1:]]
+        main = torch.cuda.current_stream(self.input_images.device)
+        for st_, ops in zip(self._side_streams, self._wgrad_branches[1:]):
+            st_.wait_stream(main)
+            sp = C.c_void_p(st_.cuda_stream)
+            for op in ops:
+                op(sp)
+        for op in self._wgrad_branches[0]:
+            op(s)
+        for st_ in self._side_streams:
+            main.wait_stream(st_)
+
     def _train_phase_a(self, s):
         """step prologue + forward + loss + backward (+ weight grads) into the flat grad buffer"""
         self._run_forward(s)
-        for op in self._bwd:
-            op(s)
+        self._run_backward(s)
 
     def _train_phase_b(self, s):
         """global-norm clip + TF-style Adam + global_step += 1 (after the all-reduce)"""
@@ -617,8 +648,7 @@ class AIRModel:
         with torch.cuda.stream(side):            # warm-up outside capture (lazy module loads, LDS attributes)
             s = self._stream()
             self._run_forward(s)
-            for op in self._bwd:
-                op(s)
+            self._run_backward(s)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         ga = torch.cuda.CUDAGraph()

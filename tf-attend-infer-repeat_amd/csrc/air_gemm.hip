@@ -1,19 +1,27 @@
 // Small-batch GEMM with fused epilogues for the AIR loop (LSTM / heads / VAE
-// MatMul + BiasAdd + activation and their gradients).
+// MatMul + BiasAdd + activation, their data- and weight-gradients).
 //
-// Shapes on this path are skinny: M = batch (64..256) for forward / data-grad,
-// or the contraction is N_steps*batch (192) for weight-grad.  The kernel is
-// therefore built for LATENCY, not for peak MFMA rate:
-//   * one workgroup = 4 waves = one (16*TM x 16*TN) output tile; the 4 waves
-//     split every K-chunk four ways (one wave per SIMD -> 4 matrix pipes work on
-//     the same tile) and are summed through LDS in a fixed order (deterministic);
-//   * operands are read from HBM/L2 exactly once per workgroup with coalesced
-//     loads, register-prefetched one chunk ahead, and transposed through LDS
-//     into the MFMA fragment order so all four layout cases (NN, NT, TN) are
-//     conflict-free on the read side;
-//   * precision 0 uses v_mfma_f32_16x16x4_f32 (exact fp32: bit-equal to an fmaf
-//     chain) -- the parity path; precision 1 rounds both operands to bf16 while
-//     staging and uses v_mfma_f32_16x16x32_bf16 with fp32 accumulation.
+// Shapes on this path are skinny (M = batch = 64..256, or the contraction is
+// N_steps*batch = 192), so the kernel is built for LATENCY, not peak MFMA rate:
+//   * one workgroup = 4 waves = one (16*TM x 16*TN) output tile.  The whole
+//     K-panel of both operands (<= ~1024 deep) is staged in LDS with ONE
+//     barrier: every thread issues all of its 16-byte global loads up front
+//     (one memory latency), the four waves then run their MFMA chains
+//     back-to-back on interleaved k-steps (one wave per SIMD = four matrix
+//     pipes on the same tile) and are summed through LDS in a fixed order
+//     (deterministic, no atomics);
+//   * lane->element maps of the staging stores are chosen per layout so that
+//     the transposing LDS stores and the fragment reads are bank-conflict free
+//     (k-major images, row strides = 17 or = 16 mod 32 dwords);
+//   * "grouped" column tiles (tile j covers columns n0 + j*gstride ..+16) put
+//     the four LSTM gates / the (mean, log-variance) pair of one unit in the
+//     same lane, so the pointwise LSTM / re-parameterisation math is fused into
+//     the GEMM epilogue (no extra launches, no round trip through HBM);
+//   * grid.z splits K into slabs for the one deep contraction (x.Wx, K = 2500);
+//     the consumer (LSTM epilogue) sums the slabs in fixed order;
+//   * precision 0: v_mfma_f32_16x16x4_f32 (exact fp32, bit-equal to an fmaf
+//     chain); precision 1: operands rounded to bf16 while staging,
+//     v_mfma_f32_16x16x32_bf16, fp32 accumulate.
 #include "air_common.h"
 
 namespace {
@@ -21,7 +29,6 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int BK = 128;        // K-chunk per workgroup iteration (32 per wave)
 constexpr int THREADS = 256;
 
 __device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
@@ -31,121 +38,145 @@ __device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
     return (unsigned short)(u >> 16);
 }
 
-struct Epilogue {
+struct Args {
+    const float* A; const float* B; float* C;
+    int M, N, K, lda, ldb, ldc;
+    int gstride, gwidth;          // grouped column tiles: col(j, c) = n0 + j*gstride + c, valid if n0 + c < gwidth
+    int kslab; long slab_stride;  // grid.z split-K: k-range per z, output slab stride (floats)
     const float* bias; const float* addend; const float* aux;
-    float* C;
-    int ldc, ldadd, ldaux;
+    int ldadd, ldaux, add_slabs; long add_slab_stride;
     float aux_scale;
-    int act, actgrad, accumulate;
-
-    __device__ __forceinline__ void apply(float v, int m, int n) const {
-        if (bias) v += bias[n];
-        if (addend) v += addend[(size_t)m * ldadd + n];
-        if (act == AIR_ACT_RELU) v = fmaxf(v, 0.0f);
-        else if (act == AIR_ACT_SOFTPLUS) v = air_softplus(v);
-        else if (act == AIR_ACT_SIGMOID_NOISE) v = air_sigmoid(v + aux[(size_t)m * ldaux + n] * aux_scale);
-        if (actgrad == AIR_GRAD_RELU) v = (aux[(size_t)m * ldaux + n] > 0.0f) ? v : 0.0f;
-        else if (actgrad == AIR_GRAD_SOFTPLUS) v = v * (1.0f - expf(-aux[(size_t)m * ldaux + n]));
-        float* c = C + (size_t)m * ldc + n;
-        if (accumulate) v += *c;
-        *c = v;
-    }
+    int act, actgrad, accumulate, epi;
+    // fused-epilogue operands
+    const float* p0; const float* p1; const float* p2; const float* p3; const float* p4;
+    float* q0; float* q1; float* q2; float* q3;
+    int i0, i1;
 };
 
-// ---------------------------------------------------------------------------
-// fp32 path: v_mfma_f32_16x16x4_f32.  A frag: lane l holds A[m=l&15][k=l>>4];
-// B frag: B[k=l>>4][n=l&15]; C/D: col = l&15, row = (l>>4)*4 + reg.
-// LDS images are k-major ([k][m] / [k][n]) so a fragment read is 16 consecutive
-// floats per k row -> conflict-free.
-// ---------------------------------------------------------------------------
-template <int TM, int TN, bool TA, bool TB>
-__global__ __launch_bounds__(THREADS) void gemm_f32_kernel(
-    const float* __restrict__ A, const float* __restrict__ B,
-    int M, int N, int K, int lda, int ldb, Epilogue ep)
-{
-    constexpr int BM = 16 * TM, BN = 16 * TN;
-    constexpr int LA = BM + 1, LB = BN + 1;          // +1 pad: transposing stores spread over banks
-    constexpr int NA = BM * BK / THREADS;            // staged floats per thread
-    constexpr int NB = BN * BK / THREADS;
-    __shared__ float As[BK * LA];
-    __shared__ float Bs[BK * LB];
-    __shared__ float Red[3 * TM * TN * 4 * 64];
+__device__ __forceinline__ void generic_store(const Args& a, float v, int m, int n) {
+    if (a.bias) v += a.bias[n];
+    if (a.addend) {
+        for (int s = 0; s < a.add_slabs; ++s) v += a.addend[s * a.add_slab_stride + (size_t)m * a.ldadd + n];
+    }
+    if (a.act == AIR_ACT_RELU) v = fmaxf(v, 0.0f);
+    else if (a.act == AIR_ACT_SOFTPLUS) v = air_softplus(v);
+    else if (a.act == AIR_ACT_SIGMOID_NOISE) v = air_sigmoid(v + a.aux[(size_t)m * a.ldaux + n] * a.aux_scale);
+    if (a.actgrad == AIR_GRAD_RELU) v = (a.aux[(size_t)m * a.ldaux + n] > 0.0f) ? v : 0.0f;
+    else if (a.actgrad == AIR_GRAD_SOFTPLUS) v = v * (1.0f - expf(-a.aux[(size_t)m * a.ldaux + n]));
+    float* c = a.C + (size_t)m * a.ldc + n;
+    if (a.accumulate) v += *c;
+    *c = v;
+}
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-
-    float ra[NA], rb[NB];
-    auto fetch = [&](int k0) {
+// Epilogue over the reduced tile values held in Red[(t*4 + q)*64 + lane]
+// (t = i*TN + j; C/D map: row = (lane>>4)*4 + q, col = lane&15).
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue(const Args& a, const float* Red, int m0, int n0, int lane, int wave) {
+    if (a.epi == AIR_EPI_GENERIC) {
+        for (int t = wave; t < TM * TN; t += 4) {
+            const int i = t / TN, j = t % TN;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int idx = tid + i * THREADS;
-            int m, k;
-            if (TA) { k = idx / BM; m = idx % BM; } else { m = idx / BK; k = idx % BK; }
-            const int gm = m0 + m, gk = k0 + k;
-            float v = 0.0f;
-            if (gm < M && gk < K) v = TA ? A[(size_t)gk * lda + gm] : A[(size_t)gm * lda + gk];
-            ra[i] = v;
+            for (int q = 0; q < 4; ++q) {
+                const int m = m0 + i * 16 + (lane >> 4) * 4 + q;
+                const int cg = n0 + (lane & 15);
+                const int n = cg + j * a.gstride;
+                if (m < a.M && cg + (a.gstride == 16 ? j * 16 : 0) < a.gwidth && n < a.N)
+                    generic_store(a, Red[(t * 4 + q) * 64 + lane], m, n);
+            }
         }
+        return;
+    }
+    // fused epilogues: one item = (row-tile i, q); all TN group values of a unit sit in the same lane
+    for (int it = wave; it < TM * 4; it += 4) {
+        const int i = it >> 2, q = it & 3;
+        const int m = m0 + i * 16 + (lane >> 4) * 4 + q;
+        const int u = n0 + (lane & 15);
+        if (m >= a.M || u >= a.gwidth) continue;
+        float v[TN];
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int idx = tid + i * THREADS;
-            int n, k;
-            if (TB) { n = idx / BK; k = idx % BK; } else { k = idx / BN; n = idx % BN; }
-            const int gn = n0 + n, gk = k0 + k;
-            float v = 0.0f;
-            if (gn < N && gk < K) v = TB ? B[(size_t)gn * ldb + gk] : B[(size_t)gk * ldb + gn];
-            rb[i] = v;
-        }
-    };
-    auto stage = [&]() {
+        for (int j = 0; j < TN; ++j) v[j] = Red[((i * TN + j) * 4 + q) * 64 + lane];
+        if (a.epi == AIR_EPI_LSTM_FWD) {
+            // BasicLSTMCell (air_model.py:286): gates = [x,h].K + b -> i, j, f, o; forget bias 1.0
+            // p0 = c_prev [M,R]; addend slabs = hoisted x.Wx; q0 = acts [M,4R], q1 = c, q2 = h
+            if (TN == 4) {
+                const int R = a.gwidth;
+                float g[4];
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int idx = tid + i * THREADS;
-            int m, k;
-            if (TA) { k = idx / BM; m = idx % BM; } else { m = idx / BK; k = idx % BK; }
-            As[k * LA + m] = ra[i];
-        }
+                for (int j = 0; j < 4; ++j) {
+                    float s = v[j % TN];
+                    const int n = u + j * R;
+                    float sl[8];
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int idx = tid + i * THREADS;
-            int n, k;
-            if (TB) { n = idx / BK; k = idx % BK; } else { k = idx / BN; n = idx % BN; }
-            Bs[k * LB + n] = rb[i];
-        }
-    };
-
-    f32x4 acc[TM][TN];
+                    for (int k = 0; k < 8; ++k)        // independent loads, fixed summation order
+                        sl[k] = (k < a.add_slabs) ? a.addend[k * a.add_slab_stride + (size_t)m * a.ldadd + n] : 0.0f;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    fetch(0);
-    for (int k0 = 0; k0 < K; k0 += BK) {
-        __syncthreads();                 // previous chunk fully consumed
-        stage();
-        __syncthreads();
-        if (k0 + BK < K) fetch(k0 + BK); // next chunk in flight under the MFMAs
-        const int kw = wave * (BK / 4);
-#pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            const int kk = kw + ks * 4 + (lane >> 4);
-            float a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[kk * LA + i * 16 + (lane & 15)];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bs[kk * LB + j * 16 + (lane & 15)];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    for (int k = 0; k < 8; ++k) s += sl[k];
+                    if (a.bias) s += a.bias[n];
+                    g[j] = s;
+                }
+                const float si = air_sigmoid(g[0]), tj = tanhf(g[1]);
+                const float sf = air_sigmoid(g[2] + 1.0f), so = air_sigmoid(g[3]);
+                const float cn = a.p0[(size_t)m * R + u] * sf + si * tj;
+                float* ac = a.q0 + (size_t)m * 4 * R;
+                ac[u] = si; ac[R + u] = tj; ac[2 * R + u] = sf; ac[3 * R + u] = so;
+                a.q1[(size_t)m * R + u] = cn;
+                a.q2[(size_t)m * R + u] = tanhf(cn) * so;
+            }
+        } else if (a.epi == AIR_EPI_REPARAM_FWD) {
+            // vae.py:16-24: mean | log_var (+bias), sample = mean + eps*sqrt(exp(lv))
+            // C = ml [M,2Z]; p0 = eps [M,Z]; q0 = zs [M,Z]
+            if (TN == 2) {
+                const int Z = a.gwidth;
+                const float mean = v[0] + (a.bias ? a.bias[u] : 0.0f);
+                const float lv = v[1 % TN] + (a.bias ? a.bias[Z + u] : 0.0f);
+                a.C[(size_t)m * a.ldc + u] = mean;
+                a.C[(size_t)m * a.ldc + Z + u] = lv;
+                a.q0[(size_t)m * Z + u] = mean + a.p0[(size_t)m * Z + u] * sqrtf(expf(lv));
+            }
+        } else if (a.epi == AIR_EPI_LSTM_BWD) {
+            // v[0] (+ addend) = d loss / d h'.  p0 = acts, p1 = c_prev, p2 = c, p3 = dc_in (nullable)
+            // q0 = dgates [M,4R], q1 = dc_prev [M,R], q2 = dgsum [M,4R] (nullable; i0 = accumulate)
+            const int R = a.gwidth;
+            float dhv = v[0];
+            if (a.addend) dhv += a.addend[(size_t)m * a.ldadd + u];
+            const float* ac = a.p0 + (size_t)m * 4 * R;
+            const float si = ac[u], tj = ac[R + u], sf = ac[2 * R + u], so = ac[3 * R + u];
+            const size_t idx = (size_t)m * R + u;
+            const float tc = tanhf(a.p2[idx]);
+            const float dc = (a.p3 ? a.p3[idx] : 0.0f) + dhv * so * (1.0f - tc * tc);
+            const float dgi = dc * tj * si * (1.0f - si);
+            const float dgj = dc * si * (1.0f - tj * tj);
+            const float dgf = dc * a.p1[idx] * sf * (1.0f - sf);
+            const float dgo = dhv * tc * so * (1.0f - so);
+            float* dg = a.q0 + (size_t)m * 4 * R;
+            dg[u] = dgi; dg[R + u] = dgj; dg[2 * R + u] = dgf; dg[3 * R + u] = dgo;
+            a.q1[idx] = dc * sf;
+            if (a.q2) {
+                float* ds = a.q2 + (size_t)m * 4 * R;
+                if (a.i0) { ds[u] += dgi; ds[R + u] += dgj; ds[2 * R + u] += dgf; ds[3 * R + u] += dgo; }
+                else { ds[u] = dgi; ds[R + u] = dgj; ds[2 * R + u] = dgf; ds[3 * R + u] = dgo; }
+            }
+        } else if (a.epi == AIR_EPI_REPARAM_BWD) {
+            // v[0] = d loss / d z-sample.  p0 = ml [M,2Z], p1 = eps, p2 = att (mask), p3 = dyn; C = d_ml [M,2Z]
+            const int Z = a.gwidth;
+            const float* r = a.p0 + (size_t)m * 2 * Z;
+            const float klg = a.p2[(size_t)m * AIR_ATT_STRIDE + AIR_ATT_MASK] * a.p3[AIR_DYN_GRAD_SCALE];
+            const float pv = a.p3[AIR_DYN_VAE_PV], pm = a.p3[AIR_DYN_VAE_PM];
+            const float var = expf(r[Z + u]);
+            const float sd = sqrtf(var);
+            const float d = v[0];
+            a.C[(size_t)m * a.ldc + u] = d + klg * (r[u] - pm) / pv;
+            a.C[(size_t)m * a.ldc + Z + u] = d * a.p1[(size_t)m * Z + u] * 0.5f * sd + klg * 0.5f * (var / pv - 1.0f);
         }
     }
+}
 
-    // cross-wave (split-K) reduction in a fixed order: ((w0 + w1) + w2) + w3
+// cross-wave (split-K) reduction in a fixed order: ((w0 + w1) + w2) + w3, result in Red region 0
+template <int TM, int TN>
+__device__ __forceinline__ void reduce_waves(f32x4 (&acc)[TM][TN], float* Red, int lane, int wave) {
+    constexpr int RS = TM * TN * 4 * 64;
     if (wave > 0) {
-        float* r = Red + (wave - 1) * (TM * TN * 4 * 64);
+        float* r = Red + (wave - 1) * RS;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -161,37 +192,237 @@ __global__ __launch_bounds__(THREADS) void gemm_f32_kernel(
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
+                    const int o = ((i * TN + j) * 4 + q) * 64 + lane;
                     float v = acc[i][j][q];
 #pragma unroll
-                    for (int w = 0; w < 3; ++w) v += Red[w * (TM * TN * 4 * 64) + ((i * TN + j) * 4 + q) * 64 + lane];
-                    Red[((i * TN + j) * 4 + q) * 64 + lane] = v;   // own slot of region 0: no hazard
+                    for (int w = 0; w < 3; ++w) v += Red[w * RS + o];
+                    Red[o] = v;
                 }
     }
     __syncthreads();
-    // epilogue by all 4 waves: tile t handled by wave (t & 3)
-    for (int t = wave; t < TM * TN; t += 4) {
-        const int i = t / TN, j = t % TN;
+}
+
+__device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// ---------------------------------------------------------------------------
+// fp32: whole K-panel in LDS, k-major images As[k][LA], Bs[k][LB].
+// A frag: lane l holds A[m = l&15][k = l>>4]; B frag: B[k = l>>4][n = l&15].
+// ---------------------------------------------------------------------------
+template <int TM, int TN, bool TA, bool TB>
+__global__ __launch_bounds__(THREADS) void gemm_f32_kernel(Args a, int KP)
+{
+    constexpr int BM = 16 * TM, BN = 16 * TN;
+    // transposing stores (NN-A, NT-B) want an odd stride; direct 16-byte stores want stride = 16 (mod 32)
+    constexpr int LA = TA ? (BM == 16 ? 16 : BM + 16) : BM + 1;
+    constexpr int LB = TB ? BN + 1 : (BN == 16 ? 16 : BN + 16);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    float* Bs = smem + (size_t)KP * LA;
+    float* Red = Bs + (size_t)KP * LB;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN / TN * (a.gstride == 16 ? TN : 1);
+    const int kbeg = blockIdx.z * a.kslab;
+    const int kend = min(a.K, kbeg + a.kslab);
+
+    f32x4 acc[TM][TN];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int m = m0 + i * 16 + (lane >> 4) * 4 + q;
-            const int n = n0 + j * 16 + (lane & 15);
-            if (m < M && n < N) ep.apply(Red[(t * 4 + q) * 64 + lane], m, n);
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const bool vecA = ((a.lda & 3) == 0) && aligned16(a.A);
+    const bool vecB = ((a.ldb & 3) == 0) && aligned16(a.B) && ((a.gstride & 3) == 0);
+
+    for (int k0 = kbeg; k0 < kend; k0 += KP) {
+        const int kp = min(KP, kend - k0);            // valid depth of this panel
+        const int kp4 = (kp + 3) & ~3;
+        if (k0 > kbeg) __syncthreads();
+        // ---------------- stage A and B: all 16-byte loads of a batch are issued before any
+        // LDS store, so a panel costs ~one memory latency, not one per row ----------------
+        const int nq = kp4 >> 2;                        // float4 columns along k
+        const int nq16 = (nq + 15) >> 4;
+        auto loadA = [&](int i) -> float4 {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!TA) {
+                // A[m*lda + k]: lane map (m_lo = l&3, k4_lo = l>>2) -> conflict-free transposing stores
+                const int g = wave + 4 * i;
+                if (g >= nq16 * (BM / 4)) return v;
+                const int m = (g % (BM / 4)) * 4 + (lane & 3);
+                const int k4 = (g / (BM / 4)) * 16 + (lane >> 2);
+                const int gm = m0 + m, gk = k0 + k4 * 4;
+                if (gm < a.M && k4 < nq) {
+                    const float* src = a.A + (size_t)gm * a.lda + gk;
+                    if (vecA && gk + 3 < kend) v = *reinterpret_cast<const float4*>(src);
+                    else {
+                        if (gk < kend) v.x = src[0];
+                        if (gk + 1 < kend) v.y = src[1];
+                        if (gk + 2 < kend) v.z = src[2];
+                        if (gk + 3 < kend) v.w = src[3];
+                    }
+                }
+            } else {
+                // A[k*lda + m]: 16-byte loads along m
+                constexpr int MQ = BM / 4;
+                const int it = tid + THREADS * i;
+                if (it >= kp4 * MQ) return v;
+                const int k = it / MQ, mq = it % MQ;
+                const int gm = m0 + mq * 4, gk = k0 + k;
+                if (gk < kend) {
+                    const float* src = a.A + (size_t)gk * a.lda + gm;
+                    if (vecA && gm + 3 < a.M) v = *reinterpret_cast<const float4*>(src);
+                    else {
+                        if (gm < a.M) v.x = src[0];
+                        if (gm + 1 < a.M) v.y = src[1];
+                        if (gm + 2 < a.M) v.z = src[2];
+                        if (gm + 3 < a.M) v.w = src[3];
+                    }
+                }
+            }
+            return v;
+        };
+        auto storeA = [&](int i, const float4& v) {
+            if (!TA) {
+                const int g = wave + 4 * i;
+                if (g >= nq16 * (BM / 4)) return;
+                const int m = (g % (BM / 4)) * 4 + (lane & 3);
+                const int k4 = (g / (BM / 4)) * 16 + (lane >> 2);
+                if (k4 < nq) {
+                    float* d = As + (size_t)(k4 * 4) * LA + m;
+                    d[0] = v.x; d[LA] = v.y; d[2 * LA] = v.z; d[3 * LA] = v.w;
+                }
+            } else {
+                constexpr int MQ = BM / 4;
+                const int it = tid + THREADS * i;
+                if (it >= kp4 * MQ) return;
+                *reinterpret_cast<float4*>(As + (size_t)(it / MQ) * LA + (it % MQ) * 4) = v;
+            }
+        };
+        auto loadB = [&](int i) -> float4 {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (TB) {
+                // B[n*ldb + k] (k contiguous): same map as NN-A
+                const int g = wave + 4 * i;
+                if (g >= nq16 * (BN / 4)) return v;
+                const int n = (g % (BN / 4)) * 4 + (lane & 3);
+                const int k4 = (g / (BN / 4)) * 16 + (lane >> 2);
+                const int gn = n0 + n, gk = k0 + k4 * 4;
+                if (gn < a.N && k4 < nq) {
+                    const float* src = a.B + (size_t)gn * a.ldb + gk;
+                    if (vecB && gk + 3 < kend) v = *reinterpret_cast<const float4*>(src);
+                    else {
+                        if (gk < kend) v.x = src[0];
+                        if (gk + 1 < kend) v.y = src[1];
+                        if (gk + 2 < kend) v.z = src[2];
+                        if (gk + 3 < kend) v.w = src[3];
+                    }
+                }
+            } else {
+                // B[k*ldb + n]: 16-byte loads along n (per 16-column group)
+                constexpr int NQ = BN / 4;
+                const int it = tid + THREADS * i;
+                if (it >= kp4 * NQ) return v;
+                const int k = it / NQ, q4 = it % NQ;
+                const int j = q4 >> 2, c = (q4 & 3) * 4;
+                const int cg = n0 + c + (a.gstride == 16 ? j * 16 : 0);   // bound-check coordinate
+                const int gn = n0 + j * a.gstride + c, gk = k0 + k;
+                if (gk < kend) {
+                    const float* src = a.B + (size_t)gk * a.ldb + gn;
+                    const int lim = min(a.gwidth - cg, a.N - gn);        // valid columns from here
+                    if (vecB && lim >= 4) v = *reinterpret_cast<const float4*>(src);
+                    else {
+                        if (lim > 0) v.x = src[0];
+                        if (lim > 1) v.y = src[1];
+                        if (lim > 2) v.z = src[2];
+                        if (lim > 3) v.w = src[3];
+                    }
+                }
+            }
+            return v;
+        };
+        auto storeB = [&](int i, const float4& v) {
+            if (TB) {
+                const int g = wave + 4 * i;
+                if (g >= nq16 * (BN / 4)) return;
+                const int n = (g % (BN / 4)) * 4 + (lane & 3);
+                const int k4 = (g / (BN / 4)) * 16 + (lane >> 2);
+                if (k4 < nq) {
+                    float* d = Bs + (size_t)(k4 * 4) * LB + n;
+                    d[0] = v.x; d[LB] = v.y; d[2 * LB] = v.z; d[3 * LB] = v.w;
+                }
+            } else {
+                constexpr int NQ = BN / 4;
+                const int it = tid + THREADS * i;
+                if (it >= kp4 * NQ) return;
+                *reinterpret_cast<float4*>(Bs + (size_t)(it / NQ) * LB + (it % NQ) * 4) = v;
+            }
+        };
+        constexpr int U = 8;
+        const int nA = TA ? (kp4 * (BM / 4) + THREADS - 1) / THREADS : (nq16 * (BM / 4) + 3) / 4;
+        const int nB = TB ? (nq16 * (BN / 4) + 3) / 4 : (kp4 * (BN / 4) + THREADS - 1) / THREADS;
+        for (int b0 = 0; b0 < max(nA, nB); b0 += U) {
+            float4 va[U], vb[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) va[u] = loadA(b0 + u);
+#pragma unroll
+            for (int u = 0; u < U; ++u) vb[u] = loadB(b0 + u);
+#pragma unroll
+            for (int u = 0; u < U; ++u) storeA(b0 + u, va[u]);
+#pragma unroll
+            for (int u = 0; u < U; ++u) storeB(b0 + u, vb[u]);
+        }
+        __syncthreads();
+        // ---------------- MFMA: wave w takes k-steps w, w+4, ...; fragments of 8 steps are read
+        // from LDS before their MFMAs issue (LDS latency paid once per 8 steps, not per step) ------
+        const int steps = kp4 >> 2;
+        constexpr int SU = 8;
+        for (int s0 = wave; s0 < steps; s0 += 4 * SU) {
+            float av[SU][TM], bv[SU][TN];
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                const int sidx = s0 + 4 * u;
+                const bool ok = sidx < steps;                       // wave-uniform
+                const int kk = (ok ? sidx : s0) * 4 + (lane >> 4);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) { const float t = As[(size_t)kk * LA + i * 16 + (lane & 15)]; av[u][i] = ok ? t : 0.0f; }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) { const float t = Bs[(size_t)kk * LB + j * 16 + (lane & 15)]; bv[u][j] = ok ? t : 0.0f; }
+            }
+#pragma unroll
+            for (int u = 0; u < SU; ++u)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][i], bv[u][j], acc[i][j], 0, 0, 0);
         }
     }
+    reduce_waves<TM, TN>(acc, Red, lane, wave);
+    if (gridDim.z > 1) {
+        // split-K slab: plain store, the consumer sums the slabs
+        float* Cz = a.C + (size_t)blockIdx.z * a.slab_stride;
+        for (int t = wave; t < TM * TN; t += 4) {
+            const int i = t / TN, j = t % TN;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = m0 + i * 16 + (lane >> 4) * 4 + q;
+                const int n = n0 + j * 16 + (lane & 15);
+                if (m < a.M && n < a.N) Cz[(size_t)m * a.ldc + n] = Red[(t * 4 + q) * 64 + lane];
+            }
+        }
+        return;
+    }
+    epilogue<TM, TN>(a, Red, m0, n0, lane, wave);
 }
 
 // ---------------------------------------------------------------------------
-// bf16 path: v_mfma_f32_16x16x32_bf16.  A frag: lane l holds 8 consecutive k
-// (k = (l>>4)*8 .. +7) of row m = l&15; B frag likewise for column n = l&15.
-// LDS images are [m][k] / [n][k] with k contiguous (one 16-byte read per
-// fragment); rows padded by 8 halves so the 16 rows of a lane group start on
-// different 16-byte slots.
+// bf16 path: 128-deep K chunks, operands rounded to bf16 while staging into
+// [m][k] / [n][k] images (k contiguous, one 16-byte fragment read per MFMA).
 // ---------------------------------------------------------------------------
 template <int TM, int TN, bool TA, bool TB>
-__global__ __launch_bounds__(THREADS) void gemm_bf16_kernel(
-    const float* __restrict__ A, const float* __restrict__ B,
-    int M, int N, int K, int lda, int ldb, Epilogue ep)
+__global__ __launch_bounds__(THREADS) void gemm_bf16_kernel(Args a)
 {
+    constexpr int BK = 128;
     constexpr int BM = 16 * TM, BN = 16 * TN;
     constexpr int LK = BK + 8;                       // halves per row
     constexpr int NA = BM * BK / THREADS;
@@ -201,7 +432,9 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16_kernel(
     __shared__ float Red[3 * TM * TN * 4 * 64];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN / TN * (a.gstride == 16 ? TN : 1);
+    const int kbeg = blockIdx.z * a.kslab;
+    const int kend = min(a.K, kbeg + a.kslab);
 
     float ra[NA], rb[NB];
     auto fetch = [&](int k0) {
@@ -212,7 +445,7 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16_kernel(
             if (TA) { k = idx / BM; m = idx % BM; } else { m = idx / BK; k = idx % BK; }
             const int gm = m0 + m, gk = k0 + k;
             float v = 0.0f;
-            if (gm < M && gk < K) v = TA ? A[(size_t)gk * lda + gm] : A[(size_t)gm * lda + gk];
+            if (gm < a.M && gk < kend) v = TA ? a.A[(size_t)gk * a.lda + gm] : a.A[(size_t)gm * a.lda + gk];
             ra[i] = v;
         }
 #pragma unroll
@@ -220,9 +453,12 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16_kernel(
             const int idx = tid + i * THREADS;
             int n, k;
             if (TB) { n = idx / BK; k = idx % BK; } else { k = idx / BN; n = idx % BN; }
-            const int gn = n0 + n, gk = k0 + k;
+            const int j = n >> 4, c = n & 15;
+            const int cg = n0 + c + (a.gstride == 16 ? j * 16 : 0);
+            const int gn = n0 + j * a.gstride + c, gk = k0 + k;
             float v = 0.0f;
-            if (gn < N && gk < K) v = TB ? B[(size_t)gn * ldb + gk] : B[(size_t)gk * ldb + gn];
+            if (cg < a.gwidth && gn < a.N && gk < kend)
+                v = TB ? a.B[(size_t)gn * a.ldb + gk] : a.B[(size_t)gk * a.ldb + gn];
             rb[i] = v;
         }
     };
@@ -249,85 +485,105 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16_kernel(
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    fetch(0);
-    for (int k0 = 0; k0 < K; k0 += BK) {
+    fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
         __syncthreads();
         stage();
         __syncthreads();
-        if (k0 + BK < K) fetch(k0 + BK);
-        // wave w owns k in [w*32, w*32+32) of the chunk: exactly one 16x16x32 step
-        const int kk = wave * 32 + (lane >> 4) * 8;
-        bf16x8 a[TM], b[TN];
+        if (k0 + BK < kend) fetch(k0 + BK);
+        const int kk = wave * 32 + (lane >> 4) * 8;   // wave w owns k in [w*32, w*32+32): one 16x16x32 step
+        bf16x8 av[TM], bv[TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(&As[(i * 16 + (lane & 15)) * LK + kk]);
+        for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const bf16x8*>(&As[(i * 16 + (lane & 15)) * LK + kk]);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8*>(&Bs[(j * 16 + (lane & 15)) * LK + kk]);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-
-    if (wave > 0) {
-        float* r = Red + (wave - 1) * (TM * TN * 4 * 64);
+        for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const bf16x8*>(&Bs[(j * 16 + (lane & 15)) * LK + kk]);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) r[((i * TN + j) * 4 + q) * 64 + lane] = acc[i][j][q];
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
     }
-    __syncthreads();
-    if (wave == 0) {
+    reduce_waves<TM, TN>(acc, Red, lane, wave);
+    if (gridDim.z > 1) {
+        float* Cz = a.C + (size_t)blockIdx.z * a.slab_stride;
+        for (int t = wave; t < TM * TN; t += 4) {
+            const int i = t / TN, j = t % TN;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float v = acc[i][j][q];
-#pragma unroll
-                    for (int w = 0; w < 3; ++w) v += Red[w * (TM * TN * 4 * 64) + ((i * TN + j) * 4 + q) * 64 + lane];
-                    Red[((i * TN + j) * 4 + q) * 64 + lane] = v;
-                }
-    }
-    __syncthreads();
-    for (int t = wave; t < TM * TN; t += 4) {
-        const int i = t / TN, j = t % TN;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int m = m0 + i * 16 + (lane >> 4) * 4 + q;
-            const int n = n0 + j * 16 + (lane & 15);
-            if (m < M && n < N) ep.apply(Red[(t * 4 + q) * 64 + lane], m, n);
+            for (int q = 0; q < 4; ++q) {
+                const int m = m0 + i * 16 + (lane >> 4) * 4 + q;
+                const int n = n0 + j * 16 + (lane & 15);
+                if (m < a.M && n < a.N) Cz[(size_t)m * a.ldc + n] = Red[(t * 4 + q) * 64 + lane];
+            }
         }
+        return;
     }
+    epilogue<TM, TN>(a, Red, m0, n0, lane, wave);
 }
 
+constexpr int LDS_BUDGET = 150 * 1024;
+
 template <int TM, int TN, bool TA, bool TB>
-int launch(const air_gemm_t* g, const Epilogue& ep, hipStream_t s) {
-    dim3 grid((g->N + 16 * TN - 1) / (16 * TN), (g->M + 16 * TM - 1) / (16 * TM));
-    if (g->precision == 1)
-        hipLaunchKernelGGL((gemm_bf16_kernel<TM, TN, TA, TB>), grid, dim3(THREADS), 0, s,
-                           g->A, g->B, g->M, g->N, g->K, g->lda, g->ldb, ep);
-    else
-        hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, TA, TB>), grid, dim3(THREADS), 0, s,
-                           g->A, g->B, g->M, g->N, g->K, g->lda, g->ldb, ep);
+int launch(const air_gemm_t* g, const Args& a0, hipStream_t s) {
+    Args a = a0;
+    constexpr int BM = 16 * TM, BN = 16 * TN;
+    const bool grouped = a.gstride != 16;
+    const int ncols = grouped ? a.gwidth : a.N;
+    dim3 grid((ncols + (grouped ? 16 : BN) - 1) / (grouped ? 16 : BN), (a.M + BM - 1) / BM, 1);
+    const int ks = g->ksplit > 1 ? g->ksplit : 1;
+    a.kslab = ((a.K + ks - 1) / ks + 3) & ~3;
+    grid.z = (a.K + a.kslab - 1) / a.kslab;
+    a.slab_stride = (long)a.M * a.ldc;
+    if (g->precision == 1) {
+        hipLaunchKernelGGL((gemm_bf16_kernel<TM, TN, TA, TB>), grid, dim3(THREADS), 0, s, a);
+    } else {
+        constexpr int LA = TA ? (BM == 16 ? 16 : BM + 16) : BM + 1;
+        constexpr int LB = TB ? BN + 1 : (BN == 16 ? 16 : BN + 16);
+        const int red = 3 * TM * TN * 4 * 64;
+        int KP = (a.kslab + 63) & ~63;
+        const int kmax = ((LDS_BUDGET / 4 - red) / (LA + LB)) & ~63;
+        if (KP > kmax) KP = kmax;
+        const size_t lds = ((size_t)KP * (LA + LB) + red) * sizeof(float);
+        auto kern = gemm_f32_kernel<TM, TN, TA, TB>;
+        static bool attr_done = false;           // per instantiation
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET);
+            if (e != hipSuccess) return (int)e;
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(THREADS), lds, s, a, KP);
+    }
     AIR_CHECK_LAUNCH();
     return 0;
 }
 
 template <bool TA, bool TB>
-int pick_tile(const air_gemm_t* g, const Epilogue& ep, hipStream_t s) {
-    // smallest tile that still yields >= ~2 workgroups per CU, else 16x16:
-    // at these sizes wall time is one workgroup's latency, so prefer many small ones.
-    const long t11 = (long)((g->M + 15) / 16) * ((g->N + 15) / 16);
-    if (t11 <= 1024) return launch<1, 1, TA, TB>(g, ep, s);
-    if (t11 <= 4096) return launch<2, 2, TA, TB>(g, ep, s);
-    return launch<2, 4, TA, TB>(g, ep, s);
+int pick_tile(const air_gemm_t* g, const Args& a, hipStream_t s) {
+    int tm = g->tile_m, tn = g->tile_n;
+    if (g->epi == AIR_EPI_LSTM_FWD) { tm = 1; tn = 4; }
+    else if (g->epi == AIR_EPI_REPARAM_FWD) { tm = 1; tn = 2; }
+    else if (g->epi != AIR_EPI_GENERIC) { tm = 1; tn = 1; }
+    if (tm == 0 || tn == 0) {
+        // at these sizes wall time ~ one workgroup's latency: prefer many small workgroups
+        const long t11 = (long)((g->M + 15) / 16) * ((g->N + 15) / 16);
+        if (t11 <= 1024) { tm = 1; tn = 1; }
+        else if (t11 <= 4096) { tm = 2; tn = 2; }
+        else { tm = 2; tn = 4; }
+    }
+#define AIR_TILE(TM_, TN_) if (tm == TM_ && tn == TN_) return launch<TM_, TN_, TA, TB>(g, a, s)
+    AIR_TILE(1, 1); AIR_TILE(1, 2); AIR_TILE(1, 4); AIR_TILE(2, 2); AIR_TILE(2, 4); AIR_TILE(4, 1); AIR_TILE(4, 2);
+#undef AIR_TILE
+    return AIR_EINVAL;
 }
 
 }  // namespace
+
+extern "C" int air_gemm_slabs(int K, int ksplit) {
+    if (K <= 0) return 0;
+    const int ks = ksplit > 1 ? ksplit : 1;
+    const int kslab = ((K + ks - 1) / ks + 3) & ~3;
+    return (K + kslab - 1) / kslab;
+}
 
 extern "C" int air_gemm(const air_gemm_t* g, void* stream) {
     if (!g || !g->A || !g->B || !g->C) return AIR_EINVAL;
@@ -335,12 +591,40 @@ extern "C" int air_gemm(const air_gemm_t* g, void* stream) {
     if (g->precision != 0 && g->precision != 1) return AIR_EINVAL;
     if ((g->act == AIR_ACT_SIGMOID_NOISE || g->actgrad != AIR_GRAD_NONE) && !g->aux) return AIR_EINVAL;
     if (g->transA && g->transB) return AIR_EINVAL;     // never needed on this path
-    Epilogue ep;
-    ep.bias = g->bias; ep.addend = g->addend; ep.aux = g->aux; ep.C = g->C;
-    ep.ldc = g->ldc; ep.ldadd = g->ldadd; ep.ldaux = g->ldaux; ep.aux_scale = g->aux_scale;
-    ep.act = g->act; ep.actgrad = g->actgrad; ep.accumulate = g->accumulate;
+    if (g->epi < AIR_EPI_GENERIC || g->epi > AIR_EPI_REPARAM_BWD) return AIR_EINVAL;
+    if (g->ksplit > 1 && g->epi != AIR_EPI_GENERIC) return AIR_EINVAL;
+    if (g->addend_slabs > 8) return AIR_ELIMIT;
+    Args a;
+    a.A = g->A; a.B = g->B; a.C = g->C;
+    a.M = g->M; a.N = g->N; a.K = g->K; a.lda = g->lda; a.ldb = g->ldb; a.ldc = g->ldc;
+    a.gstride = 16; a.gwidth = g->N;
+    a.kslab = g->K; a.slab_stride = 0;
+    a.bias = g->bias; a.addend = g->addend; a.aux = g->aux;
+    a.ldadd = g->ldadd; a.ldaux = g->ldaux;
+    a.add_slabs = g->addend ? (g->addend_slabs > 0 ? g->addend_slabs : 1) : 0;
+    a.add_slab_stride = (long)g->M * g->ldadd;
+    a.aux_scale = g->aux_scale;
+    a.act = g->act; a.actgrad = g->actgrad; a.accumulate = g->accumulate; a.epi = g->epi;
+    a.p0 = g->p0; a.p1 = g->p1; a.p2 = g->p2; a.p3 = g->p3; a.p4 = nullptr;
+    a.q0 = g->q0; a.q1 = g->q1; a.q2 = g->q2; a.q3 = nullptr;
+    a.i0 = g->i0; a.i1 = 0;
+    switch (g->epi) {
+        case AIR_EPI_LSTM_FWD:      // N = 4R gate columns, groups of R
+            if (g->transA || g->transB || (g->N & 3) || !g->p0 || !g->q0 || !g->q1 || !g->q2) return AIR_EINVAL;
+            a.gstride = g->N / 4; a.gwidth = g->N / 4; break;
+        case AIR_EPI_REPARAM_FWD:   // N = 2Z (mean | log_var)
+            if (g->transA || g->transB || (g->N & 1) || !g->p0 || !g->q0) return AIR_EINVAL;
+            a.gstride = g->N / 2; a.gwidth = g->N / 2; break;
+        case AIR_EPI_LSTM_BWD:      // N = R
+            if (!g->p0 || !g->p1 || !g->p2 || !g->q0 || !g->q1) return AIR_EINVAL;
+            a.gwidth = g->N; break;
+        case AIR_EPI_REPARAM_BWD:   // N = Z
+            if (!g->p0 || !g->p1 || !g->p2 || !g->p3) return AIR_EINVAL;
+            a.gwidth = g->N; break;
+        default: break;
+    }
     hipStream_t s = air_stream(stream);
-    if (g->transA) return pick_tile<true, false>(g, ep, s);
-    if (g->transB) return pick_tile<false, true>(g, ep, s);
-    return pick_tile<false, false>(g, ep, s);
+    if (g->transA) return pick_tile<true, false>(g, a, s);
+    if (g->transB) return pick_tile<false, true>(g, a, s);
+    return pick_tile<false, false>(g, a, s);
 }

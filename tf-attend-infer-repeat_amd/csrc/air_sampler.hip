@@ -97,25 +97,39 @@ __device__ __forceinline__ float gauss_kl_term(float plv, float lv, float var, f
 }
 
 // ---------------------------------------------------------------------------
-// attend forward: one workgroup per image
+// attend forward, TIME-BATCHED: one workgroup per (image, time step).
+// The LSTM input is the same image at every step (air_model.py:286, 535), so h'
+// of all N steps exists before any head runs; the only cross-step dependence
+// left is the scalar stopping sum S, which block (b, t) re-derives from the
+// z_pres of the earlier steps with the identical op sequence (bitwise equal).
 // ---------------------------------------------------------------------------
+constexpr int MAX_STEPS = 16;
+
+// concrete.py:20-27 + air_model.py:385-390: pre-sigmoid sample and z_pres
+__device__ __forceinline__ float concrete_presigmoid(float lo, float u, float T) {
+    const float noise = logf(u + AIR_EPS) - logf((1.0f - u) + AIR_EPS);
+    return (lo + noise) / T;
+}
+
 __global__ __launch_bounds__(THREADS) void attend_fwd_kernel(air_attend_fwd_t a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int C = a.C, w = a.w;
+    const int b = blockIdx.x, t = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int C = a.C, w = a.w, B = a.B;
     const HeadSeg hs = head_segments(a.Hs, a.Hh, a.Hz);
     const int HT = hs.off[4] + hs.wid[4];
 
     float* sh_out = smem;                       // [8]
     float* sh_sc = smem + 8;                    // [8]: s, x, y
-    Tap* sh_tx = reinterpret_cast<Tap*>(smem + 16);      // [w]
+    float* sh_zlo = smem + 16;                  // [MAX_STEPS] z log-odds of the earlier steps
+    Tap* sh_tx = reinterpret_cast<Tap*>(smem + 16 + MAX_STEPS);   // [w]
     Tap* sh_ty = sh_tx + w;                              // [w]
     int* sh_box = reinterpret_cast<int*>(sh_ty + w);     // [4]: x_lo, x_hi, y_lo, y_hi
     float* sh_hid = reinterpret_cast<float*>(sh_box + 4);   // [HT]
     float* sh_img = sh_hid + ((HT + 3) & ~3);               // [<= C*C] bounding box of the glimpse
 
-    for (int j = tid; j < HT; j += THREADS) sh_hid[j] = a.hid[(size_t)b * HT + j];
+    const size_t row = (size_t)t * B + b;
+    for (int j = tid; j < HT; j += THREADS) sh_hid[j] = a.hid[row * HT + j];
     __syncthreads();
 
     // 7 output units (air_model.py:294,299,311,316,376): x.W + b
@@ -126,24 +140,36 @@ __global__ __launch_bounds__(THREADS) void attend_fwd_kernel(air_attend_fwd_t a)
         p = air_wave_sum(p);
         if (lane == 0) sh_out[o] = p + a.bout[o];
     }
+    // z log-odds of the earlier steps t' < t (same lane assignment and reduction order as above)
+    for (int tp = wave; tp < t; tp += 4) {
+        const float* hp = a.hid + ((size_t)tp * B + b) * HT + hs.off[4];
+        float p = 0.0f;
+        for (int j = lane; j < hs.wid[4]; j += 64) p += hp[j] * a.wout[6 * a.wout_ld + j];
+        p = air_wave_sum(p);
+        if (lane == 0) sh_zlo[tp] = p + a.bout[6];
+    }
     __syncthreads();
 
     if (tid == 0) {
         const float* dyn = a.dyn;
         const float T = dyn[AIR_DYN_TEMPERATURE], thr = dyn[AIR_DYN_STOP_THRESHOLD];
+        // stopping sum on entry to step t (air_model.py:424): S += 1 - z_pres, in step order
+        float S = 0.0f;
+        for (int tp = 0; tp < t; ++tp) {
+            float zp = air_sigmoid(concrete_presigmoid(sh_zlo[tp], a.u[(size_t)tp * B + b], T));
+            if (!a.train) zp = rintf(zp);
+            S = S + (1.0f - zp);
+        }
         const float mu_s = sh_out[0], lv_s = sh_out[1];
         const float mu_x = sh_out[2], mu_y = sh_out[3], lv_x = sh_out[4], lv_y = sh_out[5];
         const float z_lo = sh_out[6];
         // scale :300-303, shift :317-320   (_sample_from_mvn :123-128)
         const float var_s = expf(lv_s);
-        const float s = air_sigmoid(mu_s + a.eps_scale[b] * sqrtf(var_s));
+        const float s = air_sigmoid(mu_s + a.eps_scale[row] * sqrtf(var_s));
         const float var_x = expf(lv_x), var_y = expf(lv_y);
-        const float x = tanhf(mu_x + a.eps_shift[2 * b] * sqrtf(var_x));
-        const float y = tanhf(mu_y + a.eps_shift[2 * b + 1] * sqrtf(var_y));
-        // concrete.py:20-27
-        const float u = a.u[b];
-        const float noise = logf(u + AIR_EPS) - logf((1.0f - u) + AIR_EPS);
-        const float ypre = (z_lo + noise) / T;
+        const float x = tanhf(mu_x + a.eps_shift[2 * row] * sqrtf(var_x));
+        const float y = tanhf(mu_y + a.eps_shift[2 * row + 1] * sqrtf(var_y));
+        const float ypre = concrete_presigmoid(z_lo, a.u[row], T);
         float z = air_sigmoid(ypre);
         if (!a.train) z = rintf(z);                       // tf.round (half-to-even) :389-390
         const float zprob = air_sigmoid(z_lo);
@@ -154,27 +180,20 @@ __global__ __launch_bounds__(THREADS) void attend_fwd_kernel(air_attend_fwd_t a)
         const float log_post = ((logf(T + AIR_EPS) - yT) + z_lo) - 2.0f * logf((1.0f + expf(-yT + z_lo)) + AIR_EPS);
         const float kl_z = log_post - log_prior;
         // stop logic :409-427
-        float S = a.stop_sum[b], L = a.run_loss[b];
         const bool mask_prev = S < thr;
-        L = L + (mask_prev ? kl_z : 0.0f);
         S = S + (1.0f - z);
         const bool mask = S < thr;
-        a.stop_sum[b] = S;
-        a.run_digits[b] += mask ? 1 : 0;
         // scale / shift KL :441-477
         const float pv_s = dyn[AIR_DYN_SCALE_PV], pv_h = dyn[AIR_DYN_SHIFT_PV];
         const float kl_s = 0.5f * gauss_kl_term(logf(pv_s), lv_s, var_s, pv_s, mu_s, dyn[AIR_DYN_SCALE_PM]);
-        L = L + (mask ? kl_s : 0.0f);
         const float plv_h = logf(pv_h), pm_h = dyn[AIR_DYN_SHIFT_PM];
         const float kl_h = 0.5f * (gauss_kl_term(plv_h, lv_x, var_x, pv_h, mu_x, pm_h) +
                                    gauss_kl_term(plv_h, lv_y, var_y, pv_h, mu_y, pm_h));
-        L = L + (mask ? kl_h : 0.0f);
-        a.run_loss[b] = L;
 
-        float* o7 = a.out7 + (size_t)b * AIR_OUT_STRIDE;
+        float* o7 = a.out7 + row * AIR_OUT_STRIDE;
         for (int o = 0; o < 7; ++o) o7[o] = sh_out[o];
         o7[7] = 0.0f;
-        float* at = a.att + (size_t)b * AIR_ATT_STRIDE;
+        float* at = a.att + row * AIR_ATT_STRIDE;
         at[AIR_ATT_S] = s; at[AIR_ATT_X] = x; at[AIR_ATT_Y] = y;
         at[AIR_ATT_ZPRE] = ypre; at[AIR_ATT_Z] = z; at[AIR_ATT_ZPROB] = zprob;
         at[AIR_ATT_KL_Z] = kl_z; at[AIR_ATT_KL_SCALE] = kl_s; at[AIR_ATT_KL_SHIFT] = kl_h;
@@ -209,7 +228,7 @@ __global__ __launch_bounds__(THREADS) void attend_fwd_kernel(air_attend_fwd_t a)
         sh_img[p] = img[(ylo + r) * C + xlo + c];     // rows of the box: coalesced segments
     }
     __syncthreads();
-    float* win = a.window + (size_t)b * w * w;
+    float* win = a.window + row * w * w;
     for (int p = tid; p < w * w; p += THREADS) {
         const int i = p / w, j = p % w;
         const Tap tx = sh_tx[j], ty = sh_ty[i];
@@ -221,15 +240,16 @@ __global__ __launch_bounds__(THREADS) void attend_fwd_kernel(air_attend_fwd_t a)
 
 // ---------------------------------------------------------------------------
 // attend backward: ST-read gradient wrt (s,x,y) + sampling / KL / head-output
-// gradients.  One workgroup per image.
+// gradients.  One workgroup per (image, time step).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(THREADS) void attend_bwd_kernel(air_attend_bwd_t a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
     const int C = a.C, w = a.w;
     const HeadSeg hs = head_segments(a.Hs, a.Hh, a.Hz);
     const int HT = hs.off[4] + hs.wid[4];
+    const size_t row = (size_t)t * a.B + b;
 
     float* sh_red = smem;                                // [4]
     float* sh_d = smem + 4;                              // [8] d_out7
@@ -239,9 +259,9 @@ __global__ __launch_bounds__(THREADS) void attend_bwd_kernel(air_attend_bwd_t a)
     int* sh_box = reinterpret_cast<int*>(sh_t + w);
     float* sh_img = reinterpret_cast<float*>(sh_box + 4);
 
-    const float* at = a.att + (size_t)b * AIR_ATT_STRIDE;
+    const float* at = a.att + row * AIR_ATT_STRIDE;
     const float s = at[AIR_ATT_S], sx = at[AIR_ATT_X], sy = at[AIR_ATT_Y];
-    if (tid < w) { float t; sh_tx[tid] = axis_tap(tid, w, C, s, sx, &t); sh_t[tid] = t; }
+    if (tid < w) { float tv; sh_tx[tid] = axis_tap(tid, w, C, s, sx, &tv); sh_t[tid] = tv; }
     else if (tid >= 64 && tid < 64 + w) sh_ty[tid - 64] = axis_tap(tid - 64, w, C, s, sy);
     __syncthreads();
     if (tid == 0) {
@@ -258,7 +278,7 @@ __global__ __launch_bounds__(THREADS) void attend_bwd_kernel(air_attend_bwd_t a)
     // d out / dX = (Ic-Ia)(y1-Y) + (Id-Ib)(Y-y0);  d out / dY = (Ib-Ia)(x1-X) + (Id-Ic)(X-x0)
     const float half_c = ((float)C - 1.001f) / 2.0f;     // dX/dx_s
     float ds = 0.f, dx = 0.f, dy = 0.f;
-    const float* g = a.d_window + (size_t)b * w * w;
+    const float* g = a.d_window + row * w * w;
     for (int p = tid; p < w * w; p += THREADS) {
         const int i = p / w, j = p % w;
         const Tap tx = sh_tx[j], ty = sh_ty[i];
@@ -280,8 +300,8 @@ __global__ __launch_bounds__(THREADS) void attend_bwd_kernel(air_attend_bwd_t a)
         const float* dyn = a.dyn;
         const float gsc = dyn[AIR_DYN_GRAD_SCALE];               // d loss / d per-item loss
         const float T = dyn[AIR_DYN_TEMPERATURE];
-        const float* o7 = a.out7 + (size_t)b * AIR_OUT_STRIDE;
-        const float* dw = a.d_sxy_write + (size_t)b * 4;
+        const float* o7 = a.out7 + row * AIR_OUT_STRIDE;
+        const float* dw = a.d_sxy_write + row * 4;
         const float mask = at[AIR_ATT_MASK], mask_prev = at[AIR_ATT_MASK_PREV];
         const float d_s = ds + dw[0], d_x = dx + dw[1], d_y = dy + dw[2], d_z = dw[3];
         const float lv_s = o7[1], lv_x = o7[4], lv_y = o7[5];
@@ -292,7 +312,7 @@ __global__ __launch_bounds__(THREADS) void attend_bwd_kernel(air_attend_bwd_t a)
         // s = sigmoid(mu + eps*sd), (x,y) = tanh(mu + eps*sd), sd = sqrt(exp(lv))
         const float da_s = d_s * s * (1.0f - s);
         const float da_x = d_x * (1.0f - sx * sx), da_y = d_y * (1.0f - sy * sy);
-        const float e_s = a.eps_scale[b], e_x = a.eps_shift[2 * b], e_y = a.eps_shift[2 * b + 1];
+        const float e_s = a.eps_scale[row], e_x = a.eps_shift[2 * row], e_y = a.eps_shift[2 * row + 1];
         sh_d[0] = da_s + klg * (o7[0] - pm_s) / pv_s;
         sh_d[1] = da_s * e_s * 0.5f * sd_s + klg * 0.5f * (sd_s * sd_s / pv_s - 1.0f);
         sh_d[2] = da_x + klg * (o7[2] - pm_h) / pv_h;
@@ -309,7 +329,7 @@ __global__ __launch_bounds__(THREADS) void attend_bwd_kernel(air_attend_bwd_t a)
         const float d_ypre = d_z * z * (1.0f - z) + dkl * (2.0f * T * (rq - rp));
         sh_d[6] = d_ypre / T + dkl * (1.0f - 2.0f * rq);
         sh_d[7] = 0.0f;
-        float* d7 = a.d_out7 + (size_t)b * AIR_OUT_STRIDE;
+        float* d7 = a.d_out7 + row * AIR_OUT_STRIDE;
         for (int o = 0; o < 8; ++o) d7[o] = sh_d[o];
     }
     __syncthreads();
@@ -321,75 +341,112 @@ __global__ __launch_bounds__(THREADS) void attend_bwd_kernel(air_attend_bwd_t a)
         float v = 0.0f;
         for (int o = 0; o < 7; ++o)
             if (kOutHead[o] == h) v += sh_d[o] * a.wout[o * a.wout_ld + jj];
-        a.d_hid[(size_t)b * HT + j] = (a.hid[(size_t)b * HT + j] > 0.0f) ? v : 0.0f;
+        a.d_hid[row * HT + j] = (a.hid[row * HT + j] > 0.0f) ? v : 0.0f;
     }
 }
 
 // ---------------------------------------------------------------------------
-// write forward: window -> canvas, scaled by z_pres, masked, accumulated
+// compose ("write" forward, time-batched): for one image, all N steps of
+// window -> canvas (x z_pres, masked, accumulated IN STEP ORDER in registers --
+// the canvas never round-trips through HBM), the per-step VAE KL, the running
+// loss in the reference's exact summation order, the digit count, and the
+// reconstruction loss + its gradient (air_model.py:351-366, 409-439, 479-496,
+// 580-593).  One workgroup per image.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(THREADS) void write_fwd_kernel(air_write_fwd_t a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x, tid = threadIdx.x;
-    const int C = a.C, w = a.w, Z = a.Z;
-    float* sh_red = smem;                                  // [4]
-    Tap* sh_tx = reinterpret_cast<Tap*>(smem + 4);         // [C]
-    Tap* sh_ty = sh_tx + C;                                // [C]
-    float* sh_win = reinterpret_cast<float*>(sh_ty + C);   // [w*w]
-
-    float* at = a.att + (size_t)b * AIR_ATT_STRIDE;
-    const float s = at[AIR_ATT_S], x = at[AIR_ATT_X], y = at[AIR_ATT_Y];
-    const float z = at[AIR_ATT_Z];
-    const bool mask = at[AIR_ATT_MASK] != 0.0f;
+    const int C = a.C, w = a.w, Z = a.Z, N = a.N, B = a.B;
+    float* sh_red = smem;                                    // [4]
+    float* sh_z = smem + 4;                                  // [MAX_STEPS] z_pres if active else 0
+    int* sh_act = reinterpret_cast<int*>(smem + 4 + MAX_STEPS);          // [MAX_STEPS]
+    Tap* sh_tx = reinterpret_cast<Tap*>(smem + 4 + 2 * MAX_STEPS);       // [N][C]
+    Tap* sh_ty = sh_tx + (size_t)N * C;                                    // [N][C]
+    float* sh_win = reinterpret_cast<float*>(sh_ty + (size_t)N * C);      // [N][w*w]
     const float* dyn = a.dyn;
 
-    // VAE KL :479-493 (needed whether or not the item is still active: it is a public output)
-    float klt = 0.0f;
-    if (tid < Z) {
-        const float* ml = a.ml + (size_t)b * 2 * Z;
-        const float pv = dyn[AIR_DYN_VAE_PV];
-        const float lv = ml[Z + tid];
-        klt = gauss_kl_term(logf(pv), lv, expf(lv), pv, ml[tid], dyn[AIR_DYN_VAE_PM]);
+    float L = 0.0f;
+    int digits = 0;
+    for (int t = 0; t < N; ++t) {
+        float* at = a.att + ((size_t)t * B + b) * AIR_ATT_STRIDE;
+        const bool mask = at[AIR_ATT_MASK] != 0.0f;
+        // VAE KL :479-493 (a public output whether or not the item is still active)
+        const float* ml = a.ml + ((size_t)t * B + b) * 2 * Z;
+        const float pv = dyn[AIR_DYN_VAE_PV], pm = dyn[AIR_DYN_VAE_PM];
+        float klt = 0.0f;
+        for (int j = tid; j < Z; j += THREADS) {
+            const float lv = ml[Z + j];
+            klt += gauss_kl_term(logf(pv), lv, expf(lv), pv, ml[j], pm);
+        }
+        const float kl = 0.5f * air_block_sum_256(klt, sh_red);
+        // running loss in the reference order: z KL (old mask), scale, shift, VAE KL (new mask) :411-493
+        L = L + (at[AIR_ATT_MASK_PREV] != 0.0f ? at[AIR_ATT_KL_Z] : 0.0f);
+        L = L + (mask ? at[AIR_ATT_KL_SCALE] : 0.0f);
+        L = L + (mask ? at[AIR_ATT_KL_SHIFT] : 0.0f);
+        L = L + (mask ? kl : 0.0f);
+        digits += mask ? 1 : 0;
+        if (tid == 0) { at[AIR_ATT_KL_VAE] = kl; sh_z[t] = at[AIR_ATT_Z]; sh_act[t] = mask ? 1 : 0; }
+        if (mask) {
+            // theta_recon :353-356
+            const float s = at[AIR_ATT_S], x = at[AIR_ATT_X], y = at[AIR_ATT_Y];
+            const float ia = 1.0f / s, bx = (-x) / s, by = (-y) / s;
+            for (int j = tid; j < C; j += THREADS) {
+                sh_tx[(size_t)t * C + j] = axis_tap(j, C, w, ia, bx);
+                sh_ty[(size_t)t * C + j] = axis_tap(j, C, w, ia, by);
+            }
+            const float* v = a.vrec + ((size_t)t * B + b) * w * w;
+            for (int p = tid; p < w * w; p += THREADS) sh_win[(size_t)t * w * w + p] = v[p];
+        }
     }
-    for (int j = tid + THREADS; j < Z; j += THREADS) {   // Z > 256 (not on the default path)
-        const float* ml = a.ml + (size_t)b * 2 * Z;
-        const float pv = dyn[AIR_DYN_VAE_PV];
-        const float lv = ml[Z + j];
-        klt += gauss_kl_term(logf(pv), lv, expf(lv), pv, ml[j], dyn[AIR_DYN_VAE_PM]);
-    }
-    const float kl = 0.5f * air_block_sum_256(klt, sh_red);
-    if (tid == 0) {
-        at[AIR_ATT_KL_VAE] = kl;
-        a.run_loss[b] = a.run_loss[b] + (mask ? kl : 0.0f);
-    }
-    if (!mask) return;                                     // running_recon += 0
-
-    // theta_recon :353-356
-    const float ia = 1.0f / s, bx = (-x) / s, by = (-y) / s;
-    for (int j = tid; j < C; j += THREADS) { sh_tx[j] = axis_tap(j, C, w, ia, bx); sh_ty[j] = axis_tap(j, C, w, ia, by); }
-    const float* v = a.vrec + (size_t)b * w * w;
-    for (int p = tid; p < w * w; p += THREADS) sh_win[p] = v[p];
     __syncthreads();
-    float* R = a.run_recon + (size_t)b * C * C;
+
+    // canvas + Bernoulli cross-entropy, pixel by pixel
+    const float gsc = dyn[AIR_DYN_GRAD_SCALE];
+    const size_t base = (size_t)b * C * C;
+    float acc = 0.0f;
     for (int p = tid; p < C * C; p += THREADS) {
         const int i = p / C, j = p % C;
-        const Tap tx = sh_tx[j], ty = sh_ty[i];
-        const float wr = bilinear4(tx, ty, sh_win[ty.i0 * w + tx.i0], sh_win[ty.i1 * w + tx.i0],
-                                   sh_win[ty.i0 * w + tx.i1], sh_win[ty.i1 * w + tx.i1]);
-        R[p] = R[p] + z * wr;                              // :433-439
+        float R = 0.0f;                                             // running_recon :552
+        for (int t = 0; t < N; ++t) {
+            if (!sh_act[t]) continue;                               // where(active, z*w, 0) :433-439
+            const Tap tx = sh_tx[(size_t)t * C + j], ty = sh_ty[(size_t)t * C + i];
+            const float* win = sh_win + (size_t)t * w * w;
+            const float wr = bilinear4(tx, ty, win[ty.i0 * w + tx.i0], win[ty.i1 * w + tx.i0],
+                                       win[ty.i0 * w + tx.i1], win[ty.i1 * w + tx.i1]);
+            R = R + sh_z[t] * wr;
+        }
+        const float x = a.images[base + p];
+        const float r = fmaxf(fminf(R, 1.0f), 0.0f);                // clipped_rec :582
+        const float p1 = r + AIR_EPS, p0 = (1.0f - r) + AIR_EPS;
+        acc += x * logf(p1) + (1.0f - x) * logf(p0);                // :586-589
+        a.recon[base + p] = r;
+        if (a.d_recon) {
+            const bool pass = (R <= 1.0f) && (fminf(R, 1.0f) >= 0.0f);   // Minimum/Maximum grads pass at ties
+            a.d_recon[base + p] = pass ? -gsc * (x / p1 - (1.0f - x) / p0) : 0.0f;
+        }
+    }
+    acc = air_block_sum_256(acc, sh_red);
+    if (tid == 0) {
+        const float rl = -acc;
+        a.rec_loss[b] = rl;
+        a.run_loss[b] = L;
+        a.run_digits[b] = digits;
+        a.loss_item[b] = L + rl;                                    // loss += reconstruction_loss :593
     }
 }
 
 // ---------------------------------------------------------------------------
 // write backward: gradient wrt the window (exact separable adjoint, gather
-// form), wrt theta_recon -> (s,x,y), and wrt z_pres.
+// form), wrt theta_recon -> (s,x,y), and wrt z_pres.  One workgroup per
+// (image, time step): every step sees the same d loss / d canvas.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(THREADS) void write_bwd_kernel(air_write_bwd_t a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
     const int C = a.C, w = a.w;
+    const size_t row = (size_t)t * a.B + b;
     float* sh_red = smem;                                  // [4]
     Tap* sh_tx = reinterpret_cast<Tap*>(smem + 4);         // [C]
     Tap* sh_ty = sh_tx + C;                                // [C]
@@ -398,9 +455,9 @@ __global__ __launch_bounds__(THREADS) void write_bwd_kernel(air_write_bwd_t a)
     float* sh_win = reinterpret_cast<float*>(sh_rng + 4 * w);   // [w*w]
     float* sh_T = sh_win + w * w;                          // [C*w]
 
-    const float* at = a.att + (size_t)b * AIR_ATT_STRIDE;
-    float* dgen = a.d_gen_pre + (size_t)b * w * w;
-    float* dsx = a.d_sxy_write + (size_t)b * 4;
+    const float* at = a.att + row * AIR_ATT_STRIDE;
+    float* dgen = a.d_gen_pre + row * w * w;
+    float* dsx = a.d_sxy_write + row * 4;
     if (at[AIR_ATT_MASK] == 0.0f) {                        // where(active, ., 0): no gradient
         for (int p = tid; p < w * w; p += THREADS) dgen[p] = 0.0f;
         if (tid < 4) dsx[tid] = 0.0f;
@@ -409,12 +466,12 @@ __global__ __launch_bounds__(THREADS) void write_bwd_kernel(air_write_bwd_t a)
     const float s = at[AIR_ATT_S], x = at[AIR_ATT_X], y = at[AIR_ATT_Y], z = at[AIR_ATT_Z];
     const float ia = 1.0f / s, bx = (-x) / s, by = (-y) / s;
     for (int j = tid; j < C; j += THREADS) {
-        float t;
-        sh_tx[j] = axis_tap(j, C, w, ia, bx, &t);
+        float tv;
+        sh_tx[j] = axis_tap(j, C, w, ia, bx, &tv);
         sh_ty[j] = axis_tap(j, C, w, ia, by);
-        sh_t[j] = t;
+        sh_t[j] = tv;
     }
-    const float* v = a.vrec + (size_t)b * w * w;
+    const float* v = a.vrec + row * w * w;
     for (int p = tid; p < w * w; p += THREADS) sh_win[p] = v[p];
     __syncthreads();
     // source-index q is touched by a contiguous range of output coordinates (taps are monotone)
@@ -423,8 +480,8 @@ __global__ __launch_bounds__(THREADS) void write_bwd_kernel(air_write_bwd_t a)
         const int q = (tid < w) ? tid : tid - w;
         int lo = C, hi = -1;
         for (int j = 0; j < C; ++j) {
-            const Tap t = tp[j];
-            if (t.i0 != t.i1 && (t.i0 == q || t.i1 == q)) { lo = min(lo, j); hi = max(hi, j); }
+            const Tap tt = tp[j];
+            if (tt.i0 != tt.i1 && (tt.i0 == q || tt.i1 == q)) { lo = min(lo, j); hi = max(hi, j); }
         }
         sh_rng[(tid < w ? 0 : 2 * w) + 2 * q] = lo;
         sh_rng[(tid < w ? 0 : 2 * w) + 2 * q + 1] = hi;
@@ -437,8 +494,8 @@ __global__ __launch_bounds__(THREADS) void write_bwd_kernel(air_write_bwd_t a)
         const int I = it / w, q = it % w;
         float acc = 0.0f;
         for (int J = sh_rng[2 * q]; J <= sh_rng[2 * q + 1]; ++J) {
-            const Tap t = sh_tx[J];
-            const float wq = (t.i0 != t.i1) ? ((t.i0 == q ? t.w0 : 0.0f) + (t.i1 == q ? t.w1 : 0.0f)) : 0.0f;
+            const Tap tt = sh_tx[J];
+            const float wq = (tt.i0 != tt.i1) ? ((tt.i0 == q ? tt.w0 : 0.0f) + (tt.i1 == q ? tt.w1 : 0.0f)) : 0.0f;
             acc += g[I * C + J] * wq;
         }
         sh_T[it] = acc;
@@ -480,8 +537,8 @@ __global__ __launch_bounds__(THREADS) void write_bwd_kernel(air_write_bwd_t a)
         const int p = it / w, q = it % w;
         float acc = 0.0f;
         for (int I = sh_rng[2 * w + 2 * p]; I <= sh_rng[2 * w + 2 * p + 1]; ++I) {
-            const Tap t = sh_ty[I];
-            const float wp = (t.i0 != t.i1) ? ((t.i0 == p ? t.w0 : 0.0f) + (t.i1 == p ? t.w1 : 0.0f)) : 0.0f;
+            const Tap tt = sh_ty[I];
+            const float wp = (tt.i0 != tt.i1) ? ((tt.i0 == p ? tt.w0 : 0.0f) + (tt.i1 == p ? tt.w1 : 0.0f)) : 0.0f;
             acc += sh_T[I * w + q] * wp;
         }
         const float r = sh_win[it];
@@ -490,12 +547,12 @@ __global__ __launch_bounds__(THREADS) void write_bwd_kernel(air_write_bwd_t a)
 }
 
 size_t attend_smem(int C, int w, int HT) {
-    return (16 + 8 * w + 4 + ((HT + 3) & ~3) + (size_t)C * C) * sizeof(float);
+    return (16 + MAX_STEPS + 8 * w + 4 + ((HT + 3) & ~3) + (size_t)C * C) * sizeof(float);
 }
 size_t attend_bwd_smem(int C, int w) {
     return (12 + 8 * w + w + 4 + (size_t)C * C) * sizeof(float);
 }
-size_t write_smem(int C, int w) { return (4 + 8 * C + (size_t)w * w) * sizeof(float); }
+size_t write_smem(int N, int C, int w) { return (4 + 2 * MAX_STEPS + (size_t)N * (8 * C + (size_t)w * w)) * sizeof(float); }
 size_t write_bwd_smem(int C, int w) { return (4 + 8 * C + C + 4 * w + (size_t)w * w + (size_t)C * w) * sizeof(float); }
 
 template <typename K>
@@ -524,14 +581,14 @@ extern "C" int air_transformer_fwd(const float* U, const float* theta, float* ou
 
 extern "C" int air_attend_fwd(const air_attend_fwd_t* a, void* stream) {
     if (!a || !a->hid || !a->wout || !a->bout || !a->canvas || !a->eps_scale || !a->eps_shift || !a->u ||
-        !a->dyn || !a->out7 || !a->att || !a->window || !a->stop_sum || !a->run_loss || !a->run_digits)
+        !a->dyn || !a->out7 || !a->att || !a->window)
         return AIR_EINVAL;
-    if (a->B <= 0 || a->C < 2 || a->w < 2 || a->Hs <= 0 || a->Hh <= 0 || a->Hz <= 0) return AIR_EINVAL;
-    if (a->w > 64) return AIR_ELIMIT;
+    if (a->B <= 0 || a->N <= 0 || a->C < 2 || a->w < 2 || a->Hs <= 0 || a->Hh <= 0 || a->Hz <= 0) return AIR_EINVAL;
+    if (a->w > 64 || a->N > MAX_STEPS) return AIR_ELIMIT;
     const size_t lds = attend_smem(a->C, a->w, 2 * a->Hs + 2 * a->Hh + a->Hz);
     int rc = ensure_lds(attend_fwd_kernel, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(attend_fwd_kernel, dim3(a->B), dim3(THREADS), lds, air_stream(stream), *a);
+    hipLaunchKernelGGL(attend_fwd_kernel, dim3(a->B, a->N), dim3(THREADS), lds, air_stream(stream), *a);
     AIR_CHECK_LAUNCH();
     return 0;
 }
@@ -540,20 +597,23 @@ extern "C" int air_attend_bwd(const air_attend_bwd_t* a, void* stream) {
     if (!a || !a->hid || !a->wout || !a->canvas || !a->eps_scale || !a->eps_shift || !a->dyn || !a->out7 ||
         !a->att || !a->d_window || !a->d_sxy_write || !a->d_hid || !a->d_out7)
         return AIR_EINVAL;
-    if (a->B <= 0 || a->C < 2 || a->w < 2 || a->Hs <= 0 || a->Hh <= 0 || a->Hz <= 0) return AIR_EINVAL;
+    if (a->B <= 0 || a->N <= 0 || a->C < 2 || a->w < 2 || a->Hs <= 0 || a->Hh <= 0 || a->Hz <= 0) return AIR_EINVAL;
     if (a->w > 64) return AIR_ELIMIT;
     const size_t lds = attend_bwd_smem(a->C, a->w);
     int rc = ensure_lds(attend_bwd_kernel, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(attend_bwd_kernel, dim3(a->B), dim3(THREADS), lds, air_stream(stream), *a);
+    hipLaunchKernelGGL(attend_bwd_kernel, dim3(a->B, a->N), dim3(THREADS), lds, air_stream(stream), *a);
     AIR_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int air_write_fwd(const air_write_fwd_t* a, void* stream) {
-    if (!a || !a->vrec || !a->ml || !a->dyn || !a->att || !a->run_recon || !a->run_loss) return AIR_EINVAL;
-    if (a->B <= 0 || a->C < 2 || a->w < 2 || a->Z <= 0) return AIR_EINVAL;
-    const size_t lds = write_smem(a->C, a->w);
+    if (!a || !a->vrec || !a->ml || !a->images || !a->dyn || !a->att || !a->recon || !a->rec_loss ||
+        !a->run_loss || !a->run_digits || !a->loss_item)
+        return AIR_EINVAL;
+    if (a->B <= 0 || a->N <= 0 || a->C < 2 || a->w < 2 || a->Z <= 0) return AIR_EINVAL;
+    if (a->N > MAX_STEPS) return AIR_ELIMIT;
+    const size_t lds = write_smem(a->N, a->C, a->w);
     int rc = ensure_lds(write_fwd_kernel, lds);
     if (rc) return rc;
     hipLaunchKernelGGL(write_fwd_kernel, dim3(a->B), dim3(THREADS), lds, air_stream(stream), *a);
@@ -563,12 +623,12 @@ extern "C" int air_write_fwd(const air_write_fwd_t* a, void* stream) {
 
 extern "C" int air_write_bwd(const air_write_bwd_t* a, void* stream) {
     if (!a || !a->d_recon || !a->vrec || !a->att || !a->d_gen_pre || !a->d_sxy_write) return AIR_EINVAL;
-    if (a->B <= 0 || a->C < 2 || a->w < 2) return AIR_EINVAL;
+    if (a->B <= 0 || a->N <= 0 || a->C < 2 || a->w < 2) return AIR_EINVAL;
     if (2 * a->w > THREADS) return AIR_ELIMIT;
     const size_t lds = write_bwd_smem(a->C, a->w);
     int rc = ensure_lds(write_bwd_kernel, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(write_bwd_kernel, dim3(a->B), dim3(THREADS), lds, air_stream(stream), *a);
+    hipLaunchKernelGGL(write_bwd_kernel, dim3(a->B, a->N), dim3(THREADS), lds, air_stream(stream), *a);
     AIR_CHECK_LAUNCH();
     return 0;
 }

@@ -16,9 +16,9 @@ for prec in ("fp32", "bf16"):
     m = am.AIRModel(torch.tensor(images, device="cuda"), torch.tensor(targets, device="cuda"), cnn=False, train=True, gemm_precision=prec, **HP)
     m.load_state_dict(params); m.set_noise(noise); m.set_dynamic(z_pres_prior_log_odds=-2.0)
     s = m._stream(); m._run_forward(s)
-    for op in m._bwd: op(s)
+    m._run_backward(s)
     torch.cuda.synchronize()
-    outs[prec] = {k: getattr(m, k).clone() for k in ("vrec", "att", "d_recon", "d_genpre", "d_ml", "d_zs", "run_recon", "ml", "zs", "window")}
+    outs[prec] = {k: getattr(m, k).clone() for k in ("vrec", "att", "d_recon", "d_genpre", "d_ml", "ml", "zs", "window")}
     outs[prec]["d_gen0"] = m.d_gen[0].clone(); outs[prec]["d_gen1"] = m.d_gen[1].clone()
     outs[prec]["g_out_b"] = m.store.G["out_b"].clone(); outs[prec]["g_out_w"] = m.store.G["out_w"].clone()
     outs[prec]["gen1"] = m.gen_act[1].clone()
