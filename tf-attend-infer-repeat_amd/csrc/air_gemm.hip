@@ -23,6 +23,7 @@
 //     chain); precision 1: operands rounded to bf16 while staging,
 //     v_mfma_f32_16x16x32_bf16, fp32 accumulate.
 #include "air_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16_kernel(Args a)
     epilogue<TM, TN>(a, Red, m0, n0, lane, wave);
 }
 
-constexpr int LDS_BUDGET = 150 * 1024;
+constexpr int LDS_MAX = 150 * 1024;
 
 template <int TM, int TN, bool TA, bool TB>
 int launch(const air_gemm_t* g, const Args& a0, hipStream_t s) {
@@ -539,15 +540,25 @@ int launch(const air_gemm_t* g, const Args& a0, hipStream_t s) {
         constexpr int LA = TA ? (BM == 16 ? 16 : BM + 16) : BM + 1;
         constexpr int LB = TB ? BN + 1 : (BN == 16 ? 16 : BN + 16);
         const int red = 3 * TM * TN * 4 * 64;
+        // panel depth: as deep as the LDS budget allows (AIR_GEMM_LDS_KB, default 72 KB ->
+        // two workgroups per CU overlap one's loads with the other's MFMAs)
+        static int budget = 0;
+        if (!budget) {
+            const char* e = getenv("AIR_GEMM_LDS_KB");
+            budget = (e ? atoi(e) : 72) * 1024;
+            if (budget < 32 * 1024) budget = 32 * 1024;
+            if (budget > LDS_MAX) budget = LDS_MAX;
+        }
         int KP = (a.kslab + 63) & ~63;
-        const int kmax = ((LDS_BUDGET / 4 - red) / (LA + LB)) & ~63;
+        int kmax = ((budget / 4 - red) / (LA + LB)) & ~63;
+        if (kmax < 64) kmax = 64;
         if (KP > kmax) KP = kmax;
         const size_t lds = ((size_t)KP * (LA + LB) + red) * sizeof(float);
         auto kern = gemm_f32_kernel<TM, TN, TA, TB>;
         static bool attr_done = false;           // per instantiation
         if (!attr_done) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET);
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
             if (e != hipSuccess) return (int)e;
             attr_done = true;
         }

@@ -131,7 +131,8 @@ __global__ __launch_bounds__(THREADS) void finalize_kernel(
     if (threadIdx.x == 0) { scalars[0] = sl / (float)B; scalars[1] = sa / (float)B; }
 }
 
-// column sums (BiasAdd_grad): blockIdx.y = problem, blockIdx.x = 64-column strip
+// column sums (BiasAdd_grad): blockIdx.y = problem, blockIdx.x = 64-column strip.
+// 4 waves take interleaved rows; 8 independent loads in flight per thread.
 struct ColsumTable { air_colsum_t p[16]; };
 __global__ __launch_bounds__(THREADS) void colsum_kernel(ColsumTable tab)
 {
@@ -141,8 +142,17 @@ __global__ __launch_bounds__(THREADS) void colsum_kernel(ColsumTable tab)
     const int wave = threadIdx.x >> 6;
     if (blockIdx.x * 64 >= pr.cols) return;
     float acc = 0.0f;
-    if (col < pr.cols)
-        for (int r = wave; r < pr.rows; r += 4) acc += pr.src[(size_t)r * pr.ld + col];
+    if (col < pr.cols) {
+        int r = wave;
+        for (; r + 28 < pr.rows; r += 32) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = pr.src[(size_t)(r + 4 * k) * pr.ld + col];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc += v[k];
+        }
+        for (; r < pr.rows; r += 4) acc += pr.src[(size_t)r * pr.ld + col];
+    }
     part[wave][threadIdx.x & 63] = acc;
     __syncthreads();
     if (wave == 0 && col < pr.cols) {
@@ -152,11 +162,13 @@ __global__ __launch_bounds__(THREADS) void colsum_kernel(ColsumTable tab)
     }
 }
 
-// gradients of the 7 head output units; one workgroup per output unit
+// gradients of the 7 head output units; one workgroup per output unit, 4 waves on interleaved
+// rows, 8 independent loads in flight per thread, fixed-order LDS reduction
 __global__ __launch_bounds__(THREADS) void heads_out_wgrad_kernel(
     const float* __restrict__ d7, const float* __restrict__ hid, float* __restrict__ dw,
     float* __restrict__ db, int rows, int Hs, int Hh, int Hz, int ld)
 {
+    __shared__ float part[4][64];
     __shared__ float red[4];
     const int o = blockIdx.x;
     const int head[7] = {0, 1, 2, 2, 3, 3, 4};
@@ -164,10 +176,29 @@ __global__ __launch_bounds__(THREADS) void heads_out_wgrad_kernel(
     int off = 0;
     for (int i = 0; i < head[o]; ++i) off += wid[i];
     const int HT = 2 * Hs + 2 * Hh + Hz;
-    for (int j = threadIdx.x; j < wid[head[o]]; j += THREADS) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int j0 = 0; j0 < wid[head[o]]; j0 += 64) {
+        const int j = j0 + lane;
         float acc = 0.0f;
-        for (int r = 0; r < rows; ++r) acc += d7[(size_t)r * AIR_OUT_STRIDE + o] * hid[(size_t)r * HT + off + j];
-        dw[o * ld + j] = acc;
+        if (j < wid[head[o]]) {
+            int r = wave;
+            for (; r + 28 < rows; r += 32) {
+                float a[8], h[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    a[k] = d7[(size_t)(r + 4 * k) * AIR_OUT_STRIDE + o];
+                    h[k] = hid[(size_t)(r + 4 * k) * HT + off + j];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc += a[k] * h[k];
+            }
+            for (; r < rows; r += 4) acc += d7[(size_t)r * AIR_OUT_STRIDE + o] * hid[(size_t)r * HT + off + j];
+        }
+        __syncthreads();
+        part[wave][lane] = acc;
+        __syncthreads();
+        if (wave == 0 && j < wid[head[o]])
+            dw[o * ld + j] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
     }
     float s = 0.0f;
     for (int r = threadIdx.x; r < rows; r += THREADS) s += d7[(size_t)r * AIR_OUT_STRIDE + o];
