@@ -142,6 +142,18 @@ typedef struct {
 int air_gemm_slabs(int K, int ksplit);
 int air_gemm(const air_gemm_t* g, void* stream);
 
+/* ---- grouped weight gradients: every dW = A^T . dY (+ db = column sums of dY) of the
+ * step in ONE launch (MatMul_grad / BiasAdd_grad nodes of all variables; weights are shared
+ * across time steps so K = N_steps * B rows).  head_pack = 1 handles the 7 head output units:
+ * A = d_out7 [K,8], dY = hid [K,HT], dW = wout [7][ldc] (unit o keeps only its head's hidden
+ * segment), db = bout [7]. */
+typedef struct {
+    const float* A; const float* dY; float* dW; float* db /*nullable*/;
+    int32_t M, N, K, lda, ldb, ldc;
+    int32_t head_pack, Hs, Hh, Hz;
+} air_wgrad_t;
+int air_wgrad_grouped(const air_wgrad_t* probs /*HOST array, <= 12*/, int count, void* stream);
+
 /* column sums db[n] = sum_r dY[r*ld + n]  (BiasAdd_grad nodes) for `count` problems */
 typedef struct { const float* src; float* dst; int32_t rows, cols, ld, accumulate; } air_colsum_t;
 int air_colsum(const air_colsum_t* probs /*HOST array*/, int count, void* stream);

@@ -51,6 +51,12 @@ class Colsum(C.Structure):
     _fields_ = [("src", _p), ("dst", _p), ("rows", _i), ("cols", _i), ("ld", _i), ("accumulate", _i)]
 
 
+class Wgrad(C.Structure):
+    _fields_ = [("A", _p), ("dY", _p), ("dW", _p), ("db", _p),
+                ("M", _i), ("N", _i), ("K", _i), ("lda", _i), ("ldb", _i), ("ldc", _i),
+                ("head_pack", _i), ("Hs", _i), ("Hh", _i), ("Hz", _i)]
+
+
 class AttendFwd(C.Structure):
     _fields_ = [("hid", _p), ("wout", _p), ("bout", _p), ("canvas", _p),
                 ("eps_scale", _p), ("eps_shift", _p), ("u", _p), ("dyn", _p),
@@ -83,6 +89,7 @@ _SIGNATURES = {
     "air_gemm": (C.c_int, [C.POINTER(Gemm), _p]),
     "air_gemm_slabs": (C.c_int, [C.c_int, C.c_int]),
     "air_colsum": (C.c_int, [C.POINTER(Colsum), C.c_int, _p]),
+    "air_wgrad_grouped": (C.c_int, [C.POINTER(Wgrad), C.c_int, _p]),
     "air_lstm_gates_fwd": (C.c_int, [_p, _p, _p, _p, _p, C.c_int, C.c_int, _p]),
     "air_lstm_gates_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, C.c_int, C.c_int, C.c_int, _p]),
     "air_transformer_fwd": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),

@@ -511,37 +511,36 @@ class AIRModel:
                                       extra_bytes=4 * B * R * 15, tag="bptt_lstm_bwd"))
         self._bwd = bwd
 
-        # weight grads: ONE GEMM per matrix over all N*B rows (weights are shared across time steps).
-        # They are mutually independent, so they are issued on forked side streams (parallel
-        # branches of the hipGraph) while the main stream is idle: the chip is otherwise empty.
-        br = [[], [], [], []]
+        # weight + bias grads of all variables: ONE grouped launch (weights are shared across the
+        # time steps, so every dW contracts over all N*B rows; the LSTM input weights over sum_t dgates)
         Gx, Gh = G["lstm_kernel"][:D], G["lstm_kernel"][D:]
-        br[0].append(self._gemm(imgs, self.dgsum, Gx, D, 4 * R, B, D, 4 * R, 4 * R, ta=1, tag="wgrad"))
-        br[1].append(self._gemm(self.h[0], self.dgates, Gh, R, 4 * R, NB, R, 4 * R, 4 * R, ta=1, tag="wgrad"))
-        br[1].append(self._gemm(self.h[1], self.d_hid, G["whid"], R, HT, NB, R, HT, HT, ta=1, tag="wgrad"))
-        br[1].append(self._call("air_heads_out_wgrad", _ptr(self.d_out7), _ptr(self.hid), _ptr(G["wout"]),
-                                _ptr(G["bout"]), NB, Hs, Hh, Hz, Hmax))
+        probs = []
+
+        def wg(A, dY, dW, db, M, Nn, K):
+            probs.append(H.Wgrad(_ptr(A), _ptr(dY), _ptr(dW), _ptr(db), M, Nn, K, M, Nn, Nn, 0, 0, 0, 0))
+        wg(imgs, self.dgsum, Gx, G["lstm_bias"], D, 4 * R, B)
+        wg(self.h[0], self.dgates, Gh, None, R, 4 * R, NB)
+        wg(self.h[1], self.d_hid, G["whid"], G["bhid"], R, HT, NB)
         x, k = self.window, d
         for i, u in enumerate(rec_u):
-            br[2].append(self._gemm(x, self.d_rec[i], G["rec%d_w" % i], k, u, NB, k, u, u, ta=1, tag="wgrad"))
+            wg(x, self.d_rec[i], G["rec%d_w" % i], G["rec%d_b" % i], k, u, NB)
             x, k = self.rec_act[i], u
-        br[2].append(self._gemm(x, self.d_ml, G["ml_w"], k, 2 * Z, NB, k, 2 * Z, 2 * Z, ta=1, tag="wgrad"))
+        wg(x, self.d_ml, G["ml_w"], G["ml_b"], k, 2 * Z, NB)
         x, k = self.zs, Z
         for i, u in enumerate(gen_u):
-            br[3].append(self._gemm(x, self.d_gen[i], G["gen%d_w" % i], k, u, NB, k, u, u, ta=1, tag="wgrad"))
+            wg(x, self.d_gen[i], G["gen%d_w" % i], G["gen%d_b" % i], k, u, NB)
             x, k = self.gen_act[i], u
-        br[3].append(self._gemm(x, self.d_genpre, G["out_w"], k, d, NB, k, d, d, ta=1, tag="wgrad"))
-        cs = [(self.dgsum, G["lstm_bias"], B, 4 * R), (self.d_hid, G["bhid"], NB, HT)]
-        cs += [(self.d_rec[i], G["rec%d_b" % i], NB, u) for i, u in enumerate(rec_u)]
-        cs += [(self.d_ml, G["ml_b"], NB, 2 * Z)]
-        cs += [(self.d_gen[i], G["gen%d_b" % i], NB, u) for i, u in enumerate(gen_u)]
-        cs += [(self.d_genpre, G["out_b"], NB, d)]
-        for i0 in range(0, len(cs), 16):
-            chunk = cs[i0:i0 + 16]
-            arr = (H.Colsum * len(chunk))(*[H.Colsum(_ptr(s), _ptr(dst), r, c, c, 0) for s, dst, r, c in chunk])
-            keep.append(arr)
-            br[2].append(self._call("air_colsum", arr, len(chunk)))
-        self._wgrad_branches = br
+        wg(x, self.d_genpre, G["out_w"], G["out_b"], k, d, NB)
+        probs.append(H.Wgrad(_ptr(self.d_out7), _ptr(self.hid), _ptr(G["wout"]), _ptr(G["bout"]),
+                             H.OUT_STRIDE, HT, NB, H.OUT_STRIDE, HT, Hmax, 1, Hs, Hh, Hz))
+        if len(probs) > 12:
+            raise NotImplementedError("more than 12 weight matrices (deeper VAE) need a second grouped launch")
+        arr = (H.Wgrad * len(probs))(*probs)
+        keep.append(arr)
+        wbytes = sum(4 * (q.M * q.N + q.K * (q.M + q.N)) for q in probs)
+        wflops = sum(2 * q.M * q.N * q.K for q in probs)
+        self._wgrad_branches = [[self._call("air_wgrad_grouped", arr, len(probs), nbytes=wbytes, flops=wflops,
+                                            tag="wgrad_grouped")]]
         self._side_streams = None
 
         self._opt = [
