@@ -206,20 +206,27 @@ __device__ __forceinline__ void reduce_waves(f32x4 (&acc)[TM][TN], float* Red, i
 __device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // ---------------------------------------------------------------------------
-// fp32: whole K-panel in LDS, k-major images As[k][LA], Bs[k][LB].
+// fp32: k-major LDS images As[k][LA], Bs[k][LB], double-buffered chunks of BKC.
 // A frag: lane l holds A[m = l&15][k = l>>4]; B frag: B[k = l>>4][n = l&15].
+// ALL 16-byte global loads of up to NCH chunks are issued before the first one
+// is consumed: a workgroup pays ONE memory round trip (~2 us when the producer
+// kernel ran on another XCD), then streams chunk by chunk through LDS with one
+// barrier each while the later loads are still landing.
 // ---------------------------------------------------------------------------
 template <int TM, int TN, bool TA, bool TB>
-__global__ __launch_bounds__(THREADS) void gemm_f32_kernel(Args a, int KP)
+__global__ __launch_bounds__(THREADS) void gemm_f32_kernel(Args a)
 {
     constexpr int BM = 16 * TM, BN = 16 * TN;
+    constexpr int BKC = (TM * TN >= 4) ? 64 : 128;
     // transposing stores (NN-A, NT-B) want an odd stride; direct 16-byte stores want stride = 16 (mod 32)
     constexpr int LA = TA ? (BM == 16 ? 16 : BM + 16) : BM + 1;
     constexpr int LB = TB ? BN + 1 : (BN == 16 ? 16 : BN + 16);
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;
-    float* Bs = smem + (size_t)KP * LA;
-    float* Red = Bs + (size_t)KP * LB;
+    constexpr int PA = BM * BKC / 1024, PB = BN * BKC / 1024;     // float4 per thread per chunk
+    constexpr int NCHR = 32 / (PA + PB);
+    constexpr int NCH = NCHR < 1 ? 1 : (NCHR > 8 ? 8 : NCHR);     // chunks in flight (<= 128 VGPRs of data)
+    __shared__ __attribute__((aligned(16))) float As[2][BKC * LA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BKC * LB];
+    __shared__ float Red[3 * TM * TN * 4 * 64];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN / TN * (a.gstride == 16 ? TN : 1);
@@ -235,167 +242,155 @@ __global__ __launch_bounds__(THREADS) void gemm_f32_kernel(Args a, int KP)
     const bool vecA = ((a.lda & 3) == 0) && aligned16(a.A);
     const bool vecB = ((a.ldb & 3) == 0) && aligned16(a.B) && ((a.gstride & 3) == 0);
 
-    for (int k0 = kbeg; k0 < kend; k0 += KP) {
-        const int kp = min(KP, kend - k0);            // valid depth of this panel
-        const int kp4 = (kp + 3) & ~3;
-        if (k0 > kbeg) __syncthreads();
-        // ---------------- stage A and B: all 16-byte loads of a batch are issued before any
-        // LDS store, so a panel costs ~one memory latency, not one per row ----------------
-        const int nq = kp4 >> 2;                        // float4 columns along k
-        const int nq16 = (nq + 15) >> 4;
-        auto loadA = [&](int i) -> float4 {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!TA) {
-                // A[m*lda + k]: lane map (m_lo = l&3, k4_lo = l>>2) -> conflict-free transposing stores
-                const int g = wave + 4 * i;
-                if (g >= nq16 * (BM / 4)) return v;
-                const int m = (g % (BM / 4)) * 4 + (lane & 3);
-                const int k4 = (g / (BM / 4)) * 16 + (lane >> 2);
-                const int gm = m0 + m, gk = k0 + k4 * 4;
-                if (gm < a.M && k4 < nq) {
-                    const float* src = a.A + (size_t)gm * a.lda + gk;
-                    if (vecA && gk + 3 < kend) v = *reinterpret_cast<const float4*>(src);
-                    else {
-                        if (gk < kend) v.x = src[0];
-                        if (gk + 1 < kend) v.y = src[1];
-                        if (gk + 2 < kend) v.z = src[2];
-                        if (gk + 3 < kend) v.w = src[3];
-                    }
-                }
-            } else {
-                // A[k*lda + m]: 16-byte loads along m
-                constexpr int MQ = BM / 4;
-                const int it = tid + THREADS * i;
-                if (it >= kp4 * MQ) return v;
-                const int k = it / MQ, mq = it % MQ;
-                const int gm = m0 + mq * 4, gk = k0 + k;
-                if (gk < kend) {
-                    const float* src = a.A + (size_t)gk * a.lda + gm;
-                    if (vecA && gm + 3 < a.M) v = *reinterpret_cast<const float4*>(src);
-                    else {
-                        if (gm < a.M) v.x = src[0];
-                        if (gm + 1 < a.M) v.y = src[1];
-                        if (gm + 2 < a.M) v.z = src[2];
-                        if (gm + 3 < a.M) v.w = src[3];
-                    }
+    auto loadA = [&](int k0, int i) -> float4 {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!TA) {
+            // A[m*lda + k]: lane map (m_lo = l&3, k4_lo = l>>2) -> conflict-free transposing stores
+            const int g = wave + 4 * i;
+            const int m = (g % (BM / 4)) * 4 + (lane & 3);
+            const int k4 = (g / (BM / 4)) * 16 + (lane >> 2);
+            const int gm = m0 + m, gk = k0 + k4 * 4;
+            if (gm < a.M && gk < kend) {
+                const float* src = a.A + (size_t)gm * a.lda + gk;
+                if (vecA && gk + 3 < kend) v = *reinterpret_cast<const float4*>(src);
+                else {
+                    v.x = src[0];
+                    if (gk + 1 < kend) v.y = src[1];
+                    if (gk + 2 < kend) v.z = src[2];
+                    if (gk + 3 < kend) v.w = src[3];
                 }
             }
-            return v;
-        };
-        auto storeA = [&](int i, const float4& v) {
-            if (!TA) {
-                const int g = wave + 4 * i;
-                if (g >= nq16 * (BM / 4)) return;
-                const int m = (g % (BM / 4)) * 4 + (lane & 3);
-                const int k4 = (g / (BM / 4)) * 16 + (lane >> 2);
-                if (k4 < nq) {
-                    float* d = As + (size_t)(k4 * 4) * LA + m;
-                    d[0] = v.x; d[LA] = v.y; d[2 * LA] = v.z; d[3 * LA] = v.w;
-                }
-            } else {
-                constexpr int MQ = BM / 4;
-                const int it = tid + THREADS * i;
-                if (it >= kp4 * MQ) return;
-                *reinterpret_cast<float4*>(As + (size_t)(it / MQ) * LA + (it % MQ) * 4) = v;
-            }
-        };
-        auto loadB = [&](int i) -> float4 {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (TB) {
-                // B[n*ldb + k] (k contiguous): same map as NN-A
-                const int g = wave + 4 * i;
-                if (g >= nq16 * (BN / 4)) return v;
-                const int n = (g % (BN / 4)) * 4 + (lane & 3);
-                const int k4 = (g / (BN / 4)) * 16 + (lane >> 2);
-                const int gn = n0 + n, gk = k0 + k4 * 4;
-                if (gn < a.N && k4 < nq) {
-                    const float* src = a.B + (size_t)gn * a.ldb + gk;
-                    if (vecB && gk + 3 < kend) v = *reinterpret_cast<const float4*>(src);
-                    else {
-                        if (gk < kend) v.x = src[0];
-                        if (gk + 1 < kend) v.y = src[1];
-                        if (gk + 2 < kend) v.z = src[2];
-                        if (gk + 3 < kend) v.w = src[3];
-                    }
-                }
-            } else {
-                // B[k*ldb + n]: 16-byte loads along n (per 16-column group)
-                constexpr int NQ = BN / 4;
-                const int it = tid + THREADS * i;
-                if (it >= kp4 * NQ) return v;
-                const int k = it / NQ, q4 = it % NQ;
-                const int j = q4 >> 2, c = (q4 & 3) * 4;
-                const int cg = n0 + c + (a.gstride == 16 ? j * 16 : 0);   // bound-check coordinate
-                const int gn = n0 + j * a.gstride + c, gk = k0 + k;
-                if (gk < kend) {
-                    const float* src = a.B + (size_t)gk * a.ldb + gn;
-                    const int lim = min(a.gwidth - cg, a.N - gn);        // valid columns from here
-                    if (vecB && lim >= 4) v = *reinterpret_cast<const float4*>(src);
-                    else {
-                        if (lim > 0) v.x = src[0];
-                        if (lim > 1) v.y = src[1];
-                        if (lim > 2) v.z = src[2];
-                        if (lim > 3) v.w = src[3];
-                    }
+        } else {
+            // A[k*lda + m]: 16-byte loads along m
+            constexpr int MQ = BM / 4;
+            const int it = tid + THREADS * i;
+            const int k = it / MQ, mq = it % MQ;
+            const int gm = m0 + mq * 4, gk = k0 + k;
+            if (gk < kend && gm < a.M) {
+                const float* src = a.A + (size_t)gk * a.lda + gm;
+                if (vecA && gm + 3 < a.M) v = *reinterpret_cast<const float4*>(src);
+                else {
+                    v.x = src[0];
+                    if (gm + 1 < a.M) v.y = src[1];
+                    if (gm + 2 < a.M) v.z = src[2];
+                    if (gm + 3 < a.M) v.w = src[3];
                 }
             }
-            return v;
-        };
-        auto storeB = [&](int i, const float4& v) {
-            if (TB) {
-                const int g = wave + 4 * i;
-                if (g >= nq16 * (BN / 4)) return;
-                const int n = (g % (BN / 4)) * 4 + (lane & 3);
-                const int k4 = (g / (BN / 4)) * 16 + (lane >> 2);
-                if (k4 < nq) {
-                    float* d = Bs + (size_t)(k4 * 4) * LB + n;
-                    d[0] = v.x; d[LB] = v.y; d[2 * LB] = v.z; d[3 * LB] = v.w;
-                }
-            } else {
-                constexpr int NQ = BN / 4;
-                const int it = tid + THREADS * i;
-                if (it >= kp4 * NQ) return;
-                *reinterpret_cast<float4*>(Bs + (size_t)(it / NQ) * LB + (it % NQ) * 4) = v;
-            }
-        };
-        constexpr int U = 8;
-        const int nA = TA ? (kp4 * (BM / 4) + THREADS - 1) / THREADS : (nq16 * (BM / 4) + 3) / 4;
-        const int nB = TB ? (nq16 * (BN / 4) + 3) / 4 : (kp4 * (BN / 4) + THREADS - 1) / THREADS;
-        for (int b0 = 0; b0 < max(nA, nB); b0 += U) {
-            float4 va[U], vb[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) va[u] = loadA(b0 + u);
-#pragma unroll
-            for (int u = 0; u < U; ++u) vb[u] = loadB(b0 + u);
-#pragma unroll
-            for (int u = 0; u < U; ++u) storeA(b0 + u, va[u]);
-#pragma unroll
-            for (int u = 0; u < U; ++u) storeB(b0 + u, vb[u]);
         }
-        __syncthreads();
-        // ---------------- MFMA: wave w takes k-steps w, w+4, ...; fragments of 8 steps are read
-        // from LDS before their MFMAs issue (LDS latency paid once per 8 steps, not per step) ------
-        const int steps = kp4 >> 2;
-        constexpr int SU = 8;
-        for (int s0 = wave; s0 < steps; s0 += 4 * SU) {
-            float av[SU][TM], bv[SU][TN];
-#pragma unroll
-            for (int u = 0; u < SU; ++u) {
-                const int sidx = s0 + 4 * u;
-                const bool ok = sidx < steps;                       // wave-uniform
-                const int kk = (ok ? sidx : s0) * 4 + (lane >> 4);
-#pragma unroll
-                for (int i = 0; i < TM; ++i) { const float t = As[(size_t)kk * LA + i * 16 + (lane & 15)]; av[u][i] = ok ? t : 0.0f; }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) { const float t = Bs[(size_t)kk * LB + j * 16 + (lane & 15)]; bv[u][j] = ok ? t : 0.0f; }
+        return v;
+    };
+    auto storeA = [&](float* as, int i, const float4& v) {
+        if (!TA) {
+            const int g = wave + 4 * i;
+            const int m = (g % (BM / 4)) * 4 + (lane & 3);
+            const int k4 = (g / (BM / 4)) * 16 + (lane >> 2);
+            float* d = as + (size_t)(k4 * 4) * LA + m;
+            d[0] = v.x; d[LA] = v.y; d[2 * LA] = v.z; d[3 * LA] = v.w;
+        } else {
+            constexpr int MQ = BM / 4;
+            const int it = tid + THREADS * i;
+            *reinterpret_cast<float4*>(as + (size_t)(it / MQ) * LA + (it % MQ) * 4) = v;
+        }
+    };
+    auto loadB = [&](int k0, int i) -> float4 {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (TB) {
+            // B[n*ldb + k] (k contiguous): same map as NN-A
+            const int g = wave + 4 * i;
+            const int n = (g % (BN / 4)) * 4 + (lane & 3);
+            const int k4 = (g / (BN / 4)) * 16 + (lane >> 2);
+            const int gn = n0 + n, gk = k0 + k4 * 4;
+            if (gn < a.N && gk < kend) {
+                const float* src = a.B + (size_t)gn * a.ldb + gk;
+                if (vecB && gk + 3 < kend) v = *reinterpret_cast<const float4*>(src);
+                else {
+                    v.x = src[0];
+                    if (gk + 1 < kend) v.y = src[1];
+                    if (gk + 2 < kend) v.z = src[2];
+                    if (gk + 3 < kend) v.w = src[3];
+                }
             }
+        } else {
+            // B[k*ldb + n]: 16-byte loads along n (per 16-column group)
+            constexpr int NQ = BN / 4;
+            const int it = tid + THREADS * i;
+            const int k = it / NQ, q4 = it % NQ;
+            const int j = q4 >> 2, c = (q4 & 3) * 4;
+            const int cg = n0 + c + (a.gstride == 16 ? j * 16 : 0);   // bound-check coordinate
+            const int gn = n0 + j * a.gstride + c, gk = k0 + k;
+            if (gk < kend) {
+                const float* src = a.B + (size_t)gk * a.ldb + gn;
+                const int lim = min(a.gwidth - cg, a.N - gn);        // valid columns from here
+                if (vecB && lim >= 4) v = *reinterpret_cast<const float4*>(src);
+                else {
+                    if (lim > 0) v.x = src[0];
+                    if (lim > 1) v.y = src[1];
+                    if (lim > 2) v.z = src[2];
+                    if (lim > 3) v.w = src[3];
+                }
+            }
+        }
+        return v;
+    };
+    auto storeB = [&](float* bs, int i, const float4& v) {
+        if (TB) {
+            const int g = wave + 4 * i;
+            const int n = (g % (BN / 4)) * 4 + (lane & 3);
+            const int k4 = (g / (BN / 4)) * 16 + (lane >> 2);
+            float* d = bs + (size_t)(k4 * 4) * LB + n;
+            d[0] = v.x; d[LB] = v.y; d[2 * LB] = v.z; d[3 * LB] = v.w;
+        } else {
+            constexpr int NQ = BN / 4;
+            const int it = tid + THREADS * i;
+            *reinterpret_cast<float4*>(bs + (size_t)(it / NQ) * LB + (it % NQ) * 4) = v;
+        }
+    };
+
+    for (int ks0 = kbeg; ks0 < kend; ks0 += NCH * BKC) {
+        if (ks0 > kbeg) __syncthreads();
+        float4 va[NCH][PA], vb[NCH][PB];
 #pragma unroll
-            for (int u = 0; u < SU; ++u)
+        for (int c = 0; c < NCH; ++c) {
+            const int k0 = ks0 + c * BKC;
+            if (k0 < kend) {                                         // block-uniform
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < PA; ++i) va[c][i] = loadA(k0, i);
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][i], bv[u][j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < PB; ++i) vb[c][i] = loadB(k0, i);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int k0 = ks0 + c * BKC;
+            if (k0 < kend) {
+                float* as = As[c & 1];
+                float* bs = Bs[c & 1];
+#pragma unroll
+                for (int i = 0; i < PA; ++i) storeA(as, i, va[c][i]);
+#pragma unroll
+                for (int i = 0; i < PB; ++i) storeB(bs, i, vb[c][i]);
+                __syncthreads();         // chunk visible; every wave is past the MFMAs of chunk c-1
+                const int steps = (min(BKC, kend - k0) + 3) >> 2;
+                constexpr int SU = BKC / 16;                         // k-steps per wave per chunk
+                float av[SU][TM], bv[SU][TN];
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    const int sidx = wave + 4 * u;
+                    const bool ok = sidx < steps;                    // wave-uniform
+                    const int kk = (ok ? sidx : 0) * 4 + (lane >> 4);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) { const float t = as[(size_t)kk * LA + i * 16 + (lane & 15)]; av[u][i] = ok ? t : 0.0f; }
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) { const float t = bs[(size_t)kk * LB + j * 16 + (lane & 15)]; bv[u][j] = ok ? t : 0.0f; }
+                }
+#pragma unroll
+                for (int u = 0; u < SU; ++u)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][i], bv[u][j], acc[i][j], 0, 0, 0);
+            }
         }
     }
     reduce_waves<TM, TN>(acc, Red, lane, wave);
@@ -521,7 +516,6 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16_kernel(Args a)
     epilogue<TM, TN>(a, Red, m0, n0, lane, wave);
 }
 
-constexpr int LDS_MAX = 150 * 1024;
 
 template <int TM, int TN, bool TA, bool TB>
 int launch(const air_gemm_t* g, const Args& a0, hipStream_t s) {
@@ -534,36 +528,10 @@ int launch(const air_gemm_t* g, const Args& a0, hipStream_t s) {
     a.kslab = ((a.K + ks - 1) / ks + 3) & ~3;
     grid.z = (a.K + a.kslab - 1) / a.kslab;
     a.slab_stride = (long)a.M * a.ldc;
-    if (g->precision == 1) {
+    if (g->precision == 1)
         hipLaunchKernelGGL((gemm_bf16_kernel<TM, TN, TA, TB>), grid, dim3(THREADS), 0, s, a);
-    } else {
-        constexpr int LA = TA ? (BM == 16 ? 16 : BM + 16) : BM + 1;
-        constexpr int LB = TB ? BN + 1 : (BN == 16 ? 16 : BN + 16);
-        const int red = 3 * TM * TN * 4 * 64;
-        // panel depth: as deep as the LDS budget allows (AIR_GEMM_LDS_KB, default 72 KB ->
-        // two workgroups per CU overlap one's loads with the other's MFMAs)
-        static int budget = 0;
-        if (!budget) {
-            const char* e = getenv("AIR_GEMM_LDS_KB");
-            budget = (e ? atoi(e) : 72) * 1024;
-            if (budget < 32 * 1024) budget = 32 * 1024;
-            if (budget > LDS_MAX) budget = LDS_MAX;
-        }
-        int KP = (a.kslab + 63) & ~63;
-        int kmax = ((budget / 4 - red) / (LA + LB)) & ~63;
-        if (kmax < 64) kmax = 64;
-        if (KP > kmax) KP = kmax;
-        const size_t lds = ((size_t)KP * (LA + LB) + red) * sizeof(float);
-        auto kern = gemm_f32_kernel<TM, TN, TA, TB>;
-        static bool attr_done = false;           // per instantiation
-        if (!attr_done) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
-            if (e != hipSuccess) return (int)e;
-            attr_done = true;
-        }
-        hipLaunchKernelGGL(kern, grid, dim3(THREADS), lds, s, a, KP);
-    }
+    else
+        hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, TA, TB>), grid, dim3(THREADS), 0, s, a);
     AIR_CHECK_LAUNCH();
     return 0;
 }

@@ -62,22 +62,31 @@ __global__ __launch_bounds__(THREADS) void wgrad_grouped_kernel(Table tab)
     const bool vecA = ((pr.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(pr.A) & 15) == 0);
     const bool vecB = ((pr.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(pr.dY) & 15) == 0);
 
+    // copy the problem descriptor out of the kernel-argument table once
+    const float* __restrict__ Ap = pr.A;
+    const float* __restrict__ Yp = pr.dY;
+    const int M = pr.M, N = pr.N, K = pr.K, lda = pr.lda, ldb = pr.ldb, ldc = pr.ldc;
+    float* dW = pr.dW;
+    float* db = pr.db;
+    const int head_pack = pr.head_pack;
+
     // staging map: 32 rows x 16 float4 columns = 512 float4 per operand chunk, 2 per thread
     const int srow = tid >> 4, scol = (tid & 15) * 4;             // rows srow and srow + 16
-    float4 ra[2], rb[2];
-    auto fetch = [&](int k0) {
+    constexpr int NCH = 8;                                        // chunks in flight: K <= 256 in one round trip
+    float4 ra[NCH][2], rb[NCH][2];
+    auto fetch = [&](int set, int k0) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int k = k0 + srow + 16 * h;
-            ra[h] = load4(pr.A, pr.lda, k, m0 + scol, pr.K, pr.M, vecA);
-            rb[h] = load4(pr.dY, pr.ldb, k, n0 + scol, pr.K, pr.N, vecB);
+            ra[set][h] = load4(Ap, lda, k, m0 + scol, K, M, vecA);
+            rb[set][h] = load4(Yp, ldb, k, n0 + scol, K, N, vecB);
         }
     };
-    auto stage = [&](int buf) {
+    auto stage = [&](int set, int buf) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            *reinterpret_cast<float4*>(&As[buf][(srow + 16 * h) * LS + scol]) = ra[h];
-            *reinterpret_cast<float4*>(&Bs[buf][(srow + 16 * h) * LS + scol]) = rb[h];
+            *reinterpret_cast<float4*>(&As[buf][(srow + 16 * h) * LS + scol]) = ra[set][h];
+            *reinterpret_cast<float4*>(&Bs[buf][(srow + 16 * h) * LS + scol]) = rb[set][h];
         }
     };
 
@@ -86,16 +95,10 @@ __global__ __launch_bounds__(THREADS) void wgrad_grouped_kernel(Table tab)
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float colsum = 0.0f;                                          // wave 0 of block-row 0: column n0 + lane
-    const bool do_bias = (pr.db != nullptr) && (m0 == 0) && (wave == 0);
+    float colsum = 0.0f;        // wave 0 of block-row 0: column n0 + lane of dY (or of A for the head units)
+    const bool do_bias = (db != nullptr) && (wave == 0) && (head_pack ? (n0 == 0) : (m0 == 0));
 
-    const int nchunks = (pr.K + KC - 1) / KC;
-    fetch(0);
-    for (int c = 0; c < nchunks; ++c) {
-        const int buf = c & 1;
-        stage(buf);
-        __syncthreads();                       // chunk c visible; everyone is past the MFMAs of chunk c-1
-        if (c + 1 < nchunks) fetch((c + 1) * KC);
+    auto compute = [&](int buf) {
         const float* as = As[buf];
         const float* bs = Bs[buf];
 #pragma unroll
@@ -113,50 +116,70 @@ __global__ __launch_bounds__(THREADS) void wgrad_grouped_kernel(Table tab)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
         if (do_bias) {
+            const float* cs = head_pack ? as : bs;                 // zero rows beyond K
 #pragma unroll 8
-            for (int k = 0; k < KC; ++k) colsum += bs[k * LS + lane];      // zero rows beyond K
+            for (int k = 0; k < KC; ++k) colsum += cs[k * LS + lane];
         }
-        // the stage() of chunk c+1 writes the OTHER buffer; the barrier of iteration c+1 orders it
-        // after every wave's reads of chunk c-1 ... and buffer `buf` is rewritten only at c+2
+    };
+    // ALL loads of up to NCH chunks are issued before the first is consumed (one memory round
+    // trip), then one barrier per chunk: stage(c+1) only overwrites the buffer every wave finished
+    // reading before it passed the barrier of iteration c.
+    for (int ks0 = 0; ks0 < K; ks0 += NCH * KC) {
+        if (ks0 > 0) __syncthreads();
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+            if (ks0 + c * KC < K) fetch(c, ks0 + c * KC);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+            if (ks0 + c * KC < K) {
+                stage(c, c & 1);
+                __syncthreads();
+                compute(c & 1);
+            }
     }
 
-    // epilogue: C/D map row = (lane>>4)*4 + q, col = lane&15
-    if (!pr.head_pack) {
+    // epilogue: C/D map row = (lane>>4)*4 + q, col = lane&15.  The tile goes through LDS so that
+    // every store instruction writes whole 256-byte rows (full cache lines).
+    __syncthreads();
+    float* Ct = &As[0][0];                      // 64 x LS floats = 20 KB: spans As[0..1]
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int m = m0 + wm + i * 16 + (lane >> 4) * 4 + q;
-                    const int n = n0 + wn + j * 16 + (lane & 15);
-                    if (m < pr.M && n < pr.N) pr.dW[(size_t)m * pr.ldc + n] = acc[i][j][q];
-                }
-        if (do_bias && n0 + lane < pr.N) pr.db[n0 + lane] = colsum;
+            for (int q = 0; q < 4; ++q)
+                Ct[(wm + i * 16 + (lane >> 4) * 4 + q) * LS + wn + j * 16 + (lane & 15)] = acc[i][j][q];
+    __syncthreads();
+    if (!head_pack) {
+        const bool vecC = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(dW) & 15) == 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = (tid >> 4) + 16 * r, col = (tid & 15) * 4;
+            const int m = m0 + row, n = n0 + col;
+            if (m >= M) continue;
+            const float4 v = *reinterpret_cast<const float4*>(&Ct[row * LS + col]);
+            float* dst = dW + (size_t)m * ldc + n;
+            if (vecC && n + 3 < N) *reinterpret_cast<float4*>(dst) = v;
+            else {
+                if (n < N) dst[0] = v.x;
+                if (n + 1 < N) dst[1] = v.y;
+                if (n + 2 < N) dst[2] = v.z;
+                if (n + 3 < N) dst[3] = v.w;
+            }
+        }
+        if (do_bias && n0 + lane < N) db[n0 + lane] = colsum;
     } else {
         // head output units (air_model.py:294-316, 376): A = d_out7 [K,8], dY = hid [K,HT];
         // unit o only owns the hidden segment of its head: dW = wout[o][n - off], db = bout[o] = sum_k d_out7[k][o]
         const int wid[5] = {pr.Hs, pr.Hs, pr.Hh, pr.Hh, pr.Hz};
         const int head[7] = {0, 1, 2, 2, 3, 3, 4};
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int o = m0 + wm + i * 16 + (lane >> 4) * 4 + q;
-                    const int n = n0 + wn + j * 16 + (lane & 15);
-                    if (o < 7 && n < pr.N) {
-                        int off = 0;
-                        for (int h = 0; h < head[o]; ++h) off += wid[h];
-                        if (n >= off && n < off + wid[head[o]]) pr.dW[(size_t)o * pr.ldc + (n - off)] = acc[i][j][q];
-                    }
-                }
-        if (pr.db != nullptr && n0 == 0 && wave == 0 && lane < 7) {
-            float s = 0.0f;
-            for (int k = 0; k < pr.K; ++k) s += pr.A[(size_t)k * pr.lda + lane];
-            pr.db[lane] = s;
+        for (int it = tid; it < 7 * BT; it += THREADS) {
+            const int o = it / BT, col = it % BT, n = n0 + col;
+            int off = 0;
+            for (int h = 0; h < head[o]; ++h) off += wid[h];
+            if (m0 == 0 && n < N && n >= off && n < off + wid[head[o]]) dW[(size_t)o * ldc + (n - off)] = Ct[o * LS + col];
         }
+        if (do_bias && lane < 7) db[lane] = colsum;
     }
 }
 
