@@ -1,0 +1,174 @@
+"""Training driver -- counterpart of the reference's training.py on the HIP AIRModel.
+
+Same constants (training.py:13-31), same CLI flags (-r/-o/-t, :35-39), same results-folder
+layout (:41-61), the same constructor call (:100-122), train + test models sharing variables
+(:95-123), periodic evaluation on the fixed 1 000-image test set with the
+shift_zero_digits_images ordering (:143-156, 169-200), checkpoints every 10 000 iterations
+(:203-207) and the same stdout line (:226).  TensorBoard summaries become JSONL scalars
+(summary/scalars.jsonl): loss, accuracy and the per-digit-count breakdown of
+AIRModel._summarize_by_digit_count (air_model.py:160-182, 614-617).
+
+The whole dataset lives in HBM; a batch is one device-side gather into the train model's
+input buffer, the step itself is a hipGraph replay.
+"""
+import argparse
+import json
+import os
+import shutil
+import time
+
+import numpy as np
+import torch
+
+from multi_mnist import generate_dataset, shift_zero_digits_images
+from air.air_model import AIRModel
+
+EPOCHS = 300
+BATCH_SIZE = 64
+CANVAS_SIZE = 50
+
+NUM_SUMMARIES_EACH_ITERATIONS = 50
+VAR_SUMMARIES_EACH_ITERATIONS = 250
+IMG_SUMMARIES_EACH_ITERATIONS = 500
+GRAD_SUMMARIES_EACH_ITERATIONS = 100
+SAVE_PARAMS_EACH_ITERATIONS = 10000
+NUM_IMAGES_TO_SAVE = 60
+
+DEFAULT_READER_THREADS = 4
+DEFAULT_RESULTS_FOLDER = "air_results"
+TRAIN_DATA_FILE = "multi_mnist_data/common.npz"
+TEST_DATA_FILE = "multi_mnist_data/test.npz"
+
+
+def load_data():
+    if os.path.exists(TRAIN_DATA_FILE) and os.path.exists(TEST_DATA_FILE):
+        tr, te = np.load(TRAIN_DATA_FILE), np.load(TEST_DATA_FILE)
+        return tr["images"], tr["digits"], te["images"], te["digits"]
+    print("Generating multi-digit dataset in memory (multi_mnist.py defaults)...")
+    ds = generate_dataset()
+    return ds["train_images"], ds["train_digits"], ds["test_images"], ds["test_digits"]
+
+
+def digit_count_summaries(name, values, digits, max_digits):
+    """air_model.py:160-182."""
+    out = {}
+    v = values.float()
+    for i in range(max_digits + 1):
+        m = digits == i
+        out["%s_%d_dig" % (name, i)] = float(v[m].mean()) if bool(m.any()) else float("nan")
+    out[name + "_all_dig"] = float(v.mean())
+    return out
+
+
+def main():
+    parser = argparse.ArgumentParser()
+    parser.add_argument("-r", "--results-folder", default=DEFAULT_RESULTS_FOLDER)
+    parser.add_argument("-o", "--overwrite-results", type=int, choices=[0, 1], default=0)
+    parser.add_argument("-t", "--reader-threads", type=int, default=DEFAULT_READER_THREADS)   # kept for CLI parity
+    parser.add_argument("--iterations", type=int, default=0, help="stop after this many iterations (0 = EPOCHS)")
+    parser.add_argument("--print-every", type=int, default=1)
+    parser.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
+    parser.add_argument("--no-graph", action="store_true")
+    parser.add_argument("--seed", type=int, default=0)
+    args = parser.parse_args()
+
+    # results folder handling, training.py:41-61
+    if os.path.exists(args.results_folder):
+        if args.overwrite_results:
+            shutil.rmtree(args.results_folder, ignore_errors=True)
+        else:
+            folder, i = args.results_folder, 0
+            args.results_folder = "{}_{}".format(folder, i)
+            while os.path.exists(args.results_folder):
+                i += 1
+                args.results_folder = "{}_{}".format(folder, i)
+    models_folder = args.results_folder + "/models/"
+    summaries_folder = args.results_folder + "/summary/"
+    for d in (args.results_folder, models_folder, summaries_folder):
+        os.makedirs(d)
+
+    dev = torch.device("cuda", 0)
+    print("Creating input pipeline...")
+    tr_im, tr_dg, te_im, te_dg = load_data()
+    te_im, te_dg = shift_zero_digits_images(te_im, te_dg)
+    train_images = torch.tensor(tr_im, device=dev)
+    train_digits = torch.tensor(tr_dg.astype(np.int32), device=dev)
+    test_data = torch.tensor(np.ascontiguousarray(te_im), device=dev)
+    test_targets = torch.tensor(np.ascontiguousarray(te_dg).astype(np.int32), device=dev)
+    train_data = torch.zeros(BATCH_SIZE, CANVAS_SIZE ** 2, device=dev)
+    train_targets = torch.zeros(BATCH_SIZE, dtype=torch.int32, device=dev)
+
+    models = []
+    model_inputs = [[train_data, train_targets], [test_data, test_targets]]
+    for i in range(2):
+        print("Creating {0} model...".format("training" if i == 0 else "testing"))
+        models.append(
+            AIRModel(
+                model_inputs[i][0], model_inputs[i][1],
+                max_steps=3, max_digits=2, rnn_units=256, canvas_size=CANVAS_SIZE, windows_size=28,
+                vae_latent_dimensions=50, vae_recognition_units=(512, 256), vae_generative_units=(256, 512),
+                scale_prior_mean=-1.0, scale_prior_variance=0.05, shift_prior_mean=0.0, shift_prior_variance=1.0,
+                vae_prior_mean=0.0, vae_prior_variance=1.0, vae_likelihood_std=0.3,
+                scale_hidden_units=64, shift_hidden_units=64, z_pres_hidden_units=64,
+                z_pres_prior_log_odds=-0.01, z_pres_temperature=1.0, stopping_threshold=0.99,
+                learning_rate=1e-4, gradient_clipping_norm=1.0, cnn=False, cnn_filters=8,
+                num_summary_images=NUM_IMAGES_TO_SAVE, train=(i == 0), reuse=(i == 1), scope="air",
+                annealing_schedules={
+                    "z_pres_prior_log_odds": {
+                        "init": 10000.0, "min": 0.000000001,
+                        "factor": 0.1, "iters": 3000,
+                        "staircase": False, "log": True
+                    },
+                },
+                seed=args.seed, gemm_precision=args.precision,
+            )
+        )
+    train_model, test_model = models
+    if not args.no_graph:
+        train_model.capture_graph()
+
+    n_train = train_images.shape[0]
+    total = args.iterations if args.iterations > 0 else (n_train // BATCH_SIZE) * EPOCHS
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(args.seed)
+    scalars = open(summaries_folder + "scalars.jsonl", "w")
+
+    print("Training...")
+    print()
+    step, ptr, perm = 0, 0, torch.randperm(n_train, device=dev, generator=gen)
+    t0 = time.perf_counter()
+    while step < total:
+        if step % NUM_SUMMARIES_EACH_ITERATIONS == 0:
+            test_model.forward()
+            digs = test_model.rec_num_digits
+            row = {"step": step, "wall_s": round(time.perf_counter() - t0, 3),
+                   "loss": float(test_model.loss), "accuracy": float(test_model.accuracy)}
+            row.update(digit_count_summaries("digit_acc", (digs == test_targets), test_targets, 2))
+            row.update(digit_count_summaries("steps", digs, test_targets, 2))
+            row.update(digit_count_summaries("rec_loss", test_model.reconstruction_loss, test_targets, 2))
+            scalars.write(json.dumps(row) + "\n")
+            scalars.flush()
+        if step % SAVE_PARAMS_EACH_ITERATIONS == 0:
+            torch.save(train_model.state_dict(), models_folder + "air-model-%d.pt" % step)
+        if ptr + BATCH_SIZE > n_train:
+            perm, ptr = torch.randperm(n_train, device=dev, generator=gen), 0
+        idx = perm[ptr:ptr + BATCH_SIZE]
+        ptr += BATCH_SIZE
+        torch.index_select(train_images, 0, idx, out=train_data)
+        torch.index_select(train_digits, 0, idx, out=train_targets)
+        train_model.training()
+        step += 1
+        if args.print_every and step % args.print_every == 0:
+            print("iteration {}\tloss {:.3f}\taccuracy {:.2f}".format(
+                int(train_model.global_step), float(train_model.loss), float(train_model.accuracy)))
+    torch.cuda.synchronize()
+    test_model.forward()
+    print()
+    print("training has ended")
+    print("test accuracy {:.4f}  test loss {:.3f}  ({} iterations, {:.1f} s)".format(
+        float(test_model.accuracy), float(test_model.loss), step, time.perf_counter() - t0))
+    torch.save(train_model.state_dict(), models_folder + "air-model-%d.pt" % step)
+
+
+if __name__ == "__main__":
+    main()
