@@ -206,6 +206,8 @@ typedef struct {
     float* d_hid;                        /* [N,B,HT] grad wrt pre-ReLU hidden */
     float* d_out7;                       /* [N,B,8]                         */
     int32_t B, N, C, w, Hs, Hh, Hz, wout_ld;
+    int32_t literal;                     /* 1: theta gradient in the reference's fp32 autodiff op order
+                                            (keeps the out-of-range rounding residue); 0: exact adjoint */
 } air_attend_bwd_t;
 int air_attend_bwd(const air_attend_bwd_t* a, void* stream);
 
@@ -249,6 +251,7 @@ typedef struct {
     float* d_gen_pre;                    /* [N,B,w*w] grad wrt gen_mean pre-sigmoid input */
     float* d_sxy_write;                  /* [N,B,4]: ds,dx,dy (via theta_recon), dz */
     int32_t B, N, C, w;
+    int32_t literal;                     /* see air_attend_bwd_t            */
 } air_write_bwd_t;
 int air_write_bwd(const air_write_bwd_t* a, void* stream);
 

@@ -69,7 +69,8 @@ class AttendBwd(C.Structure):
     _fields_ = [("hid", _p), ("wout", _p), ("canvas", _p), ("eps_scale", _p), ("eps_shift", _p),
                 ("dyn", _p), ("out7", _p), ("att", _p), ("d_window", _p), ("d_sxy_write", _p),
                 ("d_hid", _p), ("d_out7", _p),
-                ("B", _i), ("N", _i), ("C", _i), ("w", _i), ("Hs", _i), ("Hh", _i), ("Hz", _i), ("wout_ld", _i)]
+                ("B", _i), ("N", _i), ("C", _i), ("w", _i), ("Hs", _i), ("Hh", _i), ("Hz", _i), ("wout_ld", _i),
+                ("literal", _i)]
 
 
 class WriteFwd(C.Structure):
@@ -80,7 +81,7 @@ class WriteFwd(C.Structure):
 
 class WriteBwd(C.Structure):
     _fields_ = [("d_recon", _p), ("vrec", _p), ("att", _p), ("d_gen_pre", _p), ("d_sxy_write", _p),
-                ("B", _i), ("N", _i), ("C", _i), ("w", _i)]
+                ("B", _i), ("N", _i), ("C", _i), ("w", _i), ("literal", _i)]
 
 
 _SIGNATURES = {

@@ -200,7 +200,7 @@ class AIRModel:
                  z_pres_prior_log_odds=-2.0, z_pres_temperature=1.0, stopping_threshold=0.99,
                  learning_rate=1e-3, gradient_clipping_norm=100.0, cnn=True, cnn_filters=8,
                  num_summary_images=60, train=False, reuse=False, scope="air",
-                 annealing_schedules=None, seed=0, gemm_precision=None):
+                 annealing_schedules=None, seed=0, gemm_precision=None, backward="reference"):
         if cnn:
             # reference :510-533; every caller passes cnn=False (training.py:108, demo.py:24)
             raise NotImplementedError("cnn=True front-end is outside the accelerated hot path; pass cnn=False")
@@ -246,6 +246,10 @@ class AIRModel:
         if prec not in ("fp32", "bf16"):
             raise ValueError("gemm_precision must be 'fp32' or 'bf16'")
         self.gemm_precision = prec
+        if backward not in ("reference", "exact"):
+            raise ValueError("backward must be 'reference' (fp32 autodiff op order of the reference, keeps the "
+                             "out-of-range rounding residue its training dynamics rely on) or 'exact'")
+        self.backward = backward
         self._prec = 1 if prec == "bf16" else 0
 
         dev = input_images.device
@@ -466,7 +470,7 @@ class AIRModel:
 
         bwd = []
         wb = H.WriteBwd(_ptr(self.d_recon), _ptr(self.vrec), _ptr(self.att), _ptr(self.d_genpre),
-                        _ptr(self.d_sxyw), B, N, Cc, w)
+                        _ptr(self.d_sxyw), B, N, Cc, w, 1 if self.backward == "reference" else 0)
         keep.append(wb)
         bwd.append(self._call("air_write_bwd", C.byref(wb), nbytes=NB * ((D + 2 * d) * 4 + 32), tag="write_bwd"))
         # decoder data-grads over all N*B rows: dX = dY . W^T, times softplus'(saved activation)
@@ -489,7 +493,7 @@ class AIRModel:
         ab = H.AttendBwd(_ptr(self.hid), _ptr(P["wout"]), _ptr(imgs), _ptr(self.eps_scale),
                          _ptr(self.eps_shift), _ptr(self.dyn), _ptr(self.out7), _ptr(self.att),
                          _ptr(self.d_window), _ptr(self.d_sxyw), _ptr(self.d_hid), _ptr(self.d_out7),
-                         B, N, Cc, w, Hs, Hh, Hz, Hmax)
+                         B, N, Cc, w, Hs, Hh, Hz, Hmax, 1 if self.backward == "reference" else 0)
         keep.append(ab)
         bwd.append(self._call("air_attend_bwd", C.byref(ab), nbytes=NB * ((D + d + 2 * HT) * 4 + 64), tag="attend_bwd"))
         # heads' contribution to d loss / d h'[t] for every step

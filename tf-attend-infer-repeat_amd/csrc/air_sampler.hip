@@ -49,6 +49,25 @@ __device__ __forceinline__ float bilinear4(const Tap& tx, const Tap& ty,
     return ((wa * Ia + wb * Ib) + wc * Ic) + wd * Id;
 }
 
+// Gradient of one output pixel wrt its source coordinates (X, Y), evaluated the way
+// reverse-mode autodiff of the reference's expression does it in fp32 (transformer.py:108-116):
+// the four products wa..wd each own their (x1-x), (x-x0), (y1-y), (y-y0) nodes, their
+// gradients g*I*t reach x and y one by one (last-created node first: wd, wc, wb, wa) and are
+// summed as they arrive.  For an out-of-range pixel (both taps clipped to one index) the four
+// terms cancel exactly in real arithmetic but NOT in fp32 -- the rounding residue of
+// (D + C) is multiplied by g ~ 1/(residue + 1e-9) at unexplained ink.  That residue is not
+// noise to be cleaned up: it is the force that pulls glimpses towards unexplained ink, and the
+// reference's training dynamics depend on it (with the exact adjoint the model does not learn
+// to localise).  cx = (n_in - 1.001): x = (x_s + 1) * cx / 2.
+__device__ __forceinline__ void literal_dxy(float g, float Ia, float Ib, float Ic, float Id,
+                                            const Tap& tx, const Tap& ty, float cx, float& dxs, float& dys) {
+    const float ga = g * Ia, gb = g * Ib, gc = g * Ic, gd = g * Id;          // d out / d wa..wd
+    const float dX = ((gd * ty.w1 + gc * ty.w0) - gb * ty.w1) - ga * ty.w0;  // via (x-x0) [wd, wc], (x1-x) [wb, wa]
+    const float dY = ((gd * tx.w1 - gc * tx.w1) + gb * tx.w0) - ga * tx.w0;  // via (y-y0) [wd], (y1-y) [wc], (y-y0) [wb], (y1-y) [wa]
+    dxs = (dX / 2.0f) * cx;
+    dys = (dY / 2.0f) * cx;
+}
+
 // ---------------------------------------------------------------------------
 // generic transformer (any theta): one thread per output pixel
 // ---------------------------------------------------------------------------
@@ -286,8 +305,12 @@ __global__ __launch_bounds__(THREADS) void attend_bwd_kernel(air_attend_bwd_t a)
         const int c0 = tx.i0 - xlo, c1 = tx.i1 - xlo;
         const float Ia = sh_img[r0 + c0], Ib = sh_img[r1 + c0], Ic = sh_img[r0 + c1], Id = sh_img[r1 + c1];
         const float gv = g[p];
-        const float gX = gv * ((Ic - Ia) * ty.w0 + (Id - Ib) * ty.w1) * half_c;
-        const float gY = gv * ((Ib - Ia) * tx.w0 + (Id - Ic) * tx.w1) * half_c;
+        float gX, gY;
+        if (a.literal) literal_dxy(gv, Ia, Ib, Ic, Id, tx, ty, (float)C - 1.001f, gX, gY);
+        else {
+            gX = gv * ((Ic - Ia) * ty.w0 + (Id - Ib) * ty.w1) * half_c;
+            gY = gv * ((Ib - Ia) * tx.w0 + (Id - Ic) * tx.w1) * half_c;
+        }
         ds += gX * sh_t[j] + gY * sh_t[i];
         dx += gX;
         dy += gY;
@@ -451,9 +474,9 @@ __global__ __launch_bounds__(THREADS) void write_bwd_kernel(air_write_bwd_t a)
     Tap* sh_tx = reinterpret_cast<Tap*>(smem + 4);         // [C]
     Tap* sh_ty = sh_tx + C;                                // [C]
     float* sh_t = reinterpret_cast<float*>(sh_ty + C);     // [C] linspace
-    int* sh_rng = reinterpret_cast<int*>(sh_t + C);        // [4*w]: Jlo,Jhi per q ; Ilo,Ihi per p
-    float* sh_win = reinterpret_cast<float*>(sh_rng + 4 * w);   // [w*w]
-    float* sh_T = sh_win + w * w;                          // [C*w]
+    int* sh_rng = reinterpret_cast<int*>(sh_t + C);        // [8*w]: per source index, ranges of outputs whose tap0 / tap1 hit it
+    float* sh_win = reinterpret_cast<float*>(sh_rng + 8 * w);   // [w*w]
+    float* sh_T = sh_win + w * w;                          // [2][C*w]
 
     const float* at = a.att + row * AIR_ATT_STRIDE;
     float* dgen = a.d_gen_pre + row * w * w;
@@ -474,31 +497,52 @@ __global__ __launch_bounds__(THREADS) void write_bwd_kernel(air_write_bwd_t a)
     const float* v = a.vrec + row * w * w;
     for (int p = tid; p < w * w; p += THREADS) sh_win[p] = v[p];
     __syncthreads();
-    // source-index q is touched by a contiguous range of output coordinates (taps are monotone)
+    // source index q is touched by a contiguous range of output coordinates (taps are monotone).
+    // exact mode: one merged range per index, degenerate (both taps clipped to one index) outputs
+    // skipped -- their two weights cancel exactly in real arithmetic.
+    // literal mode: tap0 and tap1 keep separate ranges and degenerate outputs stay in, as in the
+    // reference's four Gather_grad scatters.
     if (tid < 2 * w) {
         const Tap* tp = (tid < w) ? sh_tx : sh_ty;
         const int q = (tid < w) ? tid : tid - w;
-        int lo = C, hi = -1;
+        int lo0 = C, hi0 = -1, lo1 = C, hi1 = -1;
         for (int j = 0; j < C; ++j) {
             const Tap tt = tp[j];
-            if (tt.i0 != tt.i1 && (tt.i0 == q || tt.i1 == q)) { lo = min(lo, j); hi = max(hi, j); }
+            if (a.literal) {
+                if (tt.i0 == q) { lo0 = min(lo0, j); hi0 = max(hi0, j); }
+                if (tt.i1 == q) { lo1 = min(lo1, j); hi1 = max(hi1, j); }
+            } else if (tt.i0 != tt.i1 && (tt.i0 == q || tt.i1 == q)) { lo0 = min(lo0, j); hi0 = max(hi0, j); }
         }
-        sh_rng[(tid < w ? 0 : 2 * w) + 2 * q] = lo;
-        sh_rng[(tid < w ? 0 : 2 * w) + 2 * q + 1] = hi;
+        int* r = sh_rng + (tid < w ? 0 : 4 * w) + 4 * q;
+        r[0] = lo0; r[1] = hi0; r[2] = lo1; r[3] = hi1;
     }
     __syncthreads();
 
     const float* g = a.d_recon + (size_t)b * C * C;
-    // stage 1: T[I][q] = sum_J g[I][J] * Rx[J][q]
-    for (int it = tid; it < C * w; it += THREADS) {
-        const int I = it / w, q = it % w;
-        float acc = 0.0f;
-        for (int J = sh_rng[2 * q]; J <= sh_rng[2 * q + 1]; ++J) {
-            const Tap tt = sh_tx[J];
-            const float wq = (tt.i0 != tt.i1) ? ((tt.i0 == q ? tt.w0 : 0.0f) + (tt.i1 == q ? tt.w1 : 0.0f)) : 0.0f;
-            acc += g[I * C + J] * wq;
+    float* T0 = sh_T;
+    float* T1 = sh_T + C * w;
+    if (!a.literal) {
+        // stage 1: T[I][q] = sum_J g[I][J] * Rx[J][q]
+        for (int it = tid; it < C * w; it += THREADS) {
+            const int I = it / w, q = it % w;
+            float acc = 0.0f;
+            for (int J = sh_rng[4 * q]; J <= sh_rng[4 * q + 1]; ++J) {
+                const Tap tt = sh_tx[J];
+                const float wq = (tt.i0 != tt.i1) ? ((tt.i0 == q ? tt.w0 : 0.0f) + (tt.i1 == q ? tt.w1 : 0.0f)) : 0.0f;
+                acc += g[I * C + J] * wq;
+            }
+            T0[it] = acc;
         }
-        sh_T[it] = acc;
+    } else {
+        // stage 1, per tap: T0 through the x0 taps, T1 through the x1 taps; g already scaled by z_pres
+        for (int it = tid; it < C * w; it += THREADS) {
+            const int I = it / w, q = it % w;
+            float a0 = 0.0f, a1 = 0.0f;
+            for (int J = sh_rng[4 * q]; J <= sh_rng[4 * q + 1]; ++J) a0 += (g[I * C + J] * z) * sh_tx[J].w0;
+            for (int J = sh_rng[4 * q + 2]; J <= sh_rng[4 * q + 3]; ++J) a1 += (g[I * C + J] * z) * sh_tx[J].w1;
+            T0[it] = a0;
+            T1[it] = a1;
+        }
     }
     // theta / z gradients, per canvas pixel (independent of stage 1)
     const float half_w = ((float)w - 1.001f) / 2.0f;
@@ -512,10 +556,15 @@ __global__ __launch_bounds__(THREADS) void write_bwd_kernel(air_write_bwd_t a)
         // a degenerate axis (both taps clipped to one index) is exactly 0 in real arithmetic;
         // the fp32 residue the forward keeps there (~1e-7) would be multiplied by g ~ 1e9/B
         // (d log(r + 1e-9) at r ~ 0) and drown d z_pres in rounding noise.
-        if (tx.i0 != tx.i1 && ty.i0 != ty.i1) dz += gv * bilinear4(tx, ty, Ia, Ib, Ic, Id);
+        // (exact mode only; the reference's autodiff multiplies the residue by g like any other value)
+        if (a.literal || (tx.i0 != tx.i1 && ty.i0 != ty.i1)) dz += gv * bilinear4(tx, ty, Ia, Ib, Ic, Id);
         const float gz = gv * z;
-        const float gX = gz * ((Ic - Ia) * ty.w0 + (Id - Ib) * ty.w1) * half_w;
-        const float gY = gz * ((Ib - Ia) * tx.w0 + (Id - Ic) * tx.w1) * half_w;
+        float gX, gY;
+        if (a.literal) literal_dxy(gz, Ia, Ib, Ic, Id, tx, ty, (float)w - 1.001f, gX, gY);
+        else {
+            gX = gz * ((Ic - Ia) * ty.w0 + (Id - Ib) * ty.w1) * half_w;
+            gY = gz * ((Ib - Ia) * tx.w0 + (Id - Ic) * tx.w1) * half_w;
+        }
         da += gX * sh_t[j] + gY * sh_t[i];
         dbx += gX;
         dby += gY;
@@ -535,14 +584,28 @@ __global__ __launch_bounds__(THREADS) void write_bwd_kernel(air_write_bwd_t a)
     // stage 2: dU[p][q] = z * sum_I Ry[I][p] * T[I][q]; fold the sigmoid of vae.py:39-41
     for (int it = tid; it < w * w; it += THREADS) {
         const int p = it / w, q = it % w;
-        float acc = 0.0f;
-        for (int I = sh_rng[2 * w + 2 * p]; I <= sh_rng[2 * w + 2 * p + 1]; ++I) {
-            const Tap tt = sh_ty[I];
-            const float wp = (tt.i0 != tt.i1) ? ((tt.i0 == p ? tt.w0 : 0.0f) + (tt.i1 == p ? tt.w1 : 0.0f)) : 0.0f;
-            acc += sh_T[I * w + q] * wp;
+        const int* ry = sh_rng + 4 * w + 4 * p;
+        float du;
+        if (!a.literal) {
+            float acc = 0.0f;
+            for (int I = ry[0]; I <= ry[1]; ++I) {
+                const Tap tt = sh_ty[I];
+                const float wp = (tt.i0 != tt.i1) ? ((tt.i0 == p ? tt.w0 : 0.0f) + (tt.i1 == p ? tt.w1 : 0.0f)) : 0.0f;
+                acc += T0[I * w + q] * wp;
+            }
+            du = z * acc;
+        } else {
+            // the four Gather_grad scatters of the reference (taps a=(y0,x0), b=(y1,x0), c=(y0,x1),
+            // d=(y1,x1)), summed as reverse-mode autodiff delivers them: ((d + c) + b) + a.  For a
+            // border source pixel the out-of-range contributions of a/c (b/d) are equal and opposite;
+            // in fp32 they leave the rounding residue the reference's gradients carry.
+            float sa = 0.0f, sb = 0.0f, sc = 0.0f, sd = 0.0f;
+            for (int I = ry[0]; I <= ry[1]; ++I) { const float wy = sh_ty[I].w0; sa += T0[I * w + q] * wy; sc += T1[I * w + q] * wy; }
+            for (int I = ry[2]; I <= ry[3]; ++I) { const float wy = sh_ty[I].w1; sb += T0[I * w + q] * wy; sd += T1[I * w + q] * wy; }
+            du = ((sd + sc) + sb) + sa;
         }
         const float r = sh_win[it];
-        dgen[it] = (z * acc) * (r * (1.0f - r));
+        dgen[it] = du * (r * (1.0f - r));
     }
 }
 
@@ -553,7 +616,7 @@ size_t attend_bwd_smem(int C, int w) {
     return (12 + 8 * w + w + 4 + (size_t)C * C) * sizeof(float);
 }
 size_t write_smem(int N, int C, int w) { return (4 + 2 * MAX_STEPS + (size_t)N * (8 * C + (size_t)w * w)) * sizeof(float); }
-size_t write_bwd_smem(int C, int w) { return (4 + 8 * C + C + 4 * w + (size_t)w * w + (size_t)C * w) * sizeof(float); }
+size_t write_bwd_smem(int C, int w) { return (4 + 8 * C + C + 8 * w + (size_t)w * w + 2 * (size_t)C * w) * sizeof(float); }
 
 template <typename K>
 int ensure_lds(K kernel, size_t bytes) {
