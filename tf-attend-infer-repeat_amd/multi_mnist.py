@@ -4,8 +4,8 @@ driver :299-414) in numpy, writing .npz instead of TFRecords.
 
 Glyph source: real MNIST idx files are used if present under ``mnist_data/`` (the reference
 downloads them, :336 -- impossible here, no network); otherwise the 1 797 8x8 glyphs of
-sklearn's ``load_digits`` (committed as data/digits8x8.npz), up-sampled to 20x20 inside a
-28x28 frame like an MNIST digit.  Everything downstream (cropping, rejection sampling of
+sklearn's ``load_digits`` (committed as data/digits8x8.npz), up-sampled to 16x16 inside a
+28x28 frame (stroke width and ink mass close to an MNIST digit).  Everything downstream (cropping, rejection sampling of
 non-overlapping positions, strata of 0..max_digits digits, shuffling, 1 000-image test split)
 follows the reference.
 
@@ -44,10 +44,12 @@ def load_glyphs():
     d = np.load(os.path.join(HERE, "data", "digits8x8.npz"))
     small = d["images"].astype(np.float32) / 16.0
     out = np.zeros((small.shape[0], IMAGE_SIZE, IMAGE_SIZE), np.float32)
+    zoom = float(os.environ.get("AIR_GLYPH_ZOOM", "2.0"))                 # 8x8 -> 16x16: MNIST-like stroke scale
     for i, g in enumerate(small):
-        big = np.clip(nd.zoom(g, 2.5, order=1), 0.0, 1.0)            # 8x8 -> 20x20
+        big = np.clip(nd.zoom(g, zoom, order=1), 0.0, 1.0)
         big = np.where(big >= 0.15, big, 0.0)
-        out[i, 4:24, 4:24] = big
+        o = (IMAGE_SIZE - big.shape[0]) // 2
+        out[i, o:o + big.shape[0], o:o + big.shape[1]] = big
     return out.reshape(-1, IMAGE_SIZE * IMAGE_SIZE), d["labels"].astype(np.int64), "digits8x8"
 
 
