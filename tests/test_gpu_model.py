@@ -290,8 +290,8 @@ def test_reference_backward_carries_the_fp32_residue(am):
     _, g32 = at.loss_and_grads(pt, torch.tensor(images), torch.tensor(targets), at.to_torch(noise), HP, 9.21)
     n32 = {k: float(v.norm()) for k, v in g32.items()}
     REPORT["residue_norms"] = {k: [norms["reference"][k], norms["exact"][k], n32[k]] for k in n32}
-    for k, ratio in (("rnn/kernel", 1.3), ("shift/mean/output/weights", 1.3), ("vae/gen_mean/weights", 3.0),
-                     ("vae/generative_2/weights", 3.0)):
+    for k, ratio in (("rnn/kernel", 1.3), ("shift/mean/output/weights", 1.3), ("vae/gen_mean/weights", 2.0),
+                     ("vae/generative_2/weights", 2.0)):
         assert norms["reference"][k] > ratio * norms["exact"][k], k
         assert 0.2 < norms["reference"][k] / n32[k] < 5.0, (k, norms["reference"][k], n32[k])
     for k in ("z_pres/log_odds/output/weights",):       # paths without out-of-range taps are unaffected

@@ -68,6 +68,22 @@ __device__ __forceinline__ void literal_dxy(float g, float Ia, float Ib, float I
     dys = (dY / 2.0f) * cx;
 }
 
+// inclusive segmented scan inside a wave: lanes with equal (contiguous) keys are summed in a fixed
+// tree order; the last lane of each run holds the run's total
+__device__ __forceinline__ float seg_scan(float v, int key, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float pv = __shfl_up(v, off, 64);
+        const int pk = __shfl_up(key, off, 64);
+        if (lane >= off && pk == key) v += pv;
+    }
+    return v;
+}
+__device__ __forceinline__ bool seg_end(int key, int lane, int nvalid) {
+    const int nk = __shfl_down(key, 1, 64);
+    return lane < nvalid && (lane == nvalid - 1 || nk != key);
+}
+
 // ---------------------------------------------------------------------------
 // generic transformer (any theta): one thread per output pixel
 // ---------------------------------------------------------------------------
@@ -379,52 +395,71 @@ __global__ __launch_bounds__(THREADS) void attend_bwd_kernel(air_attend_bwd_t a)
 __global__ __launch_bounds__(THREADS) void write_fwd_kernel(air_write_fwd_t a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int C = a.C, w = a.w, Z = a.Z, N = a.N, B = a.B;
     float* sh_red = smem;                                    // [4]
-    float* sh_z = smem + 4;                                  // [MAX_STEPS] z_pres if active else 0
+    float* sh_z = smem + 4;                                  // [MAX_STEPS] z_pres
     int* sh_act = reinterpret_cast<int*>(smem + 4 + MAX_STEPS);          // [MAX_STEPS]
-    Tap* sh_tx = reinterpret_cast<Tap*>(smem + 4 + 2 * MAX_STEPS);       // [N][C]
+    float* sh_kl = smem + 4 + 2 * MAX_STEPS;                             // [MAX_STEPS] VAE KL per step
+    Tap* sh_tx = reinterpret_cast<Tap*>(smem + 4 + 3 * MAX_STEPS);       // [N][C]
     Tap* sh_ty = sh_tx + (size_t)N * C;                                    // [N][C]
     float* sh_win = reinterpret_cast<float*>(sh_ty + (size_t)N * C);      // [N][w*w]
     const float* dyn = a.dyn;
 
-    float L = 0.0f;
-    int digits = 0;
-    for (int t = 0; t < N; ++t) {
-        float* at = a.att + ((size_t)t * B + b) * AIR_ATT_STRIDE;
-        const bool mask = at[AIR_ATT_MASK] != 0.0f;
-        // VAE KL :479-493 (a public output whether or not the item is still active)
+    // phase A -- everything that only needs the per-step records, for all steps at once
+    // (independent loads: one memory round trip instead of one per step)
+    for (int t = wave; t < N; t += 4) {
+        // VAE KL :479-493 (a public output whether or not the item is still active): one wave per step
         const float* ml = a.ml + ((size_t)t * B + b) * 2 * Z;
         const float pv = dyn[AIR_DYN_VAE_PV], pm = dyn[AIR_DYN_VAE_PM];
         float klt = 0.0f;
-        for (int j = tid; j < Z; j += THREADS) {
+        for (int j = lane; j < Z; j += 64) {
             const float lv = ml[Z + j];
             klt += gauss_kl_term(logf(pv), lv, expf(lv), pv, ml[j], pm);
         }
-        const float kl = 0.5f * air_block_sum_256(klt, sh_red);
-        // running loss in the reference order: z KL (old mask), scale, shift, VAE KL (new mask) :411-493
-        L = L + (at[AIR_ATT_MASK_PREV] != 0.0f ? at[AIR_ATT_KL_Z] : 0.0f);
-        L = L + (mask ? at[AIR_ATT_KL_SCALE] : 0.0f);
-        L = L + (mask ? at[AIR_ATT_KL_SHIFT] : 0.0f);
-        L = L + (mask ? kl : 0.0f);
-        digits += mask ? 1 : 0;
-        if (tid == 0) { at[AIR_ATT_KL_VAE] = kl; sh_z[t] = at[AIR_ATT_Z]; sh_act[t] = mask ? 1 : 0; }
-        if (mask) {
-            // theta_recon :353-356
-            const float s = at[AIR_ATT_S], x = at[AIR_ATT_X], y = at[AIR_ATT_Y];
-            const float ia = 1.0f / s, bx = (-x) / s, by = (-y) / s;
-            for (int j = tid; j < C; j += THREADS) {
-                sh_tx[(size_t)t * C + j] = axis_tap(j, C, w, ia, bx);
-                sh_ty[(size_t)t * C + j] = axis_tap(j, C, w, ia, by);
-            }
-            const float* v = a.vrec + ((size_t)t * B + b) * w * w;
-            for (int p = tid; p < w * w; p += THREADS) sh_win[(size_t)t * w * w + p] = v[p];
-        }
+        klt = air_wave_sum(klt);
+        if (lane == 0) sh_kl[t] = 0.5f * klt;
+    }
+    for (int it = tid; it < N * C; it += THREADS) {
+        const int t = it / C, j = it % C;
+        const float* at = a.att + ((size_t)t * B + b) * AIR_ATT_STRIDE;
+        // theta_recon :353-356
+        const float s = at[AIR_ATT_S], x = at[AIR_ATT_X], y = at[AIR_ATT_Y];
+        const float ia = 1.0f / s, bx = (-x) / s, by = (-y) / s;
+        sh_tx[it] = axis_tap(j, C, w, ia, bx);
+        sh_ty[it] = axis_tap(j, C, w, ia, by);
+    }
+    for (int it = tid; it < N * w * w; it += THREADS) {
+        const int t = it / (w * w);
+        sh_win[it] = a.vrec[((size_t)t * B + b) * w * w + (it - t * w * w)];
+    }
+    if (tid < N) {
+        const float* at = a.att + ((size_t)tid * B + b) * AIR_ATT_STRIDE;
+        sh_z[tid] = at[AIR_ATT_Z];
+        sh_act[tid] = at[AIR_ATT_MASK] != 0.0f ? 1 : 0;
     }
     __syncthreads();
+    if (tid == 0) {
+        // running loss in the reference order: z KL (old mask), scale, shift, VAE KL (new mask) :411-493
+        float L = 0.0f;
+        int digits = 0;
+        for (int t = 0; t < N; ++t) {
+            float* at = a.att + ((size_t)t * B + b) * AIR_ATT_STRIDE;
+            const bool mask = sh_act[t] != 0;
+            L = L + (at[AIR_ATT_MASK_PREV] != 0.0f ? at[AIR_ATT_KL_Z] : 0.0f);
+            L = L + (mask ? at[AIR_ATT_KL_SCALE] : 0.0f);
+            L = L + (mask ? at[AIR_ATT_KL_SHIFT] : 0.0f);
+            L = L + (mask ? sh_kl[t] : 0.0f);
+            digits += mask ? 1 : 0;
+            at[AIR_ATT_KL_VAE] = sh_kl[t];
+        }
+        a.run_loss[b] = L;
+        a.run_digits[b] = digits;
+    }
+    float Lkeep = 0.0f;
+    if (tid == 0) Lkeep = a.run_loss[b];          // thread 0 re-reads its own store
 
-    // canvas + Bernoulli cross-entropy, pixel by pixel
+    // phase B -- canvas + Bernoulli cross-entropy, pixel by pixel
     const float gsc = dyn[AIR_DYN_GRAD_SCALE];
     const size_t base = (size_t)b * C * C;
     float acc = 0.0f;
@@ -453,9 +488,7 @@ __global__ __launch_bounds__(THREADS) void write_fwd_kernel(air_write_fwd_t a)
     if (tid == 0) {
         const float rl = -acc;
         a.rec_loss[b] = rl;
-        a.run_loss[b] = L;
-        a.run_digits[b] = digits;
-        a.loss_item[b] = L + rl;                                    // loss += reconstruction_loss :593
+        a.loss_item[b] = Lkeep + rl;                                // loss += reconstruction_loss :593
     }
 }
 
@@ -477,6 +510,7 @@ __global__ __launch_bounds__(THREADS) void write_bwd_kernel(air_write_bwd_t a)
     int* sh_rng = reinterpret_cast<int*>(sh_t + C);        // [8*w]: per source index, ranges of outputs whose tap0 / tap1 hit it
     float* sh_win = reinterpret_cast<float*>(sh_rng + 8 * w);   // [w*w]
     float* sh_T = sh_win + w * w;                          // [2][C*w]
+    float* sh_g = sh_T + 2 * C * (w + 2);                  // [C*C] d loss / d canvas of this image
 
     const float* at = a.att + row * AIR_ATT_STRIDE;
     float* dgen = a.d_gen_pre + row * w * w;
@@ -496,6 +530,10 @@ __global__ __launch_bounds__(THREADS) void write_bwd_kernel(air_write_bwd_t a)
     }
     const float* v = a.vrec + row * w * w;
     for (int p = tid; p < w * w; p += THREADS) sh_win[p] = v[p];
+    {
+        const float* gsrc = a.d_recon + (size_t)b * C * C;   // one coalesced pass; every later access is LDS
+        for (int p = tid; p < C * C; p += THREADS) sh_g[p] = gsrc[p];
+    }
     __syncthreads();
     // source index q is touched by a contiguous range of output coordinates (taps are monotone).
     // exact mode: one merged range per index, degenerate (both taps clipped to one index) outputs
@@ -518,9 +556,10 @@ __global__ __launch_bounds__(THREADS) void write_bwd_kernel(air_write_bwd_t a)
     }
     __syncthreads();
 
-    const float* g = a.d_recon + (size_t)b * C * C;
+    const float* g = sh_g;
+    const int tstride = a.literal ? w + 2 : w;              // literal mode keeps 2 extra slots per row
     float* T0 = sh_T;
-    float* T1 = sh_T + C * w;
+    float* T1 = sh_T + C * tstride;
     if (!a.literal) {
         // stage 1: T[I][q] = sum_J g[I][J] * Rx[J][q]
         for (int it = tid; it < C * w; it += THREADS) {
@@ -531,17 +570,44 @@ __global__ __launch_bounds__(THREADS) void write_bwd_kernel(air_write_bwd_t a)
                 const float wq = (tt.i0 != tt.i1) ? ((tt.i0 == q ? tt.w0 : 0.0f) + (tt.i1 == q ? tt.w1 : 0.0f)) : 0.0f;
                 acc += g[I * C + J] * wq;
             }
-            T0[it] = acc;
+            T0[I * tstride + q] = acc;
         }
     } else {
-        // stage 1, per tap: T0 through the x0 taps, T1 through the x1 taps; g already scaled by z_pres
-        for (int it = tid; it < C * w; it += THREADS) {
-            const int I = it / w, q = it % w;
-            float a0 = 0.0f, a1 = 0.0f;
-            for (int J = sh_rng[4 * q]; J <= sh_rng[4 * q + 1]; ++J) a0 += (g[I * C + J] * z) * sh_tx[J].w0;
-            for (int J = sh_rng[4 * q + 2]; J <= sh_rng[4 * q + 3]; ++J) a1 += (g[I * C + J] * z) * sh_tx[J].w1;
-            T0[it] = a0;
-            T1[it] = a1;
+        // stage 1, per tap: T0[I][q] through the x0 taps, T1[I][q] through the x1 taps (g scaled by
+        // z_pres).  One wave per canvas row; runs of equal tap index are contiguous (monotone taps),
+        // so a segmented wave scan replaces the serial loops over the (long) out-of-range runs.
+        // Out-of-range (degenerate) runs are summed in their own segments (slots w / w+1 of each
+        // row) so that the +w and -w partners go through identical summation trees, then folded
+        // into the border slot: the residue left is the rounding of (in-range sum + huge run), as
+        // in a sequential scatter-add.
+        const int ws = w + 2;
+        for (int it = tid; it < 2 * C * ws; it += THREADS) sh_T[it] = 0.0f;
+        __syncthreads();
+        const int lane = tid & 63, wave = tid >> 6;
+        float* W0 = sh_T;
+        float* W1 = sh_T + C * ws;
+        for (int I = wave; I < C; I += 4) {
+            for (int c0 = 0; c0 < C; c0 += 64) {
+                const int J = c0 + lane, nvalid = min(64, C - c0);
+                Tap tt{0.f, 0.f, -1 - lane, -1 - lane};
+                float gz = 0.0f;
+                int k0 = -1 - lane, k1 = -1 - lane;
+                if (J < C) {
+                    tt = sh_tx[J]; gz = g[I * C + J] * z;
+                    const bool deg = tt.i0 == tt.i1;
+                    k0 = deg ? (tt.i0 == 0 ? w : w + 1) : tt.i0;
+                    k1 = deg ? (tt.i1 == 0 ? w : w + 1) : tt.i1;
+                }
+                const float s0 = seg_scan(gz * tt.w0, k0, lane);
+                const float s1 = seg_scan(gz * tt.w1, k1, lane);
+                if (seg_end(k0, lane, nvalid)) W0[I * ws + k0] += s0;
+                if (seg_end(k1, lane, nvalid)) W1[I * ws + k1] += s1;
+            }
+            if (lane < 2) {          // fold: lane 0 -> tap-0 row, lane 1 -> tap-1 row
+                float* r = (lane == 0 ? W0 : W1) + I * ws;
+                r[0] += r[w];
+                r[w - 1] += r[w + 1];
+            }
         }
     }
     // theta / z gradients, per canvas pixel (independent of stage 1)
@@ -581,6 +647,37 @@ __global__ __launch_bounds__(THREADS) void write_bwd_kernel(air_write_bwd_t a)
         dsx[2] = -dby / s;
         dsx[3] = dz;
     }
+    float* sh_S = sh_g + C * C;                            // [4][(w+2)*w]: per-tap sums a, b, c, d (literal mode)
+    const int ss = (w + 2) * w;
+    if (a.literal) {
+        for (int it = tid; it < 4 * ss; it += THREADS) sh_S[it] = 0.0f;
+        __syncthreads();
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int q = wave; q < w; q += 4) {
+            for (int c0 = 0; c0 < C; c0 += 64) {
+                const int I = c0 + lane, nvalid = min(64, C - c0);
+                Tap tt{0.f, 0.f, -1 - lane, -1 - lane};
+                float t0 = 0.0f, t1 = 0.0f;
+                int k0 = -1 - lane, k1 = -1 - lane;
+                if (I < C) {
+                    tt = sh_ty[I]; t0 = T0[I * tstride + q]; t1 = T1[I * tstride + q];
+                    const bool deg = tt.i0 == tt.i1;
+                    k0 = deg ? (tt.i0 == 0 ? w : w + 1) : tt.i0;
+                    k1 = deg ? (tt.i1 == 0 ? w : w + 1) : tt.i1;
+                }
+                const float sa = seg_scan(t0 * tt.w0, k0, lane), sc = seg_scan(t1 * tt.w0, k0, lane);
+                const float sb = seg_scan(t0 * tt.w1, k1, lane), sd = seg_scan(t1 * tt.w1, k1, lane);
+                if (seg_end(k0, lane, nvalid)) { sh_S[k0 * w + q] += sa; sh_S[2 * ss + k0 * w + q] += sc; }
+                if (seg_end(k1, lane, nvalid)) { sh_S[ss + k1 * w + q] += sb; sh_S[3 * ss + k1 * w + q] += sd; }
+            }
+            if (lane < 4) {          // fold the out-of-range runs into the border rows, per tap array
+                float* r = sh_S + lane * ss;
+                r[q] += r[w * w + q];
+                r[(w - 1) * w + q] += r[(w + 1) * w + q];
+            }
+        }
+        __syncthreads();
+    }
     // stage 2: dU[p][q] = z * sum_I Ry[I][p] * T[I][q]; fold the sigmoid of vae.py:39-41
     for (int it = tid; it < w * w; it += THREADS) {
         const int p = it / w, q = it % w;
@@ -591,7 +688,7 @@ __global__ __launch_bounds__(THREADS) void write_bwd_kernel(air_write_bwd_t a)
             for (int I = ry[0]; I <= ry[1]; ++I) {
                 const Tap tt = sh_ty[I];
                 const float wp = (tt.i0 != tt.i1) ? ((tt.i0 == p ? tt.w0 : 0.0f) + (tt.i1 == p ? tt.w1 : 0.0f)) : 0.0f;
-                acc += T0[I * w + q] * wp;
+                acc += T0[I * tstride + q] * wp;
             }
             du = z * acc;
         } else {
@@ -599,10 +696,7 @@ __global__ __launch_bounds__(THREADS) void write_bwd_kernel(air_write_bwd_t a)
             // d=(y1,x1)), summed as reverse-mode autodiff delivers them: ((d + c) + b) + a.  For a
             // border source pixel the out-of-range contributions of a/c (b/d) are equal and opposite;
             // in fp32 they leave the rounding residue the reference's gradients carry.
-            float sa = 0.0f, sb = 0.0f, sc = 0.0f, sd = 0.0f;
-            for (int I = ry[0]; I <= ry[1]; ++I) { const float wy = sh_ty[I].w0; sa += T0[I * w + q] * wy; sc += T1[I * w + q] * wy; }
-            for (int I = ry[2]; I <= ry[3]; ++I) { const float wy = sh_ty[I].w1; sb += T0[I * w + q] * wy; sd += T1[I * w + q] * wy; }
-            du = ((sd + sc) + sb) + sa;
+            du = ((sh_S[3 * ss + it] + sh_S[2 * ss + it]) + sh_S[ss + it]) + sh_S[it];
         }
         const float r = sh_win[it];
         dgen[it] = du * (r * (1.0f - r));
@@ -615,8 +709,8 @@ size_t attend_smem(int C, int w, int HT) {
 size_t attend_bwd_smem(int C, int w) {
     return (12 + 8 * w + w + 4 + (size_t)C * C) * sizeof(float);
 }
-size_t write_smem(int N, int C, int w) { return (4 + 2 * MAX_STEPS + (size_t)N * (8 * C + (size_t)w * w)) * sizeof(float); }
-size_t write_bwd_smem(int C, int w) { return (4 + 8 * C + C + 8 * w + (size_t)w * w + 2 * (size_t)C * w) * sizeof(float); }
+size_t write_smem(int N, int C, int w) { return (4 + 3 * MAX_STEPS + (size_t)N * (8 * C + (size_t)w * w)) * sizeof(float); }
+size_t write_bwd_smem(int C, int w) { return (4 + 8 * C + C + 8 * w + (size_t)w * w + 4 * (size_t)(w + 2) * w + 2 * (size_t)C * (w + 2) + (size_t)C * C) * sizeof(float); }
 
 template <typename K>
 int ensure_lds(K kernel, size_t bytes) {
