@@ -54,36 +54,89 @@ struct Args {
     int i0, i1;
 };
 
-__device__ __forceinline__ void generic_store(const Args& a, float v, int m, int n) {
-    if (a.bias) v += a.bias[n];
-    if (a.addend) {
-        for (int s = 0; s < a.add_slabs; ++s) v += a.addend[s * a.add_slab_stride + (size_t)m * a.ldadd + n];
+// Epilogue operands (bias / addend / aux / LSTM state) are PREFETCHED into registers at kernel
+// entry, in the lane->element map the epilogue will use: their memory round trip (~2 us when
+// the producer ran on another XCD) overlaps the operand panels' instead of following the MFMAs.
+// Items of the epilogue: (row-tile i, column-tile j, q) for the generic one, (i, q) for the fused
+// ones; item `it` belongs to wave it & 3.  C/D map: row = (lane>>4)*4 + q, col = lane&15.
+template <int TM, int TN>
+struct Pre {
+    static constexpr int NG = TM * TN;            // generic items per wave
+    float bias[NG], add[NG], aux[NG];
+    float f[40];                                  // fused-epilogue operands (LSTM: 32 slab values + 4 bias + state)
+};
+
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue_prefetch(const Args& a, Pre<TM, TN>& pre, int m0, int n0, int lane, int wave) {
+    if (a.epi == AIR_EPI_GENERIC) {
+#pragma unroll
+        for (int k = 0; k < TM * TN; ++k) {
+            const int it = wave + 4 * k;
+            const int i = it / (TN * 4), j = (it >> 2) % TN, q = it & 3;
+            const int m = m0 + i * 16 + (lane >> 4) * 4 + q;
+            const int n = n0 + j * 16 + (lane & 15);
+            pre.bias[k] = 0.0f; pre.add[k] = 0.0f; pre.aux[k] = 0.0f;
+            if (m < a.M && n < a.N) {
+                if (a.bias) pre.bias[k] = a.bias[n];
+                if (a.addend && a.add_slabs == 1) pre.add[k] = a.addend[(size_t)m * a.ldadd + n];
+                if (a.aux) pre.aux[k] = a.aux[(size_t)m * a.ldaux + n];
+            }
+        }
+        return;
     }
-    if (a.act == AIR_ACT_RELU) v = fmaxf(v, 0.0f);
-    else if (a.act == AIR_ACT_SOFTPLUS) v = air_softplus(v);
-    else if (a.act == AIR_ACT_SIGMOID_NOISE) v = air_sigmoid(v + a.aux[(size_t)m * a.ldaux + n] * a.aux_scale);
-    if (a.actgrad == AIR_GRAD_RELU) v = (a.aux[(size_t)m * a.ldaux + n] > 0.0f) ? v : 0.0f;
-    else if (a.actgrad == AIR_GRAD_SOFTPLUS) v = v * (1.0f - expf(-a.aux[(size_t)m * a.ldaux + n]));
-    float* c = a.C + (size_t)m * a.ldc + n;
-    if (a.accumulate) v += *c;
-    *c = v;
+    const int q = wave;                            // fused epilogues run with TM == 1: item = q
+    const int m = m0 + (lane >> 4) * 4 + q;
+    const int u = n0 + (lane & 15);
+    const bool ok = (m < a.M) && (u < a.gwidth);
+    if (a.epi == AIR_EPI_LSTM_FWD) {
+        const int R = a.gwidth;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = u + j * R;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                pre.f[j * 8 + k] = (ok && k < a.add_slabs) ? a.addend[k * a.add_slab_stride + (size_t)m * a.ldadd + n] : 0.0f;
+            pre.f[32 + j] = (ok && a.bias) ? a.bias[n] : 0.0f;
+        }
+        pre.f[36] = ok ? a.p0[(size_t)m * R + u] : 0.0f;
+    } else if (a.epi == AIR_EPI_LSTM_BWD) {
+        const int R = a.gwidth;
+        const size_t idx = (size_t)m * R + u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pre.f[j] = ok ? a.p0[(size_t)m * 4 * R + j * R + u] : 0.0f;
+        pre.f[4] = ok ? a.p1[idx] : 0.0f;
+        pre.f[5] = ok ? a.p2[idx] : 0.0f;
+        pre.f[6] = (ok && a.p3) ? a.p3[idx] : 0.0f;
+        pre.f[7] = (ok && a.addend) ? a.addend[(size_t)m * a.ldadd + u] : 0.0f;
+    }
 }
 
-// Epilogue over the reduced tile values held in Red[(t*4 + q)*64 + lane]
-// (t = i*TN + j; C/D map: row = (lane>>4)*4 + q, col = lane&15).
+// Epilogue over the reduced tile values held in Red[(t*4 + q)*64 + lane] (t = i*TN + j).
 template <int TM, int TN>
-__device__ __forceinline__ void epilogue(const Args& a, const float* Red, int m0, int n0, int lane, int wave) {
+__device__ __forceinline__ void epilogue(const Args& a, const Pre<TM, TN>& pre, const float* Red,
+                                         int m0, int n0, int lane, int wave) {
     if (a.epi == AIR_EPI_GENERIC) {
-        for (int t = wave; t < TM * TN; t += 4) {
-            const int i = t / TN, j = t % TN;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int m = m0 + i * 16 + (lane >> 4) * 4 + q;
-                const int cg = n0 + (lane & 15);
-                const int n = cg + j * a.gstride;
-                if (m < a.M && cg + (a.gstride == 16 ? j * 16 : 0) < a.gwidth && n < a.N)
-                    generic_store(a, Red[(t * 4 + q) * 64 + lane], m, n);
+        for (int k = 0; k < TM * TN; ++k) {
+            const int it = wave + 4 * k;
+            const int i = it / (TN * 4), j = (it >> 2) % TN, q = it & 3;
+            const int m = m0 + i * 16 + (lane >> 4) * 4 + q;
+            const int n = n0 + j * 16 + (lane & 15);
+            if (m >= a.M || n >= a.N) continue;
+            float v = Red[((i * TN + j) * 4 + q) * 64 + lane];
+            if (a.bias) v += pre.bias[k];
+            if (a.addend) {
+                if (a.add_slabs == 1) v += pre.add[k];
+                else for (int sl = 0; sl < a.add_slabs; ++sl) v += a.addend[sl * a.add_slab_stride + (size_t)m * a.ldadd + n];
             }
+            if (a.act == AIR_ACT_RELU) v = fmaxf(v, 0.0f);
+            else if (a.act == AIR_ACT_SOFTPLUS) v = air_softplus(v);
+            else if (a.act == AIR_ACT_SIGMOID_NOISE) v = air_sigmoid(v + pre.aux[k] * a.aux_scale);
+            if (a.actgrad == AIR_GRAD_RELU) v = (pre.aux[k] > 0.0f) ? v : 0.0f;
+            else if (a.actgrad == AIR_GRAD_SOFTPLUS) v = v * (1.0f - expf(-pre.aux[k]));
+            float* c = a.C + (size_t)m * a.ldc + n;
+            if (a.accumulate) v += *c;
+            *c = v;
         }
         return;
     }
@@ -99,25 +152,20 @@ __device__ __forceinline__ void epilogue(const Args& a, const float* Red, int m0
         if (a.epi == AIR_EPI_LSTM_FWD) {
             // BasicLSTMCell (air_model.py:286): gates = [x,h].K + b -> i, j, f, o; forget bias 1.0
             // p0 = c_prev [M,R]; addend slabs = hoisted x.Wx; q0 = acts [M,4R], q1 = c, q2 = h
-            if (TN == 4) {
+            if (TN == 4 && TM == 1) {
                 const int R = a.gwidth;
                 float g[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float s = v[j % TN];
-                    const int n = u + j * R;
-                    float sl[8];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k)        // independent loads, fixed summation order
-                        sl[k] = (k < a.add_slabs) ? a.addend[k * a.add_slab_stride + (size_t)m * a.ldadd + n] : 0.0f;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) s += sl[k];
-                    if (a.bias) s += a.bias[n];
+                    for (int k = 0; k < 8; ++k) s += pre.f[j * 8 + k];       // fixed summation order
+                    if (a.bias) s += pre.f[32 + j];
                     g[j] = s;
                 }
                 const float si = air_sigmoid(g[0]), tj = tanhf(g[1]);
                 const float sf = air_sigmoid(g[2] + 1.0f), so = air_sigmoid(g[3]);
-                const float cn = a.p0[(size_t)m * R + u] * sf + si * tj;
+                const float cn = pre.f[36] * sf + si * tj;
                 float* ac = a.q0 + (size_t)m * 4 * R;
                 ac[u] = si; ac[R + u] = tj; ac[2 * R + u] = sf; ac[3 * R + u] = so;
                 a.q1[(size_t)m * R + u] = cn;
@@ -137,25 +185,25 @@ __device__ __forceinline__ void epilogue(const Args& a, const float* Red, int m0
         } else if (a.epi == AIR_EPI_LSTM_BWD) {
             // v[0] (+ addend) = d loss / d h'.  p0 = acts, p1 = c_prev, p2 = c, p3 = dc_in (nullable)
             // q0 = dgates [M,4R], q1 = dc_prev [M,R], q2 = dgsum [M,4R] (nullable; i0 = accumulate)
-            const int R = a.gwidth;
-            float dhv = v[0];
-            if (a.addend) dhv += a.addend[(size_t)m * a.ldadd + u];
-            const float* ac = a.p0 + (size_t)m * 4 * R;
-            const float si = ac[u], tj = ac[R + u], sf = ac[2 * R + u], so = ac[3 * R + u];
-            const size_t idx = (size_t)m * R + u;
-            const float tc = tanhf(a.p2[idx]);
-            const float dc = (a.p3 ? a.p3[idx] : 0.0f) + dhv * so * (1.0f - tc * tc);
-            const float dgi = dc * tj * si * (1.0f - si);
-            const float dgj = dc * si * (1.0f - tj * tj);
-            const float dgf = dc * a.p1[idx] * sf * (1.0f - sf);
-            const float dgo = dhv * tc * so * (1.0f - so);
-            float* dg = a.q0 + (size_t)m * 4 * R;
-            dg[u] = dgi; dg[R + u] = dgj; dg[2 * R + u] = dgf; dg[3 * R + u] = dgo;
-            a.q1[idx] = dc * sf;
-            if (a.q2) {
-                float* ds = a.q2 + (size_t)m * 4 * R;
-                if (a.i0) { ds[u] += dgi; ds[R + u] += dgj; ds[2 * R + u] += dgf; ds[3 * R + u] += dgo; }
-                else { ds[u] = dgi; ds[R + u] = dgj; ds[2 * R + u] = dgf; ds[3 * R + u] = dgo; }
+            if (TM == 1) {
+                const int R = a.gwidth;
+                const float dhv = v[0] + pre.f[7];
+                const float si = pre.f[0], tj = pre.f[1], sf = pre.f[2], so = pre.f[3];
+                const size_t idx = (size_t)m * R + u;
+                const float tc = tanhf(pre.f[5]);
+                const float dc = pre.f[6] + dhv * so * (1.0f - tc * tc);
+                const float dgi = dc * tj * si * (1.0f - si);
+                const float dgj = dc * si * (1.0f - tj * tj);
+                const float dgf = dc * pre.f[4] * sf * (1.0f - sf);
+                const float dgo = dhv * tc * so * (1.0f - so);
+                float* dg = a.q0 + (size_t)m * 4 * R;
+                dg[u] = dgi; dg[R + u] = dgj; dg[2 * R + u] = dgf; dg[3 * R + u] = dgo;
+                a.q1[idx] = dc * sf;
+                if (a.q2) {
+                    float* ds = a.q2 + (size_t)m * 4 * R;
+                    if (a.i0) { ds[u] += dgi; ds[R + u] += dgj; ds[2 * R + u] += dgf; ds[3 * R + u] += dgo; }
+                    else { ds[u] = dgi; ds[R + u] = dgj; ds[2 * R + u] = dgf; ds[3 * R + u] = dgo; }
+                }
             }
         } else if (a.epi == AIR_EPI_REPARAM_BWD) {
             // v[0] = d loss / d z-sample.  p0 = ml [M,2Z], p1 = eps, p2 = att (mask), p3 = dyn; C = d_ml [M,2Z]
@@ -241,6 +289,8 @@ __global__ __launch_bounds__(THREADS) void gemm_f32_kernel(Args a)
 
     const bool vecA = ((a.lda & 3) == 0) && aligned16(a.A);
     const bool vecB = ((a.ldb & 3) == 0) && aligned16(a.B) && ((a.gstride & 3) == 0);
+    Pre<TM, TN> pre;
+    if (gridDim.z == 1) epilogue_prefetch<TM, TN>(a, pre, m0, n0, lane, wave);
 
     auto loadA = [&](int k0, int i) -> float4 {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -408,7 +458,7 @@ __global__ __launch_bounds__(THREADS) void gemm_f32_kernel(Args a)
         }
         return;
     }
-    epilogue<TM, TN>(a, Red, m0, n0, lane, wave);
+    epilogue<TM, TN>(a, pre, Red, m0, n0, lane, wave);
 }
 
 // ---------------------------------------------------------------------------
@@ -513,7 +563,9 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16_kernel(Args a)
         }
         return;
     }
-    epilogue<TM, TN>(a, Red, m0, n0, lane, wave);
+    Pre<TM, TN> pre;
+    epilogue_prefetch<TM, TN>(a, pre, m0, n0, lane, wave);
+    epilogue<TM, TN>(a, pre, Red, m0, n0, lane, wave);
 }
 
 
