@@ -79,6 +79,16 @@ __device__ __forceinline__ float seg_scan(float v, int key, int lane) {
     }
     return v;
 }
+// two / four values scanned against the same key run structure (key shuffles shared, value
+// shuffles independent -> they overlap in the LDS pipeline)
+__device__ __forceinline__ void seg_scan2(float& v0, float& v1, int key, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int pk = __shfl_up(key, off, 64);
+        const float p0 = __shfl_up(v0, off, 64), p1 = __shfl_up(v1, off, 64);
+        if (lane >= off && pk == key) { v0 += p0; v1 += p1; }
+    }
+}
 __device__ __forceinline__ bool seg_end(int key, int lane, int nvalid) {
     const int nk = __shfl_down(key, 1, 64);
     return lane < nvalid && (lane == nvalid - 1 || nk != key);
@@ -540,21 +550,18 @@ __global__ __launch_bounds__(THREADS) void write_bwd_kernel(air_write_bwd_t a)
     // skipped -- their two weights cancel exactly in real arithmetic.
     // literal mode: tap0 and tap1 keep separate ranges and degenerate outputs stay in, as in the
     // reference's four Gather_grad scatters.
-    if (tid < 2 * w) {
+    if (!a.literal && tid < 2 * w) {         // (the literal path uses segmented scans, no ranges)
         const Tap* tp = (tid < w) ? sh_tx : sh_ty;
         const int q = (tid < w) ? tid : tid - w;
-        int lo0 = C, hi0 = -1, lo1 = C, hi1 = -1;
+        int lo0 = C, hi0 = -1;
         for (int j = 0; j < C; ++j) {
             const Tap tt = tp[j];
-            if (a.literal) {
-                if (tt.i0 == q) { lo0 = min(lo0, j); hi0 = max(hi0, j); }
-                if (tt.i1 == q) { lo1 = min(lo1, j); hi1 = max(hi1, j); }
-            } else if (tt.i0 != tt.i1 && (tt.i0 == q || tt.i1 == q)) { lo0 = min(lo0, j); hi0 = max(hi0, j); }
+            if (tt.i0 != tt.i1 && (tt.i0 == q || tt.i1 == q)) { lo0 = min(lo0, j); hi0 = max(hi0, j); }
         }
         int* r = sh_rng + (tid < w ? 0 : 4 * w) + 4 * q;
-        r[0] = lo0; r[1] = hi0; r[2] = lo1; r[3] = hi1;
+        r[0] = lo0; r[1] = hi0; r[2] = C; r[3] = -1;
     }
-    __syncthreads();
+    if (!a.literal) __syncthreads();
 
     const float* g = sh_g;
     const int tstride = a.literal ? w + 2 : w;              // literal mode keeps 2 extra slots per row
@@ -574,40 +581,30 @@ __global__ __launch_bounds__(THREADS) void write_bwd_kernel(air_write_bwd_t a)
         }
     } else {
         // stage 1, per tap: T0[I][q] through the x0 taps, T1[I][q] through the x1 taps (g scaled by
-        // z_pres).  One wave per canvas row; runs of equal tap index are contiguous (monotone taps),
-        // so a segmented wave scan replaces the serial loops over the (long) out-of-range runs.
-        // Out-of-range (degenerate) runs are summed in their own segments (slots w / w+1 of each
-        // row) so that the +w and -w partners go through identical summation trees, then folded
-        // into the border slot: the residue left is the rounding of (in-range sum + huge run), as
-        // in a sequential scatter-add.
+        // z_pres).  One thread per (canvas row, tap array) walks the row left to right with a
+        // running sum per run of equal tap index (runs are contiguous: taps are monotone) -- the
+        // sequential order of the reference's scatter-add, with no cross-lane traffic.
+        // Out-of-range (degenerate) runs go to their own slots (w / w+1 of each row) so that the
+        // +w and -w partners see identical summation orders, then are folded into the border slot:
+        // the residue left is the rounding of (in-range sum + huge run).
         const int ws = w + 2;
         for (int it = tid; it < 2 * C * ws; it += THREADS) sh_T[it] = 0.0f;
         __syncthreads();
-        const int lane = tid & 63, wave = tid >> 6;
-        float* W0 = sh_T;
-        float* W1 = sh_T + C * ws;
-        for (int I = wave; I < C; I += 4) {
-            for (int c0 = 0; c0 < C; c0 += 64) {
-                const int J = c0 + lane, nvalid = min(64, C - c0);
-                Tap tt{0.f, 0.f, -1 - lane, -1 - lane};
-                float gz = 0.0f;
-                int k0 = -1 - lane, k1 = -1 - lane;
-                if (J < C) {
-                    tt = sh_tx[J]; gz = g[I * C + J] * z;
-                    const bool deg = tt.i0 == tt.i1;
-                    k0 = deg ? (tt.i0 == 0 ? w : w + 1) : tt.i0;
-                    k1 = deg ? (tt.i1 == 0 ? w : w + 1) : tt.i1;
-                }
-                const float s0 = seg_scan(gz * tt.w0, k0, lane);
-                const float s1 = seg_scan(gz * tt.w1, k1, lane);
-                if (seg_end(k0, lane, nvalid)) W0[I * ws + k0] += s0;
-                if (seg_end(k1, lane, nvalid)) W1[I * ws + k1] += s1;
+        for (int it = tid; it < 2 * C; it += THREADS) {
+            const int I = it >> 1, tap = it & 1;
+            float* Wr = sh_T + (size_t)tap * C * ws + (size_t)I * ws;
+            int key = -1;
+            float acc = 0.0f;
+            for (int J = 0; J < C; ++J) {
+                const Tap tt = sh_tx[J];
+                const int idx = tap ? tt.i1 : tt.i0;
+                const int k = (tt.i0 == tt.i1) ? (idx == 0 ? w : w + 1) : idx;
+                if (k != key) { if (key >= 0) Wr[key] += acc; key = k; acc = 0.0f; }
+                acc += (g[I * C + J] * z) * (tap ? tt.w1 : tt.w0);
             }
-            if (lane < 2) {          // fold: lane 0 -> tap-0 row, lane 1 -> tap-1 row
-                float* r = (lane == 0 ? W0 : W1) + I * ws;
-                r[0] += r[w];
-                r[w - 1] += r[w + 1];
-            }
+            if (key >= 0) Wr[key] += acc;
+            Wr[0] += Wr[w];
+            Wr[w - 1] += Wr[w + 1];
         }
     }
     // theta / z gradients, per canvas pixel (independent of stage 1)
@@ -652,29 +649,24 @@ __global__ __launch_bounds__(THREADS) void write_bwd_kernel(air_write_bwd_t a)
     if (a.literal) {
         for (int it = tid; it < 4 * ss; it += THREADS) sh_S[it] = 0.0f;
         __syncthreads();
-        const int lane = tid & 63, wave = tid >> 6;
-        for (int q = wave; q < w; q += 4) {
-            for (int c0 = 0; c0 < C; c0 += 64) {
-                const int I = c0 + lane, nvalid = min(64, C - c0);
-                Tap tt{0.f, 0.f, -1 - lane, -1 - lane};
-                float t0 = 0.0f, t1 = 0.0f;
-                int k0 = -1 - lane, k1 = -1 - lane;
-                if (I < C) {
-                    tt = sh_ty[I]; t0 = T0[I * tstride + q]; t1 = T1[I * tstride + q];
-                    const bool deg = tt.i0 == tt.i1;
-                    k0 = deg ? (tt.i0 == 0 ? w : w + 1) : tt.i0;
-                    k1 = deg ? (tt.i1 == 0 ? w : w + 1) : tt.i1;
-                }
-                const float sa = seg_scan(t0 * tt.w0, k0, lane), sc = seg_scan(t1 * tt.w0, k0, lane);
-                const float sb = seg_scan(t0 * tt.w1, k1, lane), sd = seg_scan(t1 * tt.w1, k1, lane);
-                if (seg_end(k0, lane, nvalid)) { sh_S[k0 * w + q] += sa; sh_S[2 * ss + k0 * w + q] += sc; }
-                if (seg_end(k1, lane, nvalid)) { sh_S[ss + k1 * w + q] += sb; sh_S[3 * ss + k1 * w + q] += sd; }
+        // one thread per (window column q, tap array a/b/c/d) walks the canvas rows top to bottom
+        for (int it = tid; it < 4 * w; it += THREADS) {
+            const int q = it >> 2, arr = it & 3;                 // a=(y0,x0) b=(y1,x0) c=(y0,x1) d=(y1,x1)
+            const float* Tsrc = (arr & 2) ? T1 : T0;
+            const bool y1tap = arr & 1;
+            float* Sr = sh_S + (size_t)arr * ss;
+            int key = -1;
+            float acc = 0.0f;
+            for (int I = 0; I < C; ++I) {
+                const Tap tt = sh_ty[I];
+                const int idx = y1tap ? tt.i1 : tt.i0;
+                const int k = (tt.i0 == tt.i1) ? (idx == 0 ? w : w + 1) : idx;
+                if (k != key) { if (key >= 0) Sr[key * w + q] += acc; key = k; acc = 0.0f; }
+                acc += Tsrc[I * tstride + q] * (y1tap ? tt.w1 : tt.w0);
             }
-            if (lane < 4) {          // fold the out-of-range runs into the border rows, per tap array
-                float* r = sh_S + lane * ss;
-                r[q] += r[w * w + q];
-                r[(w - 1) * w + q] += r[(w + 1) * w + q];
-            }
+            if (key >= 0) Sr[key * w + q] += acc;
+            Sr[q] += Sr[w * w + q];
+            Sr[(w - 1) * w + q] += Sr[(w + 1) * w + q];
         }
         __syncthreads();
     }
