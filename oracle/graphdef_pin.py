@@ -117,7 +117,13 @@ def main(path):
     facts["body_nodes_non_const"] = sum(1 for d in body.values() if d["op"] != "Const")
     facts["op_histogram_top"] = dict(Counter(d["op"] for d in nodes.values()).most_common(25))
     # LSTM: split order and forget bias
-    facts["lstm_split_num"] = nodes[W + "rnn/rnn_1/split"]["attr"]["num_split"]["i"] if W + "rnn/rnn_1/split" in nodes else None
+    facts["lstm_split_num"] = nodes[W + "rnn/split"]["attr"]["num_split"]["i"]
+    # the cell's pointwise wiring: which Split output feeds which nonlinearity (gate order i, j, f, o)
+    strip = lambda i: i[len(W):] if i.startswith(W) else i
+    facts["lstm_cell_wiring"] = {n[len(W):]: [d["op"]] + [strip(i) for i in d["inputs"]]
+                                 for n, d in body.items()
+                                 if n.startswith(W + "rnn/") and not n.startswith(W + "rnn/rnn_1/")
+                                 and d["op"] != "Const" and "Enter" not in n}
     lstm_nodes = sorted(n for n in body if n.startswith(W + "rnn/rnn_1/") and body[n]["op"] != "Const")
     facts["lstm_ops"] = {n[len(W):]: [body[n]["op"]] + body[n]["inputs"] for n in lstm_nodes if "Enter" not in n}
     for n in body:
@@ -150,7 +156,7 @@ def main(path):
     tr = {}
     for n, d in nodes.items():
         if d["op"] == "Const" and (n.startswith("air/training/") or n.startswith("air/z_pres_prior_log_odds")) \
-                and "gradients" not in n:
+                and "gradients" not in n and "Initializer" not in n:
             t = d["attr"]["value"]["tensor"]
             if len(t["vals"]) == 1:
                 tr[n] = t["vals"][0]
