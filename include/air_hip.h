@@ -152,7 +152,8 @@ typedef struct {
     int32_t M, N, K, lda, ldb, ldc;
     int32_t head_pack, Hs, Hh, Hz;
 } air_wgrad_t;
-int air_wgrad_grouped(const air_wgrad_t* probs /*HOST array, <= 12*/, int count, void* stream);
+/* precision: 0 = fp32 MFMA (exact fp32 products), 1 = operands rounded to bf16, fp32 accumulate */
+int air_wgrad_grouped(const air_wgrad_t* probs /*HOST array, <= 12*/, int count, int precision, void* stream);
 
 /* column sums db[n] = sum_r dY[r*ld + n]  (BiasAdd_grad nodes) for `count` problems */
 typedef struct { const float* src; float* dst; int32_t rows, cols, ld, accumulate; } air_colsum_t;

@@ -1,0 +1,175 @@
+"""GPU parity at the other BASELINE.json configurations.
+
+configs[3] (stress): 128x128 canvas, 0-4 objects, N=5 steps, batch 256 -- oracle parity at a
+  batch the numpy oracle finishes in seconds, and at the FULL batch through size-independent
+  properties: batch items are independent, so rows [0:16] of the B=256 run must
+  equal the oracle run on those 16 images with the same noise rows; batch means must equal the
+  mean of the per-image outputs; the whole step must be bit-deterministic.
+configs[4] (clutter): 50x50 canvases with a reference background added and clipped
+  (multi_mnist.py:180-181), b=64 -- forward, gradient and update parity under non-zero backgrounds
+  (every pixel is "ink" to the Bernoulli likelihood, none is exactly 0).
+Tolerances as in test_gpu_model.py (fp32 kernels vs fp32 oracle, identical injected noise).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import air_oracle as ao  # noqa: E402
+from oracle import air_oracle_torch as at  # noqa: E402
+from oracle.synth import blob_canvases  # noqa: E402
+
+STRESS_HP = dict(ao.TRAINING_HP, canvas_size=128, max_steps=5, max_digits=4)
+HP = dict(ao.TRAINING_HP)
+
+
+@pytest.fixture(scope="module")
+def am():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from air import air_model
+    return air_model
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _model(am, images, targets, hp, params, noise, train=True, lo=-2.0, backward="exact", prec="fp32"):
+    am.reset_default_graph()
+    m = am.AIRModel(torch.tensor(images, device="cuda"), torch.tensor(targets, device="cuda"),
+                    cnn=False, train=train, scope="air", gemm_precision=prec, backward=backward, **hp)
+    m.load_state_dict(params)
+    m.set_noise(noise)
+    m.set_dynamic(z_pres_prior_log_odds=lo)
+    return m
+
+
+def _slice_noise(noise, n):
+    return {k: v[:, :n].copy() for k, v in noise.items()}
+
+
+def _assert_forward(model, o, images, rows=None):
+    sl = slice(None) if rows is None else slice(0, rows)
+    assert np.abs(_np(model.reconstruction)[sl] - o["reconstruction"]).max() <= 2e-5
+    assert np.array_equal(_np(model.rec_num_digits)[sl], o["rec_num_digits"])
+    T = o["steps_executed"]
+    for k in ("rec_scales", "rec_shifts", "rec_windows", "rec_latents", "rec_st_back", "z_pres_probs"):
+        got = _np(getattr(model, k))[sl][:, :T]
+        assert np.abs(got - o[k]).max() <= 5e-5 * max(1.0, np.abs(o[k]).max()), k
+    for k in ("z_pres_kls", "scale_kls", "shift_kls", "vae_kls"):
+        got = _np(getattr(model, k))[sl][:, :T]
+        assert np.abs(got - o[k]).max() / max(1.0, np.abs(o[k]).max()) <= 1e-4, k
+    r = _np(model.reconstruction)[sl].astype(np.float64)
+    x = images.astype(np.float64)
+    bce = -np.sum(x * np.log(r + ao.EPS) + (1 - x) * np.log(1 - r + ao.EPS), axis=1)
+    np.testing.assert_allclose(_np(model.reconstruction_loss)[sl], bce, rtol=1e-5, atol=1e-3)
+
+
+def test_stress_config_forward_parity_small_batch(am):
+    hp = STRESS_HP
+    B = 16
+    images, targets = blob_canvases(B, hp["canvas_size"], hp["max_digits"], seed=5)
+    params, noise = ao.init_params(hp, 0), ao.make_noise(hp, B, 2)
+    for train in (True, False):
+        m = _model(am, images, targets, hp, params, noise, train=train)
+        m.forward()
+        o = ao.air_forward(params, images, targets, noise, hp, train, -2.0, early_exit=True)
+        assert m.steps_executed == o["steps_executed"]
+        _assert_forward(m, o, images)
+        assert abs(float(m.loss) - float(o["loss"])) / abs(float(o["loss"])) <= 1e-2
+
+
+def test_stress_config_full_batch_properties(am):
+    hp = STRESS_HP
+    B, n = 256, 16
+    images, targets = blob_canvases(B, hp["canvas_size"], hp["max_digits"], seed=6)
+    params, noise = ao.init_params(hp, 0), ao.make_noise(hp, B, 3)
+    m = _model(am, images, targets, hp, params, noise, train=True, backward="reference")
+    m.forward()
+    # (1) batch independence: the first n rows equal the oracle on those rows alone.  The oracle
+    # runs without early exit here (the full batch decides T', not the 16-row subset).
+    o = ao.air_forward(params, images[:n], targets[:n], _slice_noise(noise, n), hp, True, -2.0, early_exit=False)
+    T = m.steps_executed
+    o = dict(o, steps_executed=T, **{k: o[k][:, :T] for k in ("rec_scales", "rec_shifts", "rec_windows", "rec_latents",
+                                                            "rec_st_back", "z_pres_probs", "z_pres_kls", "scale_kls",
+                                                            "shift_kls", "vae_kls")})
+    _assert_forward(m, o, images[:n], rows=n)
+    # (2) batch means are the means of the per-image outputs (air_model.py:598-611)
+    per_item = _np(m.loss_per_item) if hasattr(m, "loss_per_item") else None
+    if per_item is not None:
+        assert abs(float(m.loss) - per_item.astype(np.float64).mean()) <= 1e-4 * abs(float(m.loss))
+    acc = (_np(m.rec_num_digits) == targets).mean()
+    assert abs(float(m.accuracy) - acc) < 1e-6
+    # (3) full train steps are bit-deterministic and change every variable
+    def run():
+        mm = _model(am, images, targets, hp, params, noise, train=True, backward="reference")
+        for _ in range(3):
+            mm.training()
+        torch.cuda.synchronize()
+        return {k: _np(v).copy() for k, v in mm.variables.items()}, float(mm.loss)
+    v1, l1 = run()
+    v2, l2 = run()
+    assert l1 == l2 and np.isfinite(l1)
+    for k in v1:
+        assert np.array_equal(v1[k], v2[k]), k
+        assert not np.array_equal(v1[k], params[k]), k
+
+
+def test_stress_config_gradients_vs_fp64(am):
+    hp = STRESS_HP
+    B = 8
+    images, targets = blob_canvases(B, hp["canvas_size"], hp["max_digits"], seed=7)
+    params, noise = ao.init_params(hp, 0), ao.make_noise(hp, B, 4)
+    m = _model(am, images, targets, hp, params, noise, train=True, backward="exact")
+    s = m._stream()
+    m._run_forward(s)
+    m._run_backward(s)
+    torch.cuda.synchronize()
+    f64 = torch.float64
+    pt = at.to_torch(params, dtype=f64, requires_grad=True)
+    _, grads = at.loss_and_grads(pt, torch.tensor(images, dtype=f64), torch.tensor(targets),
+                                 at.to_torch(noise, dtype=f64), hp, -2.0)
+    worst = 0.0
+    for k, gref in grads.items():
+        got = m.gradients[k].detach().cpu().double()
+        err = float((got - gref).norm() / (gref.norm() + 1e-30))
+        worst = max(worst, err)
+        assert err <= (5e-2 if k.startswith(("z_pres", "rnn")) else 1e-2), (k, err)
+    print("stress gradients worst rel-L2", worst)
+
+
+@pytest.mark.parametrize("bg", ["pattern1", "gray1", "blob1"])
+def test_clutter_config_parity(am, golden_dir, bg):
+    hp = HP
+    B = 64
+    back = np.load(os.path.join(golden_dir, "backgrounds.npz"))[bg].reshape(1, -1)
+    images, targets = blob_canvases(B, hp["canvas_size"], hp["max_digits"], seed=8)
+    images = np.clip(images + back, 0.0, 1.0).astype(np.float32)        # multi_mnist.py:180-181
+    params, noise = ao.init_params(hp, 0), ao.make_noise(hp, B, 5)
+    m = _model(am, images, targets, hp, params, noise, train=True)
+    m.forward()
+    o = ao.air_forward(params, images, targets, noise, hp, True, -2.0, early_exit=True)
+    assert m.steps_executed == o["steps_executed"]
+    _assert_forward(m, o, images)
+    assert abs(float(m.loss) - float(o["loss"])) / abs(float(o["loss"])) <= 1e-2
+    # gradients (exact adjoint) against the fp64 evaluation of the graph
+    s = m._stream()
+    m._run_forward(s)
+    m._run_backward(s)
+    torch.cuda.synchronize()
+    f64 = torch.float64
+    pt = at.to_torch(params, dtype=f64, requires_grad=True)
+    _, grads = at.loss_and_grads(pt, torch.tensor(images, dtype=f64), torch.tensor(targets),
+                                 at.to_torch(noise, dtype=f64), hp, -2.0)
+    for k, gref in grads.items():
+        got = m.gradients[k].detach().cpu().double()
+        err = float((got - gref).norm() / (gref.norm() + 1e-30))
+        # With a background no pixel has x = 0, so every pixel whose reconstruction is tiny (window
+        # borders, r ~ 1e-6) carries a d/dr = x/(r + 1e-9) term whose fp32 value is only good to
+        # ~1e-7/r: the where-heads (which see the sum of those terms) are looser than on clean canvases.
+        where = k.startswith(("z_pres", "rnn", "scale", "shift"))
+        assert err <= (5e-2 if where else 5e-3), (k, err)

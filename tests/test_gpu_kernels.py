@@ -380,3 +380,66 @@ def test_gemm_fused_lstm_and_reparam_match_unfused(H, prec):
     H.check(lib.air_gemm(C.byref(g), _stream()))
     torch.cuda.synchronize()
     assert float((dml0 - dml1).abs().max()) < 2e-5
+
+
+# --------------------------------------------------------------------------- grouped weight gradient
+WGRAD_CASES = [
+    # (M, N, K) of dW[M,N] = A[K,M]^T . dY[K,N]; shapes of Cfg-A plus ragged ones
+    [(2500, 1024, 64), (256, 1024, 192), (256, 320, 192), (784, 512, 192), (512, 256, 192), (256, 100, 192),
+     (50, 256, 192), (256, 512, 192), (512, 784, 192)],
+    [(70, 33, 5), (64, 64, 64), (130, 100, 200)],          # K not /8, K > 192 (second round), N not /4
+    [(100, 36, 1280)],                                     # stress-config depth: N*B = 5*256 rows
+]
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("shapes", WGRAD_CASES)
+def test_wgrad_grouped(H, shapes, prec):
+    rng = np.random.RandomState(len(shapes) + prec)
+    dev = "cuda"
+    keep, probs, refs = [], [], []
+    for (M, N, K) in shapes:
+        A = rng.randn(K, M).astype(np.float32)
+        dY = rng.randn(K, N).astype(np.float32)
+        At, Yt = torch.tensor(A, device=dev), torch.tensor(dY, device=dev)
+        Wt = torch.full((M, N), float("nan"), device=dev)
+        bt = torch.full((N,), float("nan"), device=dev)
+        keep += [At, Yt, Wt, bt]
+        probs.append(H.Wgrad(_p(At), _p(Yt), _p(Wt), _p(bt), M, N, K, M, N, N, 0, 0, 0, 0))
+        A64 = _bf16_round(A) if prec else A.astype(np.float64)
+        Y64 = _bf16_round(dY) if prec else dY.astype(np.float64)
+        refs.append((A64.T @ Y64, dY.astype(np.float64).sum(0), Wt, bt, K))       # bias sums stay fp32 in both modes
+    arr = (H.Wgrad * len(probs))(*probs)
+    H.check(H.lib().air_wgrad_grouped(arr, len(probs), prec, _stream()), "air_wgrad_grouped")
+    torch.cuda.synchronize()
+    for ref_w, ref_b, Wt, bt, K in refs:
+        tol = 2e-6 * np.sqrt(K) * 4
+        np.testing.assert_allclose(Wt.cpu().numpy(), ref_w, rtol=1e-5, atol=tol * np.abs(ref_w).max())
+        np.testing.assert_allclose(bt.cpu().numpy(), ref_b, rtol=1e-5, atol=tol * np.abs(ref_b).max())
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_wgrad_grouped_head_pack(H, prec):
+    """The 7 head output units (air_model.py:294-316, 376): unit o owns only its head's hidden segment."""
+    rng = np.random.RandomState(7)
+    K, Hs, Hh, Hz = 192, 64, 64, 64
+    HT, Hmax = 2 * Hs + 2 * Hh + Hz, max(Hs, Hh, Hz)
+    d7 = rng.randn(K, 8).astype(np.float32)
+    hid = rng.randn(K, HT).astype(np.float32)
+    dt, ht = torch.tensor(d7, device="cuda"), torch.tensor(hid, device="cuda")
+    wout = torch.full((7, Hmax), float("nan"), device="cuda")
+    bout = torch.full((7,), float("nan"), device="cuda")
+    pr = H.Wgrad(_p(dt), _p(ht), _p(wout), _p(bout), 8, HT, K, 8, HT, Hmax, 1, Hs, Hh, Hz)
+    arr = (H.Wgrad * 1)(pr)
+    H.check(H.lib().air_wgrad_grouped(arr, 1, prec, _stream()), "air_wgrad_grouped")
+    torch.cuda.synchronize()
+    D = _bf16_round(d7) if prec else d7.astype(np.float64)
+    Hd = _bf16_round(hid) if prec else hid.astype(np.float64)
+    full = D.T @ Hd                                           # [8, HT]
+    offs = np.cumsum([0, Hs, Hs, Hh, Hh, Hz])
+    head = [0, 1, 2, 2, 3, 3, 4]
+    got = wout.cpu().numpy()
+    for o in range(7):
+        h = head[o]
+        np.testing.assert_allclose(got[o, :offs[h + 1] - offs[h]], full[o, offs[h]:offs[h + 1]], rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(bout.cpu().numpy(), d7.astype(np.float64).sum(0)[:7], rtol=1e-5, atol=1e-4)

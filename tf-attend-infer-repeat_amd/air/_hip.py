@@ -90,7 +90,7 @@ _SIGNATURES = {
     "air_gemm": (C.c_int, [C.POINTER(Gemm), _p]),
     "air_gemm_slabs": (C.c_int, [C.c_int, C.c_int]),
     "air_colsum": (C.c_int, [C.POINTER(Colsum), C.c_int, _p]),
-    "air_wgrad_grouped": (C.c_int, [C.POINTER(Wgrad), C.c_int, _p]),
+    "air_wgrad_grouped": (C.c_int, [C.POINTER(Wgrad), C.c_int, C.c_int, _p]),
     "air_lstm_gates_fwd": (C.c_int, [_p, _p, _p, _p, _p, C.c_int, C.c_int, _p]),
     "air_lstm_gates_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, C.c_int, C.c_int, C.c_int, _p]),
     "air_transformer_fwd": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),

@@ -543,7 +543,7 @@ class AIRModel:
         keep.append(arr)
         wbytes = sum(4 * (q.M * q.N + q.K * (q.M + q.N)) for q in probs)
         wflops = sum(2 * q.M * q.N * q.K for q in probs)
-        self._wgrad_branches = [[self._call("air_wgrad_grouped", arr, len(probs), nbytes=wbytes, flops=wflops,
+        self._wgrad_branches = [[self._call("air_wgrad_grouped", arr, len(probs), self._prec, nbytes=wbytes, flops=wflops,
                                             tag="wgrad_grouped")]]
         self._side_streams = None
 
@@ -725,6 +725,7 @@ class AIRModel:
     reconstruction = property(lambda self: (self._ensure(), self._recon)[1])
     reconstruction_loss = property(lambda self: (self._ensure(), self._rec_loss)[1])
     rec_num_digits = property(lambda self: (self._ensure(), self.run_digits)[1])
+    loss_per_item = property(lambda self: (self._ensure(), self._loss_item)[1])     # air_model.py:598-600, before the mean
     rec_scales = property(lambda self: self._stack(self.att[:, :, H.ATT_S:H.ATT_S + 1]))
     rec_shifts = property(lambda self: self._stack(self.att[:, :, H.ATT_X:H.ATT_Y + 1]))
     rec_windows = property(lambda self: self._stack(self.vrec))

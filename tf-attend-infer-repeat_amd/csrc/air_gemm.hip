@@ -251,7 +251,7 @@ __device__ __forceinline__ void reduce_waves(f32x4 (&acc)[TM][TN], float* Red, i
     __syncthreads();
 }
 
-__device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+__host__ __device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // ---------------------------------------------------------------------------
 // fp32: k-major LDS images As[k][LA], Bs[k][LB], double-buffered chunks of BKC.
@@ -569,6 +569,203 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16_kernel(Args a)
 }
 
 
+// ---------------------------------------------------------------------------
+// bf16 path, lean variant (A row-major, 16-byte aligned operands, K % 4 == 0;
+// NN additionally N % 4 == 0).  K is cut into images of 64; every operand image
+// lives in LDS as [row or column][64 k] bf16 whose eight 16-byte slots are
+// XOR-swizzled by the row index: conflict-free for the 8-lane ds_write_b128
+// groups and the 16-lane ds_read_b128 fragment groups.  Rounding to bf16 (RNE,
+// v_cvt_pk_bf16_f32) happens on the way into LDS.  All global loads of a round
+// of up to R images are issued back to back (uniform base + 32-bit offsets, no
+// divergent bounds branches: out-of-range elements are redirected to offset 0
+// and zeroed by a select), then ONE barrier, then the four waves take the
+// images of the round cyclically -- one ds_read_b128 per MFMA operand.
+// ---------------------------------------------------------------------------
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ float4 ldg16(const char* base, unsigned off, bool ok) {
+    const float4 t = *reinterpret_cast<const float4*>(base + (ok ? off : 0u));
+    return ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+template <int TM, int TN>
+struct V2Cfg {
+    static constexpr int BM = 16 * TM, BN = 16 * TN, KB = 64;
+    static constexpr int IMG = (BM + BN) * KB;                           // bf16 elements per image pair
+    static constexpr int RL = 49152 / (IMG * 2);                         // LDS: <= 48 KB of images
+    static constexpr int RV = 28 / (TM + TN);                            // VGPRs: <= ~28 float4 in flight
+    static constexpr int R0 = RL < RV ? RL : RV;
+    static constexpr int R = R0 > 8 ? 8 : (R0 < 1 ? 1 : R0);
+    static constexpr int RED = 3 * TM * TN * 4 * 64 * 4;                 // bytes of the cross-wave reduction
+    static constexpr int BYTES = (R * IMG * 2 > RED) ? R * IMG * 2 : RED;
+};
+
+template <int TM, int TN, bool TB>
+__global__ __launch_bounds__(THREADS) void gemm_bf16v2_kernel(Args a)
+{
+    using Cfg = V2Cfg<TM, TN>;
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, KB = Cfg::KB, R = Cfg::R;
+    __shared__ __attribute__((aligned(16))) unsigned char Lds[Cfg::BYTES];
+    unsigned short* ImgA = reinterpret_cast<unsigned short*>(Lds);       // [R][BM][64]
+    unsigned short* ImgB = ImgA + R * BM * KB;                           // [R][BN][64]
+    float* Red = reinterpret_cast<float*>(Lds);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN / TN * (a.gstride == 16 ? TN : 1);
+    const int kbeg = blockIdx.z * a.kslab;
+    const int kend = min(a.K, kbeg + a.kslab);
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    Pre<TM, TN> pre;
+    if (gridDim.z == 1) epilogue_prefetch<TM, TN>(a, pre, m0, n0, lane, wave);
+
+    const char* Ab = reinterpret_cast<const char*>(a.A);
+    const char* Bb = reinterpret_cast<const char*>(a.B);
+    // tasks of one round.  k-contiguous operand (A, and B when TB): task = (image, row, k-run g) = 2 float4;
+    // NN B: task = (image, column quad, k-run g) = the same 4 columns of 8 consecutive rows = 8 float4.
+    constexpr int TA_N = (R * BM * 8 + THREADS - 1) / THREADS;           // A tasks per thread
+    constexpr int TBK_N = (R * BN * 8 + THREADS - 1) / THREADS;          // NT-B tasks per thread
+    constexpr int TBN_N = (R * BN * 2 + THREADS - 1) / THREADS;          // NN-B tasks per thread
+
+    for (int kr = kbeg; kr < kend; kr += R * KB) {
+        if (kr > kbeg) __syncthreads();                                   // images of the previous round consumed
+        float4 va[TA_N][2];
+        float4 vbk[TB ? TBK_N : 1][2];
+        float4 vbn[TB ? 1 : TBN_N][8];
+        // ---- issue every load of the round
+#pragma unroll
+        for (int i = 0; i < TA_N; ++i) {
+            const int t = tid + THREADS * i;
+            const int c = t / (BM * 8), row = (t / 8) % BM, g = t & 7;
+            const int gm = m0 + row, gk = kr + c * KB + g * 8;
+            const bool okr = (t < R * BM * 8) && gm < a.M;
+            const unsigned off = ((unsigned)gm * (unsigned)a.lda + (unsigned)gk) * 4u;
+            va[i][0] = ldg16(Ab, off, okr && gk < kend);
+            va[i][1] = ldg16(Ab, off + 16u, okr && gk + 4 < kend);
+        }
+        if (TB) {
+#pragma unroll
+            for (int i = 0; i < TBK_N; ++i) {
+                const int t = tid + THREADS * i;
+                const int c = t / (BN * 8), col = (t / 8) % BN, g = t & 7;
+                const int j = col >> 4, cc = col & 15;
+                const int gn = n0 + j * a.gstride + cc, cg = n0 + cc + (a.gstride == 16 ? j * 16 : 0);
+                const int gk = kr + c * KB + g * 8;
+                const bool okr = (t < R * BN * 8) && cg < a.gwidth && gn < a.N;
+                const unsigned off = ((unsigned)gn * (unsigned)a.ldb + (unsigned)gk) * 4u;
+                vbk[i][0] = ldg16(Bb, off, okr && gk < kend);
+                vbk[i][1] = ldg16(Bb, off + 16u, okr && gk + 4 < kend);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TBN_N; ++i) {
+                const int t = tid + THREADS * i;
+                const int c = t / (BN * 2), q = (t / 8) % (BN / 4), g = t & 7;
+                const int col = q * 4, j = col >> 4, cc = col & 15;
+                const int gn = n0 + j * a.gstride + cc, cg = n0 + cc + (a.gstride == 16 ? j * 16 : 0);
+                const int gk = kr + c * KB + g * 8;
+                const bool okc = (t < R * BN * 2) && cg < a.gwidth && gn < a.N;
+                const unsigned off = ((unsigned)gk * (unsigned)a.ldb + (unsigned)gn) * 4u;
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    vbn[i][r] = ldg16(Bb, off + (unsigned)r * ((unsigned)a.ldb * 4u), okc && gk + r < kend);
+            }
+        }
+        // ---- round to bf16 and store the images
+#pragma unroll
+        for (int i = 0; i < TA_N; ++i) {
+            const int t = tid + THREADS * i;
+            const int c = t / (BM * 8), row = (t / 8) % BM, g = t & 7;
+            uint4 w;
+            w.x = pack_bf16(va[i][0].x, va[i][0].y); w.y = pack_bf16(va[i][0].z, va[i][0].w);
+            w.z = pack_bf16(va[i][1].x, va[i][1].y); w.w = pack_bf16(va[i][1].z, va[i][1].w);
+            if (t < R * BM * 8) *reinterpret_cast<uint4*>(&ImgA[(c * BM + row) * KB + ((g ^ (row & 7)) << 3)]) = w;
+        }
+        if (TB) {
+#pragma unroll
+            for (int i = 0; i < TBK_N; ++i) {
+                const int t = tid + THREADS * i;
+                const int c = t / (BN * 8), col = (t / 8) % BN, g = t & 7;
+                uint4 w;
+                w.x = pack_bf16(vbk[i][0].x, vbk[i][0].y); w.y = pack_bf16(vbk[i][0].z, vbk[i][0].w);
+                w.z = pack_bf16(vbk[i][1].x, vbk[i][1].y); w.w = pack_bf16(vbk[i][1].z, vbk[i][1].w);
+                if (t < R * BN * 8) *reinterpret_cast<uint4*>(&ImgB[(c * BN + col) * KB + ((g ^ (col & 7)) << 3)]) = w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TBN_N; ++i) {
+                const int t = tid + THREADS * i;
+                const int c = t / (BN * 2), q = (t / 8) % (BN / 4), g = t & 7;
+                if (t < R * BN * 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int col = q * 4 + e;
+                        auto el = [&](int r) { const float4& x = vbn[i][r]; return e == 0 ? x.x : e == 1 ? x.y : e == 2 ? x.z : x.w; };
+                        uint4 w;
+                        w.x = pack_bf16(el(0), el(1)); w.y = pack_bf16(el(2), el(3));
+                        w.z = pack_bf16(el(4), el(5)); w.w = pack_bf16(el(6), el(7));
+                        *reinterpret_cast<uint4*>(&ImgB[(c * BN + col) * KB + ((g ^ (col & 7)) << 3)]) = w;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- MFMAs: wave w owns images w, w+4, ... of the round
+#pragma unroll
+        for (int cc = 0; cc < (R + 3) / 4; ++cc) {
+            const int c = wave + 4 * cc;
+            if (c < R && kr + c * KB < kend) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int slot = ks * 4 + (lane >> 4);
+                    bf16x8 av[TM], bv[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const int row = i * 16 + (lane & 15);
+                        av[i] = *reinterpret_cast<const bf16x8*>(&ImgA[(c * BM + row) * KB + ((slot ^ (row & 7)) << 3)]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int col = j * 16 + (lane & 15);
+                        bv[j] = *reinterpret_cast<const bf16x8*>(&ImgB[(c * BN + col) * KB + ((slot ^ (col & 7)) << 3)]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+    }
+    __syncthreads();                                                      // Red aliases the images
+    reduce_waves<TM, TN>(acc, Red, lane, wave);
+    if (gridDim.z > 1) {
+        float* Cz = a.C + (size_t)blockIdx.z * a.slab_stride;
+        for (int t = wave; t < TM * TN; t += 4) {
+            const int i = t / TN, j = t % TN;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = m0 + i * 16 + (lane >> 4) * 4 + q;
+                const int n = n0 + j * 16 + (lane & 15);
+                if (m < a.M && n < a.N) Cz[(size_t)m * a.ldc + n] = Red[(t * 4 + q) * 64 + lane];
+            }
+        }
+        return;
+    }
+    epilogue<TM, TN>(a, pre, Red, m0, n0, lane, wave);
+}
+
+
 template <int TM, int TN, bool TA, bool TB>
 int launch(const air_gemm_t* g, const Args& a0, hipStream_t s) {
     Args a = a0;
@@ -580,8 +777,14 @@ int launch(const air_gemm_t* g, const Args& a0, hipStream_t s) {
     a.kslab = ((a.K + ks - 1) / ks + 3) & ~3;
     grid.z = (a.K + a.kslab - 1) / a.kslab;
     a.slab_stride = (long)a.M * a.ldc;
-    if (g->precision == 1)
-        hipLaunchKernelGGL((gemm_bf16_kernel<TM, TN, TA, TB>), grid, dim3(THREADS), 0, s, a);
+    if (g->precision == 1) {
+        // lean variant needs 16-byte loads along the contiguous axis of both operands
+        const bool v2 = !TA && aligned16(a.A) && aligned16(a.B) && (a.lda & 3) == 0 && (a.ldb & 3) == 0 &&
+                        (a.K & 3) == 0 && (TB || ((a.N & 3) == 0 && (a.gstride & 3) == 0)) &&
+                        getenv("AIR_GEMM_BF16_V1") == nullptr;
+        if (v2) hipLaunchKernelGGL((gemm_bf16v2_kernel<TM, TN, TB>), grid, dim3(THREADS), 0, s, a);
+        else hipLaunchKernelGGL((gemm_bf16_kernel<TM, TN, TA, TB>), grid, dim3(THREADS), 0, s, a);
+    }
     else
         hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, TA, TB>), grid, dim3(THREADS), 0, s, a);
     AIR_CHECK_LAUNCH();

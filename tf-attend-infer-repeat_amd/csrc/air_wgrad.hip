@@ -183,9 +183,201 @@ __global__ __launch_bounds__(THREADS) void wgrad_grouped_kernel(Table tab)
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// bf16-operand variant (precision 1): operands are rounded to bf16 (RNE,
+// v_cvt_pk_bf16_f32) on their way into LDS, products run on
+// v_mfma_f32_16x16x32_bf16 with fp32 accumulation.  K sits on the slow (row)
+// axis of both operands, the MFMA wants 8 consecutive k per lane: a thread
+// loads the same 4 columns of 8 consecutive rows (8 x 16-B loads), packs one
+// 16-B k-run per column and stores it into a [column][k] image whose 16-B slots
+// are XOR-swizzled by the column index -- conflict-free for the 8-lane
+// ds_write_b128 groups and for the 16-lane ds_read_b128 fragment groups.  All
+// loads of up to 192 rows are in flight at once, one barrier before the MFMAs
+// (no per-chunk barriers); the bias column sums are taken from the fp32
+// registers before rounding.
+// ---------------------------------------------------------------------------
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+constexpr int KB = 64;          // rows per LDS image
+constexpr int NIMG = 3;         // images resident per round: K <= 192 needs one round
+
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void wgrad_grouped_bf16_kernel(Table tab)
+{
+    // [operand][image][column 0..63][k 0..63] bf16 = 2 x 3 x 8 KB; reused as the fp32 output tile
+    __shared__ __attribute__((aligned(16))) unsigned short Img[2 * NIMG * BT * KB];
+
+    int pi = 0;
+    while (pi + 1 < tab.count && (int)blockIdx.x >= tab.p[pi + 1].first_block) ++pi;
+    const Prob& pr = tab.p[pi];
+    const int local = blockIdx.x - pr.first_block;
+    const int m0 = (local / pr.tiles_n) * BT, n0 = (local % pr.tiles_n) * BT;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const float* __restrict__ Ap = pr.A;
+    const float* __restrict__ Yp = pr.dY;
+    const int M = pr.M, N = pr.N, K = pr.K, lda = pr.lda, ldb = pr.ldb, ldc = pr.ldc;
+    float* dW = pr.dW;
+    float* db = pr.db;
+    const int head_pack = pr.head_pack;
+
+    // staging role: threads 0..127 own operand A, 128..255 own dY; g = k-run (8 rows), q = column quad
+    const int op = tid >> 7, g = tid & 7, q = (tid & 127) >> 3;
+    const float* src = op ? Yp : Ap;
+    const int ld = op ? ldb : lda, cols = op ? N : M, c0 = (op ? n0 : m0) + 4 * q;
+    const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+    unsigned short* img = Img + (size_t)op * NIMG * BT * KB;
+    const bool full = vec && ((op ? n0 : m0) + BT <= cols);      // wave-uniform (op is)
+    const bool bias_block = (db != nullptr) && (head_pack ? (n0 == 0) : (m0 == 0));
+    const bool bias_thread = bias_block && (op == (head_pack ? 0 : 1));
+    float csum[4] = {0.f, 0.f, 0.f, 0.f};
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kr = 0; kr < K; kr += NIMG * KB) {
+        if (kr > 0) __syncthreads();                     // every wave is done reading the previous images
+        float4 v[NIMG][8];
+        if (full) {
+            // interior tile: uniform base + 32-bit byte offsets, rows past K read as zero
+            const char* base = reinterpret_cast<const char*>(src);
+            const unsigned off0 = ((unsigned)(kr + g * 8) * (unsigned)ld + (unsigned)c0) * 4u;
+#pragma unroll
+            for (int c = 0; c < NIMG; ++c)
+                if (kr + c * KB < K) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const bool ok = kr + c * KB + g * 8 + r < K;
+                        const unsigned off = off0 + (unsigned)(c * KB + r) * ((unsigned)ld * 4u);
+                        const float4 t = *reinterpret_cast<const float4*>(base + (ok ? off : 0u));
+                        v[c][r] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int c = 0; c < NIMG; ++c)
+                if (kr + c * KB < K) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[c][r] = load4(src, ld, kr + c * KB + g * 8 + r, c0, K, cols, vec);
+                }
+        }
+#pragma unroll
+        for (int c = 0; c < NIMG; ++c)
+            if (kr + c * KB < K) {
+                if (bias_thread) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) { csum[0] += v[c][r].x; csum[1] += v[c][r].y; csum[2] += v[c][r].z; csum[3] += v[c][r].w; }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int col = 4 * q + j;
+                    auto e = [&](int r) { const float4& t = v[c][r]; return j == 0 ? t.x : j == 1 ? t.y : j == 2 ? t.z : t.w; };
+                    uint4 w;
+                    w.x = pack_bf16(e(0), e(1)); w.y = pack_bf16(e(2), e(3));
+                    w.z = pack_bf16(e(4), e(5)); w.w = pack_bf16(e(6), e(7));
+                    *reinterpret_cast<uint4*>(&img[(size_t)c * BT * KB + col * KB + ((g ^ (col & 7)) << 3)]) = w;
+                }
+            }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < NIMG; ++c)
+            if (kr + c * KB < K) {
+                const unsigned short* ai = Img + (size_t)c * BT * KB;
+                const unsigned short* bi = Img + (size_t)(NIMG + c) * BT * KB;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int slot = ks * 4 + (lane >> 4);
+                    bf16x8 av[2], bv[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int col = wm + i * 16 + (lane & 15);
+                        av[i] = *reinterpret_cast<const bf16x8*>(&ai[col * KB + ((slot ^ (col & 7)) << 3)]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int col = wn + j * 16 + (lane & 15);
+                        bv[j] = *reinterpret_cast<const bf16x8*>(&bi[col * KB + ((slot ^ (col & 7)) << 3)]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+                }
+            }
+    }
+
+    // bias: reduce the 8 k-runs (lanes g = 0..7 are contiguous) of each column quad
+    if (bias_block) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s = csum[j];
+            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+            csum[j] = s;
+        }
+        if (bias_thread && g == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = 4 * q + j;
+                if (!head_pack) { if (n0 + col < N) db[n0 + col] = csum[j]; }
+                else if (col < 7) db[col] = csum[j];
+            }
+        }
+    }
+
+    // epilogue through LDS: whole 256-byte rows per store instruction
+    __syncthreads();
+    float* Ct = reinterpret_cast<float*>(Img);           // 64 x LS floats = 20 KB <= 48 KB
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+                Ct[(wm + i * 16 + (lane >> 4) * 4 + qq) * LS + wn + j * 16 + (lane & 15)] = acc[i][j][qq];
+    __syncthreads();
+    if (!head_pack) {
+        const bool vecC = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(dW) & 15) == 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = (tid >> 4) + 16 * r, col = (tid & 15) * 4;
+            const int m = m0 + row, n = n0 + col;
+            if (m >= M) continue;
+            const float4 t = *reinterpret_cast<const float4*>(&Ct[row * LS + col]);
+            float* dst = dW + (size_t)m * ldc + n;
+            if (vecC && n + 3 < N) *reinterpret_cast<float4*>(dst) = t;
+            else {
+                if (n < N) dst[0] = t.x;
+                if (n + 1 < N) dst[1] = t.y;
+                if (n + 2 < N) dst[2] = t.z;
+                if (n + 3 < N) dst[3] = t.w;
+            }
+        }
+    } else {
+        const int wid[5] = {pr.Hs, pr.Hs, pr.Hh, pr.Hh, pr.Hz};
+        const int head[7] = {0, 1, 2, 2, 3, 3, 4};
+        for (int it = tid; it < 7 * BT; it += THREADS) {
+            const int o = it / BT, col = it % BT, n = n0 + col;
+            int off = 0;
+            for (int h = 0; h < head[o]; ++h) off += wid[h];
+            if (m0 == 0 && n < N && n >= off && n < off + wid[head[o]]) dW[(size_t)o * ldc + (n - off)] = Ct[o * LS + col];
+        }
+    }
+}
+
 }  // namespace
 
-extern "C" int air_wgrad_grouped(const air_wgrad_t* probs, int count, void* stream) {
+extern "C" int air_wgrad_grouped(const air_wgrad_t* probs, int count, int precision, void* stream) {
     if (!probs || count <= 0) return AIR_EINVAL;
     if (count > MAXP) return AIR_ELIMIT;
     Table tab;
@@ -204,7 +396,9 @@ extern "C" int air_wgrad_grouped(const air_wgrad_t* probs, int count, void* stre
     }
     for (int i = count; i < MAXP; ++i) tab.p[i] = tab.p[0];
     tab.total_blocks = blocks;
-    hipLaunchKernelGGL(wgrad_grouped_kernel, dim3(blocks), dim3(THREADS), 0, air_stream(stream), tab);
+    if (precision != 0 && precision != 1) return AIR_EINVAL;
+    if (precision == 1) hipLaunchKernelGGL(wgrad_grouped_bf16_kernel, dim3(blocks), dim3(THREADS), 0, air_stream(stream), tab);
+    else hipLaunchKernelGGL(wgrad_grouped_kernel, dim3(blocks), dim3(THREADS), 0, air_stream(stream), tab);
     AIR_CHECK_LAUNCH();
     return 0;
 }

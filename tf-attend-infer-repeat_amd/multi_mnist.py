@@ -45,8 +45,11 @@ def load_glyphs():
     small = d["images"].astype(np.float32) / 16.0
     out = np.zeros((small.shape[0], IMAGE_SIZE, IMAGE_SIZE), np.float32)
     zoom = float(os.environ.get("AIR_GLYPH_ZOOM", "2.0"))                 # 8x8 -> 16x16: MNIST-like stroke scale
+    order = int(os.environ.get("AIR_GLYPH_ORDER", "1"))                   # spline order of the up-sampling
+    lo, hi = (float(v) for v in os.environ.get("AIR_GLYPH_CONTRAST", "0,1").split(","))   # ink ramp: MNIST strokes saturate
     for i, g in enumerate(small):
-        big = np.clip(nd.zoom(g, zoom, order=1), 0.0, 1.0)
+        big = np.clip(nd.zoom(g, zoom, order=order), 0.0, 1.0)
+        big = np.clip((big - lo) / (hi - lo), 0.0, 1.0)
         big = np.where(big >= 0.15, big, 0.0)
         o = (IMAGE_SIZE - big.shape[0]) // 2
         out[i, o:o + big.shape[0], o:o + big.shape[1]] = big

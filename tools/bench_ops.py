@@ -36,5 +36,5 @@ n = len(arr)
 for name, idx in (("dWx only", [0]), ("all but dWx", list(range(1, n))), ("heads only", [n - 1]),
                   ("rec0+out", [3, n - 2])):
     sub = (H.Wgrad * len(idx))(*[arr[i] for i in idx])
-    fn = lambda st, sub=sub, k=len(idx): H.check(m.lib.air_wgrad_grouped(sub, k, st))
+    fn = lambda st, sub=sub, k=len(idx): H.check(m.lib.air_wgrad_grouped(sub, k, m._prec, st))
     print("wgrad subset %-14s %7.2f us" % (name, timeop(fn)))
