@@ -38,6 +38,37 @@ __device__ __forceinline__ float air_wave_sum(float v) {
     return v;
 }
 
+// Phase stamps of workgroup (0,0) for tools/phase_stamps.py (debug builds with -DAIR_STAMPS only;
+// the shipped library compiles them away).  wall_clock64(): 100 MHz constant counter.
+#ifdef AIR_STAMPS
+extern __device__ unsigned long long air_stamps_dev[64];
+#define AIR_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) air_stamps_dev[i] = wall_clock64(); } while (0)
+#else
+#define AIR_STAMP(i) do { } while (0)
+#endif
+
+// four block-wide sums at once (one barrier pair) for NW waves; `red` is >= 4*NW floats of LDS.
+// Deterministic: fixed butterfly + fixed wave order.
+template <int NW>
+__device__ __forceinline__ void air_block_sum4(float (&v)[4], float* red) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = air_wave_sum(v[k]);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[k * NW + wave] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float t = red[k * NW];
+#pragma unroll
+        for (int wv = 1; wv < NW; ++wv) t += red[k * NW + wv];
+        v[k] = t;
+    }
+}
+
 // block-wide sum for blockDim.x == 256 (4 waves); `red` is >= 4 floats of LDS.
 // Deterministic: fixed butterfly + fixed wave order.  All threads get the total.
 __device__ __forceinline__ float air_block_sum_256(float v, float* red) {

@@ -15,6 +15,13 @@
 // no atomics anywhere.
 #include "air_common.h"
 
+#ifdef AIR_STAMPS
+__device__ unsigned long long air_stamps_dev[64];
+extern "C" int air_debug_stamps(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(air_stamps_dev), sizeof(unsigned long long) * (n < 64 ? n : 64));
+}
+#endif
+
 namespace {
 
 constexpr int THREADS = 256;
@@ -507,18 +514,22 @@ __global__ __launch_bounds__(THREADS) void write_fwd_kernel(air_write_fwd_t a)
 // form), wrt theta_recon -> (s,x,y), and wrt z_pres.  One workgroup per
 // (image, time step): every step sees the same d loss / d canvas.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(THREADS) void write_bwd_kernel(air_write_bwd_t a)
+// 16 waves per workgroup: every phase is a latency chain, 4 waves per SIMD hide it
+constexpr int WB_THREADS = 1024;
+__global__ __launch_bounds__(WB_THREADS) void write_bwd_kernel(air_write_bwd_t a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
     const int C = a.C, w = a.w;
     const size_t row = (size_t)t * a.B + b;
-    float* sh_red = smem;                                  // [4]
-    Tap* sh_tx = reinterpret_cast<Tap*>(smem + 4);         // [C]
+    AIR_STAMP(0);
+    float* sh_red = smem;                                  // [64]
+    Tap* sh_tx = reinterpret_cast<Tap*>(smem + 64);        // [C]
     Tap* sh_ty = sh_tx + C;                                // [C]
     float* sh_t = reinterpret_cast<float*>(sh_ty + C);     // [C] linspace
     int* sh_rng = reinterpret_cast<int*>(sh_t + C);        // [8*w]: per source index, ranges of outputs whose tap0 / tap1 hit it
-    float* sh_win = reinterpret_cast<float*>(sh_rng + 8 * w);   // [w*w]
+    int* sh_run = sh_rng + 8 * w;                          // [4][w+2][2]: literal mode, run [lo,hi] of every key of x0/x1/y0/y1
+    float* sh_win = reinterpret_cast<float*>(sh_run + 8 * (w + 2));   // [w*w]
     float* sh_T = sh_win + w * w;                          // [2][C*w]
     float* sh_g = sh_T + 2 * C * (w + 2);                  // [C*C] d loss / d canvas of this image
 
@@ -526,23 +537,31 @@ __global__ __launch_bounds__(THREADS) void write_bwd_kernel(air_write_bwd_t a)
     float* dgen = a.d_gen_pre + row * w * w;
     float* dsx = a.d_sxy_write + row * 4;
     if (at[AIR_ATT_MASK] == 0.0f) {                        // where(active, ., 0): no gradient
-        for (int p = tid; p < w * w; p += THREADS) dgen[p] = 0.0f;
+        for (int p = tid; p < w * w; p += WB_THREADS) dgen[p] = 0.0f;
         if (tid < 4) dsx[tid] = 0.0f;
         return;
     }
     const float s = at[AIR_ATT_S], x = at[AIR_ATT_X], y = at[AIR_ATT_Y], z = at[AIR_ATT_Z];
     const float ia = 1.0f / s, bx = (-x) / s, by = (-y) / s;
-    for (int j = tid; j < C; j += THREADS) {
+    for (int j = tid; j < C; j += WB_THREADS) {
         float tv;
         sh_tx[j] = axis_tap(j, C, w, ia, bx, &tv);
         sh_ty[j] = axis_tap(j, C, w, ia, by);
         sh_t[j] = tv;
     }
+    if (a.literal) for (int it = tid; it < 4 * (w + 2); it += WB_THREADS) { sh_run[2 * it] = 0; sh_run[2 * it + 1] = -1; }
     const float* v = a.vrec + row * w * w;
-    for (int p = tid; p < w * w; p += THREADS) sh_win[p] = v[p];
+    for (int p = tid; p < w * w; p += WB_THREADS) sh_win[p] = v[p];
     {
-        const float* gsrc = a.d_recon + (size_t)b * C * C;   // one coalesced pass; every later access is LDS
-        for (int p = tid; p < C * C; p += THREADS) sh_g[p] = gsrc[p];
+        // one coalesced pass with 8 loads in flight per thread; every later access is LDS
+        const float* gsrc = a.d_recon + (size_t)b * C * C;
+        for (int p0 = 0; p0 < C * C; p0 += 8 * WB_THREADS) {
+            float r[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int p = p0 + k * WB_THREADS + tid; r[k] = p < C * C ? gsrc[p] : 0.0f; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int p = p0 + k * WB_THREADS + tid; if (p < C * C) sh_g[p] = r[k]; }
+        }
     }
     __syncthreads();
     // source index q is touched by a contiguous range of output coordinates (taps are monotone).
@@ -550,6 +569,7 @@ __global__ __launch_bounds__(THREADS) void write_bwd_kernel(air_write_bwd_t a)
     // skipped -- their two weights cancel exactly in real arithmetic.
     // literal mode: tap0 and tap1 keep separate ranges and degenerate outputs stay in, as in the
     // reference's four Gather_grad scatters.
+    AIR_STAMP(1);
     if (!a.literal && tid < 2 * w) {         // (the literal path uses segmented scans, no ranges)
         const Tap* tp = (tid < w) ? sh_tx : sh_ty;
         const int q = (tid < w) ? tid : tid - w;
@@ -569,7 +589,7 @@ __global__ __launch_bounds__(THREADS) void write_bwd_kernel(air_write_bwd_t a)
     float* T1 = sh_T + C * tstride;
     if (!a.literal) {
         // stage 1: T[I][q] = sum_J g[I][J] * Rx[J][q]
-        for (int it = tid; it < C * w; it += THREADS) {
+        for (int it = tid; it < C * w; it += WB_THREADS) {
             const int I = it / w, q = it % w;
             float acc = 0.0f;
             for (int J = sh_rng[4 * q]; J <= sh_rng[4 * q + 1]; ++J) {
@@ -581,41 +601,58 @@ __global__ __launch_bounds__(THREADS) void write_bwd_kernel(air_write_bwd_t a)
         }
     } else {
         // stage 1, per tap: T0[I][q] through the x0 taps, T1[I][q] through the x1 taps (g scaled by
-        // z_pres).  One thread per (canvas row, tap array) walks the row left to right with a
-        // running sum per run of equal tap index (runs are contiguous: taps are monotone) -- the
-        // sequential order of the reference's scatter-add, with no cross-lane traffic.
-        // Out-of-range (degenerate) runs go to their own slots (w / w+1 of each row) so that the
-        // +w and -w partners see identical summation orders, then are folded into the border slot:
-        // the residue left is the rounding of (in-range sum + huge run).
+        // z_pres).  Taps are monotone, so every key (tap index) is ONE contiguous run of canvas
+        // columns; out-of-range (degenerate) columns form their own runs, keyed w (left) and w+1
+        // (right), so that the +w and -w partners see identical summation orders.  Run boundaries
+        // are found in O(1) per column; then one task per (row, tap array, key) sums its run left
+        // to right (the sequential order of a scatter-add) -- short in-range runs and the long
+        // degenerate runs are separate, balanced task groups.  The degenerate sums are folded into
+        // the border slots afterwards: the residue left is the rounding of (in-range sum + huge run).
         const int ws = w + 2;
-        for (int it = tid; it < 2 * C * ws; it += THREADS) sh_T[it] = 0.0f;
+        for (int it = tid; it < 4 * C; it += WB_THREADS) {
+            const int arr = it / C, J = it % C;             // arr: x0, x1, y0, y1
+            const Tap* tp = (arr < 2) ? sh_tx : sh_ty;
+            auto keyof = [&](int jj) {
+                const Tap tt = tp[jj];
+                const int idx = (arr & 1) ? tt.i1 : tt.i0;
+                return (tt.i0 == tt.i1) ? (idx == 0 ? w : w + 1) : idx;
+            };
+            const int k = keyof(J);
+            if (J == 0 || keyof(J - 1) != k) sh_run[(arr * ws + k) * 2] = J;
+            if (J == C - 1 || keyof(J + 1) != k) sh_run[(arr * ws + k) * 2 + 1] = J;
+        }
         __syncthreads();
-        for (int it = tid; it < 2 * C; it += THREADS) {
-            const int I = it >> 1, tap = it & 1;
-            float* Wr = sh_T + (size_t)tap * C * ws + (size_t)I * ws;
-            int key = -1;
+        const int nA = 2 * C * w, nB = 4 * C;
+        for (int it = tid; it < nA + nB; it += WB_THREADS) {
+            int I, tap, key;                                 // the long (degenerate) runs are scheduled first
+            if (it >= nB) { const int u = it - nB; key = u % w; tap = (u / w) & 1; I = u / (2 * w); }
+            else { key = w + (it & 1); tap = (it >> 1) & 1; I = it >> 2; }
+            const int lo = sh_run[(tap * ws + key) * 2], hi = sh_run[(tap * ws + key) * 2 + 1];
+            const float* gr = g + I * C;
             float acc = 0.0f;
-            for (int J = 0; J < C; ++J) {
+#pragma unroll 4
+            for (int J = lo; J <= hi; ++J) {
                 const Tap tt = sh_tx[J];
-                const int idx = tap ? tt.i1 : tt.i0;
-                const int k = (tt.i0 == tt.i1) ? (idx == 0 ? w : w + 1) : idx;
-                if (k != key) { if (key >= 0) Wr[key] += acc; key = k; acc = 0.0f; }
-                acc += (g[I * C + J] * z) * (tap ? tt.w1 : tt.w0);
+                acc += (gr[J] * z) * (tap ? tt.w1 : tt.w0);
             }
-            if (key >= 0) Wr[key] += acc;
-            Wr[0] += Wr[w];
-            Wr[w - 1] += Wr[w + 1];
+            sh_T[(size_t)tap * C * ws + (size_t)I * ws + key] = acc;
         }
     }
+    AIR_STAMP(2);
     // theta / z gradients, per canvas pixel (independent of stage 1)
     const float half_w = ((float)w - 1.001f) / 2.0f;
     float da = 0.f, dbx = 0.f, dby = 0.f, dz = 0.f;
-    for (int p = tid; p < C * C; p += THREADS) {
-        const int i = p / C, j = p % C;
+    const int di = WB_THREADS / C, dj = WB_THREADS % C;          // (i, j) advance per WB_THREADS pixels
+    int i = tid / C, j = tid % C;
+#pragma unroll 2
+    for (int p = tid; p < C * C; p += WB_THREADS) {
         const Tap tx = sh_tx[j], ty = sh_ty[i];
         const float Ia = sh_win[ty.i0 * w + tx.i0], Ib = sh_win[ty.i1 * w + tx.i0];
         const float Ic = sh_win[ty.i0 * w + tx.i1], Id = sh_win[ty.i1 * w + tx.i1];
         const float gv = g[p];
+        const int ci = i, cj = j;
+        i += di; j += dj;
+        if (j >= C) { j -= C; ++i; }
         // a degenerate axis (both taps clipped to one index) is exactly 0 in real arithmetic;
         // the fp32 residue the forward keeps there (~1e-7) would be multiplied by g ~ 1e9/B
         // (d log(r + 1e-9) at r ~ 0) and drown d z_pres in rounding noise.
@@ -628,14 +665,16 @@ __global__ __launch_bounds__(THREADS) void write_bwd_kernel(air_write_bwd_t a)
             gX = gz * ((Ic - Ia) * ty.w0 + (Id - Ib) * ty.w1) * half_w;
             gY = gz * ((Ib - Ia) * tx.w0 + (Id - Ic) * tx.w1) * half_w;
         }
-        da += gX * sh_t[j] + gY * sh_t[i];
+        da += gX * sh_t[cj] + gY * sh_t[ci];
         dbx += gX;
         dby += gY;
     }
-    da = air_block_sum_256(da, sh_red);     // contains the __syncthreads() that publishes sh_T
-    dbx = air_block_sum_256(dbx, sh_red);
-    dby = air_block_sum_256(dby, sh_red);
-    dz = air_block_sum_256(dz, sh_red);
+    AIR_STAMP(3);
+    {
+        float red4[4] = {da, dbx, dby, dz};
+        air_block_sum4<WB_THREADS / 64>(red4, sh_red);   // contains the __syncthreads() that publishes sh_T
+        da = red4[0]; dbx = red4[1]; dby = red4[2]; dz = red4[3];
+    }
     if (tid == 0) {
         // a = 1/s, bx = -x/s, by = -y/s
         const float is2 = 1.0f / (s * s);
@@ -644,34 +683,49 @@ __global__ __launch_bounds__(THREADS) void write_bwd_kernel(air_write_bwd_t a)
         dsx[2] = -dby / s;
         dsx[3] = dz;
     }
+    AIR_STAMP(4);
     float* sh_S = sh_g + C * C;                            // [4][(w+2)*w]: per-tap sums a, b, c, d (literal mode)
     const int ss = (w + 2) * w;
     if (a.literal) {
-        for (int it = tid; it < 4 * ss; it += THREADS) sh_S[it] = 0.0f;
+        // fold the degenerate runs of stage 1 into the border slots (stage 1 finished at the barrier
+        // inside the block reduction above)
+        const int ws = w + 2;
+        for (int it = tid; it < 2 * C; it += WB_THREADS) {
+            float* Wr = sh_T + (size_t)it * ws;               // (tap, I) rows are contiguous
+            Wr[0] += Wr[w];
+            Wr[w - 1] += Wr[w + 1];
+        }
         __syncthreads();
-        // one thread per (window column q, tap array a/b/c/d) walks the canvas rows top to bottom
-        for (int it = tid; it < 4 * w; it += THREADS) {
-            const int q = it >> 2, arr = it & 3;                 // a=(y0,x0) b=(y1,x0) c=(y0,x1) d=(y1,x1)
-            const float* Tsrc = (arr & 2) ? T1 : T0;
+        // one task per (window column q, tap array a/b/c/d, key = window row): the run of canvas
+        // rows of that key, top to bottom; degenerate runs (keys w, w+1) are their own tasks
+        const int nA = 4 * w * w, nB = 8 * w;
+        for (int it = tid; it < nA + nB; it += WB_THREADS) {
+            int q, arr, key;
+            if (it >= nB) { const int u = it - nB; q = u % w; arr = (u / w) & 3; key = u / (4 * w); }
+            else { q = it % w; arr = (it / w) & 3; key = w + it / (4 * w); }
+            const float* Tsrc = (arr & 2) ? T1 : T0;       // a=(y0,x0) b=(y1,x0) c=(y0,x1) d=(y1,x1)
             const bool y1tap = arr & 1;
-            float* Sr = sh_S + (size_t)arr * ss;
-            int key = -1;
+            const int lo = sh_run[((2 + (arr & 1)) * ws + key) * 2], hi = sh_run[((2 + (arr & 1)) * ws + key) * 2 + 1];
             float acc = 0.0f;
-            for (int I = 0; I < C; ++I) {
+#pragma unroll 4
+            for (int I = lo; I <= hi; ++I) {
                 const Tap tt = sh_ty[I];
-                const int idx = y1tap ? tt.i1 : tt.i0;
-                const int k = (tt.i0 == tt.i1) ? (idx == 0 ? w : w + 1) : idx;
-                if (k != key) { if (key >= 0) Sr[key * w + q] += acc; key = k; acc = 0.0f; }
                 acc += Tsrc[I * tstride + q] * (y1tap ? tt.w1 : tt.w0);
             }
-            if (key >= 0) Sr[key * w + q] += acc;
+            sh_S[(size_t)arr * ss + key * w + q] = acc;
+        }
+        __syncthreads();
+        for (int it = tid; it < 4 * w; it += WB_THREADS) {
+            float* Sr = sh_S + (size_t)(it / w) * ss;
+            const int q = it % w;
             Sr[q] += Sr[w * w + q];
             Sr[(w - 1) * w + q] += Sr[(w + 1) * w + q];
         }
         __syncthreads();
     }
+    AIR_STAMP(5);
     // stage 2: dU[p][q] = z * sum_I Ry[I][p] * T[I][q]; fold the sigmoid of vae.py:39-41
-    for (int it = tid; it < w * w; it += THREADS) {
+    for (int it = tid; it < w * w; it += WB_THREADS) {
         const int p = it / w, q = it % w;
         const int* ry = sh_rng + 4 * w + 4 * p;
         float du;
@@ -693,6 +747,7 @@ __global__ __launch_bounds__(THREADS) void write_bwd_kernel(air_write_bwd_t a)
         const float r = sh_win[it];
         dgen[it] = du * (r * (1.0f - r));
     }
+    AIR_STAMP(6);
 }
 
 size_t attend_smem(int C, int w, int HT) {
@@ -702,7 +757,7 @@ size_t attend_bwd_smem(int C, int w) {
     return (12 + 8 * w + w + 4 + (size_t)C * C) * sizeof(float);
 }
 size_t write_smem(int N, int C, int w) { return (4 + 3 * MAX_STEPS + (size_t)N * (8 * C + (size_t)w * w)) * sizeof(float); }
-size_t write_bwd_smem(int C, int w) { return (4 + 8 * C + C + 8 * w + (size_t)w * w + 4 * (size_t)(w + 2) * w + 2 * (size_t)C * (w + 2) + (size_t)C * C) * sizeof(float); }
+size_t write_bwd_smem(int C, int w) { return (64 + 8 * C + C + 8 * w + 8 * (w + 2) + (size_t)w * w + 4 * (size_t)(w + 2) * w + 2 * (size_t)C * (w + 2) + (size_t)C * C) * sizeof(float); }
 
 template <typename K>
 int ensure_lds(K kernel, size_t bytes) {
@@ -777,7 +832,7 @@ extern "C" int air_write_bwd(const air_write_bwd_t* a, void* stream) {
     const size_t lds = write_bwd_smem(a->C, a->w);
     int rc = ensure_lds(write_bwd_kernel, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(write_bwd_kernel, dim3(a->B, a->N), dim3(THREADS), lds, air_stream(stream), *a);
+    hipLaunchKernelGGL(write_bwd_kernel, dim3(a->B, a->N), dim3(WB_THREADS), lds, air_stream(stream), *a);
     AIR_CHECK_LAUNCH();
     return 0;
 }

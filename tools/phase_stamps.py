@@ -1,0 +1,42 @@
+"""Phase timing of workgroup (0,0) of the sampler kernels: builds a -DAIR_STAMPS variant of the
+library in /tmp ON THE GPU BOX, runs one train step and prints the deltas between stamps.
+  python tools/phase_stamps.py [op-name-substring ...]"""
+import ctypes as C, glob, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "tf-attend-infer-repeat_amd")
+sys.path.insert(0, ROOT); sys.path.insert(0, PKG)
+out = "/tmp/libair_hip_stamps.so"
+src = sorted(glob.glob(os.path.join(PKG, "csrc", "*.hip")))
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+                       "-shared", "-DAIR_STAMPS", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "csrc")]
+                      + src + ["-o", out])
+import torch
+from air import _hip as H
+H._LIB = H.load(out)
+H._LIB.air_debug_stamps.restype = C.c_int
+H._LIB.air_debug_stamps.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+from bench import HP, ANNEAL, synthetic_canvases
+from air import air_model as am
+images, targets = synthetic_canvases(64, 50, 2, 1)
+m = am.AIRModel(torch.tensor(images, device="cuda"), torch.tensor(targets, device="cuda"), cnn=False, train=True,
+                annealing_schedules=ANNEAL, gemm_precision="bf16", **HP)
+for _ in range(3):
+    m.training()
+torch.cuda.synchronize()
+s = m._stream()
+names = sys.argv[1:] or ["write_bwd", "compose", "attend_fwd", "attend_bwd"]
+ops = [m._begin] + m._fwd + m._bwd
+for want in names:
+    for op in ops:
+        if want in op.name:
+            buf = (C.c_ulonglong * 64)()
+            for _ in range(3):
+                op(s)
+            torch.cuda.synchronize()
+            H._LIB.air_debug_stamps(buf, 64)
+            v = [int(x) for x in buf]
+            n = max(i for i in range(64) if v[i]) + 1 if any(v) else 0
+            # only stamps of this kernel are monotone from index 0
+            d = ["%d:%.2f" % (i, (v[i] - v[i - 1]) / 100.0) for i in range(1, n) if v[i] >= v[i - 1]]
+            print("%-14s total %.2f us | deltas(us) %s" % (op.name, (v[n - 1] - v[0]) / 100.0 if n else 0, " ".join(d)))
+            break
