@@ -69,6 +69,20 @@ __device__ __forceinline__ void air_block_sum4(float (&v)[4], float* red) {
     }
 }
 
+// block-wide sum for NW waves; `red` is >= NW floats of LDS.  Fixed order; all threads get the total.
+template <int NW>
+__device__ __forceinline__ float air_block_sum_n(float v, float* red) {
+    v = air_wave_sum(v);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[wave] = v;
+    __syncthreads();
+    float t = red[0];
+#pragma unroll
+    for (int wv = 1; wv < NW; ++wv) t += red[wv];
+    return t;
+}
+
 // block-wide sum for blockDim.x == 256 (4 waves); `red` is >= 4 floats of LDS.
 // Deterministic: fixed butterfly + fixed wave order.  All threads get the total.
 __device__ __forceinline__ float air_block_sum_256(float v, float* red) {

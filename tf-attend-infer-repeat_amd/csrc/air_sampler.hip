@@ -409,23 +409,26 @@ __global__ __launch_bounds__(THREADS) void attend_bwd_kernel(air_attend_bwd_t a)
 // reconstruction loss + its gradient (air_model.py:351-366, 409-439, 479-496,
 // 580-593).  One workgroup per image.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(THREADS) void write_fwd_kernel(air_write_fwd_t a)
+// 16 waves per workgroup (one workgroup per image): the pixel loop is a chain of dependent LDS
+// gathers and two logf per pixel; 4 waves per SIMD hide that latency
+constexpr int CF_THREADS = 1024;
+__global__ __launch_bounds__(CF_THREADS) void write_fwd_kernel(air_write_fwd_t a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int C = a.C, w = a.w, Z = a.Z, N = a.N, B = a.B;
-    float* sh_red = smem;                                    // [4]
-    float* sh_z = smem + 4;                                  // [MAX_STEPS] z_pres
-    int* sh_act = reinterpret_cast<int*>(smem + 4 + MAX_STEPS);          // [MAX_STEPS]
-    float* sh_kl = smem + 4 + 2 * MAX_STEPS;                             // [MAX_STEPS] VAE KL per step
-    Tap* sh_tx = reinterpret_cast<Tap*>(smem + 4 + 3 * MAX_STEPS);       // [N][C]
+    float* sh_red = smem;                                    // [16]
+    float* sh_z = smem + 16;                                 // [MAX_STEPS] z_pres
+    int* sh_act = reinterpret_cast<int*>(smem + 16 + MAX_STEPS);         // [MAX_STEPS]
+    float* sh_kl = smem + 16 + 2 * MAX_STEPS;                            // [MAX_STEPS] VAE KL per step
+    Tap* sh_tx = reinterpret_cast<Tap*>(smem + 16 + 3 * MAX_STEPS);      // [N][C]
     Tap* sh_ty = sh_tx + (size_t)N * C;                                    // [N][C]
     float* sh_win = reinterpret_cast<float*>(sh_ty + (size_t)N * C);      // [N][w*w]
     const float* dyn = a.dyn;
 
     // phase A -- everything that only needs the per-step records, for all steps at once
     // (independent loads: one memory round trip instead of one per step)
-    for (int t = wave; t < N; t += 4) {
+    for (int t = wave; t < N; t += CF_THREADS / 64) {
         // VAE KL :479-493 (a public output whether or not the item is still active): one wave per step
         const float* ml = a.ml + ((size_t)t * B + b) * 2 * Z;
         const float pv = dyn[AIR_DYN_VAE_PV], pm = dyn[AIR_DYN_VAE_PM];
@@ -437,7 +440,7 @@ __global__ __launch_bounds__(THREADS) void write_fwd_kernel(air_write_fwd_t a)
         klt = air_wave_sum(klt);
         if (lane == 0) sh_kl[t] = 0.5f * klt;
     }
-    for (int it = tid; it < N * C; it += THREADS) {
+    for (int it = tid; it < N * C; it += CF_THREADS) {
         const int t = it / C, j = it % C;
         const float* at = a.att + ((size_t)t * B + b) * AIR_ATT_STRIDE;
         // theta_recon :353-356
@@ -446,7 +449,7 @@ __global__ __launch_bounds__(THREADS) void write_fwd_kernel(air_write_fwd_t a)
         sh_tx[it] = axis_tap(j, C, w, ia, bx);
         sh_ty[it] = axis_tap(j, C, w, ia, by);
     }
-    for (int it = tid; it < N * w * w; it += THREADS) {
+    for (int it = tid; it < N * w * w; it += CF_THREADS) {
         const int t = it / (w * w);
         sh_win[it] = a.vrec[((size_t)t * B + b) * w * w + (it - t * w * w)];
     }
@@ -480,8 +483,10 @@ __global__ __launch_bounds__(THREADS) void write_fwd_kernel(air_write_fwd_t a)
     const float gsc = dyn[AIR_DYN_GRAD_SCALE];
     const size_t base = (size_t)b * C * C;
     float acc = 0.0f;
-    for (int p = tid; p < C * C; p += THREADS) {
-        const int i = p / C, j = p % C;
+    const int di = CF_THREADS / C, dj = CF_THREADS % C;
+    int i = tid / C, j = tid % C;
+    for (int p = tid; p < C * C; p += CF_THREADS) {
+        const float x = a.images[base + p];
         float R = 0.0f;                                             // running_recon :552
         for (int t = 0; t < N; ++t) {
             if (!sh_act[t]) continue;                               // where(active, z*w, 0) :433-439
@@ -491,7 +496,8 @@ __global__ __launch_bounds__(THREADS) void write_fwd_kernel(air_write_fwd_t a)
                                        win[ty.i0 * w + tx.i1], win[ty.i1 * w + tx.i1]);
             R = R + sh_z[t] * wr;
         }
-        const float x = a.images[base + p];
+        i += di; j += dj;
+        if (j >= C) { j -= C; ++i; }
         const float r = fmaxf(fminf(R, 1.0f), 0.0f);                // clipped_rec :582
         const float p1 = r + AIR_EPS, p0 = (1.0f - r) + AIR_EPS;
         acc += x * logf(p1) + (1.0f - x) * logf(p0);                // :586-589
@@ -501,7 +507,7 @@ __global__ __launch_bounds__(THREADS) void write_fwd_kernel(air_write_fwd_t a)
             a.d_recon[base + p] = pass ? -gsc * (x / p1 - (1.0f - x) / p0) : 0.0f;
         }
     }
-    acc = air_block_sum_256(acc, sh_red);
+    acc = air_block_sum_n<CF_THREADS / 64>(acc, sh_red);
     if (tid == 0) {
         const float rl = -acc;
         a.rec_loss[b] = rl;
@@ -756,7 +762,7 @@ size_t attend_smem(int C, int w, int HT) {
 size_t attend_bwd_smem(int C, int w) {
     return (12 + 8 * w + w + 4 + (size_t)C * C) * sizeof(float);
 }
-size_t write_smem(int N, int C, int w) { return (4 + 3 * MAX_STEPS + (size_t)N * (8 * C + (size_t)w * w)) * sizeof(float); }
+size_t write_smem(int N, int C, int w) { return (16 + 3 * MAX_STEPS + (size_t)N * (8 * C + (size_t)w * w)) * sizeof(float); }
 size_t write_bwd_smem(int C, int w) { return (64 + 8 * C + C + 8 * w + 8 * (w + 2) + (size_t)w * w + 4 * (size_t)(w + 2) * w + 2 * (size_t)C * (w + 2) + (size_t)C * C) * sizeof(float); }
 
 template <typename K>
@@ -820,7 +826,7 @@ extern "C" int air_write_fwd(const air_write_fwd_t* a, void* stream) {
     const size_t lds = write_smem(a->N, a->C, a->w);
     int rc = ensure_lds(write_fwd_kernel, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(write_fwd_kernel, dim3(a->B), dim3(THREADS), lds, air_stream(stream), *a);
+    hipLaunchKernelGGL(write_fwd_kernel, dim3(a->B), dim3(CF_THREADS), lds, air_stream(stream), *a);
     AIR_CHECK_LAUNCH();
     return 0;
 }
