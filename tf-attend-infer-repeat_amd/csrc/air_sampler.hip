@@ -178,50 +178,82 @@ __global__ __launch_bounds__(THREADS) void attend_fwd_kernel(air_attend_fwd_t a)
     Tap* sh_ty = sh_tx + w;                              // [w]
     int* sh_box = reinterpret_cast<int*>(sh_ty + w);     // [4]: x_lo, x_hi, y_lo, y_hi
     float* sh_hid = reinterpret_cast<float*>(sh_box + 4);   // [HT]
-    float* sh_img = sh_hid + ((HT + 3) & ~3);               // [<= C*C] bounding box of the glimpse
+    float* sh_wout = sh_hid + ((HT + 3) & ~3);              // [7][wout_ld] output-unit weights
+    float* sh_hprev = sh_wout + 7 * a.wout_ld;              // [t][Hz] z_pres hidden segment of the earlier steps
+    float* sh_img = sh_hprev + MAX_STEPS * hs.wid[4];       // [C*C] canvas
 
     const size_t row = (size_t)t * B + b;
+    AIR_STAMP(10);
+    // every global load that does not depend on the sampled (s, x, y) is issued up front: the
+    // canvas (consumed last) rides under the head computation instead of following it
+    const float* img = a.canvas + (size_t)b * C * C;
+    constexpr int PF = 10;                                   // 2560 floats per pass: the 50x50 canvas in one
+    float pf[PF];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) { const int p = tid + k * THREADS; pf[k] = p < C * C ? img[p] : 0.0f; }
+    float eps_s = 0.f, eps_x = 0.f, eps_y = 0.f, u_t = 0.f, u_prev[MAX_STEPS];
+    if (tid == 0) {
+        eps_s = a.eps_scale[row]; eps_x = a.eps_shift[2 * row]; eps_y = a.eps_shift[2 * row + 1]; u_t = a.u[row];
+#pragma unroll
+        for (int tp = 0; tp < MAX_STEPS; ++tp) u_prev[tp] = tp < t ? a.u[(size_t)tp * B + b] : 0.0f;
+    }
     for (int j = tid; j < HT; j += THREADS) sh_hid[j] = a.hid[row * HT + j];
+    for (int j = tid; j < 7 * a.wout_ld; j += THREADS) sh_wout[j] = a.wout[j];
+    for (int j = tid; j < t * hs.wid[4]; j += THREADS) {
+        const int tp = j / hs.wid[4], jj = j % hs.wid[4];
+        sh_hprev[j] = a.hid[((size_t)tp * B + b) * HT + hs.off[4] + jj];
+    }
+    float bo[2] = {0.f, 0.f};
+    if (lane == 0) { bo[0] = a.bout[wave]; if (wave + 4 < 7) bo[1] = a.bout[wave + 4]; }
+    const float bz = a.bout[6];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) { const int p = tid + k * THREADS; if (p < C * C) sh_img[p] = pf[k]; }
+    for (int p = tid + PF * THREADS; p < C * C; p += THREADS) sh_img[p] = img[p];      // larger canvases
     __syncthreads();
 
+    AIR_STAMP(11);
     // 7 output units (air_model.py:294,299,311,316,376): x.W + b
-    for (int o = wave; o < 7; o += 4) {
+    for (int o = wave, n = 0; o < 7; o += 4, ++n) {
         const int h = kOutHead[o];
         float p = 0.0f;
-        for (int j = lane; j < hs.wid[h]; j += 64) p += sh_hid[hs.off[h] + j] * a.wout[o * a.wout_ld + j];
+        for (int j = lane; j < hs.wid[h]; j += 64) p += sh_hid[hs.off[h] + j] * sh_wout[o * a.wout_ld + j];
         p = air_wave_sum(p);
-        if (lane == 0) sh_out[o] = p + a.bout[o];
+        if (lane == 0) sh_out[o] = p + bo[n];
     }
     // z log-odds of the earlier steps t' < t (same lane assignment and reduction order as above)
     for (int tp = wave; tp < t; tp += 4) {
-        const float* hp = a.hid + ((size_t)tp * B + b) * HT + hs.off[4];
+        const float* hp = sh_hprev + tp * hs.wid[4];
         float p = 0.0f;
-        for (int j = lane; j < hs.wid[4]; j += 64) p += hp[j] * a.wout[6 * a.wout_ld + j];
+        for (int j = lane; j < hs.wid[4]; j += 64) p += hp[j] * sh_wout[6 * a.wout_ld + j];
         p = air_wave_sum(p);
-        if (lane == 0) sh_zlo[tp] = p + a.bout[6];
+        if (lane == 0) sh_zlo[tp] = p + bz;
     }
     __syncthreads();
 
+    AIR_STAMP(12);
     if (tid == 0) {
         const float* dyn = a.dyn;
         const float T = dyn[AIR_DYN_TEMPERATURE], thr = dyn[AIR_DYN_STOP_THRESHOLD];
         // stopping sum on entry to step t (air_model.py:424): S += 1 - z_pres, in step order
         float S = 0.0f;
-        for (int tp = 0; tp < t; ++tp) {
-            float zp = air_sigmoid(concrete_presigmoid(sh_zlo[tp], a.u[(size_t)tp * B + b], T));
-            if (!a.train) zp = rintf(zp);
-            S = S + (1.0f - zp);
+#pragma unroll
+        for (int tp = 0; tp < MAX_STEPS; ++tp) {
+            if (tp < t) {
+                float zp = air_sigmoid(concrete_presigmoid(sh_zlo[tp], u_prev[tp], T));
+                if (!a.train) zp = rintf(zp);
+                S = S + (1.0f - zp);
+            }
         }
         const float mu_s = sh_out[0], lv_s = sh_out[1];
         const float mu_x = sh_out[2], mu_y = sh_out[3], lv_x = sh_out[4], lv_y = sh_out[5];
         const float z_lo = sh_out[6];
         // scale :300-303, shift :317-320   (_sample_from_mvn :123-128)
         const float var_s = expf(lv_s);
-        const float s = air_sigmoid(mu_s + a.eps_scale[row] * sqrtf(var_s));
+        const float s = air_sigmoid(mu_s + eps_s * sqrtf(var_s));
         const float var_x = expf(lv_x), var_y = expf(lv_y);
-        const float x = tanhf(mu_x + a.eps_shift[2 * row] * sqrtf(var_x));
-        const float y = tanhf(mu_y + a.eps_shift[2 * row + 1] * sqrtf(var_y));
-        const float ypre = concrete_presigmoid(z_lo, a.u[row], T);
+        const float x = tanhf(mu_x + eps_x * sqrtf(var_x));
+        const float y = tanhf(mu_y + eps_y * sqrtf(var_y));
+        const float ypre = concrete_presigmoid(z_lo, u_t, T);
         float z = air_sigmoid(ypre);
         if (!a.train) z = rintf(z);                       // tf.round (half-to-even) :389-390
         const float zprob = air_sigmoid(z_lo);
@@ -261,33 +293,22 @@ __global__ __launch_bounds__(THREADS) void attend_fwd_kernel(air_attend_fwd_t a)
     }
     __syncthreads();
 
+    AIR_STAMP(13);
     // ST read :322-333 -- theta = [[s,0,x],[0,s,y]]
     const float s = sh_sc[0], sx = sh_sc[1], sy = sh_sc[2];
     if (tid < w) sh_tx[tid] = axis_tap(tid, w, C, s, sx);
     else if (tid >= 64 && tid < 64 + w) sh_ty[tid - 64] = axis_tap(tid - 64, w, C, s, sy);
     __syncthreads();
-    if (tid == 0) {
-        // taps are monotone in the output index (s > 0): the bounding box is set by the ends
-        sh_box[0] = min(sh_tx[0].i0, sh_tx[w - 1].i0); sh_box[1] = max(sh_tx[0].i1, sh_tx[w - 1].i1);
-        sh_box[2] = min(sh_ty[0].i0, sh_ty[w - 1].i0); sh_box[3] = max(sh_ty[0].i1, sh_ty[w - 1].i1);
-    }
-    __syncthreads();
-    const int xlo = sh_box[0], bw = sh_box[1] - sh_box[0] + 1;
-    const int ylo = sh_box[2], bh = sh_box[3] - sh_box[2] + 1;
-    const float* img = a.canvas + (size_t)b * C * C;
-    for (int p = tid; p < bw * bh; p += THREADS) {
-        const int r = p / bw, c = p % bw;
-        sh_img[p] = img[(ylo + r) * C + xlo + c];     // rows of the box: coalesced segments
-    }
-    __syncthreads();
+    (void)sh_box;
+    AIR_STAMP(14);
     float* win = a.window + row * w * w;
     for (int p = tid; p < w * w; p += THREADS) {
         const int i = p / w, j = p % w;
         const Tap tx = sh_tx[j], ty = sh_ty[i];
-        const int r0 = (ty.i0 - ylo) * bw, r1 = (ty.i1 - ylo) * bw;
-        const int c0 = tx.i0 - xlo, c1 = tx.i1 - xlo;
-        win[p] = bilinear4(tx, ty, sh_img[r0 + c0], sh_img[r1 + c0], sh_img[r0 + c1], sh_img[r1 + c1]);
+        const int r0 = ty.i0 * C, r1 = ty.i1 * C;
+        win[p] = bilinear4(tx, ty, sh_img[r0 + tx.i0], sh_img[r1 + tx.i0], sh_img[r0 + tx.i1], sh_img[r1 + tx.i1]);
     }
+    AIR_STAMP(15);
 }
 
 // ---------------------------------------------------------------------------
@@ -303,41 +324,55 @@ __global__ __launch_bounds__(THREADS) void attend_bwd_kernel(air_attend_bwd_t a)
     const int HT = hs.off[4] + hs.wid[4];
     const size_t row = (size_t)t * a.B + b;
 
-    float* sh_red = smem;                                // [4]
-    float* sh_d = smem + 4;                              // [8] d_out7
-    Tap* sh_tx = reinterpret_cast<Tap*>(smem + 12);
+    float* sh_red = smem;                                // [16]
+    float* sh_d = smem + 16;                             // [8] d_out7
+    Tap* sh_tx = reinterpret_cast<Tap*>(smem + 24);
     Tap* sh_ty = sh_tx + w;
     float* sh_t = reinterpret_cast<float*>(sh_ty + w);   // [w] linspace values
     int* sh_box = reinterpret_cast<int*>(sh_t + w);
     float* sh_img = reinterpret_cast<float*>(sh_box + 4);
 
+    // all global loads up front (one memory round trip): the canvas, this thread's share of
+    // d_window, and thread 0's scalars for the head-output gradients at the end
     const float* at = a.att + row * AIR_ATT_STRIDE;
+    const float* img = a.canvas + (size_t)b * C * C;
+    const float* g = a.d_window + row * w * w;
+    constexpr int PF = 10, GF = 4;
+    float pf[PF], gf[GF];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) { const int p = tid + k * THREADS; pf[k] = p < C * C ? img[p] : 0.0f; }
+#pragma unroll
+    for (int k = 0; k < GF; ++k) { const int p = tid + k * THREADS; gf[k] = p < w * w ? g[p] : 0.0f; }
+    float pre_o7[8], pre_dw[4], pre_e[3], pre_dyn[AIR_DYN_COUNT], pre_at[AIR_ATT_STRIDE];
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pre_o7[k] = a.out7[row * AIR_OUT_STRIDE + k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pre_dw[k] = a.d_sxy_write[row * 4 + k];
+        pre_e[0] = a.eps_scale[row]; pre_e[1] = a.eps_shift[2 * row]; pre_e[2] = a.eps_shift[2 * row + 1];
+#pragma unroll
+        for (int k = 0; k < AIR_DYN_COUNT; ++k) pre_dyn[k] = a.dyn[k];
+#pragma unroll
+        for (int k = 0; k < AIR_ATT_STRIDE; ++k) pre_at[k] = at[k];
+    }
     const float s = at[AIR_ATT_S], sx = at[AIR_ATT_X], sy = at[AIR_ATT_Y];
     if (tid < w) { float tv; sh_tx[tid] = axis_tap(tid, w, C, s, sx, &tv); sh_t[tid] = tv; }
     else if (tid >= 64 && tid < 64 + w) sh_ty[tid - 64] = axis_tap(tid - 64, w, C, s, sy);
-    __syncthreads();
-    if (tid == 0) {
-        sh_box[0] = min(sh_tx[0].i0, sh_tx[w - 1].i0); sh_box[1] = max(sh_tx[0].i1, sh_tx[w - 1].i1);
-        sh_box[2] = min(sh_ty[0].i0, sh_ty[w - 1].i0); sh_box[3] = max(sh_ty[0].i1, sh_ty[w - 1].i1);
-    }
-    __syncthreads();
-    const int xlo = sh_box[0], bw = sh_box[1] - sh_box[0] + 1;
-    const int ylo = sh_box[2], bh = sh_box[3] - sh_box[2] + 1;
-    const float* img = a.canvas + (size_t)b * C * C;
-    for (int p = tid; p < bw * bh; p += THREADS) sh_img[p] = img[(ylo + p / bw) * C + xlo + p % bw];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) { const int p = tid + k * THREADS; if (p < C * C) sh_img[p] = pf[k]; }
+    for (int p = tid + PF * THREADS; p < C * C; p += THREADS) sh_img[p] = img[p];      // larger canvases
+    (void)sh_box;
     __syncthreads();
 
     // d out / dX = (Ic-Ia)(y1-Y) + (Id-Ib)(Y-y0);  d out / dY = (Ib-Ia)(x1-X) + (Id-Ic)(X-x0)
     const float half_c = ((float)C - 1.001f) / 2.0f;     // dX/dx_s
     float ds = 0.f, dx = 0.f, dy = 0.f;
-    const float* g = a.d_window + row * w * w;
-    for (int p = tid; p < w * w; p += THREADS) {
+    for (int p = tid, k = 0; p < w * w; p += THREADS, ++k) {
         const int i = p / w, j = p % w;
         const Tap tx = sh_tx[j], ty = sh_ty[i];
-        const int r0 = (ty.i0 - ylo) * bw, r1 = (ty.i1 - ylo) * bw;
-        const int c0 = tx.i0 - xlo, c1 = tx.i1 - xlo;
-        const float Ia = sh_img[r0 + c0], Ib = sh_img[r1 + c0], Ic = sh_img[r0 + c1], Id = sh_img[r1 + c1];
-        const float gv = g[p];
+        const int r0 = ty.i0 * C, r1 = ty.i1 * C;
+        const float Ia = sh_img[r0 + tx.i0], Ib = sh_img[r1 + tx.i0], Ic = sh_img[r0 + tx.i1], Id = sh_img[r1 + tx.i1];
+        const float gv = k < GF ? gf[k < GF ? k : 0] : g[p];
         float gX, gY;
         if (a.literal) literal_dxy(gv, Ia, Ib, Ic, Id, tx, ty, (float)C - 1.001f, gX, gY);
         else {
@@ -348,16 +383,19 @@ __global__ __launch_bounds__(THREADS) void attend_bwd_kernel(air_attend_bwd_t a)
         dx += gX;
         dy += gY;
     }
-    ds = air_block_sum_256(ds, sh_red);
-    dx = air_block_sum_256(dx, sh_red);
-    dy = air_block_sum_256(dy, sh_red);
+    {
+        float r4[4] = {ds, dx, dy, 0.0f};
+        air_block_sum4<THREADS / 64>(r4, sh_red);
+        ds = r4[0]; dx = r4[1]; dy = r4[2];
+    }
 
     if (tid == 0) {
-        const float* dyn = a.dyn;
+        const float* dyn = pre_dyn;                              // preloaded at kernel entry
         const float gsc = dyn[AIR_DYN_GRAD_SCALE];               // d loss / d per-item loss
         const float T = dyn[AIR_DYN_TEMPERATURE];
-        const float* o7 = a.out7 + row * AIR_OUT_STRIDE;
-        const float* dw = a.d_sxy_write + row * 4;
+        const float* o7 = pre_o7;
+        const float* dw = pre_dw;
+        const float* at = pre_at;
         const float mask = at[AIR_ATT_MASK], mask_prev = at[AIR_ATT_MASK_PREV];
         const float d_s = ds + dw[0], d_x = dx + dw[1], d_y = dy + dw[2], d_z = dw[3];
         const float lv_s = o7[1], lv_x = o7[4], lv_y = o7[5];
@@ -368,7 +406,7 @@ __global__ __launch_bounds__(THREADS) void attend_bwd_kernel(air_attend_bwd_t a)
         // s = sigmoid(mu + eps*sd), (x,y) = tanh(mu + eps*sd), sd = sqrt(exp(lv))
         const float da_s = d_s * s * (1.0f - s);
         const float da_x = d_x * (1.0f - sx * sx), da_y = d_y * (1.0f - sy * sy);
-        const float e_s = a.eps_scale[row], e_x = a.eps_shift[2 * row], e_y = a.eps_shift[2 * row + 1];
+        const float e_s = pre_e[0], e_x = pre_e[1], e_y = pre_e[2];
         sh_d[0] = da_s + klg * (o7[0] - pm_s) / pv_s;
         sh_d[1] = da_s * e_s * 0.5f * sd_s + klg * 0.5f * (sd_s * sd_s / pv_s - 1.0f);
         sh_d[2] = da_x + klg * (o7[2] - pm_h) / pv_h;
@@ -757,10 +795,10 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_kernel(air_write_bwd_t a
 }
 
 size_t attend_smem(int C, int w, int HT) {
-    return (16 + MAX_STEPS + 8 * w + 4 + ((HT + 3) & ~3) + (size_t)C * C) * sizeof(float);
+    return (16 + MAX_STEPS + 8 * w + 4 + ((HT + 3) & ~3) + 7 * (size_t)HT + MAX_STEPS * (size_t)HT + (size_t)C * C) * sizeof(float);
 }
 size_t attend_bwd_smem(int C, int w) {
-    return (12 + 8 * w + w + 4 + (size_t)C * C) * sizeof(float);
+    return (24 + 8 * w + w + 4 + (size_t)C * C) * sizeof(float);
 }
 size_t write_smem(int N, int C, int w) { return (16 + 3 * MAX_STEPS + (size_t)N * (8 * C + (size_t)w * w)) * sizeof(float); }
 size_t write_bwd_smem(int C, int w) { return (64 + 8 * C + C + 8 * w + 8 * (w + 2) + (size_t)w * w + 4 * (size_t)(w + 2) * w + 2 * (size_t)C * (w + 2) + (size_t)C * C) * sizeof(float); }

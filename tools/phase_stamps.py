@@ -35,8 +35,8 @@ for want in names:
             torch.cuda.synchronize()
             H._LIB.air_debug_stamps(buf, 64)
             v = [int(x) for x in buf]
-            n = max(i for i in range(64) if v[i]) + 1 if any(v) else 0
-            # only stamps of this kernel are monotone from index 0
-            d = ["%d:%.2f" % (i, (v[i] - v[i - 1]) / 100.0) for i in range(1, n) if v[i] >= v[i - 1]]
-            print("%-14s total %.2f us | deltas(us) %s" % (op.name, (v[n - 1] - v[0]) / 100.0 if n else 0, " ".join(d)))
+            base = {"write_bwd": 0, "attend_fwd": 10, "attend_bwd": 20, "compose": 30}.get(want, 0)
+            idx = [i for i in range(base, base + 10) if v[i]]
+            d = ["%d:%.2f" % (i, (v[i] - v[j]) / 100.0) for j, i in zip(idx, idx[1:])]
+            print("%-14s total %.2f us | deltas(us) %s" % (op.name, (v[idx[-1]] - v[idx[0]]) / 100.0 if idx else 0, " ".join(d)))
             break
