@@ -152,8 +152,15 @@ typedef struct {
     int32_t M, N, K, lda, ldb, ldc;
     int32_t head_pack, Hs, Hh, Hz;
 } air_wgrad_t;
-/* precision: 0 = fp32 MFMA (exact fp32 products), 1 = operands rounded to bf16, fp32 accumulate */
-int air_wgrad_grouped(const air_wgrad_t* probs /*HOST array, <= 12*/, int count, int precision, void* stream);
+/* precision: 0 = fp32 MFMA (exact fp32 products), 1 = operands rounded to bf16, fp32 accumulate.
+ * sq_partials (nullable): [air_wgrad_num_blocks()] floats receiving the sum of squares of every
+ * gradient element each workgroup stored -- the tf.global_norm terms (air_model.py:673), handed to
+ * air_adam_clip_step instead of a separate air_grad_sqnorm pass (single-GPU path; with data
+ * parallelism the norm is taken after the all-reduce).  istate (nullable, only with sq_partials):
+ * istate[GLOBAL_STEP] += 1, as air_grad_sqnorm does. */
+int air_wgrad_num_blocks(const air_wgrad_t* probs, int count);
+int air_wgrad_grouped(const air_wgrad_t* probs /*HOST array, <= 12*/, int count, int precision,
+                      float* sq_partials, int32_t* istate, void* stream);
 
 /* column sums db[n] = sum_r dY[r*ld + n]  (BiasAdd_grad nodes) for `count` problems */
 typedef struct { const float* src; float* dst; int32_t rows, cols, ld, accumulate; } air_colsum_t;
@@ -279,7 +286,7 @@ int air_step_begin(const air_schedule_t* sched /*device*/, int nsched, float* dy
 int air_optim_num_partials(int64_t n);
 int air_grad_sqnorm(const float* grads, int64_t n, float* partials, int32_t* istate, void* stream);
 int air_adam_clip_step(float* params, const float* grads, float* m, float* v, int64_t n,
-                       const float* partials, const float* dyn, const int32_t* istate,
+                       const float* partials, int npartials, const float* dyn, const int32_t* istate,
                        float grad_prescale /* e.g. 1/world_size */, float beta1, float beta2,
                        float epsilon, uint16_t* bf16_shadow /*nullable*/, float* gnorm_out /*nullable*/,
                        void* stream);

@@ -222,7 +222,7 @@ def test_adam_and_norm_match_oracle(H):
     part = torch.zeros(H.lib().air_optim_num_partials(n), device=dev)
     gn = torch.zeros(1, device=dev)
     H.check(H.lib().air_grad_sqnorm(_p(G), n, _p(part), _p(ist), _stream()))
-    H.check(H.lib().air_adam_clip_step(_p(P), _p(G), _p(M), _p(V), n, _p(part), _p(dyn), _p(ist),
+    H.check(H.lib().air_adam_clip_step(_p(P), _p(G), _p(M), _p(V), n, _p(part), part.numel(), _p(dyn), _p(ist),
                                        1.0, 0.9, 0.999, 1e-8, None, _p(gn), _stream()))
     torch.cuda.synchronize()
     assert int(ist[0]) == 5
@@ -410,12 +410,21 @@ def test_wgrad_grouped(H, shapes, prec):
         Y64 = _bf16_round(dY) if prec else dY.astype(np.float64)
         refs.append((A64.T @ Y64, dY.astype(np.float64).sum(0), Wt, bt, K))       # bias sums stay fp32 in both modes
     arr = (H.Wgrad * len(probs))(*probs)
-    H.check(H.lib().air_wgrad_grouped(arr, len(probs), prec, _stream()), "air_wgrad_grouped")
+    nblk = H.lib().air_wgrad_num_blocks(arr, len(probs))
+    assert nblk > 0
+    part = torch.full((nblk,), float("nan"), device=dev)
+    ist = torch.zeros(8, dtype=torch.int32, device=dev)
+    H.check(H.lib().air_wgrad_grouped(arr, len(probs), prec, _p(part), _p(ist), _stream()), "air_wgrad_grouped")
     torch.cuda.synchronize()
+    sq = 0.0
     for ref_w, ref_b, Wt, bt, K in refs:
         tol = 2e-6 * np.sqrt(K) * 4
         np.testing.assert_allclose(Wt.cpu().numpy(), ref_w, rtol=1e-5, atol=tol * np.abs(ref_w).max())
         np.testing.assert_allclose(bt.cpu().numpy(), ref_b, rtol=1e-5, atol=tol * np.abs(ref_b).max())
+        sq += float((Wt.double() ** 2).sum() + (bt.double() ** 2).sum())
+    # fused global-norm partials: sum of squares of exactly what was stored; step counted once
+    assert abs(float(part.double().sum()) - sq) <= 1e-5 * sq
+    assert int(ist[H.IST_GLOBAL_STEP]) == 1
 
 
 @pytest.mark.parametrize("prec", [0, 1])
@@ -431,7 +440,8 @@ def test_wgrad_grouped_head_pack(H, prec):
     bout = torch.full((7,), float("nan"), device="cuda")
     pr = H.Wgrad(_p(dt), _p(ht), _p(wout), _p(bout), 8, HT, K, 8, HT, Hmax, 1, Hs, Hh, Hz)
     arr = (H.Wgrad * 1)(pr)
-    H.check(H.lib().air_wgrad_grouped(arr, 1, prec, _stream()), "air_wgrad_grouped")
+    part = torch.full((H.lib().air_wgrad_num_blocks(arr, 1),), float("nan"), device="cuda")
+    H.check(H.lib().air_wgrad_grouped(arr, 1, prec, _p(part), None, _stream()), "air_wgrad_grouped")
     torch.cuda.synchronize()
     D = _bf16_round(d7) if prec else d7.astype(np.float64)
     Hd = _bf16_round(hid) if prec else hid.astype(np.float64)
@@ -443,3 +453,6 @@ def test_wgrad_grouped_head_pack(H, prec):
         h = head[o]
         np.testing.assert_allclose(got[o, :offs[h + 1] - offs[h]], full[o, offs[h]:offs[h + 1]], rtol=1e-4, atol=2e-4)
     np.testing.assert_allclose(bout.cpu().numpy(), d7.astype(np.float64).sum(0)[:7], rtol=1e-5, atol=1e-4)
+    kept = sum(float((wout[o, :offs[head[o] + 1] - offs[head[o]]].double() ** 2).sum()) for o in range(7))
+    kept += float((bout.double() ** 2).sum())
+    assert abs(float(part.double().sum()) - kept) <= 1e-5 * kept

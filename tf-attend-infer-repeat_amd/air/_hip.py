@@ -90,7 +90,8 @@ _SIGNATURES = {
     "air_gemm": (C.c_int, [C.POINTER(Gemm), _p]),
     "air_gemm_slabs": (C.c_int, [C.c_int, C.c_int]),
     "air_colsum": (C.c_int, [C.POINTER(Colsum), C.c_int, _p]),
-    "air_wgrad_grouped": (C.c_int, [C.POINTER(Wgrad), C.c_int, C.c_int, _p]),
+    "air_wgrad_num_blocks": (C.c_int, [C.POINTER(Wgrad), C.c_int]),
+    "air_wgrad_grouped": (C.c_int, [C.POINTER(Wgrad), C.c_int, C.c_int, _p, _p, _p]),
     "air_lstm_gates_fwd": (C.c_int, [_p, _p, _p, _p, _p, C.c_int, C.c_int, _p]),
     "air_lstm_gates_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, C.c_int, C.c_int, C.c_int, _p]),
     "air_transformer_fwd": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
@@ -106,7 +107,7 @@ _SIGNATURES = {
     "air_step_begin": (C.c_int, [_p, C.c_int, _p, _p, _p, C.c_int64, _p, C.c_int64, C.c_uint64, _p]),
     "air_optim_num_partials": (C.c_int, [C.c_int64]),
     "air_grad_sqnorm": (C.c_int, [_p, C.c_int64, _p, _p, _p]),
-    "air_adam_clip_step": (C.c_int, [_p, _p, _p, _p, C.c_int64, _p, _p, _p, _f, _f, _f, _f, _p, _p, _p]),
+    "air_adam_clip_step": (C.c_int, [_p, _p, _p, _p, C.c_int64, _p, C.c_int, _p, _p, _f, _f, _f, _f, _p, _p, _p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

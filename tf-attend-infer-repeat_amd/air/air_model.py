@@ -99,7 +99,8 @@ class VariableStore:
         self.m = torch.zeros(self.n, dtype=torch.float32, device=device)
         self.v = torch.zeros(self.n, dtype=torch.float32, device=device)
         self.istate = torch.zeros(H.IST_COUNT, dtype=torch.int32, device=device)
-        self.partials = torch.zeros(H.lib().air_optim_num_partials(self.n), dtype=torch.float32, device=device)
+        # global-norm partial sums: air_grad_sqnorm's fixed count, or one per weight-gradient workgroup
+        self.partials = torch.zeros(max(H.lib().air_optim_num_partials(self.n), 16384), dtype=torch.float32, device=device)
         self.gnorm = torch.zeros(1, dtype=torch.float32, device=device)
 
         def views(buf):
@@ -543,14 +544,22 @@ class AIRModel:
         keep.append(arr)
         wbytes = sum(4 * (q.M * q.N + q.K * (q.M + q.N)) for q in probs)
         wflops = sum(2 * q.M * q.N * q.K for q in probs)
-        self._wgrad_branches = [[self._call("air_wgrad_grouped", arr, len(probs), self._prec, nbytes=wbytes, flops=wflops,
-                                            tag="wgrad_grouped")]]
+        self._wgrad_branches = [[self._call("air_wgrad_grouped", arr, len(probs), self._prec, None, None,
+                                            nbytes=wbytes, flops=wflops, tag="wgrad_grouped")]]
+        # single-GPU train step: the same launch also leaves the global-norm partial sums and counts
+        # the step, so no separate pass over the 16 MB gradient is needed before Adam
+        self._wgrad_blocks = self.lib.air_wgrad_num_blocks(arr, len(probs))
+        if self._wgrad_blocks <= 0:
+            H.check(self._wgrad_blocks, "air_wgrad_num_blocks")
+        if st.partials.numel() < self._wgrad_blocks:
+            raise NotImplementedError("weight-gradient launch of %d workgroups exceeds the partial-sum buffer" % self._wgrad_blocks)
+        self._wgrad_fused = self._call("air_wgrad_grouped", arr, len(probs), self._prec, _ptr(st.partials),
+                                       _ptr(st.istate), nbytes=wbytes, flops=wflops, tag="wgrad_grouped")
         self._side_streams = None
 
-        self._opt = [
-            self._call("air_grad_sqnorm", _ptr(st.grads), st.n, _ptr(st.partials), _ptr(st.istate),
-                       nbytes=4 * st.n, tag="grad_sqnorm"),
-        ]
+        self._sqnorm = self._call("air_grad_sqnorm", _ptr(st.grads), st.n, _ptr(st.partials), _ptr(st.istate),
+                                  nbytes=4 * st.n, tag="grad_sqnorm")
+        self._opt = None
         self._opt_world = None
 
     # ------------------------------------------------------------------ running
@@ -599,16 +608,24 @@ class AIRModel:
         world = self._world()
         if self._opt_world != world:
             st = self.store
+            fused = world == 1
+            npart = self._wgrad_blocks if fused else self.lib.air_optim_num_partials(st.n)
             adam = self._call("air_adam_clip_step", _ptr(st.params), _ptr(st.grads), _ptr(st.m), _ptr(st.v),
-                              st.n, _ptr(st.partials), _ptr(self.dyn), _ptr(st.istate), 1.0 / world,
+                              st.n, _ptr(st.partials), npart, _ptr(self.dyn), _ptr(st.istate), 1.0 / world,
                               0.9, 0.999, 1e-8, None, _ptr(st.gnorm), nbytes=28 * st.n, tag="adam_clip")
-            self._opt = [self._opt[0], adam]
+            # data parallel: the norm is that of the all-reduced gradient -> separate pass after the collective
+            self._opt = [adam] if fused else [self._sqnorm, adam]
             self._opt_world = world
         return self._opt
 
-    def _run_backward(self, s):
+    def _run_backward(self, s, for_update=False):
+        """for_update: this backward is followed by the optimizer of a single-GPU train step -- the
+        weight-gradient launch then also publishes the global-norm partials and counts the step."""
         for op in self._bwd:
             op(s)
+        if for_update and self._world() == 1:
+            self._wgrad_fused(s)
+            return
         # fork: independent weight-grad branches on side streams; join before the optimizer
         if os.environ.get("AIR_SIDE_STREAMS", "0") != "1":
             for ops in self._wgrad_branches:
@@ -631,7 +648,7 @@ class AIRModel:
     def _train_phase_a(self, s):
         """step prologue + forward + loss + backward (+ weight grads) into the flat grad buffer"""
         self._run_forward(s)
-        self._run_backward(s)
+        self._run_backward(s, for_update=True)
 
     def _train_phase_b(self, s):
         """global-norm clip + TF-style Adam + global_step += 1 (after the all-reduce)"""

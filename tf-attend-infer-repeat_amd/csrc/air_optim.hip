@@ -91,19 +91,19 @@ __global__ __launch_bounds__(THREADS) void grad_sqnorm_kernel(
 // m += (g-m)(1-b1); v += (g^2-v)(1-b2); var -= lr_t*m/(sqrt(v)+eps)
 __global__ __launch_bounds__(THREADS) void adam_clip_kernel(
     float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
-    const float* __restrict__ partials, const float* __restrict__ dyn, const int32_t* __restrict__ istate,
+    const float* __restrict__ partials, int npartials, const float* __restrict__ dyn, const int32_t* __restrict__ istate,
     float prescale, float b1, float b2, float eps, uint16_t* __restrict__ shadow, float* __restrict__ gnorm_out)
 {
     __shared__ float red[4];
     // every workgroup re-reduces the partials in the same fixed order: identical scale everywhere
     float s = 0.0f;
-    for (int i = threadIdx.x; i < NORM_BLOCKS; i += THREADS) s += partials[i];
+    for (int i = threadIdx.x; i < npartials; i += THREADS) s += partials[i];
     s = air_block_sum_256(s, red);
     const float gn = sqrtf(s) * prescale;              // norm of the (pre-scaled, e.g. averaged) gradient
     const float clip = dyn[AIR_DYN_CLIP_NORM];
     // t * clip_norm * min(1/global_norm, 1/clip_norm); clip <= 0 disables clipping
     const float scale = prescale * (clip > 0.0f ? clip * fminf(1.0f / gn, 1.0f / clip) : 1.0f);
-    const float t = (float)istate[AIR_IST_GLOBAL_STEP];     // already incremented by grad_sqnorm
+    const float t = (float)istate[AIR_IST_GLOBAL_STEP];     // already incremented (grad_sqnorm / fused wgrad)
     const float lr_t = dyn[AIR_DYN_LEARNING_RATE] * sqrtf(1.0f - powf(b2, t)) / (1.0f - powf(b1, t));
     if (gnorm_out && blockIdx.x == 0 && threadIdx.x == 0) *gnorm_out = gn;
     const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
@@ -186,16 +186,16 @@ extern "C" int air_grad_sqnorm(const float* grads, int64_t n, float* partials, i
 }
 
 extern "C" int air_adam_clip_step(float* params, const float* grads, float* m, float* v, int64_t n,
-                                  const float* partials, const float* dyn, const int32_t* istate,
+                                  const float* partials, int npartials, const float* dyn, const int32_t* istate,
                                   float grad_prescale, float beta1, float beta2, float epsilon,
                                   uint16_t* bf16_shadow, float* gnorm_out, void* stream) {
-    if (!params || !grads || !m || !v || !partials || !dyn || !istate || n <= 0) return AIR_EINVAL;
+    if (!params || !grads || !m || !v || !partials || npartials <= 0 || !dyn || !istate || n <= 0) return AIR_EINVAL;
     if ((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)m | (uintptr_t)v) & 15) != 0) return AIR_EALIGN;
     long blocks = (n / 4 + THREADS - 1) / THREADS;
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(adam_clip_kernel, dim3((int)blocks), dim3(THREADS), 0, air_stream(stream),
-                       params, grads, m, v, (long)n, partials, dyn, istate, grad_prescale, beta1, beta2,
+                       params, grads, m, v, (long)n, partials, npartials, dyn, istate, grad_prescale, beta1, beta2,
                        epsilon, bf16_shadow, gnorm_out);
     AIR_CHECK_LAUNCH();
     return 0;

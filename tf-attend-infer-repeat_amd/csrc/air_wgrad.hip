@@ -45,7 +45,20 @@ __device__ __forceinline__ float4 load4(const float* base, int ld, int row, int 
     return v;
 }
 
-__global__ __launch_bounds__(THREADS) void wgrad_grouped_kernel(Table tab)
+
+// sum of squares of everything this workgroup stored (tf.global_norm terms): one partial per
+// workgroup, reduced again in fixed order by the Adam kernel; workgroup 0 also counts the step
+// (apply_gradients(global_step=...), air_model.py:692-694)
+__device__ __forceinline__ void publish_sq(float sq, float* sq_partials, int32_t* istate) {
+    __shared__ float sq_red[4];
+    sq = air_block_sum_256(sq, sq_red);
+    if (threadIdx.x == 0) {
+        sq_partials[blockIdx.x] = sq;
+        if (blockIdx.x == 0 && istate) istate[AIR_IST_GLOBAL_STEP] += 1;
+    }
+}
+
+__global__ __launch_bounds__(THREADS) void wgrad_grouped_kernel(Table tab, float* __restrict__ sq_partials, int32_t* __restrict__ istate)
 {
     __shared__ __attribute__((aligned(16))) float As[2][KC * LS];
     __shared__ __attribute__((aligned(16))) float Bs[2][KC * LS];
@@ -150,6 +163,7 @@ __global__ __launch_bounds__(THREADS) void wgrad_grouped_kernel(Table tab)
             for (int q = 0; q < 4; ++q)
                 Ct[(wm + i * 16 + (lane >> 4) * 4 + q) * LS + wn + j * 16 + (lane & 15)] = acc[i][j][q];
     __syncthreads();
+    float sq = 0.0f;
     if (!head_pack) {
         const bool vecC = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(dW) & 15) == 0);
 #pragma unroll
@@ -159,15 +173,15 @@ __global__ __launch_bounds__(THREADS) void wgrad_grouped_kernel(Table tab)
             if (m >= M) continue;
             const float4 v = *reinterpret_cast<const float4*>(&Ct[row * LS + col]);
             float* dst = dW + (size_t)m * ldc + n;
-            if (vecC && n + 3 < N) *reinterpret_cast<float4*>(dst) = v;
+            if (vecC && n + 3 < N) { *reinterpret_cast<float4*>(dst) = v; sq += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w); }
             else {
-                if (n < N) dst[0] = v.x;
-                if (n + 1 < N) dst[1] = v.y;
-                if (n + 2 < N) dst[2] = v.z;
-                if (n + 3 < N) dst[3] = v.w;
+                if (n < N) { dst[0] = v.x; sq += v.x * v.x; }
+                if (n + 1 < N) { dst[1] = v.y; sq += v.y * v.y; }
+                if (n + 2 < N) { dst[2] = v.z; sq += v.z * v.z; }
+                if (n + 3 < N) { dst[3] = v.w; sq += v.w * v.w; }
             }
         }
-        if (do_bias && n0 + lane < N) db[n0 + lane] = colsum;
+        if (do_bias && n0 + lane < N) { db[n0 + lane] = colsum; sq += colsum * colsum; }
     } else {
         // head output units (air_model.py:294-316, 376): A = d_out7 [K,8], dY = hid [K,HT];
         // unit o only owns the hidden segment of its head: dW = wout[o][n - off], db = bout[o] = sum_k d_out7[k][o]
@@ -177,10 +191,15 @@ __global__ __launch_bounds__(THREADS) void wgrad_grouped_kernel(Table tab)
             const int o = it / BT, col = it % BT, n = n0 + col;
             int off = 0;
             for (int h = 0; h < head[o]; ++h) off += wid[h];
-            if (m0 == 0 && n < N && n >= off && n < off + wid[head[o]]) dW[(size_t)o * ldc + (n - off)] = Ct[o * LS + col];
+            if (m0 == 0 && n < N && n >= off && n < off + wid[head[o]]) {
+                const float v = Ct[o * LS + col];
+                dW[(size_t)o * ldc + (n - off)] = v;
+                sq += v * v;
+            }
         }
-        if (do_bias && lane < 7) db[lane] = colsum;
+        if (do_bias && lane < 7) { db[lane] = colsum; sq += colsum * colsum; }
     }
+    if (sq_partials) publish_sq(sq, sq_partials, istate);
 }
 
 
@@ -208,7 +227,7 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void wgrad_grouped_bf16_kernel(Table tab)
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void wgrad_grouped_bf16_kernel(Table tab, float* __restrict__ sq_partials, int32_t* __restrict__ istate)
 {
     // [operand][image][column 0..63][k 0..63] bf16 = 2 x 3 x 8 KB; reused as the fp32 output tile
     __shared__ __attribute__((aligned(16))) unsigned short Img[2 * NIMG * BT * KB];
@@ -317,6 +336,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
             }
     }
 
+    float sq = 0.0f;
     // bias: reduce the 8 k-runs (lanes g = 0..7 are contiguous) of each column quad
     if (bias_block) {
 #pragma unroll
@@ -329,8 +349,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int col = 4 * q + j;
-                if (!head_pack) { if (n0 + col < N) db[n0 + col] = csum[j]; }
-                else if (col < 7) db[col] = csum[j];
+                if (!head_pack) { if (n0 + col < N) { db[n0 + col] = csum[j]; sq += csum[j] * csum[j]; } }
+                else if (col < 7) { db[col] = csum[j]; sq += csum[j] * csum[j]; }
             }
         }
     }
@@ -355,12 +375,12 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
             if (m >= M) continue;
             const float4 t = *reinterpret_cast<const float4*>(&Ct[row * LS + col]);
             float* dst = dW + (size_t)m * ldc + n;
-            if (vecC && n + 3 < N) *reinterpret_cast<float4*>(dst) = t;
+            if (vecC && n + 3 < N) { *reinterpret_cast<float4*>(dst) = t; sq += (t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w); }
             else {
-                if (n < N) dst[0] = t.x;
-                if (n + 1 < N) dst[1] = t.y;
-                if (n + 2 < N) dst[2] = t.z;
-                if (n + 3 < N) dst[3] = t.w;
+                if (n < N) { dst[0] = t.x; sq += t.x * t.x; }
+                if (n + 1 < N) { dst[1] = t.y; sq += t.y * t.y; }
+                if (n + 2 < N) { dst[2] = t.z; sq += t.z * t.z; }
+                if (n + 3 < N) { dst[3] = t.w; sq += t.w * t.w; }
             }
         }
     } else {
@@ -370,17 +390,21 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
             const int o = it / BT, col = it % BT, n = n0 + col;
             int off = 0;
             for (int h = 0; h < head[o]; ++h) off += wid[h];
-            if (m0 == 0 && n < N && n >= off && n < off + wid[head[o]]) dW[(size_t)o * ldc + (n - off)] = Ct[o * LS + col];
+            if (m0 == 0 && n < N && n >= off && n < off + wid[head[o]]) {
+                const float t = Ct[o * LS + col];
+                dW[(size_t)o * ldc + (n - off)] = t;
+                sq += t * t;
+            }
         }
     }
+    if (sq_partials) publish_sq(sq, sq_partials, istate);
 }
 
 }  // namespace
 
-extern "C" int air_wgrad_grouped(const air_wgrad_t* probs, int count, int precision, void* stream) {
+static int fill_table(const air_wgrad_t* probs, int count, Table& tab) {
     if (!probs || count <= 0) return AIR_EINVAL;
     if (count > MAXP) return AIR_ELIMIT;
-    Table tab;
     tab.count = count;
     int blocks = 0;
     for (int i = 0; i < count; ++i) {
@@ -396,9 +420,23 @@ extern "C" int air_wgrad_grouped(const air_wgrad_t* probs, int count, int precis
     }
     for (int i = count; i < MAXP; ++i) tab.p[i] = tab.p[0];
     tab.total_blocks = blocks;
+    return 0;
+}
+
+extern "C" int air_wgrad_num_blocks(const air_wgrad_t* probs, int count) {
+    Table tab;
+    const int rc = fill_table(probs, count, tab);
+    return rc ? rc : tab.total_blocks;
+}
+
+extern "C" int air_wgrad_grouped(const air_wgrad_t* probs, int count, int precision,
+                                 float* sq_partials, int32_t* istate, void* stream) {
+    Table tab;
+    const int rc = fill_table(probs, count, tab);
+    if (rc) return rc;
     if (precision != 0 && precision != 1) return AIR_EINVAL;
-    if (precision == 1) hipLaunchKernelGGL(wgrad_grouped_bf16_kernel, dim3(blocks), dim3(THREADS), 0, air_stream(stream), tab);
-    else hipLaunchKernelGGL(wgrad_grouped_kernel, dim3(blocks), dim3(THREADS), 0, air_stream(stream), tab);
+    if (precision == 1) hipLaunchKernelGGL(wgrad_grouped_bf16_kernel, dim3(tab.total_blocks), dim3(THREADS), 0, air_stream(stream), tab, sq_partials, istate);
+    else hipLaunchKernelGGL(wgrad_grouped_kernel, dim3(tab.total_blocks), dim3(THREADS), 0, air_stream(stream), tab, sq_partials, istate);
     AIR_CHECK_LAUNCH();
     return 0;
 }

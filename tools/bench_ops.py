@@ -24,7 +24,7 @@ def timeop(fn, n=200):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 
-ops = [m._begin] + m._fwd + m._bwd + sum(m._wgrad_branches, []) + m._optimizer_ops()
+ops = [m._begin] + m._fwd + m._bwd + [m._wgrad_fused] + m._optimizer_ops()
 tot = 0
 for op in ops:
     t = timeop(op); tot += t
@@ -36,5 +36,5 @@ n = len(arr)
 for name, idx in (("dWx only", [0]), ("all but dWx", list(range(1, n))), ("heads only", [n - 1]),
                   ("rec0+out", [3, n - 2])):
     sub = (H.Wgrad * len(idx))(*[arr[i] for i in idx])
-    fn = lambda st, sub=sub, k=len(idx): H.check(m.lib.air_wgrad_grouped(sub, k, m._prec, st))
+    fn = lambda st, sub=sub, k=len(idx): H.check(m.lib.air_wgrad_grouped(sub, k, m._prec, None, None, st))
     print("wgrad subset %-14s %7.2f us" % (name, timeop(fn)))
