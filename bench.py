@@ -62,7 +62,7 @@ def synthetic_canvases(batch, canvas, max_digits, seed):
 def per_kernel_times(model, iters):
     """HIP-event pair around every kernel launch of the train step, on the stream the
     kernels are launched on (eager pass, same buffers as the timed region)."""
-    ops = [("step_begin", model._begin)] + [(o.name, o) for o in model._fwd + model._bwd + [model._wgrad_fused] + model._optimizer_ops()]
+    ops = [(o.name, o) for o in model.train_step_ops()]
     acc = [0.0] * len(ops)
     s = model._stream()
     for _ in range(iters):

@@ -115,7 +115,11 @@ enum {
     AIR_EPI_LSTM_BWD = 3,
     /* re-parameterisation backward + VAE-KL gradient (air_model.py:481-493): acc = d loss/d z;
      * p0 = ml [M,2Z], p1 = eps [M,Z], p2 = att, p3 = dyn; C = d_ml [M,2Z]. */
-    AIR_EPI_REPARAM_BWD = 4
+    AIR_EPI_REPARAM_BWD = 4,
+    /* rows [0, i0): plain store of acc into C; rows [i0, M): AIR_EPI_LSTM_BWD of the LAST time step
+     * (no d c' from a later step, q2 is stored not accumulated), with p0..p2 / q0..q2 indexed by
+     * (row - i0).  Lets the GEMM that produces d h' of all steps also start the BPTT chain. */
+    AIR_EPI_LSTM_BWD_TAIL = 5
 };
 typedef struct {
     const float* A; const float* B; float* C;
@@ -260,6 +264,10 @@ typedef struct {
     float* d_sxy_write;                  /* [N,B,4]: ds,dx,dy (via theta_recon), dz */
     int32_t B, N, C, w;
     int32_t literal;                     /* see air_attend_bwd_t            */
+    /* optional: workgroup (0,0) also does air_finalize's batch means (train step: saves a launch).
+     * fin_scalars == NULL disables; loss_item is the [B] output of air_write_fwd */
+    const float* fin_loss_item; const int32_t* fin_targets; const int32_t* fin_digits;
+    float* fin_scalars;
 } air_write_bwd_t;
 int air_write_bwd(const air_write_bwd_t* a, void* stream);
 

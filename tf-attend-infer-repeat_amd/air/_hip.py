@@ -24,7 +24,7 @@ ATT_KL_Z, ATT_KL_SCALE, ATT_KL_SHIFT, ATT_KL_VAE, ATT_MASK_PREV, ATT_MASK, ATT_S
 ATT_STRIDE, OUT_STRIDE = 16, 8
 ACT_NONE, ACT_RELU, ACT_SOFTPLUS, ACT_SIGMOID_NOISE = 0, 1, 2, 3
 GRAD_NONE, GRAD_RELU, GRAD_SOFTPLUS = 0, 1, 2
-EPI_GENERIC, EPI_LSTM_FWD, EPI_REPARAM_FWD, EPI_LSTM_BWD, EPI_REPARAM_BWD = 0, 1, 2, 3, 4
+EPI_GENERIC, EPI_LSTM_FWD, EPI_REPARAM_FWD, EPI_LSTM_BWD, EPI_REPARAM_BWD, EPI_LSTM_BWD_TAIL = 0, 1, 2, 3, 4, 5
 SCHED_STAIRCASE, SCHED_HAS_MIN, SCHED_HAS_MAX, SCHED_LOG = 1, 2, 4, 8
 
 _p = C.c_void_p
@@ -81,7 +81,8 @@ class WriteFwd(C.Structure):
 
 class WriteBwd(C.Structure):
     _fields_ = [("d_recon", _p), ("vrec", _p), ("att", _p), ("d_gen_pre", _p), ("d_sxy_write", _p),
-                ("B", _i), ("N", _i), ("C", _i), ("w", _i), ("literal", _i)]
+                ("B", _i), ("N", _i), ("C", _i), ("w", _i), ("literal", _i),
+                ("fin_loss_item", _p), ("fin_targets", _p), ("fin_digits", _p), ("fin_scalars", _p)]
 
 
 _SIGNATURES = {

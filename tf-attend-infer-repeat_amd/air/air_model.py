@@ -454,9 +454,10 @@ class AIRModel:
         keep.append(wf)
         fwd.append(self._call("air_write_fwd", C.byref(wf),
                               nbytes=NB * (d + 2 * Z) * 4 + B * D * 4 * (3 if self.train else 2), tag="compose_fwd"))
-        fwd.append(self._call("air_finalize", _ptr(self.run_loss), _ptr(self._rec_loss),
-                              _ptr(self.target_num_digits), _ptr(self.run_digits), _ptr(self._loss_item),
-                              _ptr(self.scalars), B))
+        # batch means: their own launch after a plain forward; inside air_write_bwd in a train step
+        self._finalize = self._call("air_finalize", _ptr(self.run_loss), _ptr(self._rec_loss),
+                                    _ptr(self.target_num_digits), _ptr(self.run_digits), _ptr(self._loss_item),
+                                    _ptr(self.scalars), B)
         self._fwd = fwd
         self._begin = self._call(
             "air_step_begin", _ptr(self.sched), self._nsched, _ptr(self.dyn), _ptr(st.istate),
@@ -470,10 +471,15 @@ class AIRModel:
             return
 
         bwd = []
+        lit = 1 if self.backward == "reference" else 0
         wb = H.WriteBwd(_ptr(self.d_recon), _ptr(self.vrec), _ptr(self.att), _ptr(self.d_genpre),
-                        _ptr(self.d_sxyw), B, N, Cc, w, 1 if self.backward == "reference" else 0)
-        keep.append(wb)
+                        _ptr(self.d_sxyw), B, N, Cc, w, lit, None, None, None, None)
+        wbf = H.WriteBwd(_ptr(self.d_recon), _ptr(self.vrec), _ptr(self.att), _ptr(self.d_genpre),
+                         _ptr(self.d_sxyw), B, N, Cc, w, lit, _ptr(self._loss_item), _ptr(self.target_num_digits),
+                         _ptr(self.run_digits), _ptr(self.scalars))
+        keep += [wb, wbf]
         bwd.append(self._call("air_write_bwd", C.byref(wb), nbytes=NB * ((D + 2 * d) * 4 + 32), tag="write_bwd"))
+        self._write_bwd_fin = self._call("air_write_bwd", C.byref(wbf), nbytes=NB * ((D + 2 * d) * 4 + 32), tag="write_bwd")
         # decoder data-grads over all N*B rows: dX = dY . W^T, times softplus'(saved activation)
         dy, n_out, wname = self.d_genpre, d, "out_w"
         for i in reversed(range(len(gen_u))):
@@ -498,15 +504,19 @@ class AIRModel:
         keep.append(ab)
         bwd.append(self._call("air_attend_bwd", C.byref(ab), nbytes=NB * ((D + d + 2 * HT) * 4 + 64), tag="attend_bwd"))
         # heads' contribution to d loss / d h'[t] for every step
-        bwd.append(self._gemm(self.d_hid, P["whid"], self.dh_heads, NB, R, HT, HT, HT, R, tb=1, tag="dh_heads"))
+        # ... whose last-step rows go straight through the LSTM cell backward (start of the BPTT chain)
+        tl = N - 1
+        bwd.append(self._gemm(self.d_hid, P["whid"], self.dh_heads, NB, R, HT, HT, HT, R, tb=1,
+                              epi=H.EPI_LSTM_BWD_TAIL, i0=tl * B,
+                              p=(self.acts[tl], self.c[tl], self.c[tl + 1]),
+                              q=(self.dgates[tl], self.dc[tl % 2], self.dgsum),
+                              extra_bytes=4 * B * R * 15, tag="dh_heads"))
         # back-propagation through time: the only sequential part of the backward
         for t in reversed(range(N)):
             last = (t == N - 1)
             dc_cur, dc_nxt = self.dc[t % 2], self.dc[(t + 1) % 2]
             if last:
-                bwd.append(self._call("air_lstm_gates_bwd", _ptr(self.dh_heads[t]), _ptr(None), _ptr(self.acts[t]),
-                                      _ptr(self.c[t]), _ptr(self.c[t + 1]), _ptr(self.dgates[t]), _ptr(dc_cur),
-                                      _ptr(self.dgsum), 0, B, R, nbytes=4 * B * R * 15, tag="lstm_bwd_last"))
+                continue
             else:
                 # d h'[t] = heads[t] + dgates[t+1] . Wh^T, LSTM pointwise backward fused in the epilogue
                 bwd.append(self._gemm(self.dgates[t + 1], Wh, self.dh_cur, B, R, 4 * R, 4 * R, 4 * R, R, tb=1,
@@ -587,10 +597,12 @@ class AIRModel:
             self.dyn[_ANNEALABLE[k]] = float(v)
         self._dirty = True
 
-    def _run_forward(self, s):
+    def _run_forward(self, s, finalize=True):
         (self._begin_sched_only if self._injected_noise else self._begin)(s)
         for op in self._fwd:
             op(s)
+        if finalize:
+            self._finalize(s)
 
     def forward(self):
         """Evaluates the model on the current contents of the input buffers."""
@@ -618,11 +630,11 @@ class AIRModel:
             self._opt_world = world
         return self._opt
 
-    def _run_backward(self, s, for_update=False):
+    def _run_backward(self, s, for_update=False, fused_finalize=False):
         """for_update: this backward is followed by the optimizer of a single-GPU train step -- the
         weight-gradient launch then also publishes the global-norm partials and counts the step."""
-        for op in self._bwd:
-            op(s)
+        for i, op in enumerate(self._bwd):
+            (self._write_bwd_fin if (i == 0 and fused_finalize) else op)(s)
         if for_update and self._world() == 1:
             self._wgrad_fused(s)
             return
@@ -645,10 +657,15 @@ class AIRModel:
         for st_ in self._side_streams:
             main.wait_stream(st_)
 
+    def train_step_ops(self):
+        """The launches of one single-GPU train step, in order (bench / profiling tools)."""
+        return ([self._begin] + self._fwd + [self._write_bwd_fin] + self._bwd[1:] + [self._wgrad_fused]
+                + self._optimizer_ops())
+
     def _train_phase_a(self, s):
         """step prologue + forward + loss + backward (+ weight grads) into the flat grad buffer"""
-        self._run_forward(s)
-        self._run_backward(s, for_update=True)
+        self._run_forward(s, finalize=False)
+        self._run_backward(s, for_update=True, fused_finalize=True)
 
     def _train_phase_b(self, s):
         """global-norm clip + TF-style Adam + global_step += 1 (after the all-reduce)"""

@@ -99,15 +99,17 @@ __device__ __forceinline__ void epilogue_prefetch(const Args& a, Pre<TM, TN>& pr
             pre.f[32 + j] = (ok && a.bias) ? a.bias[n] : 0.0f;
         }
         pre.f[36] = ok ? a.p0[(size_t)m * R + u] : 0.0f;
-    } else if (a.epi == AIR_EPI_LSTM_BWD) {
+    } else if (a.epi == AIR_EPI_LSTM_BWD || a.epi == AIR_EPI_LSTM_BWD_TAIL) {
         const int R = a.gwidth;
-        const size_t idx = (size_t)m * R + u;
+        const int mm = m - (a.epi == AIR_EPI_LSTM_BWD_TAIL ? a.i0 : 0);      // row within the step's arrays
+        const bool okk = ok && mm >= 0;
+        const size_t idx = (size_t)mm * R + u;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) pre.f[j] = ok ? a.p0[(size_t)m * 4 * R + j * R + u] : 0.0f;
-        pre.f[4] = ok ? a.p1[idx] : 0.0f;
-        pre.f[5] = ok ? a.p2[idx] : 0.0f;
-        pre.f[6] = (ok && a.p3) ? a.p3[idx] : 0.0f;
-        pre.f[7] = (ok && a.addend) ? a.addend[(size_t)m * a.ldadd + u] : 0.0f;
+        for (int j = 0; j < 4; ++j) pre.f[j] = okk ? a.p0[(size_t)mm * 4 * R + j * R + u] : 0.0f;
+        pre.f[4] = okk ? a.p1[idx] : 0.0f;
+        pre.f[5] = okk ? a.p2[idx] : 0.0f;
+        pre.f[6] = (okk && a.p3) ? a.p3[idx] : 0.0f;
+        pre.f[7] = (okk && a.addend) ? a.addend[(size_t)m * a.ldadd + u] : 0.0f;
     }
 }
 
@@ -182,26 +184,30 @@ __device__ __forceinline__ void epilogue(const Args& a, const Pre<TM, TN>& pre, 
                 a.C[(size_t)m * a.ldc + Z + u] = lv;
                 a.q0[(size_t)m * Z + u] = mean + a.p0[(size_t)m * Z + u] * sqrtf(expf(lv));
             }
-        } else if (a.epi == AIR_EPI_LSTM_BWD) {
+        } else if (a.epi == AIR_EPI_LSTM_BWD || a.epi == AIR_EPI_LSTM_BWD_TAIL) {
             // v[0] (+ addend) = d loss / d h'.  p0 = acts, p1 = c_prev, p2 = c, p3 = dc_in (nullable)
             // q0 = dgates [M,4R], q1 = dc_prev [M,R], q2 = dgsum [M,4R] (nullable; i0 = accumulate)
             if (TM == 1) {
                 const int R = a.gwidth;
+                const bool tail = a.epi == AIR_EPI_LSTM_BWD_TAIL;
+                if (tail && m < a.i0) { a.C[(size_t)m * a.ldc + u] = v[0] + pre.f[7]; continue; }
+                const int mrow = tail ? m - a.i0 : m;
+                const bool accumulate = tail ? false : (a.i0 != 0);
                 const float dhv = v[0] + pre.f[7];
                 const float si = pre.f[0], tj = pre.f[1], sf = pre.f[2], so = pre.f[3];
-                const size_t idx = (size_t)m * R + u;
+                const size_t idx = (size_t)mrow * R + u;
                 const float tc = tanhf(pre.f[5]);
                 const float dc = pre.f[6] + dhv * so * (1.0f - tc * tc);
                 const float dgi = dc * tj * si * (1.0f - si);
                 const float dgj = dc * si * (1.0f - tj * tj);
                 const float dgf = dc * pre.f[4] * sf * (1.0f - sf);
                 const float dgo = dhv * tc * so * (1.0f - so);
-                float* dg = a.q0 + (size_t)m * 4 * R;
+                float* dg = a.q0 + (size_t)mrow * 4 * R;
                 dg[u] = dgi; dg[R + u] = dgj; dg[2 * R + u] = dgf; dg[3 * R + u] = dgo;
                 a.q1[idx] = dc * sf;
                 if (a.q2) {
-                    float* ds = a.q2 + (size_t)m * 4 * R;
-                    if (a.i0) { ds[u] += dgi; ds[R + u] += dgj; ds[2 * R + u] += dgf; ds[3 * R + u] += dgo; }
+                    float* ds = a.q2 + (size_t)mrow * 4 * R;
+                    if (accumulate) { ds[u] += dgi; ds[R + u] += dgj; ds[2 * R + u] += dgf; ds[3 * R + u] += dgo; }
                     else { ds[u] = dgi; ds[R + u] = dgj; ds[2 * R + u] = dgf; ds[3 * R + u] = dgo; }
                 }
             }
@@ -825,7 +831,7 @@ extern "C" int air_gemm(const air_gemm_t* g, void* stream) {
     if (g->precision != 0 && g->precision != 1) return AIR_EINVAL;
     if ((g->act == AIR_ACT_SIGMOID_NOISE || g->actgrad != AIR_GRAD_NONE) && !g->aux) return AIR_EINVAL;
     if (g->transA && g->transB) return AIR_EINVAL;     // never needed on this path
-    if (g->epi < AIR_EPI_GENERIC || g->epi > AIR_EPI_REPARAM_BWD) return AIR_EINVAL;
+    if (g->epi < AIR_EPI_GENERIC || g->epi > AIR_EPI_LSTM_BWD_TAIL) return AIR_EINVAL;
     if (g->ksplit > 1 && g->epi != AIR_EPI_GENERIC) return AIR_EINVAL;
     if (g->addend_slabs > 8) return AIR_ELIMIT;
     Args a;
@@ -851,6 +857,9 @@ extern "C" int air_gemm(const air_gemm_t* g, void* stream) {
             a.gstride = g->N / 2; a.gwidth = g->N / 2; break;
         case AIR_EPI_LSTM_BWD:      // N = R
             if (!g->p0 || !g->p1 || !g->p2 || !g->q0 || !g->q1) return AIR_EINVAL;
+            a.gwidth = g->N; break;
+        case AIR_EPI_LSTM_BWD_TAIL: // N = R, rows >= i0 are the last step
+            if (!g->p0 || !g->p1 || !g->p2 || !g->q0 || !g->q1 || g->p3 || g->i0 < 0 || g->i0 > g->M) return AIR_EINVAL;
             a.gwidth = g->N; break;
         case AIR_EPI_REPARAM_BWD:   // N = Z
             if (!g->p0 || !g->p1 || !g->p2 || !g->p3) return AIR_EINVAL;

@@ -577,6 +577,17 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_kernel(air_write_bwd_t a
     float* sh_T = sh_win + w * w;                          // [2][C*w]
     float* sh_g = sh_T + 2 * C * (w + 2);                  // [C*C] d loss / d canvas of this image
 
+    if (a.fin_scalars && b == 0 && t == 0) {
+        // loss = mean(loss_item) :593,610; accuracy = mean(target == digits) :597-611 (air_finalize)
+        float r4[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int i = tid; i < a.B; i += WB_THREADS) {
+            r4[0] += a.fin_loss_item[i];
+            r4[1] += (a.fin_targets[i] == a.fin_digits[i]) ? 1.0f : 0.0f;
+        }
+        air_block_sum4<WB_THREADS / 64>(r4, sh_red);
+        if (tid == 0) { a.fin_scalars[0] = r4[0] / (float)a.B; a.fin_scalars[1] = r4[1] / (float)a.B; }
+        __syncthreads();                                   // sh_red is reused below
+    }
     const float* at = a.att + row * AIR_ATT_STRIDE;
     float* dgen = a.d_gen_pre + row * w * w;
     float* dsx = a.d_sxy_write + row * 4;

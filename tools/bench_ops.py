@@ -24,7 +24,7 @@ def timeop(fn, n=200):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 
-ops = [m._begin] + m._fwd + m._bwd + [m._wgrad_fused] + m._optimizer_ops()
+ops = m.train_step_ops()
 tot = 0
 for op in ops:
     t = timeop(op); tot += t
