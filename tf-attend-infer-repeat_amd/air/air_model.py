@@ -533,7 +533,6 @@ class AIRModel:
 
         def wg(A, dY, dW, db, M, Nn, K):
             probs.append(H.Wgrad(_ptr(A), _ptr(dY), _ptr(dW), _ptr(db), M, Nn, K, M, Nn, Nn, 0, 0, 0, 0))
-        wg(imgs, self.dgsum, Gx, G["lstm_bias"], D, 4 * R, B)
         wg(self.h[0], self.dgates, Gh, None, R, 4 * R, NB)
         wg(self.h[1], self.d_hid, G["whid"], G["bhid"], R, HT, NB)
         x, k = self.window, d
@@ -548,6 +547,9 @@ class AIRModel:
         wg(x, self.d_genpre, G["out_w"], G["out_b"], k, d, NB)
         probs.append(H.Wgrad(_ptr(self.d_out7), _ptr(self.hid), _ptr(G["wout"]), _ptr(G["bout"]),
                              H.OUT_STRIDE, HT, NB, H.OUT_STRIDE, HT, Hmax, 1, Hs, Hh, Hz))
+        # the input-weight gradient contracts over B rows only (sum_t dgates): its many light
+        # workgroups go LAST so that they fill the tail of the launch behind the K = N*B ones
+        wg(imgs, self.dgsum, Gx, G["lstm_bias"], D, 4 * R, B)
         if len(probs) > 12:
             raise NotImplementedError("more than 12 weight matrices (deeper VAE) need a second grouped launch")
         arr = (H.Wgrad * len(probs))(*probs)

@@ -598,6 +598,18 @@ __device__ __forceinline__ float4 ldg16(const char* base, unsigned off, bool ok)
     return ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+__device__ __forceinline__ float2 ldg8(const char* base, unsigned off, bool ok) {
+    const float2 t = *reinterpret_cast<const float2*>(base + (ok ? off : 0u));
+    return ok ? t : make_float2(0.f, 0.f);
+}
+// 16 bytes as one load, or as two 8-byte loads when the operand is only 8-byte aligned
+// (row strides / column-group strides that are even but not multiples of 4: Z = 50)
+__device__ __forceinline__ float4 ldg16x(const char* base, unsigned off, bool ok_lo, bool ok_hi, bool half) {
+    if (!half) return ldg16(base, off, ok_lo);
+    const float2 lo = ldg8(base, off, ok_lo), hi = ldg8(base, off + 8u, ok_hi);
+    return make_float4(lo.x, lo.y, hi.x, hi.y);
+}
+
 template <int TM, int TN>
 struct V2Cfg {
     static constexpr int BM = 16 * TM, BN = 16 * TN, KB = 64;
@@ -636,6 +648,9 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16v2_kernel(Args a)
 
     const char* Ab = reinterpret_cast<const char*>(a.A);
     const char* Bb = reinterpret_cast<const char*>(a.B);
+    const bool a8 = !(((a.lda & 3) == 0) && aligned16(a.A) && ((a.K & 3) == 0));
+    const bool b8 = !(((a.ldb & 3) == 0) && aligned16(a.B) &&
+                      (TB ? ((a.K & 3) == 0) : (((a.N & 3) == 0) && ((a.gstride & 3) == 0) && ((a.gwidth & 3) == 0))));
     // tasks of one round.  k-contiguous operand (A, and B when TB): task = (image, row, k-run g) = 2 float4;
     // NN B: task = (image, column quad, k-run g) = the same 4 columns of 8 consecutive rows = 8 float4.
     constexpr int TA_N = (R * BM * 8 + THREADS - 1) / THREADS;           // A tasks per thread
@@ -655,8 +670,8 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16v2_kernel(Args a)
             const int gm = m0 + row, gk = kr + c * KB + g * 8;
             const bool okr = (t < R * BM * 8) && gm < a.M;
             const unsigned off = ((unsigned)gm * (unsigned)a.lda + (unsigned)gk) * 4u;
-            va[i][0] = ldg16(Ab, off, okr && gk < kend);
-            va[i][1] = ldg16(Ab, off + 16u, okr && gk + 4 < kend);
+            va[i][0] = ldg16x(Ab, off, okr && gk < kend, okr && gk + 2 < kend, a8);
+            va[i][1] = ldg16x(Ab, off + 16u, okr && gk + 4 < kend, okr && gk + 6 < kend, a8);
         }
         if (TB) {
 #pragma unroll
@@ -668,8 +683,8 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16v2_kernel(Args a)
                 const int gk = kr + c * KB + g * 8;
                 const bool okr = (t < R * BN * 8) && cg < a.gwidth && gn < a.N;
                 const unsigned off = ((unsigned)gn * (unsigned)a.ldb + (unsigned)gk) * 4u;
-                vbk[i][0] = ldg16(Bb, off, okr && gk < kend);
-                vbk[i][1] = ldg16(Bb, off + 16u, okr && gk + 4 < kend);
+                vbk[i][0] = ldg16x(Bb, off, okr && gk < kend, okr && gk + 2 < kend, b8);
+                vbk[i][1] = ldg16x(Bb, off + 16u, okr && gk + 4 < kend, okr && gk + 6 < kend, b8);
             }
         } else {
 #pragma unroll
@@ -680,10 +695,12 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16v2_kernel(Args a)
                 const int gn = n0 + j * a.gstride + cc, cg = n0 + cc + (a.gstride == 16 ? j * 16 : 0);
                 const int gk = kr + c * KB + g * 8;
                 const bool okc = (t < R * BN * 2) && cg < a.gwidth && gn < a.N;
+                const bool okh = okc && cg + 2 < a.gwidth && gn + 2 < a.N;     // upper half of the column quad
                 const unsigned off = ((unsigned)gk * (unsigned)a.ldb + (unsigned)gn) * 4u;
 #pragma unroll
                 for (int r = 0; r < 8; ++r)
-                    vbn[i][r] = ldg16(Bb, off + (unsigned)r * ((unsigned)a.ldb * 4u), okc && gk + r < kend);
+                    vbn[i][r] = ldg16x(Bb, off + (unsigned)r * ((unsigned)a.ldb * 4u), okc && gk + r < kend,
+                                       okh && gk + r < kend, b8);
             }
         }
         // ---- round to bf16 and store the images
@@ -785,8 +802,11 @@ int launch(const air_gemm_t* g, const Args& a0, hipStream_t s) {
     a.slab_stride = (long)a.M * a.ldc;
     if (g->precision == 1) {
         // lean variant needs 16-byte loads along the contiguous axis of both operands
-        const bool v2 = !TA && aligned16(a.A) && aligned16(a.B) && (a.lda & 3) == 0 && (a.ldb & 3) == 0 &&
-                        (a.K & 3) == 0 && (TB || ((a.N & 3) == 0 && (a.gstride & 3) == 0)) &&
+        // (8-byte alignment and even K / N / group strides suffice: the kernel splits its 16-byte loads)
+        auto al8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; };
+        const bool v2 = !TA && al8(a.A) && al8(a.B) && (a.lda & 1) == 0 && (a.ldb & 1) == 0 &&
+                        (a.K & 1) == 0 &&
+                        (TB || ((a.N & 1) == 0 && (a.gstride & 1) == 0 && (a.gwidth & 1) == 0)) &&
                         getenv("AIR_GEMM_BF16_V1") == nullptr;
         if (v2) hipLaunchKernelGGL((gemm_bf16v2_kernel<TM, TN, TB>), grid, dim3(THREADS), 0, s, a);
         else hipLaunchKernelGGL((gemm_bf16_kernel<TM, TN, TA, TB>), grid, dim3(THREADS), 0, s, a);

@@ -33,8 +33,8 @@ print("sum %.1f us over %d ops" % (tot, len(ops)))
 # grouped wgrad subsets
 arr = m._keep[-1]
 n = len(arr)
-for name, idx in (("dWx only", [0]), ("all but dWx", list(range(1, n))), ("heads only", [n - 1]),
-                  ("rec0+out", [3, n - 2])):
+for name, idx in (("dWx only", [n - 1]), ("all but dWx", list(range(0, n - 1))), ("heads only", [n - 2]),
+                  ("rec0+out", [2, n - 3])):
     sub = (H.Wgrad * len(idx))(*[arr[i] for i in idx])
     fn = lambda st, sub=sub, k=len(idx): H.check(m.lib.air_wgrad_grouped(sub, k, m._prec, None, None, st))
     print("wgrad subset %-14s %7.2f us" % (name, timeop(fn)))
