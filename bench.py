@@ -115,6 +115,7 @@ def main():
     ap.add_argument("--precision", default=os.environ.get("AIR_GEMM_PRECISION", "bf16"), choices=["bf16", "fp32"])
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE: 64)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--graph-steps", type=int, default=4, help="train steps captured per hipGraph replay (1 GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -135,8 +136,12 @@ def main():
     model = am.AIRModel(torch.tensor(images, device=dev), torch.tensor(targets, device=dev), cnn=False,
                         train=True, scope="air", annealing_schedules=ANNEAL, seed=rank,
                         gemm_precision=args.precision, **HP)
+    # several train steps per hipGraph replay (single GPU): amortises the replay's own launch cost
+    gsteps = 1
     if not args.no_graph:
-        model.capture_graph()
+        if world == 1:
+            gsteps = next(g for g in (args.graph_steps, 4, 2, 1) if g >= 1 and args.steps % g == 0 and args.warmup % g == 0)
+        model.capture_graph(steps=gsteps)
 
     def sync():
         torch.cuda.synchronize()
@@ -144,11 +149,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(args.warmup // gsteps):
         model.training()
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(args.steps // gsteps):          # one replay = gsteps train steps: exactly args.steps steps
         model.training()
     sync()
     dt = time.perf_counter() - t0
@@ -169,7 +174,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "configs[1]: AIR train step, 50x50 canvas, 0-2 objects, batch 64/GPU, 3 steps, "
                                    "256 LSTM, z=50 (training.py:100-122)", "global_batch": world * B,
-                       "hipgraph": not args.no_graph, "parallelism": "dp%d" % world},
+                       "hipgraph": not args.no_graph, "steps_per_graph_replay": gsteps, "parallelism": "dp%d" % world},
             "per_gpu_images_per_sec": round(value / world, 1), "final_loss": round(loss, 3),
         }
         if not args.no_roofline and world == 1:

@@ -674,13 +674,20 @@ class AIRModel:
         for op in self._optimizer_ops():
             op(s)
 
-    def capture_graph(self):
+    def capture_graph(self, steps=1, between_steps=None):
         """Captures the train step into hipGraphs (fixed N, no host sync, no allocation inside):
-        one graph for world_size 1; [fwd+bwd] | RCCL all-reduce | [clip+Adam] for data parallel."""
+        one graph for world_size 1; [fwd+bwd] | RCCL all-reduce | [clip+Adam] for data parallel.
+        steps > 1 (single GPU only): that many consecutive train steps per replay -- noise and
+        schedules are keyed by the device-side global_step, so the steps differ as they would in
+        separate replays; `between_steps(i)` (optional, graph-capturable device work such as the
+        next batch's gather) is captured before step i.  training() then advances `steps` steps."""
         if not self.train:
             raise RuntimeError("capture_graph() is for train=True models")
         self._optimizer_ops()
         world = self._world()
+        if steps < 1 or (steps > 1 and world > 1):
+            raise ValueError("multi-step graphs need world_size 1")
+        self._graph_steps = steps
         torch.cuda.synchronize()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -692,10 +699,13 @@ class AIRModel:
         torch.cuda.synchronize()
         ga = torch.cuda.CUDAGraph()
         with torch.cuda.graph(ga):
-            s = self._stream()
-            self._train_phase_a(s)
-            if world == 1:
-                self._train_phase_b(s)
+            for i in range(steps):
+                if between_steps is not None:
+                    between_steps(i)
+                s = self._stream()
+                self._train_phase_a(s)
+                if world == 1:
+                    self._train_phase_b(s)
         gb = None
         if world > 1:
             gb = torch.cuda.CUDAGraph()

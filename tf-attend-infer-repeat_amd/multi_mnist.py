@@ -4,8 +4,9 @@ driver :299-414) in numpy, writing .npz instead of TFRecords.
 
 Glyph source: real MNIST idx files are used if present under ``mnist_data/`` (the reference
 downloads them, :336 -- impossible here, no network); otherwise the 1 797 8x8 glyphs of
-sklearn's ``load_digits`` (committed as data/digits8x8.npz), up-sampled to 16x16 inside a
-28x28 frame (stroke width and ink mass close to an MNIST digit).  Everything downstream (cropping, rejection sampling of
+sklearn's ``load_digits`` (committed as data/digits8x8.npz), up-sampled (cubic) to 16x16 inside a
+28x28 frame with the ink ramp stretched so that strokes saturate like MNIST's (the rendering
+that trains most reliably of those tried, profiles/r01_glyph_sweep_60k.jsonl).  Everything downstream (cropping, rejection sampling of
 non-overlapping positions, strata of 0..max_digits digits, shuffling, 1 000-image test split)
 follows the reference.
 
@@ -45,8 +46,8 @@ def load_glyphs():
     small = d["images"].astype(np.float32) / 16.0
     out = np.zeros((small.shape[0], IMAGE_SIZE, IMAGE_SIZE), np.float32)
     zoom = float(os.environ.get("AIR_GLYPH_ZOOM", "2.0"))                 # 8x8 -> 16x16: MNIST-like stroke scale
-    order = int(os.environ.get("AIR_GLYPH_ORDER", "1"))                   # spline order of the up-sampling
-    lo, hi = (float(v) for v in os.environ.get("AIR_GLYPH_CONTRAST", "0,1").split(","))   # ink ramp: MNIST strokes saturate
+    order = int(os.environ.get("AIR_GLYPH_ORDER", "3"))                   # spline order of the up-sampling
+    lo, hi = (float(v) for v in os.environ.get("AIR_GLYPH_CONTRAST", "0.25,0.65").split(","))   # ink ramp: MNIST strokes saturate
     for i, g in enumerate(small):
         big = np.clip(nd.zoom(g, zoom, order=order), 0.0, 1.0)
         big = np.clip((big - lo) / (hi - lo), 0.0, 1.0)

@@ -69,6 +69,7 @@ def main():
     parser.add_argument("--print-every", type=int, default=1)
     parser.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
     parser.add_argument("--no-graph", action="store_true")
+    parser.add_argument("--graph-steps", type=int, default=10, help="train steps per hipGraph replay when --print-every 0")
     parser.add_argument("--seed", type=int, default=0)
     args = parser.parse_args()
 
@@ -124,18 +125,34 @@ def main():
             )
         )
     train_model, test_model = models
-    if not args.no_graph:
-        train_model.capture_graph()
-
     n_train = train_images.shape[0]
     total = args.iterations if args.iterations > 0 else (n_train // BATCH_SIZE) * EPOCHS
     gen = torch.Generator(device=dev)
     gen.manual_seed(args.seed)
     scalars = open(summaries_folder + "scalars.jsonl", "w")
 
+    # The batch gather is device work too: a permutation and a cursor live in HBM, so several
+    # train steps (gather + step) are captured per hipGraph replay when nothing is printed per step.
+    perm = torch.randperm(n_train, device=dev, generator=gen)
+    cursor = torch.zeros(1, dtype=torch.int64, device=dev)
+    lanes = torch.arange(BATCH_SIZE, device=dev)
+
+    def next_batch(_i=0):
+        idx = perm.index_select(0, (cursor + lanes) % n_train)
+        torch.index_select(train_images, 0, idx, out=train_data)
+        torch.index_select(train_digits, 0, idx, out=train_targets)
+        cursor.add_(BATCH_SIZE)
+
+    gsteps = 1
+    if not args.no_graph:
+        if args.print_every == 0 and NUM_SUMMARIES_EACH_ITERATIONS % args.graph_steps == 0:
+            gsteps = args.graph_steps
+        train_model.capture_graph(steps=gsteps, between_steps=next_batch if gsteps > 1 else None)
+        cursor.zero_()                      # the capture warm-up must not consume data
+
     print("Training...")
     print()
-    step, ptr, perm = 0, 0, torch.randperm(n_train, device=dev, generator=gen)
+    step, epoch = 0, 0
     t0 = time.perf_counter()
     while step < total:
         if step % NUM_SUMMARIES_EACH_ITERATIONS == 0:
@@ -150,14 +167,13 @@ def main():
             scalars.flush()
         if step % SAVE_PARAMS_EACH_ITERATIONS == 0:
             torch.save(train_model.state_dict(), models_folder + "air-model-%d.pt" % step)
-        if ptr + BATCH_SIZE > n_train:
-            perm, ptr = torch.randperm(n_train, device=dev, generator=gen), 0
-        idx = perm[ptr:ptr + BATCH_SIZE]
-        ptr += BATCH_SIZE
-        torch.index_select(train_images, 0, idx, out=train_data)
-        torch.index_select(train_digits, 0, idx, out=train_targets)
+        if (step * BATCH_SIZE) // n_train != epoch:               # new epoch: reshuffle in place
+            epoch = (step * BATCH_SIZE) // n_train
+            perm.copy_(torch.randperm(n_train, device=dev, generator=gen))
+        if gsteps == 1:
+            next_batch()
         train_model.training()
-        step += 1
+        step += gsteps
         if args.print_every and step % args.print_every == 0:
             print("iteration {}\tloss {:.3f}\taccuracy {:.2f}".format(
                 int(train_model.global_step), float(train_model.loss), float(train_model.accuracy)))
