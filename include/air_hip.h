@@ -145,6 +145,8 @@ typedef struct {
 /* number of K-slabs a ksplit request produces for contraction depth K */
 int air_gemm_slabs(int K, int ksplit);
 int air_gemm(const air_gemm_t* g, void* stream);
+/* name of the kernel function `g` dispatches to, as rocprofv3 prints it (profiling aid) */
+int air_gemm_kernel_name(const air_gemm_t* g, char* buf, int n);
 
 /* ---- grouped weight gradients: every dW = A^T . dY (+ db = column sums of dY) of the
  * step in ONE launch (MatMul_grad / BiasAdd_grad nodes of all variables; weights are shared

@@ -89,6 +89,7 @@ _SIGNATURES = {
     "air_abi_version": (C.c_int, []),
     "air_strerror": (C.c_char_p, [C.c_int]),
     "air_gemm": (C.c_int, [C.POINTER(Gemm), _p]),
+    "air_gemm_kernel_name": (C.c_int, [C.POINTER(Gemm), C.c_char_p, C.c_int]),
     "air_gemm_slabs": (C.c_int, [C.c_int, C.c_int]),
     "air_colsum": (C.c_int, [C.POINTER(Colsum), C.c_int, _p]),
     "air_wgrad_num_blocks": (C.c_int, [C.POINTER(Wgrad), C.c_int]),

@@ -181,10 +181,11 @@ _ANNEALABLE = {
 
 class _Op:
     """One enqueued C-ABI call: callable(stream) + algorithmic bytes/flops for rooflines."""
-    __slots__ = ("name", "fn", "nbytes", "flops")
+    __slots__ = ("name", "fn", "nbytes", "flops", "kernel")
 
-    def __init__(self, name, fn, nbytes=0, flops=0):
+    def __init__(self, name, fn, nbytes=0, flops=0, kernel=None):
         self.name, self.fn, self.nbytes, self.flops = name, fn, nbytes, flops
+        self.kernel = kernel or name          # kernel function name as rocprofv3 prints it
 
     def __call__(self, stream):
         self.fn(stream)
@@ -388,16 +389,26 @@ class AIRModel:
                    epi, tile[0], tile[1], ksplit, addend_slabs, i0,
                    _ptr(p[0]), _ptr(p[1]), _ptr(p[2]), _ptr(p[3]), _ptr(q[0]), _ptr(q[1]), _ptr(q[2]))
         fn = self.lib.air_gemm
+        kbuf = C.create_string_buffer(96)
+        H.check(self.lib.air_gemm_kernel_name(C.byref(g), kbuf, 96), "air_gemm_kernel_name")
         extra = (addend is not None) * max(1, addend_slabs) + (aux is not None) + (1 if accumulate else 0)
         return _Op("%s[%dx%dx%d%s]" % (tag, M, N, K, "t" if ta else ("n" + ("t" if tb else "n"))),
                    lambda s, g=g, fn=fn: H.check(fn(C.byref(g), s), "air_gemm"),
                    nbytes=4 * (M * K + K * N + M * N * (1 + extra)) + (4 * N if bias is not None else 0) + extra_bytes,
-                   flops=2 * M * N * K)
+                   flops=2 * M * N * K, kernel=kbuf.value.decode())
+
+    _KERNEL_OF = {"air_step_begin": "step_begin_kernel", "air_attend_fwd": "attend_fwd_kernel",
+                  "air_attend_bwd": "attend_bwd_kernel", "air_write_fwd": "write_fwd_kernel",
+                  "air_write_bwd": "write_bwd_kernel", "air_finalize": "finalize_kernel",
+                  "air_grad_sqnorm": "grad_sqnorm_kernel", "air_adam_clip_step": "adam_clip_kernel"}
 
     def _call(self, name, *args, nbytes=0, flops=0, tag=None):
         fn = getattr(self.lib, name)
+        kernel = self._KERNEL_OF.get(name)
+        if name == "air_wgrad_grouped":
+            kernel = "wgrad_grouped_bf16_kernel" if self._prec else "wgrad_grouped_kernel"
         return _Op(tag or name, lambda s, fn=fn, args=args, name=name: H.check(fn(*args, s), name),
-                   nbytes=nbytes, flops=flops)
+                   nbytes=nbytes, flops=flops, kernel=kernel)
 
     def _build_programs(self):
         st, P, G = self.store, self.store.P, self.store.G
@@ -717,13 +728,15 @@ class AIRModel:
     def release_graph(self):
         self._graph = None
 
-    def training(self):
-        """The train op (reference :692): forward, loss, backward, clip, Adam, global_step += 1."""
+    def training(self, eager=False):
+        """The train op (reference :692): forward, loss, backward, clip, Adam, global_step += 1.
+        With a captured graph one call advances `steps` train steps (capture_graph); eager=True
+        runs exactly one step through plain launches even then."""
         if not self.train:
             raise RuntimeError("model was built with train=False")
         st = self.store
         world = self._world()
-        if self._graph is not None:
+        if self._graph is not None and not eager:
             ga, gb = self._graph
             ga.replay()
             if world > 1:
