@@ -203,6 +203,29 @@ def main():
         dt = float(t)
     loss = float(model.loss)
 
+    # the step's only collective, timed on its own (all ranks take part): SURVEY 8(e) asks for its
+    # duration and bus bandwidth against the 153 GB/s/link xGMI bound
+    ar = None
+    if world > 1:
+        try:
+            g = model.store.grads
+            for _ in range(5):
+                dist.all_reduce(g)
+            sync()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                dist.all_reduce(g)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / 20
+            nbytes = g.numel() * 4
+            ar = {"bytes": nbytes, "us": round(us, 1), "algbw_GBs": round(nbytes / us * 1e-3, 1),
+                  "busbw_GBs": round(2.0 * (world - 1) / world * nbytes / us * 1e-3, 1),
+                  "xgmi_link_peak_GBs": 153.0}
+        except Exception as e:                      # never lose the bench line over the extra report
+            ar = {"error": repr(e)}
+
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * B * args.steps / dt
@@ -248,6 +271,8 @@ def main():
                                for k, v in ranked}
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(B)
+        if world > 1 and ar is not None:
+            line["allreduce"] = ar
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
