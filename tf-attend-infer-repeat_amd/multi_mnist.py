@@ -82,11 +82,36 @@ def crop_non_empty(image):
     return image[rows[0]:rows[-1] + 1, cols[0]:cols[-1] + 1]
 
 
+def add_buffer(image, buffer_width):
+    """:44-58 -- every empty pixel within `buffer_width` (Chebyshev) of an ink pixel becomes 1:
+    a dilation by a (2b+1)^2 square, used to keep a gap between digits under pixel overlap."""
+    import scipy.ndimage as nd
+    b = buffer_width
+    near = nd.maximum_filter((image > 0).astype(np.uint8), size=2 * b + 1, mode="constant", cval=0) > 0
+    return np.where((image == 0) & near, np.float32(1.0), image).astype(image.dtype)
+
+
 def pixels_overlap(canvas, image, x, y):
     """:61-65"""
     h, w = image.shape
     window = canvas[y:y + h, x:x + w]
     return not np.array_equal(np.maximum(image, window), image + window)
+
+
+def bounding_boxes_overlap(x, y, w, h, positions, boxes, gap):
+    """:68-79, with the reference's exact tests: a candidate is rejected as soon as its
+    gap-inflated x-extent intersects a placed box's x-extent (whatever the rows), and also in the
+    (degenerate) case l1y >= r2y and l2y >= r1y."""
+    l1x, l1y, r1x, r1y = x - gap, y - gap, x + w + gap - 1, y + h + gap - 1
+    for i in range(len(positions) // 2):
+        px, py = positions[2 * i], positions[2 * i + 1]
+        bw, bh = boxes[2 * i], boxes[2 * i + 1]
+        l2x, l2y, r2x, r2y = px, py, px + bw - 1, py + bh - 1
+        if l1x <= r2x and l2x <= r1x:
+            return True
+        if l1y >= r2y and l2y >= r1y:
+            return True
+    return False
 
 
 class Generator:
@@ -98,12 +123,17 @@ class Generator:
         self.digit_ids = rng.permutation(len(glyphs))
         self.next = 0
 
-    def multi_image(self, num_images, canvas_dim=CANVAS_SIZE, image_dim=IMAGE_SIZE, bg=None, margin=0):
-        """generate_multi_image :82-183, default arguments (no scale/rotation jitter, gap 0,
-        pixel-overlap rejection, up to 100 position attempts, restart the image on failure)."""
+    def multi_image(self, num_images, canvas_dim=CANVAS_SIZE, image_dim=IMAGE_SIZE, bg=None,
+                    min_w=1.0, max_w=1.0, min_h=1.0, max_h=1.0, min_ang=0.0, max_ang=0.0,
+                    gap=0, margin=0, use_pixel_overlap=True):
+        """generate_multi_image :82-183: scale / rotation jitter with order-5 splines (:117-139),
+        rejection sampling of positions (up to 100 attempts, then the whole image is restarted)
+        under pixel overlap (with an optional gap buffer) or bounding-box overlap."""
+        import scipy.ndimage as nd
         rng = self.rng
         while True:
             canvas = np.zeros([canvas_dim, canvas_dim], np.float32)
+            canvas_with_buffer = canvas
             ids, positions, boxes = [], [], []
             if num_images == 0:
                 break
@@ -115,18 +145,40 @@ class Generator:
                     self.digit_ids = rng.permutation(self.digit_ids)
                     self.next = 0
                 image = crop_non_empty(self.glyphs[idx].reshape(image_dim, image_dim))
+                if min_w != 1.0 or max_w != 1.0 or min_h != 1.0 or max_h != 1.0:
+                    new_width = rng.uniform(min_w, max_w)
+                    new_height = rng.uniform(min_h, max_h)
+                    image = nd.affine_transform(image, matrix=np.array([[1.0 / new_height, 0.0], [0.0, 1.0 / new_width]]),
+                                                output_shape=(int(image_dim * new_height), int(image_dim * new_width)),
+                                                order=5)
+                    image = np.clip(image, 0.0, 1.0)
+                    image = crop_non_empty(np.where(image >= 0.05, image, np.zeros_like(image)))
+                if min_ang != 0.0 or max_ang != 0.0:
+                    image = nd.rotate(image, rng.uniform(min_ang, max_ang), order=5)
+                    image = np.clip(image, 0.0, 1.0)
+                    image = crop_non_empty(np.where(image >= 0.05, image, np.zeros_like(image)))
                 h, w = image.shape
+                if w + 2 * margin > canvas_dim or h + 2 * margin > canvas_dim:
+                    ok = False                                   # (the reference's IndexError path :166)
+                    break
                 found = False
                 for _ in range(100):
                     x = rng.randint(margin, canvas_dim - w - margin + 1)
                     y = rng.randint(margin, canvas_dim - h - margin + 1)
-                    found = True if i == 0 else not pixels_overlap(canvas, image, x, y)
+                    if i == 0:
+                        found = True
+                    elif use_pixel_overlap:
+                        found = not pixels_overlap(canvas_with_buffer, image, x, y)
+                    else:
+                        found = not bounding_boxes_overlap(x, y, w, h, positions, boxes, gap)
                     if found:
                         break
                 if not found:
                     ok = False
                     break
                 canvas[y:y + h, x:x + w] += image
+                if use_pixel_overlap and num_images > 1:
+                    canvas_with_buffer = add_buffer(canvas, gap) if gap > 0 else canvas
                 positions.extend([x, y])
                 boxes.extend([w, h])
                 ids.append(idx)
@@ -137,27 +189,80 @@ class Generator:
         return canvas, ids, positions, boxes
 
 
-def generate_dataset(max_digits=2, images_per_digit=20000, test_set_size=1000, seed=0, bg=None, margin=0,
-                     canvas_dim=CANVAS_SIZE, verbose=False):
-    """__main__ :341-413: strata of 0..max_digits digits, shuffled together, first
-    `test_set_size` images -> test, the rest -> train.  Returns dict of arrays."""
+def generate_strata(max_digits=2, images_per_digit=20000, seed=0, bg=None, canvas_dim=CANVAS_SIZE, verbose=False,
+                    **jitter):
+    """__main__ :341-381: one stratum of `images_per_digit` canvases per digit count, with the
+    metadata the reference stores (glyph indices, positions, boxes, labels)."""
     glyphs, labels, source = load_glyphs()
     rng = np.random.RandomState(seed)                                   # np.random.seed(0) :341
     gen = Generator(glyphs, rng)
-    images, digits = [], []
+    strata = []
     for nd_ in range(max_digits + 1):
+        st = dict(images=[], indices=[], positions=[], boxes=[], labels=[], digits=[])
         for item in range(images_per_digit):
-            img, *_ = gen.multi_image(nd_, canvas_dim=canvas_dim, bg=bg, margin=margin)
-            images.append(img.reshape(-1))
-            digits.append(nd_)
+            img, ids, pos, box = gen.multi_image(nd_, canvas_dim=canvas_dim, bg=bg, **jitter)
+            st["images"].append(img.reshape(-1))
+            st["indices"].append(list(ids)); st["positions"].append(list(pos)); st["boxes"].append(list(box))
+            st["labels"].append([int(labels[i]) for i in ids]); st["digits"].append(nd_)
             if verbose and (item + 1) % 5000 == 0:
                 print("%d digits: %d done" % (nd_, item + 1), flush=True)
-    images = np.stack(images).astype(np.float32)
-    digits = np.asarray(digits, np.int32)
+        strata.append(st)
+    return strata, rng, source
+
+
+def generate_dataset(max_digits=2, images_per_digit=20000, test_set_size=1000, seed=0, bg=None, margin=0,
+                     canvas_dim=CANVAS_SIZE, verbose=False, **jitter):
+    """__main__ :341-413: strata of 0..max_digits digits, shuffled together, first
+    `test_set_size` images -> test, the rest -> train.  Returns dict of arrays."""
+    strata, rng, source = generate_strata(max_digits, images_per_digit, seed, bg, canvas_dim, verbose,
+                                          margin=margin, **jitter)
+    images = np.stack([im for st in strata for im in st["images"]]).astype(np.float32)
+    digits = np.asarray([d for st in strata for d in st["digits"]], np.int32)
     perm = rng.permutation(len(images))                                 # shuffle_lists :215-225
     images, digits = images[perm], digits[perm]
     return dict(train_images=images[test_set_size:], train_digits=digits[test_set_size:],
                 test_images=images[:test_set_size], test_digits=digits[:test_set_size], source=source)
+
+
+# ----------------------------------------------------------------------------- reference file format
+def write_to_records(filename, images, indices, positions, boxes, labels, digits, side=None):
+    """:186-212 -- `filename`.tfrecords with the reference's feature set (height, width, digits as
+    int64; indices / positions / boxes / labels as raw int32 bytes; image as raw float32 bytes)."""
+    import tfrecord
+    recs = []
+    for k in range(len(images)):
+        img = np.asarray(images[k], np.float32)
+        rows = cols = side if side is not None else (img.shape[0] if img.ndim == 2 else int(round(np.sqrt(img.size))))
+        recs.append(tfrecord.encode_example({
+            "height": ("int64", [rows]), "width": ("int64", [cols]), "digits": ("int64", [int(digits[k])]),
+            "indices": ("bytes", [np.asarray(indices[k], np.int32).tobytes()]),
+            "positions": ("bytes", [np.asarray(positions[k], np.int32).tobytes()]),
+            "boxes": ("bytes", [np.asarray(boxes[k], np.int32).tobytes()]),
+            "labels": ("bytes", [np.asarray(labels[k], np.int32).tobytes()]),
+            "image": ("bytes", [np.ravel(img).tobytes()]),
+        }))
+    return tfrecord.write_records(filename + ".tfrecords", recs)
+
+
+def read_test_data(filename, shift_zero_digits_images=False):
+    """:254-296 -- reads a .tfrecords file written by the reference (or by write_to_records)."""
+    import tfrecord
+    images_list, digits_list = [], []
+    indices_list, positions_list, boxes_list, labels_list = [], [], [], []
+    for rec in tfrecord.read_records(filename):
+        ex = tfrecord.parse_example(rec)
+        n = int(ex["digits"][0])
+        images_list.append(np.frombuffer(ex["image"][0], np.float32))
+        digits_list.append(n)
+        i32 = lambda k: np.frombuffer(ex[k][0], np.int32) if k in ex and ex[k] else np.zeros(0, np.int32)
+        indices_list.append(i32("indices")[:n])
+        positions_list.append(i32("positions")[:n * 2])
+        boxes_list.append(i32("boxes")[:n * 2])
+        labels_list.append(i32("labels")[:n])
+    images_list, digits_list = np.array(images_list), np.array(digits_list)
+    if shift_zero_digits_images:
+        images_list, digits_list = _shift_zero(images_list, digits_list)
+    return images_list, digits_list, indices_list, positions_list, boxes_list, labels_list
 
 
 def shift_zero_digits_images(images, digits):
@@ -171,20 +276,53 @@ def shift_zero_digits_images(images, digits):
     return images[order], digits[order]
 
 
+_shift_zero = shift_zero_digits_images        # read_test_data's flag shadows the function name
+
+
 if __name__ == "__main__":
-    parser = argparse.ArgumentParser()
+    parser = argparse.ArgumentParser()                                  # flag surface of multi_mnist.py:312-329
     parser.add_argument("--max-digits", type=int, choices=list(range(7)), default=2)
+    parser.add_argument("--max-in-common", type=int, choices=list(range(7)), default=2)
     parser.add_argument("--images-per-digit", type=int, default=20000)
     parser.add_argument("--test-set-size", type=int, default=1000)
+    parser.add_argument("--digit-gap", type=int, default=0)
     parser.add_argument("--canvas-margin", type=int, default=0)
-    parser.add_argument("--canvas-size", type=int, default=CANVAS_SIZE)
     parser.add_argument("--bg-path", default="")
     parser.add_argument("--bg-max-intensity", type=float, default=1.0)
+    parser.add_argument("--min-width-scale", type=float, default=1.0)
+    parser.add_argument("--max-width-scale", type=float, default=1.0)
+    parser.add_argument("--min-height-scale", type=float, default=1.0)
+    parser.add_argument("--max-height-scale", type=float, default=1.0)
+    parser.add_argument("--min-rotation-angle", type=float, default=0.0)
+    parser.add_argument("--max-rotation-angle", type=float, default=0.0)
+    parser.add_argument("--use-bounding-box-overlap", action="store_true")
+    parser.add_argument("--canvas-size", type=int, default=CANVAS_SIZE)
+    parser.add_argument("--tfrecords", action="store_true",
+                        help="also write the reference's files: <n>.tfrecords per stratum, common.tfrecords, test.tfrecords")
     args = parser.parse_args()
     os.makedirs(MULTI_MNIST_FOLDER, exist_ok=True)
     bg = read_image(args.bg_path, args.bg_max_intensity) if args.bg_path else None
-    ds = generate_dataset(args.max_digits, args.images_per_digit, args.test_set_size, bg=bg,
-                          margin=args.canvas_margin, canvas_dim=args.canvas_size, verbose=True)
-    np.savez(MULTI_MNIST_FOLDER + "common.npz", images=ds["train_images"], digits=ds["train_digits"])
-    np.savez(MULTI_MNIST_FOLDER + "test.npz", images=ds["test_images"], digits=ds["test_digits"])
-    print("glyph source: %s; wrote %d train / %d test images" % (ds["source"], len(ds["train_images"]), len(ds["test_images"])))
+    strata, rng, source = generate_strata(
+        args.max_digits, args.images_per_digit, bg=bg, canvas_dim=args.canvas_size, verbose=True,
+        min_w=args.min_width_scale, max_w=args.max_width_scale, min_h=args.min_height_scale, max_h=args.max_height_scale,
+        min_ang=args.min_rotation_angle, max_ang=args.max_rotation_angle, gap=args.digit_gap,
+        margin=args.canvas_margin, use_pixel_overlap=not args.use_bounding_box_overlap)
+    keys = ("images", "indices", "positions", "boxes", "labels", "digits")
+    common = {k: [] for k in keys}
+    for nd_, st in enumerate(strata):                                   # :347-413
+        if args.tfrecords:
+            write_to_records(MULTI_MNIST_FOLDER + str(nd_), *[st[k] for k in keys], side=args.canvas_size)
+        if nd_ <= args.max_in_common:
+            for k in keys:
+                common[k].extend(st[k])
+    perm = rng.permutation(len(common["images"]))                       # shuffle_lists :215-225
+    common = {k: [common[k][i] for i in perm] for k in keys}
+    T = args.test_set_size
+    if args.tfrecords:
+        write_to_records(MULTI_MNIST_FOLDER + "common", *[common[k][T:] for k in keys], side=args.canvas_size)
+        write_to_records(MULTI_MNIST_FOLDER + "test", *[common[k][:T] for k in keys], side=args.canvas_size)
+    np.savez(MULTI_MNIST_FOLDER + "common.npz", images=np.stack(common["images"][T:]).astype(np.float32),
+             digits=np.asarray(common["digits"][T:], np.int32))
+    np.savez(MULTI_MNIST_FOLDER + "test.npz", images=np.stack(common["images"][:T]).astype(np.float32),
+             digits=np.asarray(common["digits"][:T], np.int32))
+    print("glyph source: %s; wrote %d train / %d test images" % (source, len(perm) - T, T))

@@ -44,6 +44,14 @@ def load_data():
     if os.path.exists(TRAIN_DATA_FILE) and os.path.exists(TEST_DATA_FILE):
         tr, te = np.load(TRAIN_DATA_FILE), np.load(TEST_DATA_FILE)
         return tr["images"], tr["digits"], te["images"], te["digits"]
+    rec_tr, rec_te = TRAIN_DATA_FILE.replace(".npz", ".tfrecords"), TEST_DATA_FILE.replace(".npz", ".tfrecords")
+    if os.path.exists(rec_tr) and os.path.exists(rec_te):
+        # the reference's own files (training.py:23-24: multi_mnist_data/common.tfrecords, test.tfrecords)
+        from multi_mnist import read_test_data
+        print("Reading the reference's TFRecord files...")
+        tri, trd, *_ = read_test_data(rec_tr)
+        tei, ted, *_ = read_test_data(rec_te)
+        return tri, trd.astype(np.int32), tei, ted.astype(np.int32)
     print("Generating multi-digit dataset in memory (multi_mnist.py defaults)...")
     ds = generate_dataset()
     return ds["train_images"], ds["train_digits"], ds["test_images"], ds["test_digits"]
