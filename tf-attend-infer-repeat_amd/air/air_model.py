@@ -136,6 +136,7 @@ class VariableStore:
             return o
         self.variables = named(self.P)
         self.gradients = named(self.G)
+        self.adam_m, self.adam_v = named(views(self.m)), named(views(self.v))   # TF slots <var>/Adam, <var>/Adam_1
         self.num_trainable = sum(v.numel() for v in self.variables.values())
         self.initialize(seed)
 
@@ -804,6 +805,36 @@ class AIRModel:
 
     def state_dict(self):
         return self.store.state_dict()
+
+    def save_tf_checkpoint(self, prefix):
+        """Writes `<prefix>.index` + `<prefix>.data-00000-of-00001` in TensorFlow's bundle format
+        with the reference graph's variable names (what tf.train.Saver writes at training.py:203-207),
+        Adam slots included -- restorable by the reference's demo.py:33 / training.py."""
+        import tf_checkpoint as tfc
+        st = self.store
+        sd = {k: v.detach().cpu().contiguous().numpy() for k, v in st.variables.items()}
+        for k in st.variables:
+            sd[k + "/Adam"] = st.adam_m[k].detach().cpu().contiguous().numpy()
+            sd[k + "/Adam_1"] = st.adam_v[k].detach().cpu().contiguous().numpy()
+        sd["global_step"] = int(st.istate[H.IST_GLOBAL_STEP])
+        shapes = {k: tuple(v.shape) for k, v in st.variables.items()}
+        return tfc.save_checkpoint(prefix, tfc.model_to_tensors(sd, shapes))
+
+    def load_tf_checkpoint(self, prefix, verify=True):
+        """Restores variables (and Adam slots / global_step when present) from a TensorFlow bundle
+        written by the reference (`model/air-model`, `air_results/model/air-model-<step>`)."""
+        import tf_checkpoint as tfc
+        st = self.store
+        sd = tfc.tensors_to_state_dict(tfc.load_checkpoint(prefix, verify))
+        for k, v in st.variables.items():
+            v.copy_(torch.from_numpy(np.asarray(sd[k], np.float32)).reshape(v.shape))
+            if k + "/Adam" in sd:
+                st.adam_m[k].copy_(torch.from_numpy(np.asarray(sd[k + "/Adam"], np.float32)).reshape(v.shape))
+                st.adam_v[k].copy_(torch.from_numpy(np.asarray(sd[k + "/Adam_1"], np.float32)).reshape(v.shape))
+        if "global_step" in sd:
+            st.istate[H.IST_GLOBAL_STEP] = int(sd["global_step"])
+        self._dirty = True
+        return self
 
     def load_state_dict(self, sd, strict=True):
         self.store.load_state_dict(sd, strict)

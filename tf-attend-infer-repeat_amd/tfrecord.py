@@ -29,8 +29,38 @@ def crc32c_many(data):
     return crc ^ np.uint32(0xFFFFFFFF)
 
 
+def _raw_update(state, data):
+    """CRC register update (no init / final xor): state uint32 [n], data uint8 [n, L]."""
+    for j in range(data.shape[1]):
+        state = _TABLE[(state ^ data[:, j]) & 0xFF] ^ (state >> np.uint32(8))
+    return state
+
+
 def crc32c(b):
-    return int(crc32c_many(np.frombuffer(bytes(b), np.uint8)[None, :])[0])
+    """CRC-32C of one buffer.  Large buffers are cut into K chunks of L bytes whose register
+    updates run side by side (numpy lanes); chunk results are chained with the linear operator
+    "advance the register over L zero bytes", obtained from 32 extra lanes fed with zeros."""
+    a = np.frombuffer(bytes(b), np.uint8)
+    n = a.size
+    if n < 4096:
+        return int(crc32c_many(a[None, :])[0])
+    L = 1 << max(8, int(np.log2(n) / 2))
+    K = n // L
+    lanes = np.zeros((K + 32, L), np.uint8)
+    lanes[:K] = a[:K * L].reshape(K, L)
+    init = np.zeros(K + 32, np.uint32)
+    init[K:] = np.uint32(1) << np.arange(32, dtype=np.uint32)        # basis states over zero bytes
+    out = _raw_update(init, lanes)
+    chunk, basis = out[:K], out[K:]
+    s = np.uint32(0xFFFFFFFF)
+    bits = np.arange(32, dtype=np.uint32)
+    for k in range(K):
+        sel = ((s >> bits) & np.uint32(1)).astype(bool)
+        s = np.bitwise_xor.reduce(basis[sel]) ^ chunk[k] if sel.any() else chunk[k]
+    tail = a[K * L:]
+    if tail.size:
+        s = _raw_update(np.array([s], np.uint32), tail[None, :])[0]
+    return int(s ^ np.uint32(0xFFFFFFFF))
 
 
 def masked(crc):
