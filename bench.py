@@ -152,6 +152,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--precision", default=os.environ.get("AIR_GEMM_PRECISION", "bf16"), choices=["bf16", "fp32"])
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE: 64)")
+    ap.add_argument("--workload", default="configs[1]", choices=["configs[1]", "configs[3]"],
+                    help="configs[1]: 50x50, N=3, b=64 (the metric); configs[3]: stress, 128x128, 0-4 objects, N=5, b=256")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--graph-steps", type=int, default=4, help="train steps captured per hipGraph replay (1 GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -170,10 +172,14 @@ def main():
 
     from air import air_model as am
     B = args.batch
-    images, targets = synthetic_canvases(B, HP["canvas_size"], HP["max_digits"], seed=1000 + rank)
+    hp = dict(HP)
+    if args.workload == "configs[3]":
+        hp.update(canvas_size=128, max_steps=5, max_digits=4)
+        B = 256 if args.batch == 64 else args.batch
+    images, targets = synthetic_canvases(B, hp["canvas_size"], hp["max_digits"], seed=1000 + rank)
     model = am.AIRModel(torch.tensor(images, device=dev), torch.tensor(targets, device=dev), cnn=False,
                         train=True, scope="air", annealing_schedules=ANNEAL, seed=rank,
-                        gemm_precision=args.precision, **HP)
+                        gemm_precision=args.precision, **hp)
     # several train steps per hipGraph replay (single GPU): amortises the replay's own launch cost
     gsteps = 1
     if not args.no_graph:
@@ -230,13 +236,16 @@ def main():
         ms = dt / args.steps * 1e3
         value = world * B * args.steps / dt
         line = {
-            "metric": "images/sec AIR train step, 50x50 multi-MNIST b=64 N=3",
+            "metric": "images/sec AIR train step, 50x50 multi-MNIST b=64 N=3" if args.workload == "configs[1]" else
+                      "images/sec AIR train step, stress 128x128 b=256 N=5",
             "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision + ("-gemm/fp32-accumulate" if args.precision == "bf16" else ""),
             "data": "synthetic",
-            "config": {"workload": "configs[1]: AIR train step, 50x50 canvas, 0-2 objects, batch 64/GPU, 3 steps, "
-                                   "256 LSTM, z=50 (training.py:100-122)", "global_batch": world * B,
+            "config": {"workload": ("configs[1]: AIR train step, 50x50 canvas, 0-2 objects, batch 64/GPU, 3 steps, "
+                                    "256 LSTM, z=50 (training.py:100-122)") if args.workload == "configs[1]" else
+                                   "configs[3]: stress, 128x128 canvas, 0-4 objects, batch %d/GPU, 5 steps" % B,
+                       "global_batch": world * B,
                        "hipgraph": not args.no_graph, "steps_per_graph_replay": gsteps, "parallelism": "dp%d" % world},
             "per_gpu_images_per_sec": round(value / world, 1), "final_loss": round(loss, 3),
         }
@@ -269,7 +278,7 @@ def main():
                                                                 / MFMA_PEAK_TF[args.precision], 5)}
             line["kernels"] = {k: {"us_per_step": round(v["us"], 2), "launches": v["launches"], "ops": v["ops"]}
                                for k, v in ranked}
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.workload == "configs[1]":
             line["cpu_baseline"] = cpu_baseline(B)
         if world > 1 and ar is not None:
             line["allreduce"] = ar

@@ -60,8 +60,10 @@ def test_visualize_identity_window_is_canvas_border():
     # image 1 took one step: a red frame along the border of both halves, nothing for image 0
     assert torch.all(out[1, 0, :100, 0] == 1.0) and torch.all(out[1, 0, :100, 1] == 0.0)
     assert torch.all(out[1, 0, 104:, 0] == 1.0)
-    big = torch.nn.functional.interpolate(orig.view(n, 1, C, C), size=(100, 100), mode="nearest")[:, 0]
-    assert float((out[0, 40:60, 40:60, 0] - big[0, 40:60, 40:60]).abs().max()) < 0.51   # untouched interior
+    from air.visualize import resize_bilinear_tf1
+    big = resize_bilinear_tf1(orig.view(n, C, C), 100, 100)
+    assert torch.equal(out[0, :, :100, 0], big[0]) and torch.equal(out[0, :, :100, 2], big[0])   # no step: untouched
+    assert torch.equal(out[1, 40:60, 40:60, 1], big[1, 40:60, 40:60])                            # interior untouched
     assert not torch.all(out[0, 0, :100, 0] == 1.0)
 
 

@@ -258,6 +258,21 @@ __device__ __forceinline__ void reduce_waves(f32x4 (&acc)[TM][TN], float* Red, i
     __syncthreads();
 }
 
+// XCD-aware workgroup -> tile map.  Workgroup b is observed to run on XCD b % 8, each XCD with a
+// private L2: the default map would spread the m-tiles that share one panel of weight columns
+// over all eight L2s (measured: 3-5x the algorithmic HBM-side traffic).  Here every XCD takes a
+// contiguous chunk of the tile list, ordered m-fastest, so a weight panel is fetched into ONE L2
+// and its other users hit there (bijective for any grid size; a speed choice only, never relied
+// on for correctness).
+__device__ __forceinline__ void xcd_tile(int& tile_m, int& tile_n) {
+    const int nx = gridDim.x, ny = gridDim.y, nwg = nx * ny;
+    const int bid = blockIdx.y * nx + blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    tile_m = swz % ny;
+    tile_n = swz / ny;
+}
+
 __host__ __device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // ---------------------------------------------------------------------------
@@ -284,7 +299,9 @@ __global__ __launch_bounds__(THREADS) void gemm_f32_kernel(Args a)
     __shared__ float Red[3 * TM * TN * 4 * 64];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN / TN * (a.gstride == 16 ? TN : 1);
+    int tile_m, tile_n;
+    xcd_tile(tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN / TN * (a.gstride == 16 ? TN : 1);
     const int kbeg = blockIdx.z * a.kslab;
     const int kend = min(a.K, kbeg + a.kslab);
 
@@ -485,7 +502,9 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16_kernel(Args a)
     __shared__ float Red[3 * TM * TN * 4 * 64];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN / TN * (a.gstride == 16 ? TN : 1);
+    int tile_m, tile_n;
+    xcd_tile(tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN / TN * (a.gstride == 16 ? TN : 1);
     const int kbeg = blockIdx.z * a.kslab;
     const int kend = min(a.K, kbeg + a.kslab);
 
@@ -634,7 +653,9 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16v2_kernel(Args a)
     float* Red = reinterpret_cast<float*>(Lds);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN / TN * (a.gstride == 16 ? TN : 1);
+    int tile_m, tile_n;
+    xcd_tile(tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN / TN * (a.gstride == 16 ? TN : 1);
     const int kbeg = blockIdx.z * a.kslab;
     const int kend = min(a.K, kbeg + a.kslab);
 

@@ -203,8 +203,9 @@ __global__ __launch_bounds__(THREADS) void attend_fwd_kernel(air_attend_fwd_t a)
         const int tp = j / hs.wid[4], jj = j % hs.wid[4];
         sh_hprev[j] = a.hid[((size_t)tp * B + b) * HT + hs.off[4] + jj];
     }
-    float bo[2] = {0.f, 0.f};
-    if (lane == 0) { bo[0] = a.bout[wave]; if (wave + 4 < 7) bo[1] = a.bout[wave + 4]; }
+    // one 16-lane group per dot product: group (wave, lane >> 4) owns dots grp0, grp0 + 16, ...
+    const int gl = lane & 15, grp0 = wave * 4 + (lane >> 4);
+    const float bo = (gl == 0 && grp0 < 7) ? a.bout[grp0] : 0.0f;
     const float bz = a.bout[6];
 #pragma unroll
     for (int k = 0; k < PF; ++k) { const int p = tid + k * THREADS; if (p < C * C) sh_img[p] = pf[k]; }
@@ -213,20 +214,25 @@ __global__ __launch_bounds__(THREADS) void attend_fwd_kernel(air_attend_fwd_t a)
 
     AIR_STAMP(11);
     // 7 output units (air_model.py:294,299,311,316,376): x.W + b
-    for (int o = wave, n = 0; o < 7; o += 4, ++n) {
-        const int h = kOutHead[o];
+    // 7 output units (air_model.py:294,299,311,316,376: x.W + b) and the z log-odds of the earlier
+    // steps t' < t, ALL in one pass: 16 lanes per dot product, 4-step butterfly.  The z unit of this
+    // step and of the earlier steps use the same lane assignment and reduction order, so a step's
+    // z is bit-identical wherever it is recomputed.
+    for (int dot = grp0; dot < 7 + t; dot += 16) {
         float p = 0.0f;
-        for (int j = lane; j < hs.wid[h]; j += 64) p += sh_hid[hs.off[h] + j] * sh_wout[o * a.wout_ld + j];
-        p = air_wave_sum(p);
-        if (lane == 0) sh_out[o] = p + bo[n];
-    }
-    // z log-odds of the earlier steps t' < t (same lane assignment and reduction order as above)
-    for (int tp = wave; tp < t; tp += 4) {
-        const float* hp = sh_hprev + tp * hs.wid[4];
-        float p = 0.0f;
-        for (int j = lane; j < hs.wid[4]; j += 64) p += hp[j] * sh_wout[6 * a.wout_ld + j];
-        p = air_wave_sum(p);
-        if (lane == 0) sh_zlo[tp] = p + bz;
+        const int tp = dot - 7;
+        if (dot < 7) {
+            const int h = kOutHead[dot];
+            for (int j = gl; j < hs.wid[h]; j += 16) p += sh_hid[hs.off[h] + j] * sh_wout[dot * a.wout_ld + j];
+        } else {
+            const float* hp = sh_hprev + tp * hs.wid[4];
+            for (int j = gl; j < hs.wid[4]; j += 16) p += hp[j] * sh_wout[6 * a.wout_ld + j];
+        }
+        p += __shfl_xor(p, 8, 64); p += __shfl_xor(p, 4, 64); p += __shfl_xor(p, 2, 64); p += __shfl_xor(p, 1, 64);
+        if (gl == 0) {
+            if (dot < 7) sh_out[dot] = p + bo;
+            else sh_zlo[tp] = p + bz;
+        }
     }
     __syncthreads();
 

@@ -57,15 +57,39 @@ def load_data():
     return ds["train_images"], ds["train_digits"], ds["test_images"], ds["test_digits"]
 
 
-def digit_count_summaries(name, values, digits, max_digits):
-    """air_model.py:160-182."""
-    out = {}
-    v = values.float()
-    for i in range(max_digits + 1):
-        m = digits == i
-        out["%s_%d_dig" % (name, i)] = float(v[m].mean()) if bool(m.any()) else float("nan")
-    out[name + "_all_dig"] = float(v.mean())
-    return out
+class Summaries:
+    """Scalar summaries of the reference (air_model.py:160-209, 614-632), collected as device
+    scalars and fetched with ONE device->host copy per evaluation."""
+
+    def __init__(self, targets, max_digits, max_steps):
+        self.targets, self.max_digits, self.max_steps = targets, max_digits, max_steps
+        self.names, self.vals = [], []
+
+    def _mean(self, v, mask):
+        m = mask.float()
+        return (v * m).sum() / m.sum()                              # NaN when the group is empty, as tf.reduce_mean
+
+    def by_digit_count(self, name, values, mask=None):
+        """_summarize_by_digit_count :160-182"""
+        v = values.float()
+        ok = torch.ones_like(v, dtype=torch.bool) if mask is None else mask
+        for i in range(self.max_digits + 1):
+            self.names.append("%s_%d_dig" % (name, i))
+            self.vals.append(self._mean(v, ok & (self.targets == i)))
+        self.names.append(name + "_all_dig")
+        self.vals.append(self._mean(v, ok))
+
+    def by_step(self, tensor, steps, name, one_more_step=False, all_steps=False):
+        """_summarize_by_step :184-209 (tensor [B, T'] is padded to max_steps columns)"""
+        T = tensor.shape[1]
+        for i in range(self.max_steps):
+            col = tensor[:, i] if i < T else torch.zeros_like(tensor[:, 0])
+            mask = None if all_steps else steps > (i - (1 if one_more_step else 0))
+            self.by_digit_count("%s_%d_step" % (name, i + 1), col, mask)
+
+    def fetch(self):
+        vals = torch.stack(self.vals).cpu().tolist()
+        return dict(zip(self.names, vals))
 
 
 def main():
@@ -166,11 +190,21 @@ def main():
         if step % NUM_SUMMARIES_EACH_ITERATIONS == 0:
             test_model.forward()
             digs = test_model.rec_num_digits
-            row = {"step": step, "wall_s": round(time.perf_counter() - t0, 3),
-                   "loss": float(test_model.loss), "accuracy": float(test_model.accuracy)}
-            row.update(digit_count_summaries("digit_acc", (digs == test_targets), test_targets, 2))
-            row.update(digit_count_summaries("steps", digs, test_targets, 2))
-            row.update(digit_count_summaries("rec_loss", test_model.reconstruction_loss, test_targets, 2))
+            sm = Summaries(test_targets, 2, 3)
+            sm.names += ["loss", "accuracy"]
+            sm.vals += [test_model.loss.float(), test_model.accuracy.float()]
+            sm.by_digit_count("steps", digs)                                        # :614-617
+            sm.by_digit_count("rec_loss", test_model.reconstruction_loss)
+            sm.by_digit_count("digit_acc", digs == test_targets)
+            sm.by_digit_count("total_loss", test_model.loss_per_item)
+            sm.by_step(test_model.rec_scales[:, :, 0], digs, "scale")               # :620-625
+            sm.by_step(test_model.z_pres_probs, digs, "z_pres_prob", all_steps=True)
+            sm.by_step(test_model.z_pres_kls, digs, "z_pres_kl", one_more_step=True)
+            sm.by_step(test_model.scale_kls, digs, "scale_kl")
+            sm.by_step(test_model.shift_kls, digs, "shift_kl")
+            sm.by_step(test_model.vae_kls, digs, "vae_kl")
+            row = {"step": step, "wall_s": round(time.perf_counter() - t0, 3)}
+            row.update({k: (round(v, 5) if v == v else None) for k, v in sm.fetch().items()})
             scalars.write(json.dumps(row) + "\n")
             scalars.flush()
         if step % SAVE_PARAMS_EACH_ITERATIONS == 0:
