@@ -40,7 +40,7 @@ TRAIN_DATA_FILE = "multi_mnist_data/common.npz"
 TEST_DATA_FILE = "multi_mnist_data/test.npz"
 
 
-def load_data():
+def load_data(bg_path="", bg_max_intensity=1.0):
     if os.path.exists(TRAIN_DATA_FILE) and os.path.exists(TEST_DATA_FILE):
         tr, te = np.load(TRAIN_DATA_FILE), np.load(TEST_DATA_FILE)
         return tr["images"], tr["digits"], te["images"], te["digits"]
@@ -53,7 +53,17 @@ def load_data():
         tei, ted, *_ = read_test_data(rec_te)
         return tri, trd.astype(np.int32), tei, ted.astype(np.int32)
     print("Generating multi-digit dataset in memory (multi_mnist.py defaults)...")
-    ds = generate_dataset()
+    bg = None
+    if bg_path:                                            # clutter (multi_mnist.py --bg-path / --bg-max-intensity)
+        if ".npz:" in bg_path:                             # "<file>.npz:<key>": an already decoded background
+            f, key = bg_path.rsplit(":", 1)
+            bg = np.load(f)[key].astype(np.float32)
+            if bg.max() > 0:
+                bg = bg / bg.max() * min(bg_max_intensity, 1.0)
+        else:
+            from multi_mnist import read_image
+            bg = read_image(bg_path, bg_max_intensity)
+    ds = generate_dataset(bg=bg)
     return ds["train_images"], ds["train_digits"], ds["test_images"], ds["test_digits"]
 
 
@@ -101,6 +111,8 @@ def main():
     parser.add_argument("--print-every", type=int, default=1)
     parser.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
     parser.add_argument("--no-graph", action="store_true")
+    parser.add_argument("--bg-path", default="", help="clutter background for the in-memory dataset (png, or file.npz:key)")
+    parser.add_argument("--bg-max-intensity", type=float, default=1.0)
     parser.add_argument("--graph-steps", type=int, default=10, help="train steps per hipGraph replay when --print-every 0")
     parser.add_argument("--seed", type=int, default=0)
     args = parser.parse_args()
@@ -122,7 +134,7 @@ def main():
 
     dev = torch.device("cuda", 0)
     print("Creating input pipeline...")
-    tr_im, tr_dg, te_im, te_dg = load_data()
+    tr_im, tr_dg, te_im, te_dg = load_data(args.bg_path, args.bg_max_intensity)
     te_im, te_dg = shift_zero_digits_images(te_im, te_dg)
     train_images = torch.tensor(tr_im, device=dev)
     train_digits = torch.tensor(tr_dg.astype(np.int32), device=dev)
