@@ -240,7 +240,7 @@ def main():
                       "images/sec AIR train step, stress 128x128 b=256 N=5",
             "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.precision + ("-gemm/fp32-accumulate" if args.precision == "bf16" else ""),
+            "vs_baseline": None, "dtype": args.precision, "accumulate_dtype": "fp32",
             "data": "synthetic",
             "config": {"workload": ("configs[1]: AIR train step, 50x50 canvas, 0-2 objects, batch 64/GPU, 3 steps, "
                                     "256 LSTM, z=50 (training.py:100-122)") if args.workload == "configs[1]" else
