@@ -290,10 +290,12 @@ def test_reference_backward_carries_the_fp32_residue(am):
     _, g32 = at.loss_and_grads(pt, torch.tensor(images), torch.tensor(targets), at.to_torch(noise), HP, 9.21)
     n32 = {k: float(v.norm()) for k, v in g32.items()}
     REPORT["residue_norms"] = {k: [norms["reference"][k], norms["exact"][k], n32[k]] for k in n32}
-    for k, ratio in (("rnn/kernel", 1.3), ("shift/mean/output/weights", 1.3), ("vae/gen_mean/weights", 2.0),
-                     ("vae/generative_2/weights", 2.0)):
+    # measured (r01, fp32 GEMMs): decoder 7.4-8x the exact norm and 1.01x the torch twin's; scale/mean
+    # head 6-7x and 0.9-1.05x; the thresholds leave room for another rounding realisation
+    for k, ratio in (("scale/mean/output/weights", 2.0), ("vae/gen_mean/weights", 2.0),
+                     ("vae/generative_2/weights", 2.0), ("vae/recognition_1/weights", 1.5)):
         assert norms["reference"][k] > ratio * norms["exact"][k], k
-        assert 0.2 < norms["reference"][k] / n32[k] < 5.0, (k, norms["reference"][k], n32[k])
+        assert 0.5 < norms["reference"][k] / n32[k] < 2.0, (k, norms["reference"][k], n32[k])
     for k in ("z_pres/log_odds/output/weights",):       # paths without out-of-range taps are unaffected
         assert abs(norms["reference"][k] - norms["exact"][k]) / norms["exact"][k] < 0.2
 

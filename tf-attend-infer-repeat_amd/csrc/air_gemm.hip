@@ -811,6 +811,198 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16v2_kernel(Args a)
 }
 
 
+
+// fp32 twin of the lean kernel: the same images with fp32 elements (16 swizzled 16-byte slots per
+// row), exact fp32 products on v_mfma_f32_16x16x4_f32; dynamic LDS (up to 80 KB).
+template <int TM, int TN>
+struct F32V2Cfg {
+    static constexpr int BM = 16 * TM, BN = 16 * TN, KB = 64;
+    static constexpr int IMG = (BM + BN) * KB * 4;                       // bytes per image pair
+    static constexpr int RL = 81920 / IMG;
+    static constexpr int RV = 24 / (TM + TN);
+    static constexpr int R0 = RL < RV ? RL : RV;
+    static constexpr int R = R0 > 8 ? 8 : (R0 < 1 ? 1 : R0);
+    static constexpr int RED = 3 * TM * TN * 4 * 64 * 4;
+    static constexpr int BYTES = (R * IMG > RED) ? R * IMG : RED;
+};
+
+template <int TM, int TN, bool TB>
+__global__ __launch_bounds__(THREADS) void gemm_f32v2_kernel(Args a)
+{
+    using Cfg = F32V2Cfg<TM, TN>;
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, KB = Cfg::KB, R = Cfg::R;
+    extern __shared__ __attribute__((aligned(16))) unsigned char Lds[];  // Cfg::BYTES (may exceed 64 KB)
+    float* ImgA = reinterpret_cast<float*>(Lds);                         // [R][BM][64]
+    float* ImgB = ImgA + R * BM * KB;                                    // [R][BN][64]
+    float* Red = reinterpret_cast<float*>(Lds);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int tile_m, tile_n;
+    xcd_tile(tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN / TN * (a.gstride == 16 ? TN : 1);
+    const int kbeg = blockIdx.z * a.kslab;
+    const int kend = min(a.K, kbeg + a.kslab);
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    Pre<TM, TN> pre;
+    if (gridDim.z == 1) epilogue_prefetch<TM, TN>(a, pre, m0, n0, lane, wave);
+
+    const char* Ab = reinterpret_cast<const char*>(a.A);
+    const char* Bb = reinterpret_cast<const char*>(a.B);
+    const bool a8 = !(((a.lda & 3) == 0) && aligned16(a.A) && ((a.K & 3) == 0));
+    const bool b8 = !(((a.ldb & 3) == 0) && aligned16(a.B) &&
+                      (TB ? ((a.K & 3) == 0) : (((a.N & 3) == 0) && ((a.gstride & 3) == 0) && ((a.gwidth & 3) == 0))));
+    // tasks of one round.  k-contiguous operand (A, and B when TB): task = (image, row, k-run g) = 2 float4;
+    // NN B: task = (image, column quad, k-run g) = the same 4 columns of 8 consecutive rows = 8 float4.
+    constexpr int TA_N = (R * BM * 8 + THREADS - 1) / THREADS;           // A tasks per thread
+    constexpr int TBK_N = (R * BN * 8 + THREADS - 1) / THREADS;          // NT-B tasks per thread
+    constexpr int TBN_N = (R * BN * 2 + THREADS - 1) / THREADS;          // NN-B tasks per thread
+
+    for (int kr = kbeg; kr < kend; kr += R * KB) {
+        if (kr > kbeg) __syncthreads();                                   // images of the previous round consumed
+        float4 va[TA_N][2];
+        float4 vbk[TB ? TBK_N : 1][2];
+        float4 vbn[TB ? 1 : TBN_N][8];
+        // ---- issue every load of the round
+#pragma unroll
+        for (int i = 0; i < TA_N; ++i) {
+            const int t = tid + THREADS * i;
+            const int c = t / (BM * 8), row = (t / 8) % BM, g = t & 7;
+            const int gm = m0 + row, gk = kr + c * KB + g * 8;
+            const bool okr = (t < R * BM * 8) && gm < a.M;
+            const unsigned off = ((unsigned)gm * (unsigned)a.lda + (unsigned)gk) * 4u;
+            va[i][0] = ldg16x(Ab, off, okr && gk < kend, okr && gk + 2 < kend, a8);
+            va[i][1] = ldg16x(Ab, off + 16u, okr && gk + 4 < kend, okr && gk + 6 < kend, a8);
+        }
+        if (TB) {
+#pragma unroll
+            for (int i = 0; i < TBK_N; ++i) {
+                const int t = tid + THREADS * i;
+                const int c = t / (BN * 8), col = (t / 8) % BN, g = t & 7;
+                const int j = col >> 4, cc = col & 15;
+                const int gn = n0 + j * a.gstride + cc, cg = n0 + cc + (a.gstride == 16 ? j * 16 : 0);
+                const int gk = kr + c * KB + g * 8;
+                const bool okr = (t < R * BN * 8) && cg < a.gwidth && gn < a.N;
+                const unsigned off = ((unsigned)gn * (unsigned)a.ldb + (unsigned)gk) * 4u;
+                vbk[i][0] = ldg16x(Bb, off, okr && gk < kend, okr && gk + 2 < kend, b8);
+                vbk[i][1] = ldg16x(Bb, off + 16u, okr && gk + 4 < kend, okr && gk + 6 < kend, b8);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TBN_N; ++i) {
+                const int t = tid + THREADS * i;
+                const int c = t / (BN * 2), q = (t / 8) % (BN / 4), g = t & 7;
+                const int col = q * 4, j = col >> 4, cc = col & 15;
+                const int gn = n0 + j * a.gstride + cc, cg = n0 + cc + (a.gstride == 16 ? j * 16 : 0);
+                const int gk = kr + c * KB + g * 8;
+                const bool okc = (t < R * BN * 2) && cg < a.gwidth && gn < a.N;
+                const bool okh = okc && cg + 2 < a.gwidth && gn + 2 < a.N;     // upper half of the column quad
+                const unsigned off = ((unsigned)gk * (unsigned)a.ldb + (unsigned)gn) * 4u;
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    vbn[i][r] = ldg16x(Bb, off + (unsigned)r * ((unsigned)a.ldb * 4u), okc && gk + r < kend,
+                                       okh && gk + r < kend, b8);
+            }
+        }
+        // ---- round to bf16 and store the images
+#pragma unroll
+        for (int i = 0; i < TA_N; ++i) {
+            const int t = tid + THREADS * i;
+            const int c = t / (BM * 8), row = (t / 8) % BM, g = t & 7;
+            if (t < R * BM * 8) {
+                float* dst = &ImgA[(c * BM + row) * KB];
+                *reinterpret_cast<float4*>(dst + (((2 * g) ^ (row & 15)) << 2)) = va[i][0];
+                *reinterpret_cast<float4*>(dst + (((2 * g + 1) ^ (row & 15)) << 2)) = va[i][1];
+            }
+        }
+        if (TB) {
+#pragma unroll
+            for (int i = 0; i < TBK_N; ++i) {
+                const int t = tid + THREADS * i;
+                const int c = t / (BN * 8), col = (t / 8) % BN, g = t & 7;
+                if (t < R * BN * 8) {
+                    float* dst = &ImgB[(c * BN + col) * KB];
+                    *reinterpret_cast<float4*>(dst + (((2 * g) ^ (col & 15)) << 2)) = vbk[i][0];
+                    *reinterpret_cast<float4*>(dst + (((2 * g + 1) ^ (col & 15)) << 2)) = vbk[i][1];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TBN_N; ++i) {
+                const int t = tid + THREADS * i;
+                const int c = t / (BN * 2), q = (t / 8) % (BN / 4), g = t & 7;
+                if (t < R * BN * 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int col = q * 4 + e;
+                        auto el = [&](int r) { const float4& x = vbn[i][r]; return e == 0 ? x.x : e == 1 ? x.y : e == 2 ? x.z : x.w; };
+                        float* dst = &ImgB[(c * BN + col) * KB];
+                        *reinterpret_cast<float4*>(dst + (((2 * g) ^ (col & 15)) << 2)) = make_float4(el(0), el(1), el(2), el(3));
+                        *reinterpret_cast<float4*>(dst + (((2 * g + 1) ^ (col & 15)) << 2)) = make_float4(el(4), el(5), el(6), el(7));
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- MFMAs: wave w owns images w, w+4, ... of the round
+#pragma unroll
+        for (int cc = 0; cc < (R + 3) / 4; ++cc) {
+            const int c = wave + 4 * cc;
+            if (c < R && kr + c * KB < kend) {
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    // lane l supplies k = 16 kb + 4 (l >> 4) + e to the e-th of four MFMAs: one 16-byte
+                    // read per operand tile feeds four v_mfma_f32_16x16x4_f32 (A and B use the same k map)
+                    const int slot = kb * 4 + (lane >> 4);
+                    float4 av[TM], bv[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const int row = i * 16 + (lane & 15);
+                        av[i] = *reinterpret_cast<const float4*>(&ImgA[(c * BM + row) * KB + ((slot ^ (row & 15)) << 2)]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int col = j * 16 + (lane & 15);
+                        bv[j] = *reinterpret_cast<const float4*>(&ImgB[(c * BN + col) * KB + ((slot ^ (col & 15)) << 2)]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j) {
+                                const float ae = e == 0 ? av[i].x : e == 1 ? av[i].y : e == 2 ? av[i].z : av[i].w;
+                                const float be = e == 0 ? bv[j].x : e == 1 ? bv[j].y : e == 2 ? bv[j].z : bv[j].w;
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae, be, acc[i][j], 0, 0, 0);
+                            }
+                }
+            }
+        }
+    }
+    __syncthreads();                                                      // Red aliases the images
+    reduce_waves<TM, TN>(acc, Red, lane, wave);
+    if (gridDim.z > 1) {
+        float* Cz = a.C + (size_t)blockIdx.z * a.slab_stride;
+        for (int t = wave; t < TM * TN; t += 4) {
+            const int i = t / TN, j = t % TN;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = m0 + i * 16 + (lane >> 4) * 4 + q;
+                const int n = n0 + j * 16 + (lane & 15);
+                if (m < a.M && n < a.N) Cz[(size_t)m * a.ldc + n] = Red[(t * 4 + q) * 64 + lane];
+            }
+        }
+        return;
+    }
+    epilogue<TM, TN>(a, pre, Red, m0, n0, lane, wave);
+}
+
+
 bool use_bf16_v2(const Args& a, bool ta, bool tb);
 
 template <int TM, int TN, bool TA, bool TB>
@@ -829,7 +1021,17 @@ int launch(const air_gemm_t* g, const Args& a0, hipStream_t s) {
         if (v2) hipLaunchKernelGGL((gemm_bf16v2_kernel<TM, TN, TB>), grid, dim3(THREADS), 0, s, a);
         else hipLaunchKernelGGL((gemm_bf16_kernel<TM, TN, TA, TB>), grid, dim3(THREADS), 0, s, a);
     }
-    else
+    else if (use_bf16_v2(a, TA, TB) && getenv("AIR_GEMM_F32_V1") == nullptr) {   // same operand requirements
+        using Cfg = F32V2Cfg<TM, TN>;
+        static bool attr_set = false;
+        if (!attr_set && Cfg::BYTES > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32v2_kernel<TM, TN, TB>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::BYTES);
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((gemm_f32v2_kernel<TM, TN, TB>), grid, dim3(THREADS), Cfg::BYTES, s, a);
+    } else
         hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, TA, TB>), grid, dim3(THREADS), 0, s, a);
     AIR_CHECK_LAUNCH();
     return 0;
@@ -900,6 +1102,8 @@ extern "C" int air_gemm_kernel_name(const air_gemm_t* g, char* buf, int n) {
     const bool ta = g->transA != 0, tb = g->transB != 0;
     if (g->precision == 1 && use_bf16_v2(a, ta, tb))
         snprintf(buf, n, "gemm_bf16v2_kernel<%d, %d, %s>", tm, tn, tb ? "true" : "false");
+    else if (g->precision == 0 && use_bf16_v2(a, ta, tb) && getenv("AIR_GEMM_F32_V1") == nullptr)
+        snprintf(buf, n, "gemm_f32v2_kernel<%d, %d, %s>", tm, tn, tb ? "true" : "false");
     else
         snprintf(buf, n, "gemm_%s_kernel<%d, %d, %s, %s>", g->precision == 1 ? "bf16" : "f32", tm, tn,
                  ta ? "true" : "false", tb ? "true" : "false");
