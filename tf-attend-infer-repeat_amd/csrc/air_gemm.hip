@@ -679,12 +679,11 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16v2_kernel(Args a)
     constexpr int TBK_N = (R * BN * 8 + THREADS - 1) / THREADS;          // NT-B tasks per thread
     constexpr int TBN_N = (R * BN * 2 + THREADS - 1) / THREADS;          // NN-B tasks per thread
 
-    for (int kr = kbeg; kr < kend; kr += R * KB) {
-        if (kr > kbeg) __syncthreads();                                   // images of the previous round consumed
-        float4 va[TA_N][2];
-        float4 vbk[TB ? TBK_N : 1][2];
-        float4 vbn[TB ? 1 : TBN_N][8];
-        // ---- issue every load of the round
+    float4 va[TA_N][2];
+    float4 vbk[TB ? TBK_N : 1][2];
+    float4 vbn[TB ? 1 : TBN_N][8];
+    // ---- every load of one round, issued back to back
+    auto issue_loads = [&](int kr) {
 #pragma unroll
         for (int i = 0; i < TA_N; ++i) {
             const int t = tid + THREADS * i;
@@ -725,6 +724,12 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16v2_kernel(Args a)
                                        okh && gk + r < kend, b8);
             }
         }
+    };
+    // software pipeline over rounds: the loads of round r+1 are issued right after the registers of
+    // round r were drained into LDS, so their latency runs under the barrier and the MFMAs of round r
+    issue_loads(kbeg);
+    for (int kr = kbeg; kr < kend; kr += R * KB) {
+        if (kr > kbeg) __syncthreads();                                   // images of the previous round consumed
         // ---- round to bf16 and store the images
 #pragma unroll
         for (int i = 0; i < TA_N; ++i) {
@@ -763,6 +768,7 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16v2_kernel(Args a)
                 }
             }
         }
+        if (kr + R * KB < kend) issue_loads(kr + R * KB);
         __syncthreads();
         // ---- MFMAs: wave w owns images w, w+4, ... of the round
 #pragma unroll
@@ -863,12 +869,11 @@ __global__ __launch_bounds__(THREADS) void gemm_f32v2_kernel(Args a)
     constexpr int TBK_N = (R * BN * 8 + THREADS - 1) / THREADS;          // NT-B tasks per thread
     constexpr int TBN_N = (R * BN * 2 + THREADS - 1) / THREADS;          // NN-B tasks per thread
 
-    for (int kr = kbeg; kr < kend; kr += R * KB) {
-        if (kr > kbeg) __syncthreads();                                   // images of the previous round consumed
-        float4 va[TA_N][2];
-        float4 vbk[TB ? TBK_N : 1][2];
-        float4 vbn[TB ? 1 : TBN_N][8];
-        // ---- issue every load of the round
+    float4 va[TA_N][2];
+    float4 vbk[TB ? TBK_N : 1][2];
+    float4 vbn[TB ? 1 : TBN_N][8];
+    // ---- every load of one round, issued back to back
+    auto issue_loads = [&](int kr) {
 #pragma unroll
         for (int i = 0; i < TA_N; ++i) {
             const int t = tid + THREADS * i;
@@ -909,6 +914,12 @@ __global__ __launch_bounds__(THREADS) void gemm_f32v2_kernel(Args a)
                                        okh && gk + r < kend, b8);
             }
         }
+    };
+    // software pipeline over rounds: the loads of round r+1 are issued right after the registers of
+    // round r were drained into LDS, so their latency runs under the barrier and the MFMAs of round r
+    issue_loads(kbeg);
+    for (int kr = kbeg; kr < kend; kr += R * KB) {
+        if (kr > kbeg) __syncthreads();                                   // images of the previous round consumed
         // ---- round to bf16 and store the images
 #pragma unroll
         for (int i = 0; i < TA_N; ++i) {
@@ -948,6 +959,7 @@ __global__ __launch_bounds__(THREADS) void gemm_f32v2_kernel(Args a)
                 }
             }
         }
+        if (kr + R * KB < kend) issue_loads(kr + R * KB);
         __syncthreads();
         // ---- MFMAs: wave w owns images w, w+4, ... of the round
 #pragma unroll

@@ -8,9 +8,13 @@ from bench import HP, ANNEAL, synthetic_canvases
 from air import air_model as am, _hip as H
 
 prec = sys.argv[1] if len(sys.argv) > 1 else "fp32"
-images, targets = synthetic_canvases(64, 50, 2, 1)
+hp, B = dict(HP), 64
+if len(sys.argv) > 2 and sys.argv[2] == "stress":            # BASELINE configs[3]
+    hp.update(canvas_size=128, max_steps=5, max_digits=4)
+    B = 256
+images, targets = synthetic_canvases(B, hp["canvas_size"], hp["max_digits"], 1)
 m = am.AIRModel(torch.tensor(images, device="cuda"), torch.tensor(targets, device="cuda"), cnn=False, train=True,
-                annealing_schedules=ANNEAL, gemm_precision=prec, **HP)
+                annealing_schedules=ANNEAL, gemm_precision=prec, **hp)
 for _ in range(3):
     m.training()
 torch.cuda.synchronize()
