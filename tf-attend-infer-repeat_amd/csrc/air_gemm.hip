@@ -915,11 +915,11 @@ __global__ __launch_bounds__(THREADS) void gemm_f32v2_kernel(Args a)
             }
         }
     };
-    // software pipeline over rounds: the loads of round r+1 are issued right after the registers of
-    // round r were drained into LDS, so their latency runs under the barrier and the MFMAs of round r
-    issue_loads(kbeg);
+    // (no software pipeline over rounds here: measured A/B it costs the fp32 kernel 15-20 % --
+    // its rounds are MFMA-bound already, the early loads only lengthen the register live ranges)
     for (int kr = kbeg; kr < kend; kr += R * KB) {
         if (kr > kbeg) __syncthreads();                                   // images of the previous round consumed
+        issue_loads(kr);
         // ---- round to bf16 and store the images
 #pragma unroll
         for (int i = 0; i < TA_N; ++i) {
@@ -959,7 +959,6 @@ __global__ __launch_bounds__(THREADS) void gemm_f32v2_kernel(Args a)
                 }
             }
         }
-        if (kr + R * KB < kend) issue_loads(kr + R * KB);
         __syncthreads();
         // ---- MFMAs: wave w owns images w, w+4, ... of the round
 #pragma unroll
