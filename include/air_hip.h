@@ -121,6 +121,11 @@ enum {
      * (row - i0).  Lets the GEMM that produces d h' of all steps also start the BPTT chain. */
     AIR_EPI_LSTM_BWD_TAIL = 5
 };
+/* air_step_begin's work as a descriptor, so that a GEMM launch can carry it (air_gemm_t.step_job) */
+typedef struct {
+    const air_schedule_t* sched /*device*/; int32_t nsched; float* dyn; const int32_t* istate;
+    float* normals; int64_t n_normal; float* uniforms; int64_t n_uniform; uint64_t seed;
+} air_step_job_t;
 typedef struct {
     const float* A; const float* B; float* C;
     int32_t M, N, K, lda, ldb, ldc;
@@ -141,6 +146,10 @@ typedef struct {
     int32_t i0;
     const float* p0; const float* p1; const float* p2; const float* p3;
     float* q0; float* q1; float* q2;
+    /* optional (HOST pointer, read during the call): the step prologue of air_step_begin is run by
+     * an extra plane of workgroups of THIS launch.  Only for a GEMM that reads neither the noise nor
+     * dyn (the hoisted x.Wx): the train step then has no separate prologue launch. */
+    const air_step_job_t* step_job;
 } air_gemm_t;
 /* number of K-slabs a ksplit request produces for contraction depth K */
 int air_gemm_slabs(int K, int ksplit);

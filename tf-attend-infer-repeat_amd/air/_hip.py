@@ -37,6 +37,12 @@ class Schedule(C.Structure):
                 ("vmin", _f), ("vmax", _f)]
 
 
+class StepJob(C.Structure):
+    _fields_ = [("sched", _p), ("nsched", _i), ("dyn", _p), ("istate", _p),
+                ("normals", _p), ("n_normal", C.c_int64), ("uniforms", _p), ("n_uniform", C.c_int64),
+                ("seed", C.c_uint64)]
+
+
 class Gemm(C.Structure):
     _fields_ = [("A", _p), ("B", _p), ("C", _p),
                 ("M", _i), ("N", _i), ("K", _i), ("lda", _i), ("ldb", _i), ("ldc", _i),
@@ -44,7 +50,8 @@ class Gemm(C.Structure):
                 ("bias", _p), ("addend", _p), ("ldadd", _i), ("aux", _p), ("ldaux", _i),
                 ("aux_scale", _f), ("act", _i), ("actgrad", _i), ("accumulate", _i), ("precision", _i),
                 ("epi", _i), ("tile_m", _i), ("tile_n", _i), ("ksplit", _i), ("addend_slabs", _i), ("i0", _i),
-                ("p0", _p), ("p1", _p), ("p2", _p), ("p3", _p), ("q0", _p), ("q1", _p), ("q2", _p)]
+                ("p0", _p), ("p1", _p), ("p2", _p), ("p3", _p), ("q0", _p), ("q1", _p), ("q2", _p),
+                ("step_job", C.POINTER(StepJob))]
 
 
 class Colsum(C.Structure):

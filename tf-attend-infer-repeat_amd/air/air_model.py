@@ -382,19 +382,20 @@ class AIRModel:
     # ------------------------------------------------------------- launch lists
     def _gemm(self, A, Bm, Cm, M, N, K, lda, ldb, ldc, ta=0, tb=0, bias=None, addend=None, ldadd=0,
               aux=None, ldaux=0, aux_scale=0.0, act=H.ACT_NONE, actgrad=H.GRAD_NONE, accumulate=0, tag="gemm",
-              epi=H.EPI_GENERIC, tile=(0, 0), ksplit=0, addend_slabs=0, i0=0, p=(), q=(), extra_bytes=0):
+              epi=H.EPI_GENERIC, tile=(0, 0), ksplit=0, addend_slabs=0, i0=0, p=(), q=(), extra_bytes=0, step_job=None):
         p = list(p) + [None] * (4 - len(p))
         q = list(q) + [None] * (3 - len(q))
         g = H.Gemm(_ptr(A), _ptr(Bm), _ptr(Cm), M, N, K, lda, ldb, ldc, ta, tb, _ptr(bias), _ptr(addend), ldadd,
                    _ptr(aux), ldaux, aux_scale, act, actgrad, accumulate, self._prec,
                    epi, tile[0], tile[1], ksplit, addend_slabs, i0,
-                   _ptr(p[0]), _ptr(p[1]), _ptr(p[2]), _ptr(p[3]), _ptr(q[0]), _ptr(q[1]), _ptr(q[2]))
+                   _ptr(p[0]), _ptr(p[1]), _ptr(p[2]), _ptr(p[3]), _ptr(q[0]), _ptr(q[1]), _ptr(q[2]),
+                   C.pointer(step_job) if step_job is not None else None)
         fn = self.lib.air_gemm
         kbuf = C.create_string_buffer(96)
         H.check(self.lib.air_gemm_kernel_name(C.byref(g), kbuf, 96), "air_gemm_kernel_name")
         extra = (addend is not None) * max(1, addend_slabs) + (aux is not None) + (1 if accumulate else 0)
         return _Op("%s[%dx%dx%d%s]" % (tag, M, N, K, "t" if ta else ("n" + ("t" if tb else "n"))),
-                   lambda s, g=g, fn=fn: H.check(fn(C.byref(g), s), "air_gemm"),
+                   lambda s, g=g, fn=fn, keep=step_job: H.check(fn(C.byref(g), s), "air_gemm"),
                    nbytes=4 * (M * K + K * N + M * N * (1 + extra)) + (4 * N if bias is not None else 0) + extra_bytes,
                    flops=2 * M * N * K, kernel=kbuf.value.decode())
 
@@ -428,6 +429,14 @@ class AIRModel:
         # hoisted x.W_x (the reference recomputes it every step, :286); split-K slabs
         fwd.append(self._gemm(imgs, Wx, self.xw, B, 4 * R, D, D, 4 * R, 4 * R, ksplit=self._xw_ksplit,
                               tile=self._xw_tile, tag="xWx"))
+        # the same launch carrying the step prologue (schedules + Philox noise) as an extra plane of
+        # workgroups: x.Wx reads neither, so the train step needs no prologue launch of its own
+        job = H.StepJob(_ptr(self.sched), self._nsched, _ptr(self.dyn), _ptr(st.istate),
+                        _ptr(self.normals), self.normals.numel(), _ptr(self.uniforms), self.uniforms.numel(),
+                        self._seed)
+        self._xwx_with_begin = self._gemm(imgs, Wx, self.xw, B, 4 * R, D, D, 4 * R, 4 * R, ksplit=self._xw_ksplit,
+                                          tile=self._xw_tile, tag="xWx+step_begin", step_job=job,
+                                          extra_bytes=4 * (self.normals.numel() + self.uniforms.numel()))
         # the recurrence: N chained LSTM steps (the only sequential part of the loop -- the LSTM
         # sees the same image every step and nothing downstream feeds back into it, :286/:535)
         for t in range(N):
@@ -612,9 +621,14 @@ class AIRModel:
         self._dirty = True
 
     def _run_forward(self, s, finalize=True):
-        (self._begin_sched_only if self._injected_noise else self._begin)(s)
-        for op in self._fwd:
-            op(s)
+        if self._injected_noise or os.environ.get("AIR_SEPARATE_STEP_BEGIN") == "1":
+            (self._begin_sched_only if self._injected_noise else self._begin)(s)
+            for op in self._fwd:
+                op(s)
+        else:
+            self._xwx_with_begin(s)
+            for op in self._fwd[1:]:
+                op(s)
         if finalize:
             self._finalize(s)
 
@@ -673,7 +687,7 @@ class AIRModel:
 
     def train_step_ops(self):
         """The launches of one single-GPU train step, in order (bench / profiling tools)."""
-        return ([self._begin] + self._fwd + [self._write_bwd_fin] + self._bwd[1:] + [self._wgrad_fused]
+        return ([self._xwx_with_begin] + self._fwd[1:] + [self._write_bwd_fin] + self._bwd[1:] + [self._wgrad_fused]
                 + self._optimizer_ops())
 
     def _train_phase_a(self, s):

@@ -23,6 +23,7 @@
 //     chain); precision 1: operands rounded to bf16 while staging,
 //     v_mfma_f32_16x16x32_bf16, fp32 accumulate.
 #include "air_common.h"
+#include "air_philox.h"
 #include <cstdlib>
 #include <cstdio>
 
@@ -53,6 +54,9 @@ struct Args {
     const float* p0; const float* p1; const float* p2; const float* p3; const float* p4;
     float* q0; float* q1; float* q2; float* q3;
     int i0, i1;
+    // optional step prologue (schedules + Philox noise) carried by the workgroups of an extra grid.z
+    // plane: the hoisted x.Wx launch needs neither, so the prologue costs no launch of its own
+    int job_on; AirStepJob job;   // job_on = number of grid.z planes given to the prologue (0 = none)
 };
 
 // Epilogue operands (bias / addend / aux / LSTM state) are PREFETCHED into registers at kernel
@@ -298,11 +302,18 @@ __global__ __launch_bounds__(THREADS) void gemm_f32_kernel(Args a)
     __shared__ __attribute__((aligned(16))) float Bs[2][BKC * LB];
     __shared__ float Red[3 * TM * TN * 4 * 64];
 
+    if ((int)blockIdx.z < a.job_on) {                    // block-uniform: the prologue's planes of workgroups (dispatched first)
+        const long plane = (long)gridDim.x * gridDim.y;
+        air_step_job_run(a.job, blockIdx.z * plane + (long)blockIdx.y * gridDim.x + blockIdx.x, plane * a.job_on);
+        return;
+    }
+    const int nslab = (int)gridDim.z - a.job_on;
+    const int zslab = (int)blockIdx.z - a.job_on;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int tile_m, tile_n;
     xcd_tile(tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN / TN * (a.gstride == 16 ? TN : 1);
-    const int kbeg = blockIdx.z * a.kslab;
+    const int kbeg = zslab * a.kslab;
     const int kend = min(a.K, kbeg + a.kslab);
 
     f32x4 acc[TM][TN];
@@ -314,7 +325,7 @@ __global__ __launch_bounds__(THREADS) void gemm_f32_kernel(Args a)
     const bool vecA = ((a.lda & 3) == 0) && aligned16(a.A);
     const bool vecB = ((a.ldb & 3) == 0) && aligned16(a.B) && ((a.gstride & 3) == 0);
     Pre<TM, TN> pre;
-    if (gridDim.z == 1) epilogue_prefetch<TM, TN>(a, pre, m0, n0, lane, wave);
+    if (nslab == 1) epilogue_prefetch<TM, TN>(a, pre, m0, n0, lane, wave);
 
     auto loadA = [&](int k0, int i) -> float4 {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -468,9 +479,9 @@ __global__ __launch_bounds__(THREADS) void gemm_f32_kernel(Args a)
         }
     }
     reduce_waves<TM, TN>(acc, Red, lane, wave);
-    if (gridDim.z > 1) {
+    if (nslab > 1) {
         // split-K slab: plain store, the consumer sums the slabs
-        float* Cz = a.C + (size_t)blockIdx.z * a.slab_stride;
+        float* Cz = a.C + (size_t)zslab * a.slab_stride;
         for (int t = wave; t < TM * TN; t += 4) {
             const int i = t / TN, j = t % TN;
 #pragma unroll
@@ -501,11 +512,18 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16_kernel(Args a)
     __shared__ __attribute__((aligned(16))) unsigned short Bs[BN * LK];
     __shared__ float Red[3 * TM * TN * 4 * 64];
 
+    if ((int)blockIdx.z < a.job_on) {                    // block-uniform: the prologue's planes of workgroups (dispatched first)
+        const long plane = (long)gridDim.x * gridDim.y;
+        air_step_job_run(a.job, blockIdx.z * plane + (long)blockIdx.y * gridDim.x + blockIdx.x, plane * a.job_on);
+        return;
+    }
+    const int nslab = (int)gridDim.z - a.job_on;
+    const int zslab = (int)blockIdx.z - a.job_on;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int tile_m, tile_n;
     xcd_tile(tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN / TN * (a.gstride == 16 ? TN : 1);
-    const int kbeg = blockIdx.z * a.kslab;
+    const int kbeg = zslab * a.kslab;
     const int kend = min(a.K, kbeg + a.kslab);
 
     float ra[NA], rb[NB];
@@ -576,8 +594,8 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16_kernel(Args a)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
     }
     reduce_waves<TM, TN>(acc, Red, lane, wave);
-    if (gridDim.z > 1) {
-        float* Cz = a.C + (size_t)blockIdx.z * a.slab_stride;
+    if (nslab > 1) {
+        float* Cz = a.C + (size_t)zslab * a.slab_stride;
         for (int t = wave; t < TM * TN; t += 4) {
             const int i = t / TN, j = t % TN;
 #pragma unroll
@@ -652,11 +670,18 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16v2_kernel(Args a)
     unsigned short* ImgB = ImgA + R * BM * KB;                           // [R][BN][64]
     float* Red = reinterpret_cast<float*>(Lds);
 
+    if ((int)blockIdx.z < a.job_on) {                    // block-uniform: the prologue's planes of workgroups (dispatched first)
+        const long plane = (long)gridDim.x * gridDim.y;
+        air_step_job_run(a.job, blockIdx.z * plane + (long)blockIdx.y * gridDim.x + blockIdx.x, plane * a.job_on);
+        return;
+    }
+    const int nslab = (int)gridDim.z - a.job_on;
+    const int zslab = (int)blockIdx.z - a.job_on;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int tile_m, tile_n;
     xcd_tile(tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN / TN * (a.gstride == 16 ? TN : 1);
-    const int kbeg = blockIdx.z * a.kslab;
+    const int kbeg = zslab * a.kslab;
     const int kend = min(a.K, kbeg + a.kslab);
 
     f32x4 acc[TM][TN];
@@ -666,7 +691,7 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16v2_kernel(Args a)
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     Pre<TM, TN> pre;
-    if (gridDim.z == 1) epilogue_prefetch<TM, TN>(a, pre, m0, n0, lane, wave);
+    if (nslab == 1) epilogue_prefetch<TM, TN>(a, pre, m0, n0, lane, wave);
 
     const char* Ab = reinterpret_cast<const char*>(a.A);
     const char* Bb = reinterpret_cast<const char*>(a.B);
@@ -800,8 +825,8 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16v2_kernel(Args a)
     }
     __syncthreads();                                                      // Red aliases the images
     reduce_waves<TM, TN>(acc, Red, lane, wave);
-    if (gridDim.z > 1) {
-        float* Cz = a.C + (size_t)blockIdx.z * a.slab_stride;
+    if (nslab > 1) {
+        float* Cz = a.C + (size_t)zslab * a.slab_stride;
         for (int t = wave; t < TM * TN; t += 4) {
             const int i = t / TN, j = t % TN;
 #pragma unroll
@@ -842,11 +867,18 @@ __global__ __launch_bounds__(THREADS) void gemm_f32v2_kernel(Args a)
     float* ImgB = ImgA + R * BM * KB;                                    // [R][BN][64]
     float* Red = reinterpret_cast<float*>(Lds);
 
+    if ((int)blockIdx.z < a.job_on) {                    // block-uniform: the prologue's planes of workgroups (dispatched first)
+        const long plane = (long)gridDim.x * gridDim.y;
+        air_step_job_run(a.job, blockIdx.z * plane + (long)blockIdx.y * gridDim.x + blockIdx.x, plane * a.job_on);
+        return;
+    }
+    const int nslab = (int)gridDim.z - a.job_on;
+    const int zslab = (int)blockIdx.z - a.job_on;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int tile_m, tile_n;
     xcd_tile(tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN / TN * (a.gstride == 16 ? TN : 1);
-    const int kbeg = blockIdx.z * a.kslab;
+    const int kbeg = zslab * a.kslab;
     const int kend = min(a.K, kbeg + a.kslab);
 
     f32x4 acc[TM][TN];
@@ -856,7 +888,7 @@ __global__ __launch_bounds__(THREADS) void gemm_f32v2_kernel(Args a)
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     Pre<TM, TN> pre;
-    if (gridDim.z == 1) epilogue_prefetch<TM, TN>(a, pre, m0, n0, lane, wave);
+    if (nslab == 1) epilogue_prefetch<TM, TN>(a, pre, m0, n0, lane, wave);
 
     const char* Ab = reinterpret_cast<const char*>(a.A);
     const char* Bb = reinterpret_cast<const char*>(a.B);
@@ -997,8 +1029,8 @@ __global__ __launch_bounds__(THREADS) void gemm_f32v2_kernel(Args a)
     }
     __syncthreads();                                                      // Red aliases the images
     reduce_waves<TM, TN>(acc, Red, lane, wave);
-    if (gridDim.z > 1) {
-        float* Cz = a.C + (size_t)blockIdx.z * a.slab_stride;
+    if (nslab > 1) {
+        float* Cz = a.C + (size_t)zslab * a.slab_stride;
         for (int t = wave; t < TM * TN; t += 4) {
             const int i = t / TN, j = t % TN;
 #pragma unroll
@@ -1025,7 +1057,14 @@ int launch(const air_gemm_t* g, const Args& a0, hipStream_t s) {
     dim3 grid((ncols + (grouped ? 16 : BN) - 1) / (grouped ? 16 : BN), (a.M + BM - 1) / BM, 1);
     const int ks = g->ksplit > 1 ? g->ksplit : 1;
     a.kslab = ((a.K + ks - 1) / ks + 3) & ~3;
-    grid.z = (a.K + a.kslab - 1) / a.kslab;
+    if (a.job_on) {
+        // enough planes for ~1 quad of noise per thread (the prologue then ends well inside the GEMM)
+        const long quads = (a.job.n_normal + 3) / 4 + (a.job.n_uniform + 3) / 4;
+        const long plane = (long)grid.x * grid.y * THREADS;
+        long planes = (quads + plane - 1) / plane;
+        a.job_on = (int)(planes < 1 ? 1 : (planes > 16 ? 16 : planes));
+    }
+    grid.z = (a.K + a.kslab - 1) / a.kslab + a.job_on;
     a.slab_stride = (long)a.M * a.ldc;
     if (g->precision == 1) {
         const bool v2 = use_bf16_v2(a, TA, TB);
@@ -1143,6 +1182,15 @@ static int fill_args(const air_gemm_t* g, Args& a) {
     a.p0 = g->p0; a.p1 = g->p1; a.p2 = g->p2; a.p3 = g->p3; a.p4 = nullptr;
     a.q0 = g->q0; a.q1 = g->q1; a.q2 = g->q2; a.q3 = nullptr;
     a.i0 = g->i0; a.i1 = 0;
+    a.job_on = 0;
+    if (g->step_job) {
+        const air_step_job_t& j = *g->step_job;
+        if (!j.dyn || !j.istate || j.nsched < 0 || j.nsched > THREADS || (j.nsched > 0 && !j.sched)) return AIR_EINVAL;
+        if (j.n_normal < 0 || j.n_uniform < 0 || (j.n_normal > 0 && !j.normals) || (j.n_uniform > 0 && !j.uniforms)) return AIR_EINVAL;
+        a.job_on = 1;
+        a.job = AirStepJob{j.sched, j.nsched, j.dyn, j.istate, j.normals, (long)j.n_normal, j.uniforms, (long)j.n_uniform,
+                           (uint32_t)(j.seed & 0xffffffffu), (uint32_t)(j.seed >> 32)};
+    }
     switch (g->epi) {
         case AIR_EPI_LSTM_FWD:      // N = 4R gate columns, groups of R
             if (g->transA || g->transB || (g->N & 3) || !g->p0 || !g->q0 || !g->q1 || !g->q2) return AIR_EINVAL;

@@ -3,68 +3,16 @@
 // Both are pure HBM streams: float4 accesses, grid sized to fill 256 CUs,
 // deterministic two-level reduction for the global norm.
 #include "air_common.h"
+#include "air_philox.h"
 
 namespace {
 
 constexpr int THREADS = 256;
 constexpr int NORM_BLOCKS = 1024;      // partial sums; reduced again inside the Adam kernel
 
-// ---- Philox4x32-10 ---------------------------------------------------------
-__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
-    const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
-    const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
-    const uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
-    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-}
-__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        philox_round(c, k0, k1);
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-}
-__device__ __forceinline__ float u01_open_low(uint32_t x) { return ((float)(x >> 8) + 1.0f) * 5.9604644775390625e-8f; }  // (0,1]
-__device__ __forceinline__ float u01_half_open(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-8f; }          // [0,1)
-
-// air_model.py:94-121: exponential_decay(init, step, iters, factor, staircase) -> max(min) -> min(max) -> log(.+eps)
-__device__ float eval_schedule(const air_schedule_t& s, int step) {
-    float p = (float)step / s.iters;
-    if (s.flags & 1) p = floorf(p);
-    float v = s.init * powf(s.factor, p);
-    if (s.flags & 2) v = fmaxf(v, s.vmin);
-    if (s.flags & 4) v = fminf(v, s.vmax);
-    if (s.flags & 8) v = logf(v + AIR_EPS);
-    return v;
-}
-
-__global__ __launch_bounds__(THREADS) void step_begin_kernel(
-    const air_schedule_t* __restrict__ sched, int nsched, float* __restrict__ dyn,
-    const int32_t* __restrict__ istate, float* __restrict__ normals, long n_normal,
-    float* __restrict__ uniforms, long n_uniform, uint32_t seed_lo, uint32_t seed_hi)
+__global__ __launch_bounds__(THREADS) void step_begin_kernel(AirStepJob job)
 {
-    const int step = istate[AIR_IST_GLOBAL_STEP];
-    if (blockIdx.x == 0 && threadIdx.x < nsched) {
-        const air_schedule_t s = sched[threadIdx.x];
-        dyn[s.slot] = eval_schedule(s, step);
-    }
-    const long quads_n = (n_normal + 3) / 4, quads_u = (n_uniform + 3) / 4;
-    for (long q = (long)blockIdx.x * THREADS + threadIdx.x; q < quads_n + quads_u; q += (long)gridDim.x * THREADS) {
-        uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)step, 0x41495221u};
-        philox4x32_10(c, seed_lo, seed_hi);
-        float v[4];
-        if (q < quads_n) {
-            // Box-Muller on two pairs
-            const float r0 = sqrtf(-2.0f * logf(u01_open_low(c[0]))), a0 = 6.283185307179586f * u01_half_open(c[1]);
-            const float r1 = sqrtf(-2.0f * logf(u01_open_low(c[2]))), a1 = 6.283185307179586f * u01_half_open(c[3]);
-            v[0] = r0 * cosf(a0); v[1] = r0 * sinf(a0); v[2] = r1 * cosf(a1); v[3] = r1 * sinf(a1);
-            const long base = q * 4;
-            for (int k = 0; k < 4; ++k) if (base + k < n_normal) normals[base + k] = v[k];
-        } else {
-            const long base = (q - quads_n) * 4;
-            for (int k = 0; k < 4; ++k) if (base + k < n_uniform) uniforms[base + k] = u01_half_open(c[k]);
-        }
-    }
+    air_step_job_run(job, blockIdx.x, gridDim.x);
 }
 
 // sum of squares, NORM_BLOCKS partials (tf.clip_by_global_norm's 2*l2_loss terms)
@@ -167,9 +115,9 @@ extern "C" int air_step_begin(const air_schedule_t* sched, int nsched, float* dy
     long blocks = (quads + THREADS - 1) / THREADS;
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(step_begin_kernel, dim3((int)blocks), dim3(THREADS), 0, air_stream(stream),
-                       sched, nsched, dyn, istate, normals, (long)n_normal, uniforms, (long)n_uniform,
-                       (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32));
+    AirStepJob job{sched, nsched, dyn, istate, normals, (long)n_normal, uniforms, (long)n_uniform,
+                   (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32)};
+    hipLaunchKernelGGL(step_begin_kernel, dim3((int)blocks), dim3(THREADS), 0, air_stream(stream), job);
     AIR_CHECK_LAUNCH();
     return 0;
 }
