@@ -63,8 +63,11 @@ def per_kernel_times(model, iters):
     """HIP-event pair around every kernel launch of the train step, on the stream the
     kernels are launched on (eager pass, same buffers as the timed region)."""
     ops = [(o.name, o) for o in model.train_step_ops()]
-    acc = [0.0] * len(ops)
     s = model._stream()
+    # all iterations are enqueued before the single synchronize: the host runs ahead of the device,
+    # so an interval does not contain the host-side cost of a launch (the weight-gradient call
+    # fills a 1 KB descriptor table); the per-op MEDIAN over iterations drops the ramp-up ones
+    all_evs = []
     for _ in range(iters):
         evs = []
         for i, (name, op) in enumerate(ops):
@@ -73,9 +76,12 @@ def per_kernel_times(model, iters):
             op(s)
             e1.record()
             evs.append((e0, e1))
-        torch.cuda.synchronize()
-        for i, (e0, e1) in enumerate(evs):
-            acc[i] += e0.elapsed_time(e1) * 1e3           # us
+        all_evs.append(evs)
+    torch.cuda.synchronize()
+    acc = []
+    for i in range(len(ops)):
+        ts = sorted(evs[i][0].elapsed_time(evs[i][1]) * 1e3 for evs in all_evs)           # us
+        acc.append(ts[len(ts) // 2] * iters)
     # Each interval also contains the launch gap and the processing of its closing event record.
     # That per-launch overhead is calibrated live: the same eager step WITHOUT inner events, timed by
     # one outer event pair, is the sum of the kernels' in-situ durations (the stream never idles:
