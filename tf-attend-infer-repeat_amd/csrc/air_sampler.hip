@@ -188,9 +188,12 @@ __global__ __launch_bounds__(THREADS) void attend_fwd_kernel(air_attend_fwd_t a)
     // canvas (consumed last) rides under the head computation instead of following it
     const float* img = a.canvas + (size_t)b * C * C;
     constexpr int PF = 10;                                   // 2560 floats per pass: the 50x50 canvas in one
+    // a canvas beyond one pass (stress config: 128x128 = 64 KB per workgroup) is not prefetched whole:
+    // only the bounding box of the glimpse is read, once (s, x, y) are known
+    const bool whole = C * C <= PF * THREADS;
     float pf[PF];
 #pragma unroll
-    for (int k = 0; k < PF; ++k) { const int p = tid + k * THREADS; pf[k] = p < C * C ? img[p] : 0.0f; }
+    for (int k = 0; k < PF; ++k) { const int p = tid + k * THREADS; pf[k] = (whole && p < C * C) ? img[p] : 0.0f; }
     float eps_s = 0.f, eps_x = 0.f, eps_y = 0.f, u_t = 0.f, u_prev[MAX_STEPS];
     if (tid == 0) {
         eps_s = a.eps_scale[row]; eps_x = a.eps_shift[2 * row]; eps_y = a.eps_shift[2 * row + 1]; u_t = a.u[row];
@@ -207,9 +210,10 @@ __global__ __launch_bounds__(THREADS) void attend_fwd_kernel(air_attend_fwd_t a)
     const int gl = lane & 15, grp0 = wave * 4 + (lane >> 4);
     const float bo = (gl == 0 && grp0 < 7) ? a.bout[grp0] : 0.0f;
     const float bz = a.bout[6];
+    if (whole) {
 #pragma unroll
-    for (int k = 0; k < PF; ++k) { const int p = tid + k * THREADS; if (p < C * C) sh_img[p] = pf[k]; }
-    for (int p = tid + PF * THREADS; p < C * C; p += THREADS) sh_img[p] = img[p];      // larger canvases
+        for (int k = 0; k < PF; ++k) { const int p = tid + k * THREADS; if (p < C * C) sh_img[p] = pf[k]; }
+    }
     __syncthreads();
 
     AIR_STAMP(11);
@@ -305,13 +309,26 @@ __global__ __launch_bounds__(THREADS) void attend_fwd_kernel(air_attend_fwd_t a)
     if (tid < w) sh_tx[tid] = axis_tap(tid, w, C, s, sx);
     else if (tid >= 64 && tid < 64 + w) sh_ty[tid - 64] = axis_tap(tid - 64, w, C, s, sy);
     __syncthreads();
-    (void)sh_box;
+    int xlo = 0, ylo = 0, bw = C;
+    if (!whole) {
+        if (tid == 0) {
+            // taps are monotone in the output index (s > 0): the bounding box is set by the ends
+            sh_box[0] = min(sh_tx[0].i0, sh_tx[w - 1].i0); sh_box[1] = max(sh_tx[0].i1, sh_tx[w - 1].i1);
+            sh_box[2] = min(sh_ty[0].i0, sh_ty[w - 1].i0); sh_box[3] = max(sh_ty[0].i1, sh_ty[w - 1].i1);
+        }
+        __syncthreads();
+        xlo = sh_box[0]; bw = sh_box[1] - sh_box[0] + 1;
+        ylo = sh_box[2];
+        const int bh = sh_box[3] - sh_box[2] + 1;
+        for (int p = tid; p < bw * bh; p += THREADS) sh_img[p] = img[(ylo + p / bw) * C + xlo + p % bw];   // coalesced row segments
+        __syncthreads();
+    }
     AIR_STAMP(14);
     float* win = a.window + row * w * w;
     for (int p = tid; p < w * w; p += THREADS) {
         const int i = p / w, j = p % w;
         const Tap tx = sh_tx[j], ty = sh_ty[i];
-        const int r0 = ty.i0 * C, r1 = ty.i1 * C;
+        const int r0 = (ty.i0 - ylo) * bw - xlo, r1 = (ty.i1 - ylo) * bw - xlo;
         win[p] = bilinear4(tx, ty, sh_img[r0 + tx.i0], sh_img[r1 + tx.i0], sh_img[r0 + tx.i1], sh_img[r1 + tx.i1]);
     }
     AIR_STAMP(15);
@@ -344,9 +361,10 @@ __global__ __launch_bounds__(THREADS) void attend_bwd_kernel(air_attend_bwd_t a)
     const float* img = a.canvas + (size_t)b * C * C;
     const float* g = a.d_window + row * w * w;
     constexpr int PF = 10, GF = 4;
+    const bool whole = C * C <= PF * THREADS;            // larger canvases: bounding box only (see attend_fwd)
     float pf[PF], gf[GF];
 #pragma unroll
-    for (int k = 0; k < PF; ++k) { const int p = tid + k * THREADS; pf[k] = p < C * C ? img[p] : 0.0f; }
+    for (int k = 0; k < PF; ++k) { const int p = tid + k * THREADS; pf[k] = (whole && p < C * C) ? img[p] : 0.0f; }
 #pragma unroll
     for (int k = 0; k < GF; ++k) { const int p = tid + k * THREADS; gf[k] = p < w * w ? g[p] : 0.0f; }
     float pre_o7[8], pre_dw[4], pre_e[3], pre_dyn[AIR_DYN_COUNT], pre_at[AIR_ATT_STRIDE];
@@ -364,11 +382,24 @@ __global__ __launch_bounds__(THREADS) void attend_bwd_kernel(air_attend_bwd_t a)
     const float s = at[AIR_ATT_S], sx = at[AIR_ATT_X], sy = at[AIR_ATT_Y];
     if (tid < w) { float tv; sh_tx[tid] = axis_tap(tid, w, C, s, sx, &tv); sh_t[tid] = tv; }
     else if (tid >= 64 && tid < 64 + w) sh_ty[tid - 64] = axis_tap(tid - 64, w, C, s, sy);
+    if (whole) {
 #pragma unroll
-    for (int k = 0; k < PF; ++k) { const int p = tid + k * THREADS; if (p < C * C) sh_img[p] = pf[k]; }
-    for (int p = tid + PF * THREADS; p < C * C; p += THREADS) sh_img[p] = img[p];      // larger canvases
-    (void)sh_box;
+        for (int k = 0; k < PF; ++k) { const int p = tid + k * THREADS; if (p < C * C) sh_img[p] = pf[k]; }
+    }
     __syncthreads();
+    int xlo = 0, ylo = 0, bw = C;
+    if (!whole) {
+        if (tid == 0) {
+            sh_box[0] = min(sh_tx[0].i0, sh_tx[w - 1].i0); sh_box[1] = max(sh_tx[0].i1, sh_tx[w - 1].i1);
+            sh_box[2] = min(sh_ty[0].i0, sh_ty[w - 1].i0); sh_box[3] = max(sh_ty[0].i1, sh_ty[w - 1].i1);
+        }
+        __syncthreads();
+        xlo = sh_box[0]; bw = sh_box[1] - sh_box[0] + 1;
+        ylo = sh_box[2];
+        const int bh = sh_box[3] - sh_box[2] + 1;
+        for (int p = tid; p < bw * bh; p += THREADS) sh_img[p] = img[(ylo + p / bw) * C + xlo + p % bw];
+        __syncthreads();
+    }
 
     // d out / dX = (Ic-Ia)(y1-Y) + (Id-Ib)(Y-y0);  d out / dY = (Ib-Ia)(x1-X) + (Id-Ic)(X-x0)
     const float half_c = ((float)C - 1.001f) / 2.0f;     // dX/dx_s
@@ -376,7 +407,7 @@ __global__ __launch_bounds__(THREADS) void attend_bwd_kernel(air_attend_bwd_t a)
     for (int p = tid, k = 0; p < w * w; p += THREADS, ++k) {
         const int i = p / w, j = p % w;
         const Tap tx = sh_tx[j], ty = sh_ty[i];
-        const int r0 = ty.i0 * C, r1 = ty.i1 * C;
+        const int r0 = (ty.i0 - ylo) * bw - xlo, r1 = (ty.i1 - ylo) * bw - xlo;
         const float Ia = sh_img[r0 + tx.i0], Ib = sh_img[r1 + tx.i0], Ic = sh_img[r0 + tx.i1], Id = sh_img[r1 + tx.i1];
         const float gv = k < GF ? gf[k < GF ? k : 0] : g[p];
         float gX, gY;
