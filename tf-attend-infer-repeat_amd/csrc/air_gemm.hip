@@ -104,6 +104,18 @@ __device__ __forceinline__ void epilogue_prefetch(const Args& a, Pre<TM, TN>& pr
             pre.f[32 + j] = (ok && a.bias) ? a.bias[n] : 0.0f;
         }
         pre.f[36] = ok ? a.p0[(size_t)m * R + u] : 0.0f;
+    } else if (a.epi == AIR_EPI_REPARAM_FWD) {
+        const int Z = a.gwidth;
+        pre.f[0] = (ok && a.bias) ? a.bias[u] : 0.0f;
+        pre.f[1] = (ok && a.bias) ? a.bias[Z + u] : 0.0f;
+        pre.f[2] = ok ? a.p0[(size_t)m * Z + u] : 0.0f;
+    } else if (a.epi == AIR_EPI_REPARAM_BWD) {
+        const int Z = a.gwidth;
+        pre.f[0] = ok ? a.p0[(size_t)m * 2 * Z + u] : 0.0f;
+        pre.f[1] = ok ? a.p0[(size_t)m * 2 * Z + Z + u] : 0.0f;
+        pre.f[2] = ok ? a.p1[(size_t)m * Z + u] : 0.0f;
+        pre.f[3] = ok ? a.p2[(size_t)m * AIR_ATT_STRIDE + AIR_ATT_MASK] : 0.0f;
+        pre.f[4] = a.p3[AIR_DYN_GRAD_SCALE]; pre.f[5] = a.p3[AIR_DYN_VAE_PV]; pre.f[6] = a.p3[AIR_DYN_VAE_PM];
     } else if (a.epi == AIR_EPI_LSTM_BWD || a.epi == AIR_EPI_LSTM_BWD_TAIL) {
         const int R = a.gwidth;
         const int mm = m - (a.epi == AIR_EPI_LSTM_BWD_TAIL ? a.i0 : 0);      // row within the step's arrays
@@ -183,11 +195,11 @@ __device__ __forceinline__ void epilogue(const Args& a, const Pre<TM, TN>& pre, 
             // C = ml [M,2Z]; p0 = eps [M,Z]; q0 = zs [M,Z]
             if (TN == 2) {
                 const int Z = a.gwidth;
-                const float mean = v[0] + (a.bias ? a.bias[u] : 0.0f);
-                const float lv = v[1 % TN] + (a.bias ? a.bias[Z + u] : 0.0f);
+                const float mean = v[0] + pre.f[0];
+                const float lv = v[1 % TN] + pre.f[1];
                 a.C[(size_t)m * a.ldc + u] = mean;
                 a.C[(size_t)m * a.ldc + Z + u] = lv;
-                a.q0[(size_t)m * Z + u] = mean + a.p0[(size_t)m * Z + u] * sqrtf(expf(lv));
+                a.q0[(size_t)m * Z + u] = mean + pre.f[2] * sqrtf(expf(lv));
             }
         } else if (a.epi == AIR_EPI_LSTM_BWD || a.epi == AIR_EPI_LSTM_BWD_TAIL) {
             // v[0] (+ addend) = d loss / d h'.  p0 = acts, p1 = c_prev, p2 = c, p3 = dc_in (nullable)
@@ -219,14 +231,13 @@ __device__ __forceinline__ void epilogue(const Args& a, const Pre<TM, TN>& pre, 
         } else if (a.epi == AIR_EPI_REPARAM_BWD) {
             // v[0] = d loss / d z-sample.  p0 = ml [M,2Z], p1 = eps, p2 = att (mask), p3 = dyn; C = d_ml [M,2Z]
             const int Z = a.gwidth;
-            const float* r = a.p0 + (size_t)m * 2 * Z;
-            const float klg = a.p2[(size_t)m * AIR_ATT_STRIDE + AIR_ATT_MASK] * a.p3[AIR_DYN_GRAD_SCALE];
-            const float pv = a.p3[AIR_DYN_VAE_PV], pm = a.p3[AIR_DYN_VAE_PM];
-            const float var = expf(r[Z + u]);
+            const float klg = pre.f[3] * pre.f[4];
+            const float pv = pre.f[5], pm = pre.f[6];
+            const float var = expf(pre.f[1]);
             const float sd = sqrtf(var);
             const float d = v[0];
-            a.C[(size_t)m * a.ldc + u] = d + klg * (r[u] - pm) / pv;
-            a.C[(size_t)m * a.ldc + Z + u] = d * a.p1[(size_t)m * Z + u] * 0.5f * sd + klg * 0.5f * (var / pv - 1.0f);
+            a.C[(size_t)m * a.ldc + u] = d + klg * (pre.f[0] - pm) / pv;
+            a.C[(size_t)m * a.ldc + Z + u] = d * pre.f[2] * 0.5f * sd + klg * 0.5f * (var / pv - 1.0f);
         }
     }
 }
