@@ -488,7 +488,7 @@ class AIRModel:
             "air_step_begin", _ptr(self.sched), self._nsched, _ptr(self.dyn), _ptr(st.istate),
             None, 0, None, 0, C.c_uint64(self._seed))
         if not self.train:
-            self._bwd, self._opt, self._wgrad_branches = [], [], [[]]
+            self._bwd, self._opt, self._wgrad_plain = [], [], None
             return
 
         bwd = []
@@ -577,8 +577,8 @@ class AIRModel:
         keep.append(arr)
         wbytes = sum(4 * (q.M * q.N + q.K * (q.M + q.N)) for q in probs)
         wflops = sum(2 * q.M * q.N * q.K for q in probs)
-        self._wgrad_branches = [[self._call("air_wgrad_grouped", arr, len(probs), self._prec, None, None,
-                                            nbytes=wbytes, flops=wflops, tag="wgrad_grouped")]]
+        self._wgrad_plain = self._call("air_wgrad_grouped", arr, len(probs), self._prec, None, None,
+                                       nbytes=wbytes, flops=wflops, tag="wgrad_grouped")
         # single-GPU train step: the same launch also leaves the global-norm partial sums and counts
         # the step, so no separate pass over the 16 MB gradient is needed before Adam
         self._wgrad_blocks = self.lib.air_wgrad_num_blocks(arr, len(probs))
@@ -588,7 +588,6 @@ class AIRModel:
             raise NotImplementedError("weight-gradient launch of %d workgroups exceeds the partial-sum buffer" % self._wgrad_blocks)
         self._wgrad_fused = self._call("air_wgrad_grouped", arr, len(probs), self._prec, _ptr(st.partials),
                                        _ptr(st.istate), nbytes=wbytes, flops=wflops, tag="wgrad_grouped")
-        self._side_streams = None
 
         self._sqnorm = self._call("air_grad_sqnorm", _ptr(st.grads), st.n, _ptr(st.partials), _ptr(st.istate),
                                   nbytes=4 * st.n, tag="grad_sqnorm")
@@ -666,24 +665,7 @@ class AIRModel:
         if for_update and self._world() == 1:
             self._wgrad_fused(s)
             return
-        # fork: independent weight-grad branches on side streams; join before the optimizer
-        if os.environ.get("AIR_SIDE_STREAMS", "0") != "1":
-            for ops in self._wgrad_branches:
-                for op in ops:
-                    op(s)
-            return
-        if self._side_streams is None:
-            self._side_streams = [torch.cuda.Stream(self.input_images.device) for _ in self._wgrad_branches[1:]]
-        main = torch.cuda.current_stream(self.input_images.device)
-        for st_, ops in zip(self._side_streams, self._wgrad_branches[1:]):
-            st_.wait_stream(main)
-            sp = C.c_void_p(st_.cuda_stream)
-            for op in ops:
-                op(sp)
-        for op in self._wgrad_branches[0]:
-            op(s)
-        for st_ in self._side_streams:
-            main.wait_stream(st_)
+        self._wgrad_plain(s)
 
     def train_step_ops(self):
         """The launches of one single-GPU train step, in order (bench / profiling tools)."""
