@@ -456,3 +456,72 @@ def test_wgrad_grouped_head_pack(H, prec):
     kept = sum(float((wout[o, :offs[head[o] + 1] - offs[head[o]]].double() ** 2).sum()) for o in range(7))
     kept += float((bout.double() ** 2).sum())
     assert abs(float(part.double().sum()) - kept) <= 1e-5 * kept
+
+
+# --------------------------------------------------------------------------- un-fused entry points of the ABI
+def test_bce_fwd_bwd_matches_oracle_formula(H):
+    """air_model.py:580-593: clip, Bernoulli cross-entropy with +1e-9 inside the logs, and its gradient
+    (Minimum/Maximum pass their gradient at ties)."""
+    rng = np.random.RandomState(3)
+    B, D = 5, 2500
+    x = (rng.rand(B, D) * (rng.rand(B, D) > 0.8)).astype(np.float32)
+    R = rng.uniform(-0.2, 1.3, size=(B, D)).astype(np.float32)
+    R[0, :7] = [0.0, 1.0, -0.0, 0.5, 1.0000001, -1e-8, 0.25]            # ties and just-outside values
+    dyn = torch.zeros(H.DYN_COUNT, device="cuda")
+    dyn[H.DYN_GRAD_SCALE] = 1.0 / B
+    xt, Rt = torch.tensor(x, device="cuda"), torch.tensor(R, device="cuda")
+    rec = torch.full((B, D), float("nan"), device="cuda")
+    loss = torch.full((B,), float("nan"), device="cuda")
+    dR = torch.full((B, D), float("nan"), device="cuda")
+    H.check(H.lib().air_bce_fwd_bwd(_p(xt), _p(Rt), _p(dyn), _p(rec), _p(loss), _p(dR), B, D, _stream()))
+    torch.cuda.synchronize()
+    r = np.clip(R.astype(np.float64), 0.0, 1.0)
+    np.testing.assert_array_equal(rec.cpu().numpy(), np.clip(R, 0.0, 1.0))
+    p1, p0 = r.astype(np.float32) + np.float32(1e-9), (np.float32(1.0) - r.astype(np.float32)) + np.float32(1e-9)
+    want = -np.sum(x * np.log(p1.astype(np.float64)) + (1 - x) * np.log(p0.astype(np.float64)), axis=1)
+    np.testing.assert_allclose(loss.cpu().numpy(), want, rtol=2e-5)
+    g = -(x / p1.astype(np.float64) - (1 - x) / p0.astype(np.float64)) / B
+    g[(R > 1.0) | (R < 0.0)] = 0.0                                      # clipped away: no gradient
+    np.testing.assert_allclose(dR.cpu().numpy(), g, rtol=2e-4, atol=1e-7)      # fp32 difference of two quotients
+
+
+def test_colsum_problems(H):
+    rng = np.random.RandomState(4)
+    shapes = [(192, 512, 512), (64, 1024, 1024), (192, 100, 100), (7, 3, 5)]      # rows, cols, ld
+    keep, probs, want = [], [], []
+    for i, (rows, cols, ld) in enumerate(shapes):
+        src = rng.randn(rows, ld).astype(np.float32)
+        init = rng.randn(cols).astype(np.float32)
+        st, dt = torch.tensor(src, device="cuda"), torch.tensor(init, device="cuda")
+        acc = i % 2
+        keep += [st, dt]
+        probs.append(H.Colsum(_p(st), _p(dt), rows, cols, ld, acc))
+        want.append((dt, src[:, :cols].astype(np.float64).sum(0) + (init if acc else 0.0)))
+    arr = (H.Colsum * len(probs))(*probs)
+    H.check(H.lib().air_colsum(arr, len(probs), _stream()))
+    torch.cuda.synchronize()
+    for dt, w in want:
+        np.testing.assert_allclose(dt.cpu().numpy(), w, rtol=1e-5, atol=1e-4)
+
+
+def test_heads_out_wgrad_matches_grouped_launch(H):
+    """The stand-alone gradient of the 7 head output units equals the head_pack problem of the
+    grouped launch and the plain contraction."""
+    rng = np.random.RandomState(5)
+    K, Hs, Hh, Hz = 192, 64, 48, 16
+    HT, Hmax = 2 * Hs + 2 * Hh + Hz, max(Hs, Hh, Hz)
+    d7 = rng.randn(K, 8).astype(np.float32)
+    hid = rng.randn(K, HT).astype(np.float32)
+    dt, ht = torch.tensor(d7, device="cuda"), torch.tensor(hid, device="cuda")
+    dw = torch.zeros(7, Hmax, device="cuda")
+    db = torch.zeros(7, device="cuda")
+    H.check(H.lib().air_heads_out_wgrad(_p(dt), _p(ht), _p(dw), _p(db), K, Hs, Hh, Hz, Hmax, _stream()))
+    torch.cuda.synchronize()
+    full = d7.astype(np.float64).T @ hid.astype(np.float64)
+    offs = np.cumsum([0, Hs, Hs, Hh, Hh, Hz])
+    head = [0, 1, 2, 2, 3, 3, 4]
+    got = dw.cpu().numpy()
+    for o in range(7):
+        h = head[o]
+        np.testing.assert_allclose(got[o, :offs[h + 1] - offs[h]], full[o, offs[h]:offs[h + 1]], rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(db.cpu().numpy(), d7.astype(np.float64).sum(0)[:7], rtol=1e-5, atol=1e-4)
