@@ -284,6 +284,21 @@ def main():
                                                                 / MFMA_PEAK_TF[args.precision], 5)}
             line["kernels"] = {k: {"us_per_step": round(v["us"], 2), "launches": v["launches"], "ops": v["ops"]}
                                for k, v in ranked}
+        if not args.no_roofline and world == 1:
+            # secondary metric of SURVEY 8(d): inference (train=False forward, z_pres rounded) on the same batch
+            inf = am.AIRModel(model.input_images, model.target_num_digits, cnn=False, train=False, reuse=True,
+                              scope="air", annealing_schedules=ANNEAL, seed=rank, gemm_precision=args.precision, **hp)
+            for _ in range(20):
+                inf.forward()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(200):
+                inf.forward()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / 200
+            line["inference"] = {"images_per_sec": round(B / us * 1e6, 1), "us_per_forward": round(us, 1),
+                                 "launches": len(inf._fwd) + 1, "mode": "eager launches, train=False"}
         if not args.no_cpu_baseline and world == 1 and args.workload == "configs[1]":
             line["cpu_baseline"] = cpu_baseline(B)
         if world > 1 and ar is not None:
