@@ -56,7 +56,10 @@ def main():
         train=False, reuse=False, scope="air", gemm_precision=args.precision,
     )
     print("Restoring model...")
-    air_model.load_state_dict(torch.load(args.model, map_location="cpu"))
+    if os.path.exists(args.model + ".index"):                 # a TensorFlow bundle (the reference's model/air-model)
+        air_model.load_tf_checkpoint(args.model)
+    else:
+        air_model.load_state_dict(torch.load(args.model, map_location="cpu"))
     wrapper = ModelWrapper(air_model, None, test_data, CANVAS_SIZE, WINDOW_SIZE)
 
     digits, positions, recs, windows, latents, loss = wrapper.infer(list(images))

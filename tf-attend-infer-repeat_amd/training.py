@@ -111,6 +111,8 @@ def main():
     parser.add_argument("--print-every", type=int, default=1)
     parser.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
     parser.add_argument("--no-graph", action="store_true")
+    parser.add_argument("--tf-checkpoints", action="store_true",
+                        help="also write TensorFlow bundles models/air-model-<step>.{index,data-00000-of-00001} (tf.train.Saver layout)")
     parser.add_argument("--bg-path", default="", help="clutter background for the in-memory dataset (png, or file.npz:key)")
     parser.add_argument("--bg-max-intensity", type=float, default=1.0)
     parser.add_argument("--graph-steps", type=int, default=10, help="train steps per hipGraph replay when --print-every 0")
@@ -221,6 +223,8 @@ def main():
             scalars.flush()
         if step % SAVE_PARAMS_EACH_ITERATIONS == 0:
             torch.save(train_model.state_dict(), models_folder + "air-model-%d.pt" % step)
+            if args.tf_checkpoints:                                   # training.py:203-207 saver.save(..., global_step)
+                train_model.save_tf_checkpoint(models_folder + "air-model-%d" % step)
         if (step * BATCH_SIZE) // n_train != epoch:               # new epoch: reshuffle in place
             epoch = (step * BATCH_SIZE) // n_train
             perm.copy_(torch.randperm(n_train, device=dev, generator=gen))
@@ -238,6 +242,8 @@ def main():
     print("test accuracy {:.4f}  test loss {:.3f}  ({} iterations, {:.1f} s)".format(
         float(test_model.accuracy), float(test_model.loss), step, time.perf_counter() - t0))
     torch.save(train_model.state_dict(), models_folder + "air-model-%d.pt" % step)
+    if args.tf_checkpoints:
+        train_model.save_tf_checkpoint(models_folder + "air-model-%d" % step)
 
 
 if __name__ == "__main__":
