@@ -345,6 +345,9 @@ class AIRModel:
         self.c = f(N + 1, B, R); self.h = f(N + 1, B, R)         # [0] stays zero (zero_state :540)
 
         self._xw_ksplit, self._xw_tile = 8, (2, 2)
+        if os.environ.get("AIR_XW_TILE"):                    # tuning hook: "tm,tn,ksplit" (ksplit <= 8 slabs)
+            tm_, tn_, ks_ = (int(v) for v in os.environ["AIR_XW_TILE"].split(","))
+            self._xw_ksplit, self._xw_tile = ks_, (tm_, tn_)
         self._xw_slabs = self.lib.air_gemm_slabs(D, self._xw_ksplit)
         self.xw = f(self._xw_slabs, B, 4 * R)            # split-K slabs of the hoisted x.Wx
         self.gates_pre = f(B, 4 * R)
