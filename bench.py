@@ -151,6 +151,42 @@ def cpu_baseline(batch, seconds=15.0):
                        % (n, batch, dt, threads))
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU, RCCL)
+    and relay rank 0's JSON line.  The parent never touches the GPU (device_count() does not
+    initialise it) and never execs; it exits non-zero if any rank fails."""
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        sys.stderr.write("bench.py: --gpus %d requested but this node exposes %d GPU(s); refusing to report a "
+                         "%d-GPU number from fewer devices\n" % (n, have, n))
+        return 3
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    if any(rcs):
+        sys.stderr.write("bench.py: rank exit codes %r\n" % rcs)
+        return 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -166,13 +202,19 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node equal to --gpus)"
+                 % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        assert dist.get_world_size() == args.gpus
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -184,8 +226,10 @@ def main():
         B = 256 if args.batch == 64 else args.batch
     images, targets = synthetic_canvases(B, hp["canvas_size"], hp["max_digits"], seed=1000 + rank)
     model = am.AIRModel(torch.tensor(images, device=dev), torch.tensor(targets, device=dev), cnn=False,
-                        train=True, scope="air", annealing_schedules=ANNEAL, seed=rank,
+                        train=True, scope="air", annealing_schedules=ANNEAL, seed=0, noise_seed=rank,
                         gemm_precision=args.precision, **hp)
+    if world > 1:
+        model.sync_parameters()            # replicas start (and, with one shared all-reduce, stay) identical
     # several train steps per hipGraph replay (single GPU): amortises the replay's own launch cost
     gsteps = 1
     if not args.no_graph:
@@ -214,6 +258,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
     loss = float(model.loss)
+    replicas_identical = None
+    if world > 1:
+        # every rank applied the same all-reduced gradient to the same state: the parameters must be
+        # bit-identical across ranks after the run (int64 sum of the raw words, min == max over ranks)
+        chk = model.store.params.view(torch.int32).to(torch.int64).sum().reshape(1)
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        replicas_identical = bool(int(lo) == int(hi))
 
     # the step's only collective, timed on its own (all ranks take part): SURVEY 8(e) asks for its
     # duration and bus bandwidth against the 153 GB/s/link xGMI bound
@@ -303,6 +356,8 @@ def main():
             line["cpu_baseline"] = cpu_baseline(B)
         if world > 1 and ar is not None:
             line["allreduce"] = ar
+        if world > 1:
+            line["replicas_bit_identical"] = replicas_identical
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -102,6 +102,7 @@ class VariableStore:
         # global-norm partial sums: air_grad_sqnorm's fixed count, or one per weight-gradient workgroup
         self.partials = torch.zeros(max(H.lib().air_optim_num_partials(self.n), 16384), dtype=torch.float32, device=device)
         self.gnorm = torch.zeros(1, dtype=torch.float32, device=device)
+        self.synced_world = 1            # world size the replicas were last made identical for (AIRModel.sync_parameters)
 
         def views(buf):
             return OrderedDict((k, buf[self.offsets[k]:self.offsets[k] + int(np.prod(s))].view(*s))
@@ -203,7 +204,7 @@ class AIRModel:
                  z_pres_prior_log_odds=-2.0, z_pres_temperature=1.0, stopping_threshold=0.99,
                  learning_rate=1e-3, gradient_clipping_norm=100.0, cnn=True, cnn_filters=8,
                  num_summary_images=60, train=False, reuse=False, scope="air",
-                 annealing_schedules=None, seed=0, gemm_precision=None, backward="reference"):
+                 annealing_schedules=None, seed=0, gemm_precision=None, backward="reference", noise_seed=None):
         if cnn:
             # reference :510-533; every caller passes cnn=False (training.py:108, demo.py:24)
             raise NotImplementedError("cnn=True front-end is outside the accelerated hot path; pass cnn=False")
@@ -283,7 +284,10 @@ class AIRModel:
         self.variables = self.store.variables
         self.gradients = self.store.gradients
 
-        self._seed = seed + (0 if train else 7919)
+        # `seed` initialises the variables (identical on every data-parallel rank); `noise_seed`
+        # (default: seed) keys the device Philox stream -- DP ranks pass different ones, otherwise
+        # every shard would draw the same noise
+        self._seed = (seed if noise_seed is None else noise_seed) + (0 if train else 7919)
         self._injected_noise = False
         self._graph = None
         self._dirty = True
@@ -646,6 +650,18 @@ class AIRModel:
             return torch.distributed.get_world_size()
         return 1
 
+    def sync_parameters(self, src=0):
+        """Data parallel: every rank continues from rank `src`'s variables, Adam slots and global_step
+        (one broadcast each; DESIGN section 6 needs clip + Adam to run on identical state everywhere).
+        Called by capture_graph() / the first training() after the process group exists."""
+        world = self._world()
+        if world > 1:
+            st = self.store
+            for buf in (st.params, st.m, st.v, st.istate):
+                torch.distributed.broadcast(buf, src)
+        self.store.synced_world = world
+        self._dirty = True
+
     def _optimizer_ops(self):
         world = self._world()
         if self._opt_world != world:
@@ -696,6 +712,8 @@ class AIRModel:
             raise RuntimeError("capture_graph() is for train=True models")
         self._optimizer_ops()
         world = self._world()
+        if self.store.synced_world != world:
+            self.sync_parameters()
         if steps < 1 or (steps > 1 and world > 1):
             raise ValueError("multi-step graphs need world_size 1")
         self._graph_steps = steps
@@ -736,6 +754,8 @@ class AIRModel:
             raise RuntimeError("model was built with train=False")
         st = self.store
         world = self._world()
+        if self.store.synced_world != world:
+            self.sync_parameters()
         if self._graph is not None and not eager:
             ga, gb = self._graph
             ga.replay()
