@@ -4,14 +4,20 @@ Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
 leg may import this module.  The product path (``tf-attend-infer-repeat_amd/``)
 never imports it and fails loudly when the HIP library is missing.
 
-PARITY UNPINNED BY REFERENCE TESTS: the reference (aakhundov/tf-attend-infer-
-repeat) ships no tests, golden vectors or fixtures for this path and its
-arithmetic lives in TensorFlow 1.3.0 (un-vendored, not installable here: no
-cp310 wheel, no network).  This file is a numpy restatement that follows the
-reference sources op for op; TF-internal semantics that the sources do not show
-(LSTM gate order, forget bias, FC = BiasAdd + ReLU, Adam constants) are pinned
-by the reference's own serialized graph ``model/air-model.meta`` -- see
-``oracle/graphdef_pin.py`` and ``tests/golden/graphdef_facts.json``.
+PARITY PIN: the reference (aakhundov/tf-attend-infer-repeat) ships no tests, golden
+vectors or fixtures for this path, and its arithmetic lives in TensorFlow 1.3.0
+(un-vendored, not installable here: no cp310 wheel, no network) -- so no output
+of a RUNNING reference exists.  What does exist is the reference's own
+serialized training graph, ``model/air-model.meta`` (written by TF 1.3 after 270k
+iterations).  ``oracle/graphdef_exec.py`` executes that graph node by node in numpy
+(forward while-loop, loss, the whole tf.gradients backward, clip, ApplyAdam) and
+``tests/test_graph_exec.py`` asserts that this restatement is BIT-IDENTICAL to it in
+fp32 on every fetched output (train model B=64, test model at dynamic B, annealing,
+early loop exit), and equal to <= 2e-4 / 1e-9 on all 36 gradients / the Adam update
+in fp64.  ``tests/golden/graph_b64.npz`` holds vectors produced by that graph
+execution.  The pin is to the graph's dataflow and constants with numpy's
+elementary kernels -- not to the last-bit rounding of TF's Eigen kernels, which
+cannot be run here.
 
 Every function cites the reference file:line it follows (paths relative to
 /root/reference).  All arithmetic is done in ``dtype`` (np.float32 mirrors the

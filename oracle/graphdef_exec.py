@@ -234,19 +234,13 @@ def _strided_index(n, begin, end, strides):
 
 
 def _bcast_grad_args(s0, s1):
+    # tensorflow/core/util/bcast.cc: shapes right-aligned and padded with 1; an operand's gradient is
+    # summed over every axis where that operand has extent 1 (incl. axes where both have extent 1)
     s0, s1 = [int(x) for x in s0], [int(x) for x in s1]
     n = max(len(s0), len(s1))
     p0, p1 = [1] * (n - len(s0)) + s0, [1] * (n - len(s1)) + s1
-    r0 = [i for i in range(n) if p0[i] == 1 and not (p1[i] == 1 and i >= n - len(s0) and False)]
-    r1 = [i for i in range(n) if p1[i] == 1]
-    # TF reduces an axis of an operand when that operand has extent 1 there (or lacks the axis)
-    r0 = [i for i in range(n) if p0[i] == 1 and (p1[i] != 1 or i < n - len(s0))]
-    r1 = [i for i in range(n) if p1[i] == 1 and (p0[i] != 1 or i < n - len(s1))]
-    both1 = [i for i in range(n) if p0[i] == 1 and p1[i] == 1]
-    # axes where both are 1: TF lists them for both operands (harmless sums over extent 1)
-    r0 = sorted(set(r0) | set(both1))
-    r1 = sorted(set(r1) | set(both1))
-    return np.array(r0, np.int32), np.array(r1, np.int32)
+    return (np.array([i for i in range(n) if p0[i] == 1], np.int32),
+            np.array([i for i in range(n) if p1[i] == 1], np.int32))
 
 
 def _softplus(x):
@@ -454,15 +448,17 @@ class Executor:
             return a.astype(self.fd)
         return a
 
-    def run(self, fetches):
-        """evaluates the fetches ("node" / "node:i"; root-frame tensors) in a big-stack thread"""
+    def run(self, fetches, iters=None):
+        """evaluates the fetches ("node" / "node:i") in a big-stack thread.  Tensors inside a
+        while-loop frame need `iters` = {frame_name: iteration} (FWD_FRAME / BWD_FRAME below)."""
         out, err = {}, []
+        iters = dict(iters or {})
 
         def work():
             try:
                 for t in fetches:
                     name, idx = _split_input(t)[0]
-                    out[t] = self.ev(name, idx, {})
+                    out[t] = self.ev(name, idx, iters)
             except BaseException as e:              # noqa: BLE001 -- re-raised in the caller's thread
                 err.append(e)
         old = sys.getrecursionlimit()
@@ -608,6 +604,9 @@ class Executor:
 
 SCOPE = "air/rnn/"
 W = "air/rnn/while/"
+G = "air/training/gradients/"
+FWD_FRAME = "air/rnn/while/air/rnn/while/"
+BWD_FRAME = "air/training/gradients/air/rnn/while/air/rnn/while/"
 # the five unseeded RNG nodes of the loop body (air_model.py:127 x2, vae.py:23, 37, concrete.py:23)
 RNG_NODES = {
     "eps_scale": W + "scale/random_normal/RandomStandardNormal",
@@ -630,9 +629,13 @@ def air_feeds(nodes, params, images, targets, noise, global_step=0, adam=None, f
     for k, node in RNG_NODES.items():
         arr = np.asarray(noise[k], fd)
         feeds[node] = (lambda i, arr=arr: arr[i])
-    t = global_step
-    feeds["air/training/beta1_power"] = fd.type(0.9) ** fd.type(t + 1)
-    feeds["air/training/beta2_power"] = fd.type(0.999) ** fd.type(t + 1)
+    # the beta power accumulators after `global_step` updates: initialised to beta and multiplied by
+    # the (fp32) beta constant once per apply_gradients (tf.train.AdamOptimizer._finish)
+    b1p, b2p = np.float32(0.9), np.float32(0.999)
+    for _ in range(global_step):
+        b1p, b2p = b1p * np.float32(0.9), b2p * np.float32(0.999)
+    feeds["air/training/beta1_power"] = fd.type(b1p)
+    feeds["air/training/beta2_power"] = fd.type(b2p)
     for k, v in params.items():
         m, vv = (adam[k] if adam else (np.zeros_like(v), np.zeros_like(v)))
         feeds["air/training/" + SCOPE + k + "/Adam"] = np.asarray(m, fd)
@@ -640,9 +643,65 @@ def air_feeds(nodes, params, images, targets, noise, global_step=0, adam=None, f
     return feeds
 
 
-# what the reference's callers fetch (training.py:212-224, demo/model_wrapper.py:22-25) and where
-# those attributes live in the graph (names verified by tests/test_graph_exec.py)
-FORWARD_FETCHES = {
-    "loss": "air/loss/Mean", "accuracy": "air/accuracy/Mean",
-    "reconstruction": "air/loss/reconstruction/clipped_rec", "rec_num_digits": "air/rnn/while/Exit_4",
+def test_model_feeds(params, images, targets, noise, global_step=0, float_dtype=np.float32):
+    """feeds for the test model `air_1/` (reuse=True, train=False, dynamic batch: training.py:109-123)"""
+    fd = np.dtype(float_dtype)
+    feeds = {"pipeline/Placeholder": np.asarray(images, fd), "pipeline/Placeholder_1": np.asarray(targets, np.int32),
+             "air/global_step": np.int32(global_step)}
+    for k, v in params.items():
+        feeds[SCOPE + k] = np.asarray(v, fd)
+    for k, node in RNG_NODES.items():
+        arr = np.asarray(noise[k], fd)
+        feeds[node.replace("air/", "air_1/", 1)] = (lambda i, arr=arr: arr[i])
+    return feeds
+
+
+# The attributes the reference's callers fetch (training.py:212-224, demo/model_wrapper.py:22-25,
+# air_model.py:568-611) -> the tensor of the SAVED graph that holds them.  The graph was saved from a
+# slightly older source revision: loss / accuracy means live under summaries/, and `rec_windows_1`
+# (the latents array) holds the SAMPLE where air/vae.py:43 now returns the mean (SURVEY section 4).
+def output_tensors(scope="air"):
+    s = scope + "/"
+    return {
+        "loss": s + "summaries/loss", "accuracy": s + "summaries/accuracy",
+        "reconstruction": s + "loss/reconstruction/clipped_rec",
+        "reconstruction_loss": s + "loss/reconstruction/Neg",
+        "rec_num_digits": s + "rnn/while/Exit_6",
+        "rec_scales": s + "rec_scales", "rec_shifts": s + "rec_shifts", "rec_st_back": s + "rec_st_back",
+        "rec_windows": s + "rec_windows", "_graph_latent_samples": s + "rec_windows_1",
+        "z_pres_probs": s + "z_pres_probs", "z_pres_kls": s + "z_pres_kls", "scale_kls": s + "scale_kls",
+        "shift_kls": s + "shift_kls", "vae_kls": s + "vae_kls",
+        "z_pres_prior_log_odds": s + "z_pres_prior_log_odds_log",
+    }
+
+
+def adam_nodes(nodes):
+    """{variable name (relative to air/rnn/): ApplyAdam node}"""
+    return {n.inputs[0][0][len(SCOPE):]: n for n in nodes.values()
+            if n.op == "ApplyAdam" and n.name.startswith("air/")}
+
+
+def raw_gradient_tensor(nodes, adam_node):
+    """tensor name of the UNCLIPPED gradient of the variable an ApplyAdam node updates: its grad
+    input is clip_by_global_norm's `grad * scale` (air_model.py:673)"""
+    t = adam_node.inputs[9]
+    x = nodes[t[0]]
+    while x.op == "Identity":
+        t = x.inputs[0]
+        x = nodes[t[0]]
+    assert x.op == "Mul", x.op
+    return "%s:%d" % x.inputs[0]
+
+
+# tensors of the gradient loop body that are the interface of the two sampler backward kernels
+# (backward-frame iteration j <-> forward step T' - 1 - j)
+SAMPLER_BWD_TENSORS = {
+    "g_select": G + W + "canvas/add_grad/tuple/control_dependency_1",        # d loss / d (masked z*window_recon) [B,D]
+    "g_window_recon": G + W + "canvas/Reshape_grad/Reshape",                 # z * that, [B,C,C]
+    "d_z_canvas": G + W + "canvas/ExpandDims_grad/Reshape",                  # [B]
+    "d_vae_recon": G + W + "st_backward/Reshape_grad/Reshape",               # [B,d]: the UnsortedSegmentSum result
+    "d_theta_recon": G + W + "st_backward/SpatialTransformer/_transform/Reshape_grad/Reshape",   # [B,2,3]
+    "d_window": G + W + "st_forward/strided_slice_grad/StridedSliceGrad",    # [B,w,w,1] d loss / d glimpse
+    "d_theta": G + W + "st_forward/SpatialTransformer/_transform/Reshape_grad/Reshape",          # [B,2,3]
+    "d_scale": G + "AddN_24", "d_shift_x": G + "AddN_23", "d_shift_y": G + "AddN_25",           # [B] totals wrt s, x, y
 }
