@@ -229,8 +229,13 @@ typedef struct {
     float* d_hid;                        /* [N,B,HT] grad wrt pre-ReLU hidden */
     float* d_out7;                       /* [N,B,8]                         */
     int32_t B, N, C, w, Hs, Hh, Hz, wout_ld;
-    int32_t literal;                     /* 1: theta gradient in the reference's fp32 autodiff op order
-                                            (keeps the out-of-range rounding residue); 0: exact adjoint */
+    int32_t literal;                     /* 0: exact adjoint.
+                                            2: the op order of the reference's saved graph (model/air-model.meta):
+                                               AddN_10/11 (AddN_20/21) input order for the coordinate gradients and,
+                                               in air_write_bwd, ONE fp32 accumulator per window pixel through the four
+                                               concatenated Gather gradients (the graph's single UnsortedSegmentSum) --
+                                               keeps the out-of-range rounding residue, bit-identical to the executed graph.
+                                            1: per-tap partial sums added ((d+c)+b)+a (a much smaller residue)        */
 } air_attend_bwd_t;
 int air_attend_bwd(const air_attend_bwd_t* a, void* stream);
 

@@ -704,4 +704,23 @@ SAMPLER_BWD_TENSORS = {
     "d_window": G + W + "st_forward/strided_slice_grad/StridedSliceGrad",    # [B,w,w,1] d loss / d glimpse
     "d_theta": G + W + "st_forward/SpatialTransformer/_transform/Reshape_grad/Reshape",          # [B,2,3]
     "d_scale": G + "AddN_24", "d_shift_x": G + "AddN_23", "d_shift_y": G + "AddN_25",           # [B] totals wrt s, x, y
+    "d_gen_pre": G + W + "vae/gen_sample/Sigmoid_grad/SigmoidGrad",          # [B,d] grad wrt the decoder's pre-sigmoid output
+    "d_s_write_0": G + W + "st_backward/truediv_grad/tuple/control_dependency_1",     # the write's four legs into s
+    "d_s_write_1": G + W + "st_backward/truediv_1_grad/tuple/control_dependency_1",
+    "d_s_write_2": G + W + "st_backward/truediv_2_grad/tuple/control_dependency_1",
+    "d_s_write_3": G + W + "st_backward/truediv_3_grad/tuple/control_dependency_1",
+    "d_x_write": G + W + "st_backward/Neg_grad/Neg", "d_y_write": G + W + "st_backward/Neg_1_grad/Neg",
+    # gradients wrt the five head outputs (inputs of their BiasAddGrad nodes)
+    "d_out_scale_mean": G + "AddN_27", "d_out_scale_lv": G + "AddN_31", "d_out_shift_mean": G + "AddN_28",
+    "d_out_shift_lv": G + "AddN_32",
+    "d_out_z_log_odds": G + W + "z_pres/log_odds/output/strided_slice_grad/StridedSliceGrad",
+}
+# forward tensors of the loop body that the sampler kernels take as inputs
+SAMPLER_FWD_TENSORS = {
+    "z_pres": W + "z_pres/gumbel/Sigmoid", "z_pre": W + "z_pres/gumbel/truediv", "mask": W + "canvas/Less",
+    "mask_prev": W + "loss/z_pres_kl/Less", "vae_recon": W + "vae/gen_sample/Sigmoid",
+    "s": W + "scale/strided_slice", "x": W + "shift/strided_slice", "y": W + "shift/strided_slice_1",
+    "out_scale_mean": W + "scale/mean/output/BiasAdd", "out_scale_lv": W + "scale/log_variance/output/BiasAdd",
+    "out_shift_mean": W + "shift/mean/output/BiasAdd", "out_shift_lv": W + "shift/log_variance/output/BiasAdd",
+    "out_z_log_odds": W + "z_pres/log_odds/output/BiasAdd",
 }

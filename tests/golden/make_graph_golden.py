@@ -81,10 +81,8 @@ def main():
     # sampler-kernel interface tensors, per forward step t (backward iteration trips-1-t), first KB images
     for t in range(trips):
         j = trips - 1 - t
-        fw = ex.run([gx.W + "z_pres/gumbel/Sigmoid", gx.W + "canvas/Less", gx.W + "vae/gen_sample/Sigmoid",
-                     gx.W + "scale/strided_slice", gx.W + "shift/strided_slice", gx.W + "shift/strided_slice_1"],
-                    {gx.FWD_FRAME: t})
-        for k, v in zip(("z_pres", "mask", "vae_recon", "s", "x", "y"), fw):
+        fw = ex.run(list(gx.SAMPLER_FWD_TENSORS.values()), {gx.FWD_FRAME: t})
+        for k, v in zip(gx.SAMPLER_FWD_TENSORS, fw):
             out["kern/t%d/%s" % (t, k)] = np.asarray(v)[:KB]
         bw = ex.run(list(gx.SAMPLER_BWD_TENSORS.values()), {gx.BWD_FRAME: j})
         for k, v in zip(gx.SAMPLER_BWD_TENSORS, bw):

@@ -1,0 +1,252 @@
+"""HIP path vs vectors produced by EXECUTING the reference's own saved graph
+(tests/golden/graph_b64.npz, written by tests/golden/make_graph_golden.py from
+/root/reference/model/air-model.meta; the reference itself does not travel to the GPU box).
+
+  * whole model, fp32: forward outputs / ELBO vs the graph's (same tolerances as vs the oracle);
+    backward="exact" gradients and the clipped Adam update vs the graph evaluated in fp64;
+  * kernel level, identical inputs: `air_write_bwd(literal=2)` -- the default backward="reference" --
+    reproduces the graph's UnsortedSegmentSum result (d loss / d vae_recon, rounding residue of the
+    out-of-range taps included) BIT FOR BIT, and the gradients wrt (s, x, y, z_pres) to <= 1e-5;
+    `air_attend_bwd(literal=2)`: gradients wrt the seven head outputs vs the graph's AddN_27..32;
+  * whole model, backward="reference": per-variable gradient norms carry the same residue as the
+    graph's fp32 backward (the two differ element-wise only because upstream expf/logf/GEMM rounding
+    differs by an ulp, which the residue amplifies chaotically -- compared in magnitude).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import air_oracle as ao  # noqa: E402
+from oracle.synth import blob_canvases  # noqa: E402
+
+HP = dict(ao.TRAINING_HP)
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "graph_b64.npz")
+SEEDS = dict(images=3, params=0, noise=1)            # tests/golden/make_graph_golden.py
+KB, SUB = 16, 2048
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+@pytest.fixture(scope="module")
+def H():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from air import _hip
+    return _hip
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _cuda(a, dtype=torch.float32):
+    return torch.tensor(np.ascontiguousarray(a), dtype=dtype, device="cuda")
+
+
+def _inputs(batch=64, seed_images=SEEDS["images"], seed_noise=SEEDS["noise"]):
+    images, targets = blob_canvases(batch, HP["canvas_size"], HP["max_digits"], seed=seed_images)
+    return images, targets, ao.init_params(HP, SEEDS["params"]), ao.make_noise(HP, batch, seed_noise)
+
+
+def _subsample_index(name, numel):
+    if numel <= 2 * SUB:
+        return np.arange(numel)
+    h = 0
+    for ch in name:
+        h = (h * 131 + ord(ch)) % (2 ** 31 - 1)
+    return np.sort(np.random.RandomState(abs(h) % (2 ** 31)).choice(numel, SUB, replace=False))
+
+
+def _model(batch, train, lo, backward="exact", prec="fp32", **kw):
+    from air import air_model as am
+    images, targets, params, noise = _inputs(batch, **kw)
+    am.reset_default_graph()
+    m = am.AIRModel(_cuda(images), _cuda(targets, torch.int32), cnn=False, train=train, scope="air",
+                    gemm_precision=prec, backward=backward, **HP)
+    m.load_state_dict(params)
+    m.set_noise(noise)
+    m.set_dynamic(z_pres_prior_log_odds=float(lo))
+    return m, images, params
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------ whole model vs the graph
+
+@pytest.mark.parametrize("tag,batch,train,kw", [("train0", 64, True, {}),
+                                                ("train3000", 64, True, dict(seed_images=11, seed_noise=7)),
+                                                ("test40000_b4", 4, False, {})])
+def test_forward_matches_executed_graph(gold, tag, batch, train, kw):
+    m, images, _ = _model(batch, train, gold[tag + "/z_pres_prior_log_odds"], **kw)
+    m.forward()
+    torch.cuda.synchronize()
+    assert m.steps_executed == int(gold[tag + "/steps_executed"])
+    assert np.array_equal(_np(m.rec_num_digits), gold[tag + "/rec_num_digits"])
+    assert abs(float(m.accuracy) - float(gold[tag + "/accuracy"])) < 1e-6
+    assert abs(float(m.loss) - float(gold[tag + "/loss"])) / abs(float(gold[tag + "/loss"])) <= 1e-2
+    for k in ("z_pres_kls", "vae_kls"):
+        np.testing.assert_allclose(_np(getattr(m, k)), gold[tag + "/" + k], rtol=2e-4, atol=2e-4)
+    if tag != "train3000":
+        assert np.abs(_np(m.reconstruction) - gold[tag + "/reconstruction"]).max() <= 2e-5
+        for k in ("rec_scales", "rec_shifts", "rec_st_back", "z_pres_probs", "scale_kls", "shift_kls"):
+            g = gold[tag + "/" + k]
+            assert np.abs(_np(getattr(m, k)) - g).max() <= 5e-5 * max(1.0, np.abs(g).max()), k
+    if tag == "train0":
+        assert np.abs(_np(m.rec_windows)[:KB] - gold["train0/rec_windows_first"]).max() <= 5e-5
+    if tag == "test40000_b4":
+        assert np.abs(_np(m.rec_windows) - gold[tag + "/rec_windows"]).max() <= 5e-5
+
+
+def test_exact_backward_and_adam_match_graph_fp64(gold):
+    m, images, params = _model(64, True, gold["train0/z_pres_prior_log_odds"], backward="exact")
+    p0 = {k: _np(v).astype(np.float64) for k, v in m.variables.items()}
+    m.training()
+    torch.cuda.synchronize()
+    worst = {}
+    for k, g in m.gradients.items():
+        idx = _subsample_index(k, g.numel())
+        got = _np(g).reshape(-1)[idx].astype(np.float64)
+        ref = gold["train0/grad64_sub/" + k]
+        worst[k] = np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30)
+        tol = 2e-2 if k.startswith(("z_pres/", "rnn/")) else 5e-3
+        assert worst[k] < tol, (k, worst[k])
+    gn = float(m.store.gnorm[0])
+    assert abs(gn - float(gold["train0/global_norm_fp64"])) / float(gold["train0/global_norm_fp64"]) < 2e-3
+    for k, v in m.variables.items():
+        idx = _subsample_index(k, v.numel())
+        d = (_np(v).astype(np.float64) - p0[k]).reshape(-1)[idx]
+        ref = gold["train0/adam64_delta_sub/" + k]
+        if np.linalg.norm(ref) > 0:
+            # first Adam step: every element moves by ~lr * sign(g); elements with g ~ 0 may flip
+            assert np.linalg.norm(d - ref) / np.linalg.norm(ref) < 5e-2, k
+
+
+def test_reference_backward_carries_the_graphs_residue(gold):
+    """backward="reference": same order of magnitude per variable as the graph's own fp32 backward
+    (|g| 1.6e6 against 1.1e3 exact at initialisation), far above what the exact adjoint gives."""
+    m, _, _ = _model(64, True, gold["train0/z_pres_prior_log_odds"], backward="reference")
+    m.training()
+    torch.cuda.synchronize()
+    gn = float(m.store.gnorm[0])
+    ref = float(gold["train0/global_norm_fp32"])
+    assert 0.25 < gn / ref < 4.0, (gn, ref)
+    for k, g in m.gradients.items():
+        if g.numel() < 16:
+            continue                      # one- and two-element biases: a single residue realisation each
+        a, b = float(g.double().norm()), float(gold["train0/grad32_norm/" + k])
+        assert 0.2 < a / b < 5.0, (k, a, b)
+    # the heads of z_pres see no sampler residue: they agree with the exact math
+    for k in ("z_pres/log_odds/output/biases", "z_pres/log_odds/output/weights"):
+        a, b = float(m.gradients[k].double().norm()), float(gold["train0/grad64_norm/" + k])
+        assert abs(a - b) / b < 0.1, (k, a, b)
+
+
+# ------------------------------------------------------------------ kernel level, identical inputs
+
+def _att(H, gold, N):
+    att = np.zeros((N, KB, H.ATT_STRIDE), np.float32)
+    for t in range(N):
+        k = "kern/t%d/" % t
+        att[t, :, H.ATT_S], att[t, :, H.ATT_X], att[t, :, H.ATT_Y] = gold[k + "s"], gold[k + "x"], gold[k + "y"]
+        att[t, :, H.ATT_Z], att[t, :, H.ATT_ZPRE] = gold[k + "z_pres"], gold[k + "z_pre"]
+        att[t, :, H.ATT_MASK] = gold[k + "mask"].astype(np.float32)
+        att[t, :, H.ATT_MASK_PREV] = gold[k + "mask_prev"].astype(np.float32)
+    return att
+
+
+def test_write_bwd_reproduces_the_graphs_scatter_bit_for_bit(H, gold):
+    N, Cc, w = int(gold["train0/steps_executed"]), HP["canvas_size"], HP["windows_size"]
+    att = _cuda(_att(H, gold, N))
+    # d loss / d running_recon is the same tensor at every step (the canvas is a running sum)
+    g_sel = np.zeros((KB, Cc * Cc), np.float32)
+    for t in range(N):
+        act = gold["kern/t%d/mask" % t].astype(bool)
+        g_sel[act] = gold["kern/t%d/g_select" % t].reshape(KB, -1)[act]
+    d_recon = _cuda(g_sel)
+    vrec = _cuda(np.stack([gold["kern/t%d/vae_recon" % t] for t in range(N)]))
+    dgen = torch.full((N, KB, w * w), 7.0, device="cuda")
+    dsx = torch.full((N, KB, 4), 7.0, device="cuda")
+    wb = H.WriteBwd(_p(d_recon), _p(vrec), _p(att), _p(dgen), _p(dsx), KB, N, Cc, w, 2, None, None, None, None)
+    H.check(H.lib().air_write_bwd(C.byref(wb), _stream()), "air_write_bwd")
+    torch.cuda.synchronize()
+    dgen, dsx = _np(dgen), _np(dsx)
+    n_active = 0
+    for t in range(N):
+        k = "kern/t%d/" % t
+        act = gold[k + "mask"].astype(bool)
+        n_active += int(act.sum())
+        ref = gold[k + "d_gen_pre"].reshape(KB, -1)
+        # inactive items: Select(active, ., 0) passes no gradient
+        assert not dgen[t][~act].any() and not dsx[t][~act].any()
+        assert not ref[~act].any()
+        # active items: the UnsortedSegmentSum accumulation order, bit for bit (residue included)
+        assert np.array_equal(dgen[t][act], ref[act]), (t, float(np.abs(dgen[t][act] - ref[act]).max()))
+        assert np.abs(ref[act]).max() > 1.0          # the residue is there: the exact gradient is ~1e-2
+        # theta_recon legs: reductions over 2500 pixels (order differs from numpy's matmul) -> 1e-5
+        ds_ref = ((gold[k + "d_s_write_0"] + gold[k + "d_s_write_1"]) + gold[k + "d_s_write_2"]) + gold[k + "d_s_write_3"]
+        for got, ref1, nm in ((dsx[t, :, 0], ds_ref, "ds"), (dsx[t, :, 1], gold[k + "d_x_write"], "dx"),
+                              (dsx[t, :, 2], gold[k + "d_y_write"], "dy"), (dsx[t, :, 3], gold[k + "d_z_canvas"], "dz")):
+            scale = np.abs(ref1[act]).max()
+            assert np.abs(got[act] - ref1[act]).max() <= 2e-5 * scale, (t, nm, got[act], ref1[act])
+    assert n_active >= KB
+
+
+def test_attend_bwd_matches_graph_head_gradients(H, gold):
+    N, Cc, w = int(gold["train0/steps_executed"]), HP["canvas_size"], HP["windows_size"]
+    images, targets, params, noise = _inputs()
+    Hs = Hh = Hz = 64
+    HT = 2 * Hs + 2 * Hh + Hz
+    att = _cuda(_att(H, gold, N))
+    out7 = np.zeros((N, KB, H.OUT_STRIDE), np.float32)
+    d_win = np.zeros((N, KB, w * w), np.float32)
+    d_sxyw = np.zeros((N, KB, 4), np.float32)
+    for t in range(N):
+        k = "kern/t%d/" % t
+        out7[t, :, 0], out7[t, :, 1] = gold[k + "out_scale_mean"][:, 0], gold[k + "out_scale_lv"][:, 0]
+        out7[t, :, 2:4], out7[t, :, 4:6] = gold[k + "out_shift_mean"], gold[k + "out_shift_lv"]
+        out7[t, :, 6] = gold[k + "out_z_log_odds"][:, 0]
+        d_win[t] = gold[k + "d_window"].reshape(KB, -1)
+        ds = ((gold[k + "d_s_write_0"] + gold[k + "d_s_write_1"]) + gold[k + "d_s_write_2"]) + gold[k + "d_s_write_3"]
+        d_sxyw[t] = np.stack([ds, gold[k + "d_x_write"], gold[k + "d_y_write"], gold[k + "d_z_canvas"]], 1)
+    dyn = np.zeros(H.DYN_COUNT, np.float32)
+    dyn[H.DYN_PRIOR_LOG_ODDS] = gold["train0/z_pres_prior_log_odds"]
+    dyn[H.DYN_TEMPERATURE], dyn[H.DYN_STOP_THRESHOLD] = HP["z_pres_temperature"], HP["stopping_threshold"]
+    dyn[H.DYN_SCALE_PM], dyn[H.DYN_SCALE_PV] = HP["scale_prior_mean"], HP["scale_prior_variance"]
+    dyn[H.DYN_SHIFT_PM], dyn[H.DYN_SHIFT_PV] = HP["shift_prior_mean"], HP["shift_prior_variance"]
+    dyn[H.DYN_VAE_PM], dyn[H.DYN_VAE_PV] = HP["vae_prior_mean"], HP["vae_prior_variance"]
+    dyn[H.DYN_GRAD_SCALE] = 1.0 / 64                     # the graph's batch: d mean / d item
+    hid = torch.ones(N, KB, HT, device="cuda")
+    wout = torch.zeros(7, 64, device="cuda")
+    d_hid = torch.zeros(N, KB, HT, device="cuda")
+    d_out7 = torch.zeros(N, KB, H.OUT_STRIDE, device="cuda")
+    # (device tensors are kept in named variables: the ABI takes raw pointers)
+    canvas, e_s, e_h = _cuda(images[:KB]), _cuda(noise["eps_scale"][:N, :KB]), _cuda(noise["eps_shift"][:N, :KB])
+    dyn_d, out7_d, d_win_d, d_sxyw_d = _cuda(dyn), _cuda(out7), _cuda(d_win), _cuda(d_sxyw)
+    ab = H.AttendBwd(_p(hid), _p(wout), _p(canvas), _p(e_s), _p(e_h), _p(dyn_d), _p(out7_d), _p(att),
+                     _p(d_win_d), _p(d_sxyw_d), _p(d_hid), _p(d_out7), KB, N, Cc, w, Hs, Hh, Hz, 64, 2)
+    H.check(H.lib().air_attend_bwd(C.byref(ab), _stream()), "air_attend_bwd")
+    torch.cuda.synchronize()
+    got = _np(d_out7)
+    for t in range(N):
+        k = "kern/t%d/" % t
+        ref = np.concatenate([gold[k + "d_out_scale_mean"].reshape(KB, 1), gold[k + "d_out_scale_lv"].reshape(KB, 1),
+                              gold[k + "d_out_shift_mean"].reshape(KB, 2), gold[k + "d_out_shift_lv"].reshape(KB, 2),
+                              gold[k + "d_out_z_log_odds"].reshape(KB, 1)], axis=1)
+        # totals wrt (s, x, y) first: the read's theta gradient + the write legs (AddN_23..25)
+        for o in range(7):
+            scale = max(np.abs(ref[:, o]).max(), 1e-6)
+            assert np.abs(got[t, :, o] - ref[:, o]).max() <= 1e-4 * scale, (t, o, got[t, :, o], ref[:, o])

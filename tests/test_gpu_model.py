@@ -262,9 +262,11 @@ def test_annealed_training_runs_and_loss_drops(am):
     REPORT["train60_losses"] = losses
 
 
-def test_reference_backward_carries_the_fp32_residue(am):
-    """backward="reference" evaluates the sampler gradients in the fp32 autodiff op order of the
-    reference (four Gather_grad scatters, per-product (x1-x)/(x-x0) nodes).  At out-of-range taps
+def test_taps_backward_matches_the_torch_autograd_twin_residue(am):
+    """backward="taps" evaluates the sampler gradients the way torch-CPU fp32 autograd orders them
+    (four separate Gather_grad scatters added ((d+c)+b)+a, per-product (x1-x)/(x-x0) nodes); the
+    reference's own graph order -- backward="reference" -- is pinned in tests/test_gpu_graph_golden.py
+    against the executed graph and carries a ~400x larger residue.  At out-of-range taps
     the +/- pairs cancel only to rounding and are multiplied by g ~ 1/(r + 1e-9): the where-heads,
     the LSTM and the VAE decoder then receive gradients several times the exact ones -- same
     orders of magnitude as the torch-fp32 autograd twin of the reference graph."""
@@ -274,7 +276,7 @@ def test_reference_backward_carries_the_fp32_residue(am):
     images, targets = ds["train_images"][:B], ds["train_digits"][:B]
     params, noise = ao.init_params(HP, 0), ao.make_noise(HP, B, 5)
     norms = {}
-    for mode in ("reference", "exact"):
+    for mode in ("taps", "exact"):
         am.reset_default_graph()
         m = am.AIRModel(torch.tensor(images, device="cuda"), torch.tensor(targets, device="cuda"), cnn=False,
                         train=True, backward=mode, **HP)
@@ -289,7 +291,8 @@ def test_reference_backward_carries_the_fp32_residue(am):
     pt = at.to_torch(params, requires_grad=True)
     _, g32 = at.loss_and_grads(pt, torch.tensor(images), torch.tensor(targets), at.to_torch(noise), HP, 9.21)
     n32 = {k: float(v.norm()) for k, v in g32.items()}
-    REPORT["residue_norms"] = {k: [norms["reference"][k], norms["exact"][k], n32[k]] for k in n32}
+    norms["reference"] = norms["taps"]
+    REPORT["residue_norms"] = {k: [norms["taps"][k], norms["exact"][k], n32[k]] for k in n32}
     # Which tensors carry most residue depends on the images (ink mass): with the 16x16 glyphs the
     # decoder was 7-8x the exact norm, with the 12x12 default the LSTM kernel and the scale head are
     # (7x) and the decoder 1.3x.  Data-independent statements: (a) several tensors are far above
@@ -317,7 +320,7 @@ def test_reference_backward_learns_exact_does_not(am):
     td = torch.tensor(ds["train_digits"], device=dev)
     hp = dict(HP, learning_rate=1e-3)
     out = {}
-    for mode in ("reference", "exact"):
+    for mode in ("reference", "taps", "exact"):
         am.reset_default_graph()
         xin = torch.zeros(64, 2500, device=dev)
         tin = torch.zeros(64, dtype=torch.int32, device=dev)
@@ -335,8 +338,8 @@ def test_reference_backward_learns_exact_does_not(am):
                 rec.append(float(m.reconstruction_loss.mean()))
         out[mode] = float(np.mean(rec))
     REPORT["rec_loss_after_1500_steps"] = out
-    assert out["reference"] < 600.0, out
-    assert out["exact"] > 2.0 * out["reference"], out
+    assert out["reference"] < 600.0 and out["taps"] < 600.0, out
+    assert out["exact"] > 2.0 * max(out["reference"], out["taps"]), out
 
 
 def test_reference_and_exact_backward_agree_without_residues(am):
@@ -344,7 +347,7 @@ def test_reference_and_exact_backward_agree_without_residues(am):
     d loss / d canvas stays O(1) and the fp32 residue of the out-of-range taps is ~1e-7 of it) the
     reference-order backward must equal the exact adjoint to rounding, for every variable."""
     grads = {}
-    for mode in ("exact", "reference"):
+    for mode in ("exact", "reference", "taps"):
         model, *_ = _make(am, 64, True, blank=True, backward=mode)
         s = model._stream()
         model._run_forward(s)
@@ -353,7 +356,9 @@ def test_reference_and_exact_backward_agree_without_residues(am):
         grads[mode] = {k: v.detach().cpu().double().clone() for k, v in model.gradients.items()}
     worst = 0.0
     for k, ge in grads["exact"].items():
-        err = float((grads["reference"][k] - ge).norm() / (ge.norm() + 1e-30))
-        worst = max(worst, err)
-        assert err <= 2e-4, (k, err)
+        for mode in ("reference", "taps"):
+            err = float((grads[mode][k] - ge).norm() / (ge.norm() + 1e-30))
+            worst = max(worst, err)
+            # the graph-order accumulator keeps a larger residue than the per-tap sums even here
+            assert err <= (2e-3 if mode == "reference" else 2e-4), (mode, k, err)
     REPORT["reference_vs_exact_smooth_regime_worst_rel"] = worst

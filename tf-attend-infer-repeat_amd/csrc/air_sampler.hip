@@ -75,6 +75,20 @@ __device__ __forceinline__ void literal_dxy(float g, float Ia, float Ib, float I
     dys = (dY / 2.0f) * cx;
 }
 
+// The same gradient in the op order of the reference's SAVED graph (model/air-model.meta, executed by
+// oracle/graphdef_exec.py): d wa..wd = g*Ia..Id (mul_10..13_grad), each product's two factors get
+// grad*other (mul_6..9_grad), the Sub nodes negate the (x1-x)/(y1-y) legs, and the four legs that
+// reach x (y) are summed by AddN_10 / AddN_20 (AddN_11 / AddN_21) left to right in the order
+// wa, wb, wc, wd.  Then x = (x_s + 1)*(W - 1.001)/2: truediv_grad then mul_grad.
+__device__ __forceinline__ void graph_dxy(float g, float Ia, float Ib, float Ic, float Id,
+                                          const Tap& tx, const Tap& ty, float cx, float& dxs, float& dys) {
+    const float ga = g * Ia, gb = g * Ib, gc = g * Ic, gd = g * Id;
+    const float dX = ((-(ga * ty.w0) + -(gb * ty.w1)) + gc * ty.w0) + gd * ty.w1;
+    const float dY = ((-(tx.w0 * ga) + tx.w0 * gb) + -(tx.w1 * gc)) + tx.w1 * gd;
+    dxs = (dX / 2.0f) * cx;
+    dys = (dY / 2.0f) * cx;
+}
+
 // inclusive segmented scan inside a wave: lanes with equal (contiguous) keys are summed in a fixed
 // tree order; the last lane of each run holds the run's total
 __device__ __forceinline__ float seg_scan(float v, int key, int lane) {
@@ -411,7 +425,8 @@ __global__ __launch_bounds__(THREADS) void attend_bwd_kernel(air_attend_bwd_t a)
         const float Ia = sh_img[r0 + tx.i0], Ib = sh_img[r1 + tx.i0], Ic = sh_img[r0 + tx.i1], Id = sh_img[r1 + tx.i1];
         const float gv = k < GF ? gf[k < GF ? k : 0] : g[p];
         float gX, gY;
-        if (a.literal) literal_dxy(gv, Ia, Ib, Ic, Id, tx, ty, (float)C - 1.001f, gX, gY);
+        if (a.literal == 2) graph_dxy(gv, Ia, Ib, Ic, Id, tx, ty, (float)C - 1.001f, gX, gY);
+        else if (a.literal) literal_dxy(gv, Ia, Ib, Ic, Id, tx, ty, (float)C - 1.001f, gX, gY);
         else {
             gX = gv * ((Ic - Ia) * ty.w0 + (Id - Ib) * ty.w1) * half_c;
             gY = gv * ((Ib - Ia) * tx.w0 + (Id - Ic) * tx.w1) * half_c;
@@ -842,6 +857,186 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_kernel(air_write_bwd_t a
     AIR_STAMP(6);
 }
 
+
+// ---------------------------------------------------------------------------
+// write backward in the op order of the reference's SAVED graph (literal == 2; the default
+// backward="reference" of AIRModel).  What the graph does with d loss / d window_recon
+// (model/air-model.meta, executed node by node by oracle/graphdef_exec.py):
+//   * the four Gather gradients (taps a=(y0,x0), b=(y1,x0), c=(y0,x1), d=(y1,x1)) are CONCATENATED and
+//     reduced by ONE UnsortedSegmentSum: every window pixel ("slot") is a single fp32 accumulator
+//     that receives its a-terms in canvas-pixel order, then its b-, c- and d-terms.  The terms of an
+//     out-of-range canvas pixel cancel exactly in real arithmetic (both taps clip to one border
+//     index), but not in this accumulation order: the border slots keep a rounding residue of
+//     ~ulp(sum of |terms|), which at unexplained ink (d log(r + 1e-9) ~ 1e9/B) is orders of magnitude
+//     above the exact gradient -- that residue is part of the reference's training signal
+//     (tests/golden/graph_b64.npz: |g| 1.6e6 in fp32 vs 1.1e3 in fp64 at initialisation).
+//   * per canvas pixel, the gradients wrt the sampling coordinates are summed by AddN_10 / AddN_11 in
+//     the order wa, wb, wc, wd (graph_dxy).
+// Reproduced here bit for bit (tests/test_gpu_graph_golden.py) and without atomics:
+//   stage T: all threads compute term = (wx*wy) * (z*g) of one tap for every canvas pixel and
+//            store it in a "rectangle-blocked" layout: taps are monotone, so the pixels of one slot
+//            form a rectangle (row run x column run) and each slot's terms are one contiguous stream
+//            in exactly the accumulation order;
+//   stage C: one lane per slot streams its four runs through a single fp32 accumulator (16-byte LDS
+//            reads, two loads in flight: the chain is bound by the dependent v_add_f32, 4 cycles each).
+// The longest chains belong to the four corner slots (all pixels outside the glimpse in both axes).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float stream_add(float acc, const float* T, int start, int n) {
+    int k = start;
+    const int end = start + n;
+    while (k < end && (k & 3)) { acc += T[k]; ++k; }
+    const int nb = (end - k) >> 2;
+    if (nb > 0) {
+        // two 16-byte LDS reads in flight ahead of the dependent adds; the look-ahead index is clamped
+        // (a harmless re-read) so that every access stays an LDS access of this stream
+        const float4* p4 = reinterpret_cast<const float4*>(T + k);
+        float4 c0 = p4[0], c1 = p4[min(1, nb - 1)];
+        for (int b = 0; b < nb; ++b) {
+            const float4 nx = p4[min(b + 2, nb - 1)];
+            acc += c0.x; acc += c0.y; acc += c0.z; acc += c0.w;
+            c0 = c1; c1 = nx;
+        }
+        k += nb * 4;
+    }
+    while (k < end) { acc += T[k]; ++k; }
+    return acc;
+}
+
+__global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_bwd_t a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
+    const int C = a.C, w = a.w, CC = C * C;
+    const size_t row = (size_t)t * a.B + b;
+    float* sh_red = smem;                                  // [128]
+    Tap* sh_tx = reinterpret_cast<Tap*>(smem + 128);       // [C]
+    Tap* sh_ty = sh_tx + C;                                // [C]
+    float* sh_t = reinterpret_cast<float*>(sh_ty + C);     // [C] linspace
+    int* sh_run = reinterpret_cast<int*>(sh_t + C);        // [4][w][2]: run [lo,hi] of every key of x0 / x1 / y0 / y1
+    float* sh_win = reinterpret_cast<float*>(sh_run + 8 * w);   // [w*w]
+    float* sh_g = sh_win + ((w * w + 3) & ~3);             // [C*C] d loss / d (masked z * window_recon)
+    float* sh_T = sh_g + ((CC + 3) & ~3);                  // [C*C] terms of one tap, rectangle-blocked
+
+    if (a.fin_scalars && b == 0 && t == 0) {
+        float r4[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int i = tid; i < a.B; i += WB_THREADS) {
+            r4[0] += a.fin_loss_item[i];
+            r4[1] += (a.fin_targets[i] == a.fin_digits[i]) ? 1.0f : 0.0f;
+        }
+        air_block_sum4<WB_THREADS / 64>(r4, sh_red);
+        if (tid == 0) { a.fin_scalars[0] = r4[0] / (float)a.B; a.fin_scalars[1] = r4[1] / (float)a.B; }
+        __syncthreads();
+    }
+    const float* at = a.att + row * AIR_ATT_STRIDE;
+    float* dgen = a.d_gen_pre + row * w * w;
+    float* dsx = a.d_sxy_write + row * 4;
+    if (at[AIR_ATT_MASK] == 0.0f) {                        // Select(active, ., 0): no gradient
+        for (int p = tid; p < w * w; p += WB_THREADS) dgen[p] = 0.0f;
+        if (tid < 4) dsx[tid] = 0.0f;
+        return;
+    }
+    const float s = at[AIR_ATT_S], x = at[AIR_ATT_X], y = at[AIR_ATT_Y], z = at[AIR_ATT_Z];
+    const float ia = 1.0f / s, bx = (-x) / s, by = (-y) / s;
+    for (int j = tid; j < C; j += WB_THREADS) {
+        float tv;
+        sh_tx[j] = axis_tap(j, C, w, ia, bx, &tv);
+        sh_ty[j] = axis_tap(j, C, w, ia, by);
+        sh_t[j] = tv;
+    }
+    for (int it = tid; it < 4 * w; it += WB_THREADS) { sh_run[2 * it] = 0; sh_run[2 * it + 1] = -1; }
+    const float* v = a.vrec + row * w * w;
+    for (int p = tid; p < w * w; p += WB_THREADS) sh_win[p] = v[p];
+    {
+        const float* gsrc = a.d_recon + (size_t)b * CC;
+        for (int p0 = 0; p0 < CC; p0 += 8 * WB_THREADS) {
+            float r[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int p = p0 + k * WB_THREADS + tid; r[k] = p < CC ? gsrc[p] : 0.0f; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int p = p0 + k * WB_THREADS + tid; if (p < CC) sh_g[p] = r[k]; }
+        }
+    }
+    __syncthreads();
+    // every key (tap index) owns ONE contiguous run of canvas columns / rows (taps are monotone)
+    for (int it = tid; it < 4 * C; it += WB_THREADS) {
+        const int arr = it / C, J = it % C;                 // arr: x0, x1, y0, y1
+        const Tap* tp = (arr < 2) ? sh_tx : sh_ty;
+        const int k = (arr & 1) ? tp[J].i1 : tp[J].i0;
+        const int kp = J > 0 ? ((arr & 1) ? tp[J - 1].i1 : tp[J - 1].i0) : -1;
+        const int kn = J < C - 1 ? ((arr & 1) ? tp[J + 1].i1 : tp[J + 1].i0) : -1;
+        if (kp != k) sh_run[(arr * w + k) * 2] = J;
+        if (kn != k) sh_run[(arr * w + k) * 2 + 1] = J;
+    }
+    __syncthreads();
+
+    // theta / z gradients, per canvas pixel (independent of the terms)
+    float d00 = 0.f, d02 = 0.f, d11 = 0.f, d12 = 0.f, dz = 0.f;
+    {
+        const int di = WB_THREADS / C, dj = WB_THREADS % C;
+        int i = tid / C, j = tid % C;
+        for (int p = tid; p < CC; p += WB_THREADS) {
+            const Tap tx = sh_tx[j], ty = sh_ty[i];
+            const float Ia = sh_win[ty.i0 * w + tx.i0], Ib = sh_win[ty.i1 * w + tx.i0];
+            const float Ic = sh_win[ty.i0 * w + tx.i1], Id = sh_win[ty.i1 * w + tx.i1];
+            const float gv = sh_g[p];
+            dz += gv * bilinear4(tx, ty, Ia, Ib, Ic, Id);            // canvas/mul_grad: Select_grad * window_recon
+            float gX, gY;
+            graph_dxy(z * gv, Ia, Ib, Ic, Id, tx, ty, (float)w - 1.001f, gX, gY);
+            d00 += gX * sh_t[j]; d02 += gX;                          // MatMul_grad: rows of theta x (x_t, y_t, 1)
+            d11 += gY * sh_t[i]; d12 += gY;
+            i += di; j += dj;
+            if (j >= C) { j -= C; ++i; }
+        }
+    }
+    {
+        float red4[4] = {d00, d02, d11, d12};
+        air_block_sum4<WB_THREADS / 64>(red4, sh_red);
+        d00 = red4[0]; d02 = red4[1]; d11 = red4[2]; d12 = red4[3];
+        dz = air_block_sum_n<WB_THREADS / 64>(dz, sh_red + 64);
+    }
+    if (tid == 0) {
+        // theta_recon = [[1/s, 0, -x/s], [0, 1/s, -y/s]] (air_model.py:353-356): truediv_grad .. truediv_3_grad,
+        // summed in AddN_24's order; Neg_grad / Neg_1_grad for x, y
+        const float n1 = (-1.0f / s) / s;
+        dsx[0] = ((d00 * n1 + d02 * ((x / s) / s)) + d11 * n1) + d12 * ((y / s) / s);
+        dsx[1] = -(d02 / s);
+        dsx[2] = -(d12 / s);
+        dsx[3] = dz;
+    }
+    // tap ph = a, b, c, d <-> (y0,x0), (y1,x0), (y0,x1), (y1,x1): terms of one tap (stage T), then every
+    // slot's run of that tap goes through the slot's accumulator (stage C); the accumulator lives in a
+    // register across the four taps
+    const int di = WB_THREADS / C, dj = WB_THREADS % C;
+    const int sp = tid / w, sq = tid % w;
+    float acc = 0.0f;
+    for (int ph = 0; ph < 4; ++ph) {
+        const int xa = ph >> 1, ya = 2 + (ph & 1);
+        int i = tid / C, j = tid % C;
+        for (int p = tid; p < CC; p += WB_THREADS) {
+            const Tap tx = sh_tx[j], ty = sh_ty[i];
+            const float wgt = (xa ? tx.w1 : tx.w0) * ((ph & 1) ? ty.w1 : ty.w0);   // wa..wd (transformer.py:108-115)
+            const float gp = z * sh_g[p];                                           // canvas/mul_grad: z * Select_grad
+            const int kx = xa ? tx.i1 : tx.i0, ky = (ph & 1) ? ty.i1 : ty.i0;
+            const int clo = sh_run[(xa * w + kx) * 2], ncols = sh_run[(xa * w + kx) * 2 + 1] - clo + 1;
+            const int rlo = sh_run[(ya * w + ky) * 2], nrows = sh_run[(ya * w + ky) * 2 + 1] - rlo + 1;
+            sh_T[rlo * C + nrows * clo + (i - rlo) * ncols + (j - clo)] = wgt * gp;
+            i += di; j += dj;
+            if (j >= C) { j -= C; ++i; }
+        }
+        __syncthreads();
+        if (tid < w * w) {
+            const int clo = sh_run[(xa * w + sq) * 2], ncols = sh_run[(xa * w + sq) * 2 + 1] - clo + 1;
+            const int rlo = sh_run[(ya * w + sp) * 2], nrows = sh_run[(ya * w + sp) * 2 + 1] - rlo + 1;
+            acc = stream_add(acc, sh_T, rlo * C + nrows * clo, nrows * ncols);
+        }
+        __syncthreads();
+    }
+    if (tid < w * w) {
+        const float r = sh_win[tid];
+        dgen[tid] = (acc * r) * (1.0f - r);                  // SigmoidGrad of vae.py:39-41: dy * y * (1 - y)
+    }
+}
+
 size_t attend_smem(int C, int w, int HT) {
     return (16 + MAX_STEPS + 8 * w + 4 + ((HT + 3) & ~3) + 7 * (size_t)HT + MAX_STEPS * (size_t)HT + (size_t)C * C) * sizeof(float);
 }
@@ -849,6 +1044,9 @@ size_t attend_bwd_smem(int C, int w) {
     return (24 + 8 * w + w + 4 + (size_t)C * C) * sizeof(float);
 }
 size_t write_smem(int N, int C, int w) { return (16 + 3 * MAX_STEPS + (size_t)N * (8 * C + (size_t)w * w)) * sizeof(float); }
+size_t write_bwd_graph_smem(int C, int w) {
+    return (128 + 8 * C + C + 8 * w + (((size_t)w * w + 3) & ~3) + 2 * (((size_t)C * C + 3) & ~3)) * sizeof(float);
+}
 size_t write_bwd_smem(int C, int w) { return (64 + 8 * C + C + 8 * w + 8 * (w + 2) + (size_t)w * w + 4 * (size_t)(w + 2) * w + 2 * (size_t)C * (w + 2) + (size_t)C * C) * sizeof(float); }
 
 template <typename K>
@@ -921,6 +1119,15 @@ extern "C" int air_write_bwd(const air_write_bwd_t* a, void* stream) {
     if (!a || !a->d_recon || !a->vrec || !a->att || !a->d_gen_pre || !a->d_sxy_write) return AIR_EINVAL;
     if (a->B <= 0 || a->N <= 0 || a->C < 2 || a->w < 2) return AIR_EINVAL;
     if (2 * a->w > THREADS) return AIR_ELIMIT;
+    if (a->literal == 2) {
+        if (a->w * a->w > WB_THREADS) return AIR_ELIMIT;
+        const size_t lds = write_bwd_graph_smem(a->C, a->w);
+        int rc = ensure_lds(write_bwd_graph_kernel, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(write_bwd_graph_kernel, dim3(a->B, a->N), dim3(WB_THREADS), lds, air_stream(stream), *a);
+        AIR_CHECK_LAUNCH();
+        return 0;
+    }
     const size_t lds = write_bwd_smem(a->C, a->w);
     int rc = ensure_lds(write_bwd_kernel, lds);
     if (rc) return rc;
