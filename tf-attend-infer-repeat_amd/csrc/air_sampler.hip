@@ -872,14 +872,22 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_kernel(air_write_bwd_t a
 //     (tests/golden/graph_b64.npz: |g| 1.6e6 in fp32 vs 1.1e3 in fp64 at initialisation).
 //   * per canvas pixel, the gradients wrt the sampling coordinates are summed by AddN_10 / AddN_11 in
 //     the order wa, wb, wc, wd (graph_dxy).
-// Reproduced here bit for bit (tests/test_gpu_graph_golden.py) and without atomics:
-//   stage T: all threads compute term = (wx*wy) * (z*g) of one tap for every canvas pixel and
-//            store it in a "rectangle-blocked" layout: taps are monotone, so the pixels of one slot
-//            form a rectangle (row run x column run) and each slot's terms are one contiguous stream
-//            in exactly the accumulation order;
-//   stage C: one lane per slot streams its four runs through a single fp32 accumulator (16-byte LDS
-//            reads, two loads in flight: the chain is bound by the dependent v_add_f32, 4 cycles each).
-// The longest chains belong to the four corner slots (all pixels outside the glimpse in both axes).
+// Reproduced here bit for bit (tests/test_gpu_graph_golden.py) and deterministically:
+//   stage T: all threads compute term = (wx*wy) * (z*g) of every tap of every canvas pixel and store it
+//            in a "rectangle-blocked" layout: taps are monotone, so the pixels of one slot form a
+//            rectangle (row run x column run) and each slot's terms of a tap are one contiguous
+//            stream in exactly the accumulation order;
+//   stage C: one lane per slot streams its four runs through a single fp32 register accumulator
+//            (a lone wave issues a dependent v_add_f32 every ~8 cycles -- fine for the short
+//            in-range and edge runs).  The FOUR CORNER slots own every pixel that is outside the
+//            glimpse in both axes -- (C - s*C)^2 terms per tap, most of the canvas -- and go through
+//            the LDS instead: the last wave feeds their streams, 64 terms per instruction, to
+//            ds_add_f32 on one LDS word per corner.  gfx950's LDS applies the lanes of one
+//            instruction in ascending lane order and a wave's instructions in program order
+//            (measured: tools/exp/lds_atomic_order.hip; pinned by the bit-for-bit test), i.e. it IS
+//            a sequential fp32 accumulator, at ~4 cycles per term and without occupying the VALU:
+//            the other 15 waves run the coordinate-gradient pixel loop and the short chains
+//            underneath it.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float stream_add(float acc, const float* T, int start, int n) {
     int k = start;
@@ -902,20 +910,31 @@ __device__ __forceinline__ float stream_add(float acc, const float* T, int start
     return acc;
 }
 
+typedef __attribute__((address_space(3))) float air_lds_float;
+// no-return LDS float add (inline asm: no compare-and-swap loop may be substituted)
+__device__ __forceinline__ void lds_fadd(float* p, float v) {
+    asm volatile("ds_add_f32 %0, %1" :: "v"((unsigned)(size_t)(air_lds_float*)p), "v"(v) : "memory");
+}
+
+// ALLPH: the terms of all four taps are resident (4*C*C floats of LDS, no barrier between taps);
+// otherwise one tap at a time through one buffer (large canvases)
+template <bool ALLPH>
 __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_bwd_t a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int b = blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
-    const int C = a.C, w = a.w, CC = C * C;
+    const int b = blockIdx.x, t = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = WB_THREADS / 64, FEED = NW - 1;     // the last wave feeds the corner accumulators
+    const int C = a.C, w = a.w, CC = C * C, CCp = (CC + 3) & ~3;
     const size_t row = (size_t)t * a.B + b;
-    float* sh_red = smem;                                  // [128]
-    Tap* sh_tx = reinterpret_cast<Tap*>(smem + 128);       // [C]
+    float* sh_red = smem;                                  // [128]: fin sums / per-wave partials [NW][8]
+    float* sh_acc = smem + 128;                            // [4] corner accumulators (+4 pad)
+    Tap* sh_tx = reinterpret_cast<Tap*>(smem + 136);       // [C]
     Tap* sh_ty = sh_tx + C;                                // [C]
     float* sh_t = reinterpret_cast<float*>(sh_ty + C);     // [C] linspace
-    int* sh_run = reinterpret_cast<int*>(sh_t + C);        // [4][w][2]: run [lo,hi] of every key of x0 / x1 / y0 / y1
-    float* sh_win = reinterpret_cast<float*>(sh_run + 8 * w);   // [w*w]
+    int* sh_run = reinterpret_cast<int*>(sh_t + ((C + 3) & ~3));   // [4][w][2]: run [lo,hi] of every key of x0 / x1 / y0 / y1
+    float* sh_win = reinterpret_cast<float*>(sh_run + ((8 * w + 3) & ~3));   // [w*w]
     float* sh_g = sh_win + ((w * w + 3) & ~3);             // [C*C] d loss / d (masked z * window_recon)
-    float* sh_T = sh_g + ((CC + 3) & ~3);                  // [C*C] terms of one tap, rectangle-blocked
+    float* sh_T = sh_g + CCp;                              // [4 or 1][C*C] terms, rectangle-blocked per tap (16-byte aligned)
 
     if (a.fin_scalars && b == 0 && t == 0) {
         float r4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -923,10 +942,11 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
             r4[0] += a.fin_loss_item[i];
             r4[1] += (a.fin_targets[i] == a.fin_digits[i]) ? 1.0f : 0.0f;
         }
-        air_block_sum4<WB_THREADS / 64>(r4, sh_red);
+        air_block_sum4<NW>(r4, sh_red);
         if (tid == 0) { a.fin_scalars[0] = r4[0] / (float)a.B; a.fin_scalars[1] = r4[1] / (float)a.B; }
         __syncthreads();
     }
+    AIR_STAMP(40);
     const float* at = a.att + row * AIR_ATT_STRIDE;
     float* dgen = a.d_gen_pre + row * w * w;
     float* dsx = a.d_sxy_write + row * 4;
@@ -944,6 +964,7 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
         sh_t[j] = tv;
     }
     for (int it = tid; it < 4 * w; it += WB_THREADS) { sh_run[2 * it] = 0; sh_run[2 * it + 1] = -1; }
+    if (tid < 8) sh_acc[tid] = 0.0f;
     const float* v = a.vrec + row * w * w;
     for (int p = tid; p < w * w; p += WB_THREADS) sh_win[p] = v[p];
     {
@@ -957,6 +978,7 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
         }
     }
     __syncthreads();
+    AIR_STAMP(41);
     // every key (tap index) owns ONE contiguous run of canvas columns / rows (taps are monotone)
     for (int it = tid; it < 4 * C; it += WB_THREADS) {
         const int arr = it / C, J = it % C;                 // arr: x0, x1, y0, y1
@@ -968,73 +990,166 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
         if (kn != k) sh_run[(arr * w + k) * 2 + 1] = J;
     }
     __syncthreads();
+    AIR_STAMP(42);
 
-    // theta / z gradients, per canvas pixel (independent of the terms)
-    float d00 = 0.f, d02 = 0.f, d11 = 0.f, d12 = 0.f, dz = 0.f;
-    {
-        const int di = WB_THREADS / C, dj = WB_THREADS % C;
-        int i = tid / C, j = tid % C;
-        for (int p = tid; p < CC; p += WB_THREADS) {
-            const Tap tx = sh_tx[j], ty = sh_ty[i];
-            const float Ia = sh_win[ty.i0 * w + tx.i0], Ib = sh_win[ty.i1 * w + tx.i0];
-            const float Ic = sh_win[ty.i0 * w + tx.i1], Id = sh_win[ty.i1 * w + tx.i1];
-            const float gv = sh_g[p];
-            dz += gv * bilinear4(tx, ty, Ia, Ib, Ic, Id);            // canvas/mul_grad: Select_grad * window_recon
-            float gX, gY;
-            graph_dxy(z * gv, Ia, Ib, Ic, Id, tx, ty, (float)w - 1.001f, gX, gY);
-            d00 += gX * sh_t[j]; d02 += gX;                          // MatMul_grad: rows of theta x (x_t, y_t, 1)
-            d11 += gY * sh_t[i]; d12 += gY;
-            i += di; j += dj;
-            if (j >= C) { j -= C; ++i; }
-        }
-    }
-    {
-        float red4[4] = {d00, d02, d11, d12};
-        air_block_sum4<WB_THREADS / 64>(red4, sh_red);
-        d00 = red4[0]; d02 = red4[1]; d11 = red4[2]; d12 = red4[3];
-        dz = air_block_sum_n<WB_THREADS / 64>(dz, sh_red + 64);
-    }
-    if (tid == 0) {
-        // theta_recon = [[1/s, 0, -x/s], [0, 1/s, -y/s]] (air_model.py:353-356): truediv_grad .. truediv_3_grad,
-        // summed in AddN_24's order; Neg_grad / Neg_1_grad for x, y
-        const float n1 = (-1.0f / s) / s;
-        dsx[0] = ((d00 * n1 + d02 * ((x / s) / s)) + d11 * n1) + d12 * ((y / s) / s);
-        dsx[1] = -(d02 / s);
-        dsx[2] = -(d12 / s);
-        dsx[3] = dz;
-    }
-    // tap ph = a, b, c, d <-> (y0,x0), (y1,x0), (y0,x1), (y1,x1): terms of one tap (stage T), then every
-    // slot's run of that tap goes through the slot's accumulator (stage C); the accumulator lives in a
-    // register across the four taps
+    // tap ph = a, b, c, d <-> (y0,x0), (y1,x0), (y0,x1), (y1,x1)
     const int di = WB_THREADS / C, dj = WB_THREADS % C;
-    const int sp = tid / w, sq = tid % w;
-    float acc = 0.0f;
-    for (int ph = 0; ph < 4; ++ph) {
-        const int xa = ph >> 1, ya = 2 + (ph & 1);
+    auto stage_T = [&](int ph0, int ph1) {
         int i = tid / C, j = tid % C;
         for (int p = tid; p < CC; p += WB_THREADS) {
             const Tap tx = sh_tx[j], ty = sh_ty[i];
-            const float wgt = (xa ? tx.w1 : tx.w0) * ((ph & 1) ? ty.w1 : ty.w0);   // wa..wd (transformer.py:108-115)
             const float gp = z * sh_g[p];                                           // canvas/mul_grad: z * Select_grad
-            const int kx = xa ? tx.i1 : tx.i0, ky = (ph & 1) ? ty.i1 : ty.i0;
-            const int clo = sh_run[(xa * w + kx) * 2], ncols = sh_run[(xa * w + kx) * 2 + 1] - clo + 1;
-            const int rlo = sh_run[(ya * w + ky) * 2], nrows = sh_run[(ya * w + ky) * 2 + 1] - rlo + 1;
-            sh_T[rlo * C + nrows * clo + (i - rlo) * ncols + (j - clo)] = wgt * gp;
+            const int cl0 = sh_run[tx.i0 * 2], cn0 = sh_run[tx.i0 * 2 + 1] - cl0 + 1;               // x0 run
+            const int cl1 = sh_run[(w + tx.i1) * 2], cn1 = sh_run[(w + tx.i1) * 2 + 1] - cl1 + 1;   // x1 run
+            const int rl0 = sh_run[(2 * w + ty.i0) * 2], rn0 = sh_run[(2 * w + ty.i0) * 2 + 1] - rl0 + 1;
+            const int rl1 = sh_run[(3 * w + ty.i1) * 2], rn1 = sh_run[(3 * w + ty.i1) * 2 + 1] - rl1 + 1;
+            for (int ph = ph0; ph < ph1; ++ph) {
+                const bool x1 = ph >> 1, y1 = ph & 1;
+                const float wgt = (x1 ? tx.w1 : tx.w0) * (y1 ? ty.w1 : ty.w0);      // wa..wd (transformer.py:108-115)
+                const int clo = x1 ? cl1 : cl0, ncols = x1 ? cn1 : cn0, rlo = y1 ? rl1 : rl0, nrows = y1 ? rn1 : rn0;
+                sh_T[(ALLPH ? ph * CCp : 0) + rlo * C + nrows * clo + (i - rlo) * ncols + (j - clo)] = wgt * gp;
+            }
             i += di; j += dj;
             if (j >= C) { j -= C; ++i; }
         }
-        __syncthreads();
-        if (tid < w * w) {
-            const int clo = sh_run[(xa * w + sq) * 2], ncols = sh_run[(xa * w + sq) * 2 + 1] - clo + 1;
-            const int rlo = sh_run[(ya * w + sp) * 2], nrows = sh_run[(ya * w + sp) * 2 + 1] - rlo + 1;
-            acc = stream_add(acc, sh_T, rlo * C + nrows * clo, nrows * ncols);
+    };
+    // start / length of slot (p, q)'s stream of tap ph
+    auto slot_run = [&](int ph, int p, int q, int& start, int& n) {
+        const int xa = ph >> 1, ya = 2 + (ph & 1);
+        const int clo = sh_run[(xa * w + q) * 2], ncols = sh_run[(xa * w + q) * 2 + 1] - clo + 1;
+        const int rlo = sh_run[(ya * w + p) * 2], nrows = sh_run[(ya * w + p) * 2 + 1] - rlo + 1;
+        start = (ALLPH ? ph * CCp : 0) + rlo * C + nrows * clo;
+        n = nrows * ncols;
+    };
+    const int sp = tid / w, sq = tid % w;
+    const bool is_slot = tid < w * w;
+    const bool corner = is_slot && (sp == 0 || sp == w - 1) && (sq == 0 || sq == w - 1);
+    float acc = 0.0f;
+    float d00 = 0.f, d02 = 0.f, d11 = 0.f, d12 = 0.f, dz = 0.f;
+    auto stage_C = [&](int ph0, int ph1) {
+        if (wave == FEED) {
+            // The corner slots' streams -> ds_add_f32, 64 consecutive terms per instruction, 8 instructions
+            // per batch.  A wave's LDS operations execute in order, so a read queued behind an add
+            // waits for it: the reads of batch i+1 are issued right behind the adds of batch i and
+            // have landed when those finish; the wave then only has to issue the next 8 adds.  Reads,
+            // adds and waits are inline asm (the compiler's own s_waitcnt bookkeeping would put an
+            // lgkmcnt(0) in front of every add); the register dependence is carried through the wait.
+            int ph = ph0, c = -1, k0 = 0, start = 0, n = 0;
+            auto advance = [&]() -> bool {               // next non-empty batch (uniform)
+                k0 += 8 * 64;
+                while (k0 >= n) {
+                    if (++c == 4) { c = 0; if (++ph >= ph1) return false; }
+                    slot_run(ph, (c & 2) ? w - 1 : 0, (c & 1) ? w - 1 : 0, start, n);
+                    k0 = 0;
+                    if (n > 0) break;
+                }
+                return true;
+            };
+            auto reads = [&](float (&r)[8]) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const unsigned addr = (unsigned)(size_t)(air_lds_float*)(sh_T + start + min(k0 + u * 64 + lane, n - 1));
+                    asm volatile("ds_read_b32 %0, %1" : "=v"(r[u]) : "v"(addr) : "memory");
+                }
+            };
+            auto adds = [&](float (&r)[8], int bc, int bk0, int bn) {
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) :: "memory");
+                const unsigned acc_addr = (unsigned)(size_t)(air_lds_float*)(sh_acc + bc);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (bk0 + u * 64 < bn) {             // uniform; lanes past the end add -0.0f (x + -0 == x)
+                        const float tv = (bk0 + u * 64 + lane < bn) ? r[u] : -0.0f;
+                        asm volatile("ds_add_f32 %0, %1" :: "v"(acc_addr), "v"(tv) : "memory");
+                    }
+                }
+            };
+            c = -1; ph = ph0; n = 0; k0 = 0;
+            float ra[8], rb[8];
+            bool more = advance();
+            if (more) reads(ra);
+            while (more) {
+                int bc = c, bk0 = k0, bn = n;
+                more = advance();
+                adds(ra, bc, bk0, bn);
+                if (!more) break;
+                reads(rb);
+                bc = c; bk0 = k0; bn = n;
+                more = advance();
+                adds(rb, bc, bk0, bn);
+                if (more) reads(ra);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            return;
         }
+        if (ph0 == 0) {
+            // theta / z gradients, per canvas pixel, under the corner accumulation
+            constexpr int PT = FEED * 64;
+            const int ei = PT / C, ej = PT % C;
+            int i = tid / C, j = tid % C;
+            for (int p = tid; p < CC; p += PT) {
+                const Tap tx = sh_tx[j], ty = sh_ty[i];
+                const float Ia = sh_win[ty.i0 * w + tx.i0], Ib = sh_win[ty.i1 * w + tx.i0];
+                const float Ic = sh_win[ty.i0 * w + tx.i1], Id = sh_win[ty.i1 * w + tx.i1];
+                const float gv = sh_g[p];
+                dz += gv * bilinear4(tx, ty, Ia, Ib, Ic, Id);        // canvas/mul_grad: Select_grad * window_recon
+                float gX, gY;
+                graph_dxy(z * gv, Ia, Ib, Ic, Id, tx, ty, (float)w - 1.001f, gX, gY);
+                d00 += gX * sh_t[j]; d02 += gX;                      // MatMul_grad: rows of theta x (x_t, y_t, 1)
+                d11 += gY * sh_t[i]; d12 += gY;
+                i += ei; j += ej;
+                if (j >= C) { j -= C; ++i; }
+            }
+        }
+        if (is_slot && !corner)
+            for (int ph = ph0; ph < ph1; ++ph) {
+                int start, n;
+                slot_run(ph, sp, sq, start, n);
+                acc = stream_add(acc, sh_T, start, n);
+            }
+    };
+    if (ALLPH) {
+        stage_T(0, 4);
         __syncthreads();
+        AIR_STAMP(43);
+        stage_C(0, 4);
+        __syncthreads();
+        AIR_STAMP(44);
+    } else {
+        for (int ph = 0; ph < 4; ++ph) {
+            stage_T(ph, ph + 1);
+            __syncthreads();
+            stage_C(ph, ph + 1);
+            __syncthreads();
+        }
     }
-    if (tid < w * w) {
+    // coordinate / z gradients: wave partials combined in a fixed order
+    d00 = air_wave_sum(d00); d02 = air_wave_sum(d02); d11 = air_wave_sum(d11); d12 = air_wave_sum(d12); dz = air_wave_sum(dz);
+    if (lane == 0) { float* r = sh_red + wave * 8; r[0] = d00; r[1] = d02; r[2] = d11; r[3] = d12; r[4] = dz; }
+    if (is_slot) {
+        if (corner) acc = sh_acc[(sp ? 2 : 0) + (sq ? 1 : 0)];
         const float r = sh_win[tid];
         dgen[tid] = (acc * r) * (1.0f - r);                  // SigmoidGrad of vae.py:39-41: dy * y * (1 - y)
     }
+    __syncthreads();
+    if (tid < 64) {
+        // lanes 0..4 each combine one quantity over the waves; lane 0 collects them by shuffle
+        float u = 0.0f;
+        if (lane < 5) { u = sh_red[lane]; for (int wv = 1; wv < FEED; ++wv) u += sh_red[wv * 8 + lane]; }
+        float t5[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) t5[k] = __shfl(u, k, 64);
+        if (tid == 0) {
+        // theta_recon = [[1/s, 0, -x/s], [0, 1/s, -y/s]] (air_model.py:353-356): truediv_grad .. truediv_3_grad,
+        // summed in AddN_24's order; Neg_grad / Neg_1_grad for x, y
+        const float n1 = (-1.0f / s) / s;
+        dsx[0] = ((t5[0] * n1 + t5[1] * ((x / s) / s)) + t5[2] * n1) + t5[3] * ((y / s) / s);
+        dsx[1] = -(t5[1] / s);
+        dsx[2] = -(t5[3] / s);
+        dsx[3] = t5[4];
+        }
+    }
+    AIR_STAMP(45);
 }
 
 size_t attend_smem(int C, int w, int HT) {
@@ -1044,8 +1159,9 @@ size_t attend_bwd_smem(int C, int w) {
     return (24 + 8 * w + w + 4 + (size_t)C * C) * sizeof(float);
 }
 size_t write_smem(int N, int C, int w) { return (16 + 3 * MAX_STEPS + (size_t)N * (8 * C + (size_t)w * w)) * sizeof(float); }
-size_t write_bwd_graph_smem(int C, int w) {
-    return (128 + 8 * C + C + 8 * w + (((size_t)w * w + 3) & ~3) + 2 * (((size_t)C * C + 3) & ~3)) * sizeof(float);
+size_t write_bwd_graph_smem(int C, int w, bool allph) {
+    return (136 + 8 * C + ((C + 3) & ~3) + ((8 * w + 3) & ~3) + (((size_t)w * w + 3) & ~3) +
+            (allph ? 5 : 2) * (((size_t)C * C + 3) & ~3)) * sizeof(float);
 }
 size_t write_bwd_smem(int C, int w) { return (64 + 8 * C + C + 8 * w + 8 * (w + 2) + (size_t)w * w + 4 * (size_t)(w + 2) * w + 2 * (size_t)C * (w + 2) + (size_t)C * C) * sizeof(float); }
 
@@ -1121,10 +1237,13 @@ extern "C" int air_write_bwd(const air_write_bwd_t* a, void* stream) {
     if (2 * a->w > THREADS) return AIR_ELIMIT;
     if (a->literal == 2) {
         if (a->w * a->w > WB_THREADS) return AIR_ELIMIT;
-        const size_t lds = write_bwd_graph_smem(a->C, a->w);
-        int rc = ensure_lds(write_bwd_graph_kernel, lds);
+        // all four taps' terms resident when they fit next to a second workgroup's share of the LDS
+        const bool allph = write_bwd_graph_smem(a->C, a->w, true) <= 80 * 1024;
+        const size_t lds = write_bwd_graph_smem(a->C, a->w, allph);
+        int rc = allph ? ensure_lds(write_bwd_graph_kernel<true>, lds) : ensure_lds(write_bwd_graph_kernel<false>, lds);
         if (rc) return rc;
-        hipLaunchKernelGGL(write_bwd_graph_kernel, dim3(a->B, a->N), dim3(WB_THREADS), lds, air_stream(stream), *a);
+        if (allph) hipLaunchKernelGGL(write_bwd_graph_kernel<true>, dim3(a->B, a->N), dim3(WB_THREADS), lds, air_stream(stream), *a);
+        else hipLaunchKernelGGL(write_bwd_graph_kernel<false>, dim3(a->B, a->N), dim3(WB_THREADS), lds, air_stream(stream), *a);
         AIR_CHECK_LAUNCH();
         return 0;
     }
