@@ -49,6 +49,9 @@ enum {
     AIR_DYN_VAE_PM   = 9, AIR_DYN_VAE_PV   = 10,  /* vae prior                    :42-43 */
     AIR_DYN_LIK_STD  = 11,                        /* vae_likelihood_std           :44    */
     AIR_DYN_GRAD_SCALE = 12,     /* d(loss)/d(per-item loss) = 1/B (reduce_mean, :610) */
+    /* log of the prior variances AS PASSED TO THE CONSTRUCTOR (air_model.py:72-74: tf.log(...) is taken
+     * before any annealing schedule replaces the attribute, :76-82) -- never written by a schedule */
+    AIR_DYN_SCALE_PLV = 13, AIR_DYN_SHIFT_PLV = 14, AIR_DYN_VAE_PLV = 15,
     AIR_DYN_COUNT    = 16
 };
 

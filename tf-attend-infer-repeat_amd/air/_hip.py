@@ -18,6 +18,7 @@ ABI_VERSION = 1
 DYN_PRIOR_LOG_ODDS, DYN_TEMPERATURE, DYN_STOP_THRESHOLD, DYN_LEARNING_RATE, DYN_CLIP_NORM = 0, 1, 2, 3, 4
 DYN_SCALE_PM, DYN_SCALE_PV, DYN_SHIFT_PM, DYN_SHIFT_PV, DYN_VAE_PM, DYN_VAE_PV = 5, 6, 7, 8, 9, 10
 DYN_LIK_STD, DYN_GRAD_SCALE, DYN_COUNT = 11, 12, 16
+DYN_SCALE_PLV, DYN_SHIFT_PLV, DYN_VAE_PLV = 13, 14, 15
 IST_GLOBAL_STEP, IST_COUNT = 0, 4
 ATT_S, ATT_X, ATT_Y, ATT_ZPRE, ATT_Z, ATT_ZPROB = 0, 1, 2, 3, 4, 5
 ATT_KL_Z, ATT_KL_SCALE, ATT_KL_SHIFT, ATT_KL_VAE, ATT_MASK_PREV, ATT_MASK, ATT_ST_BACK = 6, 7, 8, 9, 10, 11, 12

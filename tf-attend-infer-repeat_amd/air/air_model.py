@@ -251,7 +251,7 @@ class AIRModel:
             raise ValueError("gemm_precision must be 'fp32' or 'bf16'")
         self.gemm_precision = prec
         # "reference": the sampler backward in the op order of the reference's saved graph
-        #   (model/air-model.meta executed by oracle/graphdef_exec.py): one fp32 accumulator per window
+        #   (model/air-model.meta, executed node by node by tests/test_graph_exec.py): one fp32 accumulator per window
         #   pixel through the four concatenated Gather gradients (UnsortedSegmentSum order), AddN_10/11
         #   order for the coordinate gradients -- keeps the out-of-range rounding residue the
         #   reference's training signal carries; bit-identical to the graph at kernel level.
@@ -321,6 +321,10 @@ class AIRModel:
         dyn[H.DYN_SHIFT_PM], dyn[H.DYN_SHIFT_PV] = self.shift_prior_mean, self.shift_prior_variance
         dyn[H.DYN_VAE_PM], dyn[H.DYN_VAE_PV] = self.vae_prior_mean, self.vae_prior_variance
         dyn[H.DYN_LIK_STD] = self.vae_likelihood_std
+        # tf.log of the constructor values, taken before any schedule replaces the attribute (:72-82)
+        dyn[H.DYN_SCALE_PLV] = np.log(np.float32(self.scale_prior_variance))
+        dyn[H.DYN_SHIFT_PLV] = np.log(np.float32(self.shift_prior_variance))
+        dyn[H.DYN_VAE_PLV] = np.log(np.float32(self.vae_prior_variance))
         dyn[H.DYN_GRAD_SCALE] = 1.0 / B
         self.dyn = torch.from_numpy(dyn).to(dv)
         sched = []

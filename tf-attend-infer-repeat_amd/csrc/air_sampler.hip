@@ -14,6 +14,7 @@
 // the exact adjoint in separable form (R_y^T g R_x) as a deterministic gather:
 // no atomics anywhere.
 #include "air_common.h"
+#include <atomic>
 
 #ifdef AIR_STAMPS
 __device__ unsigned long long air_stamps_dev[64];
@@ -76,7 +77,7 @@ __device__ __forceinline__ void literal_dxy(float g, float Ia, float Ib, float I
 }
 
 // The same gradient in the op order of the reference's SAVED graph (model/air-model.meta, executed by
-// oracle/graphdef_exec.py): d wa..wd = g*Ia..Id (mul_10..13_grad), each product's two factors get
+// the graph executor of tests/test_graph_exec.py): d wa..wd = g*Ia..Id (mul_10..13_grad), each product's two factors get
 // grad*other (mul_6..9_grad), the Sub nodes negate the (x1-x)/(y1-y) legs, and the four legs that
 // reach x (y) are summed by AddN_10 / AddN_20 (AddN_11 / AddN_21) left to right in the order
 // wa, wb, wc, wd.  Then x = (x_s + 1)*(W - 1.001)/2: truediv_grad then mul_grad.
@@ -293,8 +294,8 @@ __global__ __launch_bounds__(THREADS) void attend_fwd_kernel(air_attend_fwd_t a)
         const bool mask = S < thr;
         // scale / shift KL :441-477
         const float pv_s = dyn[AIR_DYN_SCALE_PV], pv_h = dyn[AIR_DYN_SHIFT_PV];
-        const float kl_s = 0.5f * gauss_kl_term(logf(pv_s), lv_s, var_s, pv_s, mu_s, dyn[AIR_DYN_SCALE_PM]);
-        const float plv_h = logf(pv_h), pm_h = dyn[AIR_DYN_SHIFT_PM];
+        const float kl_s = 0.5f * gauss_kl_term(dyn[AIR_DYN_SCALE_PLV], lv_s, var_s, pv_s, mu_s, dyn[AIR_DYN_SCALE_PM]);
+        const float plv_h = dyn[AIR_DYN_SHIFT_PLV], pm_h = dyn[AIR_DYN_SHIFT_PM];
         const float kl_h = 0.5f * (gauss_kl_term(plv_h, lv_x, var_x, pv_h, mu_x, pm_h) +
                                    gauss_kl_term(plv_h, lv_y, var_y, pv_h, mu_y, pm_h));
 
@@ -521,11 +522,11 @@ __global__ __launch_bounds__(CF_THREADS) void write_fwd_kernel(air_write_fwd_t a
     for (int t = wave; t < N; t += CF_THREADS / 64) {
         // VAE KL :479-493 (a public output whether or not the item is still active): one wave per step
         const float* ml = a.ml + ((size_t)t * B + b) * 2 * Z;
-        const float pv = dyn[AIR_DYN_VAE_PV], pm = dyn[AIR_DYN_VAE_PM];
+        const float pv = dyn[AIR_DYN_VAE_PV], pm = dyn[AIR_DYN_VAE_PM], plv = dyn[AIR_DYN_VAE_PLV];
         float klt = 0.0f;
         for (int j = lane; j < Z; j += 64) {
             const float lv = ml[Z + j];
-            klt += gauss_kl_term(logf(pv), lv, expf(lv), pv, ml[j], pm);
+            klt += gauss_kl_term(plv, lv, expf(lv), pv, ml[j], pm);
         }
         klt = air_wave_sum(klt);
         if (lane == 0) sh_kl[t] = 0.5f * klt;
@@ -861,7 +862,7 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_kernel(air_write_bwd_t a
 // ---------------------------------------------------------------------------
 // write backward in the op order of the reference's SAVED graph (literal == 2; the default
 // backward="reference" of AIRModel).  What the graph does with d loss / d window_recon
-// (model/air-model.meta, executed node by node by oracle/graphdef_exec.py):
+// (model/air-model.meta, executed node by node by the graph executor of tests/test_graph_exec.py):
 //   * the four Gather gradients (taps a=(y0,x0), b=(y1,x0), c=(y0,x1), d=(y1,x1)) are CONCATENATED and
 //     reduced by ONE UnsortedSegmentSum: every window pixel ("slot") is a single fp32 accumulator
 //     that receives its a-terms in canvas-pixel order, then its b-, c- and d-terms.  The terms of an
@@ -1165,14 +1166,24 @@ size_t write_bwd_graph_smem(int C, int w, bool allph) {
 }
 size_t write_bwd_smem(int C, int w) { return (64 + 8 * C + C + 8 * w + 8 * (w + 2) + (size_t)w * w + 4 * (size_t)(w + 2) * w + 2 * (size_t)C * (w + 2) + (size_t)C * C) * sizeof(float); }
 
+// Opt-in to > 48 KB of dynamic LDS, ONCE per kernel function (the full 160 KB is granted the first
+// time a kernel asks for more than the default): hipFuncSetAttribute is a host-side driver call
+// and must not sit on every launch -- in particular not inside stream capture.
 template <typename K>
 int ensure_lds(K kernel, size_t bytes) {
+    static std::atomic<const void*> granted[16];           // kernels that already hold the large-LDS attribute
     if (bytes > 160 * 1024) return AIR_ELIMIT;
-    if (bytes > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        if (e != hipSuccess) return (int)e;
+    if (bytes <= 48 * 1024) return 0;
+    const void* fn = reinterpret_cast<const void*>(kernel);
+    int free_slot = -1;
+    for (int i = 0; i < 16; ++i) {
+        const void* g = granted[i].load(std::memory_order_acquire);
+        if (g == fn) return 0;
+        if (!g && free_slot < 0) free_slot = i;
     }
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    if (free_slot >= 0) granted[free_slot].store(fn, std::memory_order_release);
     return 0;
 }
 

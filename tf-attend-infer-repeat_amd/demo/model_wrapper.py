@@ -20,39 +20,34 @@ class ModelWrapper:
         self.window_size = window_size
 
     def infer(self, images):
-        m = self.model
-        B = m.batch_size
-        flat = np.stack([np.ravel(np.asarray(img, dtype=np.float32)) for img in images]) if len(images) else \
-            np.zeros((0, self.canvas_size ** 2), np.float32)
-        all_digits, all_positions = [], []
-        all_windows, all_latents = [], []
-        all_reconstructions, all_loss = [], []
-        for start in range(0, len(flat), B):
-            chunk = flat[start:start + B]
-            buf = np.zeros((B, flat.shape[1]), np.float32)
-            buf[:len(chunk)] = chunk
-            m.input_images.copy_(torch.from_numpy(buf))
+        """Returns (digit counts, [n_i, 3] (s, x, y) rows, [C, C] reconstructions, [n_i, w, w] windows,
+        [n_i, Z] latents, reconstruction losses) -- one entry per image, n_i = inferred count."""
+        m, B, cs, ws = self.model, self.model.batch_size, self.canvas_size, self.window_size
+        flat = np.zeros((len(images), cs * cs), np.float32)
+        for i, img in enumerate(images):
+            flat[i] = np.asarray(img, dtype=np.float32).reshape(-1)
+        out = ([], [], [], [], [], [])
+        staging = torch.zeros(B, cs * cs)
+        for lo in range(0, len(flat), B):
+            k = min(B, len(flat) - lo)
+            staging.zero_()                                   # blank canvases pad the last chunk
+            staging[:k] = torch.from_numpy(flat[lo:lo + k])
+            m.input_images.copy_(staging)
             m.forward()
-            # the fetch set of model_wrapper.py:19-25, one device->host copy each
-            rec_digits = m.rec_num_digits.cpu().numpy()
-            rec_scales = m.rec_scales.cpu().numpy()
-            rec_shifts = m.rec_shifts.cpu().numpy()
-            reconstructions = m.reconstruction.cpu().numpy()
-            rec_windows = m.rec_windows.cpu().numpy()
-            rec_latents = m.rec_latents.cpu().numpy()
-            rec_loss = m.reconstruction_loss.cpu().numpy()
-            for i in range(len(chunk)):
-                digits = int(rec_digits[i])
-                reconstruction = np.reshape(reconstructions[i], (self.canvas_size, self.canvas_size))
-                positions, windows, latents = [], [], []
-                for j in range(digits):
-                    positions.append(np.array([rec_scales[i][j][0]] + list(rec_shifts[i][j])))
-                    windows.append(np.reshape(rec_windows[i][j], (self.window_size, self.window_size)))
-                    latents.append(rec_latents[i][j])
-                all_digits.append(digits)
-                all_positions.append(np.array(positions))
-                all_reconstructions.append(reconstruction)
-                all_windows.append(np.array(windows))
-                all_latents.append(np.array(latents))
-                all_loss.append(rec_loss[i])
-        return all_digits, all_positions, all_reconstructions, all_windows, all_latents, all_loss
+            # the fetch set of the reference wrapper (model_wrapper.py:19-25), sliced to this chunk
+            counts = m.rec_num_digits[:k].cpu().numpy().astype(int)
+            sxy = torch.cat([m.rec_scales[:k], m.rec_shifts[:k]], dim=2).cpu().numpy()          # [k, T', 3]
+            wins = m.rec_windows[:k].cpu().numpy().reshape(k, -1, ws, ws)
+            lats = m.rec_latents[:k].cpu().numpy()
+            recs = m.reconstruction[:k].cpu().numpy().reshape(k, cs, cs)
+            loss = m.reconstruction_loss[:k].cpu().numpy()
+            # only the first `count` steps of an image are objects; an image without objects gets the
+            # empty array the reference's np.array([]) produces (shape (0,))
+            none = np.array([])
+            out[0].extend(int(c) for c in counts)
+            out[1].extend(sxy[i, :c] if c else none for i, c in enumerate(counts))
+            out[2].extend(recs)
+            out[3].extend(wins[i, :c] if c else none for i, c in enumerate(counts))
+            out[4].extend(lats[i, :c] if c else none for i, c in enumerate(counts))
+            out[5].extend(loss)
+        return out
