@@ -113,17 +113,38 @@ def per_kernel_times(model, iters):
     return out
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE and
-    WRITE_SIZE cannot share a pass and cannot be collected from inside this process); None if the
-    profile of this round is not there."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if not os.path.exists(path):
-        return None
-    for k, v in json.load(open(path)).items():
+def source_sha16():
+    """sha256 of the kernel sources (csrc/*, include/*.h): profiles are only valid for the build they measured"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "tf-attend-infer-repeat_amd", "csrc", "*")) +
+                    glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+_PROFILE = None
+
+
+def kernel_profile(kernel):
+    """rocprofv3 numbers for `kernel` from the committed profile round (profiles/kernel_profile.json,
+    written by tools/profile_round.sh + profile_merge.py: --kernel-trace --stats average duration,
+    FETCH_SIZE / WRITE_SIZE traffic from separate --pmc passes, SQ_VALU_MFMA_BUSY_CYCLES).  PMC
+    counters cannot be collected from inside this process.  A profile taken from other kernel
+    sources than the ones built now is refused (stale=True, no numbers)."""
+    global _PROFILE
+    if _PROFILE is None:
+        path = os.path.join(ROOT, "profiles", "kernel_profile.json")
+        _PROFILE = json.load(open(path)) if os.path.exists(path) else {}
+        _PROFILE["_stale"] = bool(_PROFILE) and _PROFILE.get("source_sha16") != source_sha16()
+    if not _PROFILE.get("kernels") or _PROFILE["_stale"]:
+        return {"stale": True} if _PROFILE.get("_stale") else {}
+    for k, v in _PROFILE["kernels"].items():
         if k.startswith(kernel):
-            return int(v["hbm_bytes_per_launch"])
-    return None
+            return v
+    return {}
 
 
 def cpu_baseline(batch, seconds=15.0):
@@ -200,6 +221,8 @@ def main():
     ap.add_argument("--graph-steps", type=int, default=4, help="train steps captured per hipGraph replay (1 GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary blocks (fp32 step, stress config, inference)")
+    ap.add_argument("--backward", default="reference", choices=["reference", "taps", "exact"])
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -227,7 +250,7 @@ def main():
     images, targets = synthetic_canvases(B, hp["canvas_size"], hp["max_digits"], seed=1000 + rank)
     model = am.AIRModel(torch.tensor(images, device=dev), torch.tensor(targets, device=dev), cnn=False,
                         train=True, scope="air", annealing_schedules=ANNEAL, seed=0, noise_seed=rank,
-                        gemm_precision=args.precision, **hp)
+                        gemm_precision=args.precision, backward=args.backward, **hp)
     if world > 1:
         model.sync_parameters()            # replicas start (and, with one shared all-reduce, stay) identical
     # several train steps per hipGraph replay (single GPU): amortises the replay's own launch cost
@@ -305,7 +328,8 @@ def main():
                                     "256 LSTM, z=50 (training.py:100-122)") if args.workload == "configs[1]" else
                                    "configs[3]: stress, 128x128 canvas, 0-4 objects, batch %d/GPU, 5 steps" % B,
                        "global_batch": world * B,
-                       "hipgraph": not args.no_graph, "steps_per_graph_replay": gsteps, "parallelism": "dp%d" % world},
+                       "hipgraph": not args.no_graph, "steps_per_graph_replay": gsteps, "parallelism": "dp%d" % world,
+                       "backward": args.backward},
             "per_gpu_images_per_sec": round(value / world, 1), "final_loss": round(loss, 3),
         }
         if not args.no_roofline and world == 1:
@@ -317,10 +341,21 @@ def main():
                 avg_us = d["us"] / d["launches"]
                 per_launch = d["nbytes"] / d["launches"]
                 gbs = per_launch / avg_us * 1e-3 if avg_us > 0 else 0.0
-                return {"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(name),
-                        "avg_us": round(avg_us, 2), "launches_per_step": d["launches"],
-                        "algorithmic_bytes": int(per_launch), "share_of_step": round(d["us"] / total_us, 3)}
+                prof = kernel_profile(name)
+                r = {"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": prof.get("hbm_bytes_per_launch"),
+                     "avg_us": round(avg_us, 2), "avg_us_rocprofv3": prof.get("avg_us"),
+                     "launches_per_step": d["launches"],
+                     "algorithmic_bytes": int(per_launch), "share_of_step": round(d["us"] / total_us, 3)}
+                if d["flops"]:
+                    r["mfma"] = {"flops_per_launch": int(d["flops"] / d["launches"]),
+                                 "frac_of_peak_from_flops": round(d["flops"] / d["launches"] / (avg_us * 1e-6) * 1e-12
+                                                                  / MFMA_PEAK_TF[args.precision], 5) if avg_us > 0 else None,
+                                 "busy_counter_util": prof.get("mfma_util"),        # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE*256*4)
+                                 "busy_cycles_per_launch": prof.get("mfma_busy_cycles")}
+                if prof.get("stale"):
+                    r["profile_stale"] = True        # profiles/kernel_profile.json was taken from other sources
+                return r
             # dominant kernel = the kernel function with the largest share of the step (what the
             # rocprofv3 stats table lists first); the other functions follow in `roofline_all`
             ranked = sorted(kt.items(), key=lambda kv: -kv[1]["us"])
@@ -337,21 +372,59 @@ def main():
                                                                 / MFMA_PEAK_TF[args.precision], 5)}
             line["kernels"] = {k: {"us_per_step": round(v["us"], 2), "launches": v["launches"], "ops": v["ops"]}
                                for k, v in ranked}
-        if not args.no_roofline and world == 1:
+        if not args.no_extras and world == 1:
             # secondary metric of SURVEY 8(d): inference (train=False forward, z_pres rounded) on the same batch
             inf = am.AIRModel(model.input_images, model.target_num_digits, cnn=False, train=False, reuse=True,
                               scope="air", annealing_schedules=ANNEAL, seed=rank, gemm_precision=args.precision, **hp)
-            for _ in range(20):
-                inf.forward()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(200):
-                inf.forward()
-            e1.record()
-            torch.cuda.synchronize()
-            us = e0.elapsed_time(e1) * 1e3 / 200
-            line["inference"] = {"images_per_sec": round(B / us * 1e6, 1), "us_per_forward": round(us, 1),
-                                 "launches": len(inf._fwd) + 1, "mode": "eager launches, train=False"}
+
+            def time_forward(n=200):
+                for _ in range(20):
+                    inf.forward()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(n):
+                    inf.forward()
+                e1.record()
+                torch.cuda.synchronize()
+                return e0.elapsed_time(e1) * 1e3 / n
+            us_eager = time_forward()
+            inf.capture_graph()
+            us_graph = time_forward()
+            line["inference"] = {"images_per_sec": round(B / us_graph * 1e6, 1), "us_per_forward": round(us_graph, 1),
+                                 "us_per_forward_eager": round(us_eager, 1), "launches": len(inf._fwd) + 1,
+                                 "mode": "one hipGraph replay per forward, train=False"}
+        if not args.no_extras and world == 1 and args.workload == "configs[1]":
+            # the same step at the reference's own precision (fp32 operands, exact-fp32 MFMA) ...
+            def secondary(tag, prec, hp2, B2, steps):
+                im2, tg2 = synthetic_canvases(B2, hp2["canvas_size"], hp2["max_digits"], seed=2000)
+                m2 = am.AIRModel(torch.tensor(im2, device=dev), torch.tensor(tg2, device=dev), cnn=False, train=True,
+                                 scope=tag, annealing_schedules=ANNEAL, seed=0, gemm_precision=prec,
+                                 backward=args.backward, **hp2)
+                g2 = 1 if args.no_graph else 4
+                if not args.no_graph:
+                    m2.capture_graph(steps=g2)
+                for _ in range(max(1, 8 // g2)):
+                    m2.training()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(steps // g2):
+                    m2.training()
+                torch.cuda.synchronize()
+                dt2 = time.perf_counter() - t1
+                out = {"ms_per_step": round(dt2 / (steps // g2 * g2) * 1e3, 4),
+                       "images_per_sec": round(B2 * (steps // g2 * g2) / dt2, 1), "batch": B2, "dtype": prec,
+                       "steps": steps // g2 * g2, "final_loss": round(float(m2.loss), 3)}
+                m2.release_graph()
+                del m2
+                return out
+            line["fp32"] = secondary("air_fp32", "fp32", hp, B, 100)
+            # ... and BASELINE configs[3], the stress configuration (128x128 canvas, 0-4 objects, N=5, b=256)
+            hp3 = dict(HP, canvas_size=128, max_steps=5, max_digits=4)
+            line["stress_configs3"] = secondary("air_stress", args.precision, hp3, 256, 40)
+            line["stress_configs3"]["workload"] = "configs[3]: 128x128 canvas, 0-4 objects, batch 256, 5 steps"
+            P3 = sum(int(np.prod(v)) for v in [(128 * 128 + 256, 1024)]) + (model.store.num_trainable - (2756 * 1024))
+            line["stress_configs3"]["frac_of_hbm_peak"] = round(
+                (40 * P3 + 4 * 256 * 128 * 128) / (line["stress_configs3"]["ms_per_step"] * 1e-3) * 1e-9 / HBM_PEAK_GBS, 4)
         if not args.no_cpu_baseline and world == 1 and args.workload == "configs[1]":
             line["cpu_baseline"] = cpu_baseline(B)
         if world > 1 and ar is not None:

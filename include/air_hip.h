@@ -199,6 +199,13 @@ int air_lstm_gates_bwd(const float* dh, const float* dc_in /*nullable*/, const f
  * 4-product / add_n op order, indices clipped before the weights. */
 int air_transformer_fwd(const float* U, const float* theta, float* out,
                         int B, int Hi, int Wi, int Ho, int Wo, void* stream);
+/* its gradient (what tf.gradients builds for transformer.py:56-171): d_U [B,Hi,Wi] and / or d_theta [B,2,3]
+ * (either may be NULL) from d_out [B,Ho,Wo], in the reference graph's op order -- AddN order for the
+ * coordinate gradients; d_U through ONE fp32 accumulator per input pixel that receives the a-, b-, c-,
+ * d-tap terms in output-pixel order (the graph's single UnsortedSegmentSum over the concatenated Gather
+ * gradients).  Hi*Wi <= ~20 000 (U and d_U of one image live in LDS). */
+int air_transformer_bwd(const float* U, const float* theta, const float* d_out, float* d_U, float* d_theta,
+                        int B, int Hi, int Wi, int Ho, int Wo, void* stream);
 
 /* ---- "attend": heads output layer + sampling + KLs + stop logic + ST read -----
  * air_model.py:288-333 (scale/shift heads, theta, transformer canvas->window) and

@@ -264,6 +264,46 @@ def transformer(U, theta, out_size, return_aux=False):
     return out
 
 
+def transformer_backward(U, theta, out_size, d_out):
+    """What tf.gradients builds for transformer(U, theta, out_size) (transformer.py:56-171), in the op
+    order of the reference's saved graph (model/air-model.meta, `.../st_backward/...` gradient nodes;
+    executed by oracle/graphdef_exec.py, pinned to this function by tests/test_graph_exec.py):
+
+      * d U: the four Gather gradients are concatenated (a, b, c, d) and reduced by ONE
+        UnsortedSegmentSum -- np.add.at visits the terms in that order, like the TF CPU kernel;
+      * coordinate gradients: mul_10..13_grad / mul_6..9_grad products, Sub negations, then AddN_10
+        (x) and AddN_11 (y) over the legs of wa, wb, wc, wd left to right; truediv_grad, mul_grad;
+      * d theta: MatMul_grad -- contraction of (d x_s, d y_s) with the grid rows (x_t, y_t, 1).
+    Returns (d_U [B,Hi,Wi], d_theta [B,2,3])."""
+    dtype = U.dtype
+    f = dtype.type
+    B, Hi, Wi = U.shape
+    Ho, Wo = out_size
+    _, aux = transformer(U, theta, out_size, return_aux=True)
+    x, y, x0, x1, y0, y1 = (aux[k] for k in ("x", "y", "x0", "x1", "y0", "y1"))
+    g = d_out.reshape(B, Ho * Wo).astype(dtype)
+    x0_f, x1_f, y0_f, y1_f = (v.astype(dtype) for v in (x0, x1, y0, y1))
+    wx0, wx1, wy0, wy1 = x1_f - x, x - x0_f, y1_f - y, y - y0_f
+    bidx = np.arange(B)[:, None]
+    Ia, Ib, Ic, Id = U[bidx, y0, x0], U[bidx, y1, x0], U[bidx, y0, x1], U[bidx, y1, x1]
+    # d U: [a-terms of every output pixel, then b, c, d] into one accumulator per input pixel
+    d_U = np.zeros((B, Hi * Wi), dtype)
+    for b in range(B):
+        idx = np.concatenate([y0[b] * Wi + x0[b], y1[b] * Wi + x0[b], y0[b] * Wi + x1[b], y1[b] * Wi + x1[b]])
+        val = np.concatenate([(wx0[b] * wy0[b]) * g[b], (wx0[b] * wy1[b]) * g[b],
+                              (wx1[b] * wy0[b]) * g[b], (wx1[b] * wy1[b]) * g[b]])
+        np.add.at(d_U[b], idx, val)
+    ga, gb, gc, gd = g * Ia, g * Ib, g * Ic, g * Id
+    dX = ((-(ga * wy0) + -(gb * wy1)) + gc * wy0) + gd * wy1
+    dY = ((-(wx0 * ga) + wx0 * gb) + -(wx1 * gc)) + wx1 * gd
+    dxs = (dX / f(2.0)) * (f(Wi) - f(1.001))
+    dys = (dY / f(2.0)) * (f(Hi) - f(1.001))
+    x_t, y_t = meshgrid(Ho, Wo, dtype)
+    grid = np.stack([x_t, y_t, np.ones_like(x_t)])                       # [3, Ho*Wo]
+    d_theta = np.stack([dxs @ grid.T, dys @ grid.T], axis=1)             # [B, 2, 3]
+    return d_U.reshape(B, Hi, Wi), d_theta.astype(dtype)
+
+
 # --------------------------------------------------------------------------- #
 # Concrete / Gumbel-Softmax -- air/concrete.py
 # --------------------------------------------------------------------------- #

@@ -525,3 +525,29 @@ def test_heads_out_wgrad_matches_grouped_launch(H):
         h = head[o]
         np.testing.assert_allclose(got[o, :offs[h + 1] - offs[h]], full[o, offs[h]:offs[h + 1]], rtol=1e-4, atol=2e-4)
     np.testing.assert_allclose(db.cpu().numpy(), d7.astype(np.float64).sum(0)[:7], rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("Hi,Wi,Ho,Wo", [(28, 28, 50, 50), (50, 50, 28, 28), (9, 11, 7, 8), (128, 128, 28, 28)])
+def test_transformer_bwd_generic_matches_oracle(H, Hi, Wi, Ho, Wo):
+    """air_transformer_bwd (any theta: rotation / shear / out-of-range) vs oracle.transformer_backward,
+    which is pinned to the reference's executed graph (tests/test_graph_exec.py): d U bit for bit (the
+    UnsortedSegmentSum accumulation order), d theta to 2e-5 (a contraction over the output pixels)."""
+    from air.transformer import transformer, transformer_grad
+    rng = np.random.RandomState(Hi * 7 + Wo)
+    B = 5
+    U = rng.uniform(0, 1, (B, Hi, Wi)).astype(np.float32)
+    base = np.array([[0.55, 0.25, 0.3], [-0.2, 0.6, -0.4]], np.float32)
+    th = (np.tile(base, (B, 1, 1)) + rng.randn(B, 2, 3).astype(np.float32) * 0.15).astype(np.float32)
+    th[0] = [[1.6, 0.0, 0.9], [0.0, 1.6, -0.9]]              # mostly out of range: border slots collect long chains
+    d = (rng.randn(B, Ho, Wo) * np.where(rng.uniform(size=(B, Ho, Wo)) < 0.1, 1e6, 1.0)).astype(np.float32)
+    dU_ref, dth_ref = ao.transformer_backward(U, th, (Ho, Wo), d)
+    Ut, tt, dt = (torch.tensor(v, device="cuda") for v in (U, th, d))
+    dU, dth = transformer_grad(Ut, tt, (Ho, Wo), dt)
+    torch.cuda.synchronize()
+    assert np.array_equal(dU.cpu().numpy(), dU_ref)
+    scale = np.abs(dth_ref).max(axis=(1, 2), keepdims=True)
+    assert (np.abs(dth.cpu().numpy().reshape(B, 2, 3) - dth_ref) <= 2e-5 * scale).all()
+    # through torch.autograd (the drop-in op is differentiable like the reference's under tf.gradients)
+    Ug, tg = Ut.clone().requires_grad_(True), tt.clone().requires_grad_(True)
+    transformer(Ug, tg, (Ho, Wo)).backward(dt)
+    assert torch.equal(Ug.grad, dU) and torch.equal(tg.grad.reshape(B, 6), dth)

@@ -362,3 +362,30 @@ def test_reference_and_exact_backward_agree_without_residues(am):
             # the graph-order accumulator keeps a larger residue than the per-tap sums even here
             assert err <= (2e-3 if mode == "reference" else 2e-4), (mode, k, err)
     REPORT["reference_vs_exact_smooth_regime_worst_rel"] = worst
+
+
+def test_inference_graph_replay_equals_eager(am):
+    """train=False models capture the whole forward as ONE hipGraph (the demo's hot call,
+    demo/model_wrapper.py:19-30); a replay is bit-identical to the eager launches."""
+    images, targets = blob_canvases(64, HP["canvas_size"], HP["max_digits"], seed=9)
+    am.reset_default_graph()
+    tr = am.AIRModel(torch.tensor(images, device="cuda"), torch.tensor(targets, device="cuda"), cnn=False,
+                     train=True, scope="air", **HP)
+    inf = am.AIRModel(tr.input_images, tr.target_num_digits, cnn=False, train=False, reuse=True, scope="air", **HP)
+    inf.forward()
+    torch.cuda.synchronize()
+    eager = {k: _np(getattr(inf, k)).copy() for k in ("reconstruction", "rec_num_digits", "rec_scales", "rec_windows",
+                                                     "reconstruction_loss", "vae_kls")}
+    l0 = float(inf.loss)
+    inf.capture_graph()
+    inf._recon.zero_()
+    inf.forward()
+    torch.cuda.synchronize()
+    for k, v in eager.items():
+        assert np.array_equal(_np(getattr(inf, k)), v), k
+    assert float(inf.loss) == l0
+    # the captured graph follows the shared variables: a train step changes the next replay
+    tr.training()
+    inf.forward()
+    torch.cuda.synchronize()
+    assert float(inf.loss) != l0

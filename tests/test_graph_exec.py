@@ -249,3 +249,33 @@ def test_fixture_is_what_the_graph_produces(graph, gold):
     # the reference's fp32 backward carries a rounding residue far above the exact gradient
     # (out-of-range sampler taps x d log(r + 1e-9)): pinned as measured
     assert 1e2 < float(gold["train0/global_norm_fp32"]) / float(gold["train0/global_norm_fp64"]) < 1e5
+
+
+# ------------------------------------------------------------------ transformer backward (generic op)
+
+def test_oracle_transformer_backward_matches_graph_fixture_and_autograd(gold):
+    """oracle.transformer_backward (graph op order) vs (a) the executed graph's st_backward gradient
+    tensors -- bit-identical d U, d theta to 1e-6 -- and (b) torch autograd in fp64, any theta."""
+    f = np.float32
+    for t in range(int(gold["train0/steps_executed"])):
+        k = "kern/t%d/" % t
+        s, x, y = gold[k + "s"], gold[k + "x"], gold[k + "y"]
+        n = len(s)
+        th = np.zeros((n, 2, 3), f)
+        th[:, 0, 0] = f(1) / s; th[:, 0, 2] = (-x) / s; th[:, 1, 1] = f(1) / s; th[:, 1, 2] = (-y) / s   # air_model.py:353-356
+        dU, dth = ao.transformer_backward(gold[k + "vae_recon"].reshape(n, 28, 28), th, (50, 50),
+                                          gold[k + "g_window_recon"].reshape(n, 50, 50))
+        act = gold[k + "mask"].astype(bool)
+        assert np.array_equal(dU.reshape(n, -1)[act], gold[k + "d_vae_recon"].reshape(n, -1)[act])
+        ref = gold[k + "d_theta_recon"].reshape(n, 6)[act]
+        assert np.abs(dth.reshape(n, 6)[act] - ref).max() <= 1e-6 * np.abs(ref).max()
+    rng = np.random.RandomState(0)
+    B, Hi, Wi, Ho, Wo = 3, 9, 11, 7, 8
+    U = rng.uniform(0, 1, (B, Hi, Wi))
+    th = np.tile(np.array([[0.7, 0.2, 0.1], [-0.15, 0.8, -0.05]]), (B, 1, 1)) + rng.randn(B, 2, 3) * 0.1
+    d = rng.randn(B, Ho, Wo)
+    dU, dth = ao.transformer_backward(U, th, (Ho, Wo), d)
+    Ut, tt = torch.tensor(U, requires_grad=True), torch.tensor(th, requires_grad=True)
+    at.transformer(Ut, tt, (Ho, Wo)).backward(torch.tensor(d))
+    np.testing.assert_allclose(dU, Ut.grad.numpy(), atol=1e-12)
+    np.testing.assert_allclose(dth, tt.grad.numpy(), atol=1e-12)

@@ -105,6 +105,7 @@ _SIGNATURES = {
     "air_lstm_gates_fwd": (C.c_int, [_p, _p, _p, _p, _p, C.c_int, C.c_int, _p]),
     "air_lstm_gates_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, C.c_int, C.c_int, C.c_int, _p]),
     "air_transformer_fwd": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
+    "air_transformer_bwd": (C.c_int, [_p, _p, _p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "air_attend_fwd": (C.c_int, [C.POINTER(AttendFwd), _p]),
     "air_attend_bwd": (C.c_int, [C.POINTER(AttendBwd), _p]),
     "air_heads_out_wgrad": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),

@@ -651,7 +651,10 @@ class AIRModel:
 
     def forward(self):
         """Evaluates the model on the current contents of the input buffers."""
-        self._run_forward(self._stream())
+        if self._graph is not None and not self.train and not self._injected_noise:
+            self._graph[0].replay()
+        else:
+            self._run_forward(self._stream())
         self._dirty = False
         self._steps_executed = None
         return self
@@ -720,7 +723,7 @@ class AIRModel:
         separate replays; `between_steps(i)` (optional, graph-capturable device work such as the
         next batch's gather) is captured before step i.  training() then advances `steps` steps."""
         if not self.train:
-            raise RuntimeError("capture_graph() is for train=True models")
+            return self._capture_forward_graph()
         self._optimizer_ops()
         world = self._world()
         if self.store.synced_world != world:
@@ -752,6 +755,24 @@ class AIRModel:
             with torch.cuda.graph(gb):
                 self._train_phase_b(self._stream())
         self._graph = (ga, gb)
+        return self
+
+    def _capture_forward_graph(self):
+        """train=False models (the demo / evaluation call, demo/model_wrapper.py:19-30): the whole
+        forward -- schedules + noise, hoisted x.Wx, N x (LSTM, heads, read, VAE), compose, batch means --
+        as ONE hipGraph; forward() then is a single replay."""
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):            # warm-up outside capture (lazy module loads, LDS attributes)
+            self._run_forward(self._stream())
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._run_forward(self._stream())
+        self._graph = (g, None)
+        self._graph_steps = 1
         return self
 
     def release_graph(self):

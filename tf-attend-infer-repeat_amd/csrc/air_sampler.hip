@@ -146,6 +146,101 @@ __global__ __launch_bounds__(THREADS) void transformer_fwd_kernel(
     }
 }
 
+typedef __attribute__((address_space(3))) float air_lds_float;
+// no-return LDS float add (inline asm: no compare-and-swap loop may be substituted)
+__device__ __forceinline__ void lds_fadd(float* p, float v) {
+    asm volatile("ds_add_f32 %0, %1" :: "v"((unsigned)(size_t)(air_lds_float*)p), "v"(v) : "memory");
+}
+
+// ---------------------------------------------------------------------------
+// generic transformer backward (any theta): gradients wrt the input image U and wrt theta, in the
+// op order of the reference's graph (transformer.py:56-171 differentiated by tf.gradients; node
+// orders from model/air-model.meta):
+//   * d theta: per output pixel, graph_dxy's AddN order for the coordinate gradients, then the
+//     MatMul_grad contraction over the output pixels with (x_t, y_t, 1);
+//   * d U: the four Gather gradients concatenated and reduced by one UnsortedSegmentSum -- every input
+//     pixel is ONE fp32 accumulator receiving its a-terms in output-pixel order, then b, c, d.  For an
+//     arbitrary theta the contributors of a slot are not a rectangle, so the accumulation is done
+//     where the hardware already provides that order: one wave walks the 4*Ho*Wo terms in sequence,
+//     64 per ds_add_f32; gfx950's LDS applies the lanes of an instruction in ascending order and a
+//     wave's instructions in program order (tools/exp/lds_atomic_order.hip), i.e. exactly the scatter
+//     order of the reference's CPU kernel.  One workgroup per image; U and d U live in LDS.
+// ---------------------------------------------------------------------------
+struct GenTap { float wx0, wx1, wy0, wy1; int x0, x1, y0, y1; float xt, yt; };
+__device__ __forceinline__ GenTap generic_tap(const float* th, int i, int j, int Hi, int Wi, int Ho, int Wo) {
+    GenTap t;
+    t.xt = (Wo > 1) ? (-1.0f + (2.0f / (float)(Wo - 1)) * (float)j) : -1.0f;
+    t.yt = (Ho > 1) ? (-1.0f + (2.0f / (float)(Ho - 1)) * (float)i) : -1.0f;
+    const float xs = (th[0] * t.xt + th[1] * t.yt) + th[2] * 1.0f;
+    const float ys = (th[3] * t.xt + th[4] * t.yt) + th[5] * 1.0f;
+    const float X = ((xs + 1.0f) * ((float)Wi - 1.001f)) / 2.0f;
+    const float Y = ((ys + 1.0f) * ((float)Hi - 1.001f)) / 2.0f;
+    const float fx = floorf(X), fy = floorf(Y);
+    const float x0 = fminf(fmaxf(fx, 0.f), (float)(Wi - 1)), x1 = fminf(fmaxf(fx + 1.f, 0.f), (float)(Wi - 1));
+    const float y0 = fminf(fmaxf(fy, 0.f), (float)(Hi - 1)), y1 = fminf(fmaxf(fy + 1.f, 0.f), (float)(Hi - 1));
+    t.wx0 = x1 - X; t.wx1 = X - x0; t.wy0 = y1 - Y; t.wy1 = Y - y0;
+    t.x0 = (int)x0; t.x1 = (int)x1; t.y0 = (int)y0; t.y1 = (int)y1;
+    return t;
+}
+
+__global__ __launch_bounds__(THREADS) void transformer_bwd_kernel(
+    const float* __restrict__ U, const float* __restrict__ theta, const float* __restrict__ d_out,
+    float* __restrict__ d_U, float* __restrict__ d_theta, int Hi, int Wi, int Ho, int Wo)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NI = Hi * Wi, NO = Ho * Wo;
+    float* sh_red = smem;                      // [32]
+    float* sh_th = smem + 32;                  // [8]
+    float* sh_U = smem + 40;                   // [NI]
+    float* sh_dU = sh_U + ((NI + 3) & ~3);     // [NI]
+    const float* img = U + (size_t)b * NI;
+    const float* g = d_out + (size_t)b * NO;
+    if (tid < 6) sh_th[tid] = theta[(size_t)b * 6 + tid];
+    for (int p = tid; p < NI; p += THREADS) { sh_U[p] = img[p]; sh_dU[p] = 0.0f; }
+    __syncthreads();
+    if (d_theta) {
+        float s6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int p = tid; p < NO; p += THREADS) {
+            const GenTap t = generic_tap(sh_th, p / Wo, p % Wo, Hi, Wi, Ho, Wo);
+            const float Ia = sh_U[t.y0 * Wi + t.x0], Ib = sh_U[t.y1 * Wi + t.x0];
+            const float Ic = sh_U[t.y0 * Wi + t.x1], Id = sh_U[t.y1 * Wi + t.x1];
+            // graph_dxy's order (AddN over wa, wb, wc, wd); the two axes have their own (W - 1.001) here
+            const float ga = g[p] * Ia, gb = g[p] * Ib, gc = g[p] * Ic, gd = g[p] * Id;
+            const float dX = ((-(ga * t.wy0) + -(gb * t.wy1)) + gc * t.wy0) + gd * t.wy1;
+            const float dY = ((-(t.wx0 * ga) + t.wx0 * gb) + -(t.wx1 * gc)) + t.wx1 * gd;
+            const float gX = (dX / 2.0f) * ((float)Wi - 1.001f);
+            const float gY = (dY / 2.0f) * ((float)Hi - 1.001f);
+            s6[0] += gX * t.xt; s6[1] += gX * t.yt; s6[2] += gX;
+            s6[3] += gY * t.xt; s6[4] += gY * t.yt; s6[5] += gY;
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const float v = air_block_sum_256(s6[k], sh_red + 4 * k);
+            if (tid == 0) d_theta[(size_t)b * 6 + k] = v;
+        }
+    }
+    if (d_U) {
+        __syncthreads();
+        if (wave == 0) {
+            for (int ph = 0; ph < 4; ++ph)
+                for (int p0 = 0; p0 < NO; p0 += 64) {
+                    const int p = p0 + lane;
+                    if (p < NO) {
+                        const GenTap t = generic_tap(sh_th, p / Wo, p % Wo, Hi, Wi, Ho, Wo);
+                        const float wgt = ((ph & 2) ? t.wx1 : t.wx0) * ((ph & 1) ? t.wy1 : t.wy0);   // wa, wb, wc, wd
+                        const int idx = ((ph & 1) ? t.y1 : t.y0) * Wi + ((ph & 2) ? t.x1 : t.x0);
+                        lds_fadd(sh_dU + idx, wgt * g[p]);
+                    }
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        float* dst = d_U + (size_t)b * NI;
+        for (int p = tid; p < NI; p += THREADS) dst[p] = sh_dU[p];
+    }
+}
+
 // head index -> (offset, width) inside the concatenated hidden vector
 struct HeadSeg { int off[5]; int wid[5]; };
 __device__ __forceinline__ HeadSeg head_segments(int Hs, int Hh, int Hz) {
@@ -911,12 +1006,6 @@ __device__ __forceinline__ float stream_add(float acc, const float* T, int start
     return acc;
 }
 
-typedef __attribute__((address_space(3))) float air_lds_float;
-// no-return LDS float add (inline asm: no compare-and-swap loop may be substituted)
-__device__ __forceinline__ void lds_fadd(float* p, float v) {
-    asm volatile("ds_add_f32 %0, %1" :: "v"((unsigned)(size_t)(air_lds_float*)p), "v"(v) : "memory");
-}
-
 // ALLPH: the terms of all four taps are resident (4*C*C floats of LDS, no barrier between taps);
 // otherwise one tap at a time through one buffer (large canvases)
 template <bool ALLPH>
@@ -1196,6 +1285,18 @@ extern "C" int air_transformer_fwd(const float* U, const float* theta, float* ou
     const int blocks = (int)((total + THREADS - 1) / THREADS < 2048 ? (total + THREADS - 1) / THREADS : 2048);
     hipLaunchKernelGGL(transformer_fwd_kernel, dim3(blocks), dim3(THREADS), 0, air_stream(stream),
                        U, theta, out, B, Hi, Wi, Ho, Wo);
+    AIR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int air_transformer_bwd(const float* U, const float* theta, const float* d_out, float* d_U, float* d_theta,
+                                   int B, int Hi, int Wi, int Ho, int Wo, void* stream) {
+    if (!U || !theta || !d_out || (!d_U && !d_theta) || B <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return AIR_EINVAL;
+    const size_t lds = (40 + 2 * (((size_t)Hi * Wi + 3) & ~3)) * sizeof(float);
+    int rc = ensure_lds(transformer_bwd_kernel, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(transformer_bwd_kernel, dim3(B), dim3(THREADS), lds, air_stream(stream),
+                       U, theta, d_out, d_U, d_theta, Hi, Wi, Ho, Wo);
     AIR_CHECK_LAUNCH();
     return 0;
 }
