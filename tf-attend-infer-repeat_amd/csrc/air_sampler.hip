@@ -1116,81 +1116,109 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
     const bool corner = is_slot && (sp == 0 || sp == w - 1) && (sq == 0 || sq == w - 1);
     float acc = 0.0f;
     float d00 = 0.f, d02 = 0.f, d11 = 0.f, d12 = 0.f, dz = 0.f;
-    auto stage_C = [&](int ph0, int ph1) {
-        if (wave == FEED) {
-            // The corner slots' streams -> ds_add_f32, 64 consecutive terms per instruction, 8 instructions
-            // per batch.  A wave's LDS operations execute in order, so a read queued behind an add
-            // waits for it: the reads of batch i+1 are issued right behind the adds of batch i and
-            // have landed when those finish; the wave then only has to issue the next 8 adds.  Reads,
-            // adds and waits are inline asm (the compiler's own s_waitcnt bookkeeping would put an
-            // lgkmcnt(0) in front of every add); the register dependence is carried through the wait.
-            int ph = ph0, c = -1, k0 = 0, start = 0, n = 0;
-            auto advance = [&]() -> bool {               // next non-empty batch (uniform)
-                k0 += 8 * 64;
-                while (k0 >= n) {
-                    if (++c == 4) { c = 0; if (++ph >= ph1) return false; }
-                    slot_run(ph, (c & 2) ? w - 1 : 0, (c & 1) ? w - 1 : 0, start, n);
-                    k0 = 0;
-                    if (n > 0) break;
-                }
-                return true;
-            };
-            auto reads = [&](float (&r)[8]) {
+    // The corner slots' streams -> ds_add_f32 on one LDS word per corner: wave c feeds corner c, 64
+    // consecutive terms per instruction, tap after tap (an instruction costs ~140 + 1.8 cycles per active
+    // lane, tools/exp/lds_atomic_cost.hip: full instructions, and the four corners' fixed parts
+    // overlap across the four waves).  16 instructions per batch: a wave's LDS operations execute in
+    // order, so a read queued behind an add waits for it -- the reads of batch i+1 are issued right
+    // behind the adds of batch i and have landed when those finish.  Reads, adds and waits are inline
+    // asm (the compiler's own s_waitcnt bookkeeping would put an lgkmcnt(0) in front of every add);
+    // the register dependence is carried through the wait.
+    auto feed_corner = [&](int c, int ph0, int ph1) {
+        constexpr int NB = 16;
+        // stream descriptors of this corner: lane ph computes tap ph's run, broadcast to scalars
+        int my_start = 0, my_n = 0;
+        if (lane < 4) slot_run(lane, (c & 2) ? w - 1 : 0, (c & 1) ? w - 1 : 0, my_start, my_n);
+        int st[4], ln[4], cum[5];
+        cum[0] = 0;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const unsigned addr = (unsigned)(size_t)(air_lds_float*)(sh_T + start + min(k0 + u * 64 + lane, n - 1));
-                    asm volatile("ds_read_b32 %0, %1" : "=v"(r[u]) : "v"(addr) : "memory");
-                }
-            };
-            auto adds = [&](float (&r)[8], int bc, int bk0, int bn) {
-                asm volatile("s_waitcnt lgkmcnt(0)"
-                             : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) :: "memory");
-                const unsigned acc_addr = (unsigned)(size_t)(air_lds_float*)(sh_acc + bc);
+        for (int k = 0; k < 4; ++k) {
+            st[k] = __builtin_amdgcn_readlane(my_start, k);
+            ln[k] = (k >= ph0 && k < ph1) ? __builtin_amdgcn_readlane(my_n, k) : 0;
+            cum[k + 1] = cum[k] + ((ln[k] + 63) >> 6);           // instructions of taps 0..k
+        }
+        const int ninstr = cum[4];
+        const unsigned acc_addr = (unsigned)(size_t)(air_lds_float*)(sh_acc + c);
+        for (int base = 0; base < ninstr; base += 128) {
+            // the instruction list is tabulated in registers, lane l holding entries base + l and
+            // base + 64 + l (first-term offset, valid lanes); the issue loop below reads them with
+            // v_readlane and stays a few hundred instructions long (a fully unrolled state machine
+            // over taps x chunks grew to tens of thousands and ran out of the instruction cache)
+            int ent_a[2], ent_n[2];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if (bk0 + u * 64 < bn) {             // uniform; lanes past the end add -0.0f (x + -0 == x)
-                        const float tv = (bk0 + u * 64 + lane < bn) ? r[u] : -0.0f;
-                        asm volatile("ds_add_f32 %0, %1" :: "v"(acc_addr), "v"(tv) : "memory");
+            for (int h = 0; h < 2; ++h) {
+                const int i = base + h * 64 + lane;
+                const int ph = (i >= cum[1]) + (i >= cum[2]) + (i >= cum[3]);
+                const int k0 = (i - (ph == 0 ? cum[0] : ph == 1 ? cum[1] : ph == 2 ? cum[2] : cum[3])) * 64;
+                ent_a[h] = (ph == 0 ? st[0] : ph == 1 ? st[1] : ph == 2 ? st[2] : st[3]) + k0;
+                ent_n[h] = i < ninstr ? min(64, (ph == 0 ? ln[0] : ph == 1 ? ln[1] : ph == 2 ? ln[2] : ln[3]) - k0) : 0;
+            }
+            const int m = min(128, ninstr - base);
+            auto reads = [&](float (&r)[NB], int (&d)[NB], int j0) {
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int j = j0 + u;                          // uniform
+                    d[u] = 0;
+                    if (j < m) {
+                        const int a0 = __builtin_amdgcn_readlane(j < 64 ? ent_a[0] : ent_a[1], j & 63);
+                        d[u] = __builtin_amdgcn_readlane(j < 64 ? ent_n[0] : ent_n[1], j & 63);
+                        const unsigned addr = (unsigned)(size_t)(air_lds_float*)(sh_T + a0 + min(lane, d[u] - 1));
+                        asm volatile("ds_read_b32 %0, %1" : "=v"(r[u]) : "v"(addr) : "memory");
                     }
                 }
             };
-            c = -1; ph = ph0; n = 0; k0 = 0;
-            float ra[8], rb[8];
-            bool more = advance();
-            if (more) reads(ra);
-            while (more) {
-                int bc = c, bk0 = k0, bn = n;
-                more = advance();
-                adds(ra, bc, bk0, bn);
-                if (!more) break;
-                reads(rb);
-                bc = c; bk0 = k0; bn = n;
-                more = advance();
-                adds(rb, bc, bk0, bn);
-                if (more) reads(ra);
+            auto adds = [&](float (&r)[NB], const int (&d)[NB]) {
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]),
+                               "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15]) :: "memory");
+#pragma unroll
+                for (int u = 0; u < NB; ++u)
+                    if (lane < d[u]) asm volatile("ds_add_f32 %0, %1" :: "v"(acc_addr), "v"(r[u]) : "memory");   // valid lanes only (EXEC)
+            };
+            float ra[NB], rb[NB];
+            int da[NB], db[NB];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) { ra[u] = 0.f; rb[u] = 0.f; }
+            reads(ra, da, 0);
+#pragma unroll 1
+            for (int j0 = 0; j0 < m; j0 += 2 * NB) {
+                if (j0 + NB < m) reads(rb, db, j0 + NB);
+                adds(ra, da);
+                if (j0 + NB >= m) break;
+                if (j0 + 2 * NB < m) reads(ra, da, j0 + 2 * NB);
+                adds(rb, db);
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            return;
         }
-        if (ph0 == 0) {
-            // theta / z gradients, per canvas pixel, under the corner accumulation
-            constexpr int PT = FEED * 64;
-            const int ei = PT / C, ej = PT % C;
-            int i = tid / C, j = tid % C;
-            for (int p = tid; p < CC; p += PT) {
-                const Tap tx = sh_tx[j], ty = sh_ty[i];
-                const float Ia = sh_win[ty.i0 * w + tx.i0], Ib = sh_win[ty.i1 * w + tx.i0];
-                const float Ic = sh_win[ty.i0 * w + tx.i1], Id = sh_win[ty.i1 * w + tx.i1];
-                const float gv = sh_g[p];
-                dz += gv * bilinear4(tx, ty, Ia, Ib, Ic, Id);        // canvas/mul_grad: Select_grad * window_recon
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    // theta / z gradients, per canvas pixel: NT threads share the canvas, three pixels in flight per thread
+    auto theta_loop = [&](int NT) {
+        if (tid >= NT) return;
+        for (int p0 = tid; p0 < CC; p0 += 3 * NT) {
+            Tap tx[3], ty[3];
+            float Iv[3][4], gv[3], tj[3], ti[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int p = min(p0 + k * NT, CC - 1), i = p / C, j = p - i * C;
+                tx[k] = sh_tx[j]; ty[k] = sh_ty[i]; tj[k] = sh_t[j]; ti[k] = sh_t[i];
+                gv[k] = (p0 + k * NT < CC) ? sh_g[p] : 0.0f;     // a pixel past the end contributes exact zeros
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                Iv[k][0] = sh_win[ty[k].i0 * w + tx[k].i0]; Iv[k][1] = sh_win[ty[k].i1 * w + tx[k].i0];
+                Iv[k][2] = sh_win[ty[k].i0 * w + tx[k].i1]; Iv[k][3] = sh_win[ty[k].i1 * w + tx[k].i1];
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                dz += gv[k] * bilinear4(tx[k], ty[k], Iv[k][0], Iv[k][1], Iv[k][2], Iv[k][3]);   // canvas/mul_grad: Select_grad * window_recon
                 float gX, gY;
-                graph_dxy(z * gv, Ia, Ib, Ic, Id, tx, ty, (float)w - 1.001f, gX, gY);
-                d00 += gX * sh_t[j]; d02 += gX;                      // MatMul_grad: rows of theta x (x_t, y_t, 1)
-                d11 += gY * sh_t[i]; d12 += gY;
-                i += ei; j += ej;
-                if (j >= C) { j -= C; ++i; }
+                graph_dxy(z * gv[k], Iv[k][0], Iv[k][1], Iv[k][2], Iv[k][3], tx[k], ty[k], (float)w - 1.001f, gX, gY);
+                d00 += gX * tj[k]; d02 += gX;                    // MatMul_grad: rows of theta x (x_t, y_t, 1)
+                d11 += gY * ti[k]; d12 += gY;
             }
         }
+    };
+    auto chains = [&](int ph0, int ph1) {
         if (is_slot && !corner)
             for (int ph = ph0; ph < ph1; ++ph) {
                 int start, n;
@@ -1198,34 +1226,50 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
                 acc = stream_add(acc, sh_T, start, n);
             }
     };
+    // everything a wave owes besides the corner slots: its coordinate / z gradient partials (combined
+    // over the waves in a fixed order at the end) and the non-corner slots' outputs
+    auto publish = [&]() {
+        d00 = air_wave_sum(d00); d02 = air_wave_sum(d02); d11 = air_wave_sum(d11); d12 = air_wave_sum(d12); dz = air_wave_sum(dz);
+        if (lane == 0) { float* r = sh_red + wave * 8; r[0] = d00; r[1] = d02; r[2] = d11; r[3] = d12; r[4] = dz; }
+        if (is_slot && !corner) {
+            const float r = sh_win[tid];
+            dgen[tid] = (acc * r) * (1.0f - r);              // SigmoidGrad of vae.py:39-41: dy * y * (1 - y)
+        }
+    };
     if (ALLPH) {
+        // [terms of all taps] | [pixel loop + short chains + outputs on all waves: no LDS atomics in flight,
+        // every dependent LDS read returns at full speed] | [corner accumulation, the LDS to itself]
         stage_T(0, 4);
         __syncthreads();
         AIR_STAMP(43);
-        stage_C(0, 4);
+        theta_loop(WB_THREADS);
+        chains(0, 4);
+        publish();
         __syncthreads();
         AIR_STAMP(44);
+        if (wave < 4) feed_corner(wave, 0, 4);
+        __syncthreads();
     } else {
         for (int ph = 0; ph < 4; ++ph) {
             stage_T(ph, ph + 1);
             __syncthreads();
-            stage_C(ph, ph + 1);
+            if (ph == 0) theta_loop(WB_THREADS);
+            chains(ph, ph + 1);
+            __syncthreads();
+            if (wave < 4) feed_corner(wave, ph, ph + 1);
             __syncthreads();
         }
     }
-    // coordinate / z gradients: wave partials combined in a fixed order
-    d00 = air_wave_sum(d00); d02 = air_wave_sum(d02); d11 = air_wave_sum(d11); d12 = air_wave_sum(d12); dz = air_wave_sum(dz);
-    if (lane == 0) { float* r = sh_red + wave * 8; r[0] = d00; r[1] = d02; r[2] = d11; r[3] = d12; r[4] = dz; }
-    if (is_slot) {
-        if (corner) acc = sh_acc[(sp ? 2 : 0) + (sq ? 1 : 0)];
+    if (!ALLPH) { publish(); __syncthreads(); }
+    AIR_STAMP(45);
+    if (corner) {
         const float r = sh_win[tid];
-        dgen[tid] = (acc * r) * (1.0f - r);                  // SigmoidGrad of vae.py:39-41: dy * y * (1 - y)
+        dgen[tid] = (sh_acc[(sp ? 2 : 0) + (sq ? 1 : 0)] * r) * (1.0f - r);
     }
-    __syncthreads();
     if (tid < 64) {
         // lanes 0..4 each combine one quantity over the waves; lane 0 collects them by shuffle
         float u = 0.0f;
-        if (lane < 5) { u = sh_red[lane]; for (int wv = 1; wv < FEED; ++wv) u += sh_red[wv * 8 + lane]; }
+        if (lane < 5) { u = sh_red[lane]; for (int wv = 1; wv < NW; ++wv) u += sh_red[wv * 8 + lane]; }
         float t5[5];
 #pragma unroll
         for (int k = 0; k < 5; ++k) t5[k] = __shfl(u, k, 64);
@@ -1239,7 +1283,7 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
         dsx[3] = t5[4];
         }
     }
-    AIR_STAMP(45);
+    AIR_STAMP(47);
 }
 
 size_t attend_smem(int C, int w, int HT) {

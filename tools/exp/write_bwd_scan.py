@@ -25,14 +25,16 @@ if STAMPS:               # phase stamps of workgroup (0,0): -DAIR_STAMPS build i
     H._LIB.air_debug_stamps.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 
 p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
-B, N, Cc, w = 64, 3, int(os.environ.get("C", 50)), 28
+B, N, Cc, w = int(os.environ.get("B", 64)), 3, int(os.environ.get("C", 50)), 28
 rng = np.random.RandomState(0)
 d_recon = torch.tensor(rng.randn(B, Cc * Cc).astype(np.float32), device="cuda")
+if os.environ.get("CONST_G") == "1":
+    d_recon.fill_(1.0)
 vrec = torch.tensor(rng.uniform(0.05, 0.95, (N, B, w * w)).astype(np.float32), device="cuda")
 dgen = torch.zeros(N, B, w * w, device="cuda")
 dsx = torch.zeros(N, B, 4, device="cuda")
 stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-for s, x, y in ((0.3, 0.0, 0.0), (0.3, 0.6, 0.6), (0.3, -0.9, -0.9), (0.15, 0.95, 0.95), (0.6, 0.0, 0.0), (0.9, 0.0, 0.0)):
+for s, x, y in ((0.3, 0.0, 0.0), (0.3, 0.9, 0.9), (0.15, 0.95, 0.95), (0.9, 0.0, 0.0)):
     att = torch.zeros(N, B, H.ATT_STRIDE, device="cuda")
     att[..., H.ATT_S], att[..., H.ATT_X], att[..., H.ATT_Y], att[..., H.ATT_Z], att[..., H.ATT_MASK] = s, x, y, 0.7, 1.0
     line = "s=%.2f x=%.2f y=%.2f:" % (s, x, y)
@@ -51,6 +53,7 @@ for s, x, y in ((0.3, 0.0, 0.0), (0.3, 0.6, 0.6), (0.3, -0.9, -0.9), (0.15, 0.95
             buf = (C.c_ulonglong * 64)()
             H._LIB.air_debug_stamps(buf, 64)
             v = [int(q) for q in buf]
-            idx = [i for i in range(40, 56) if v[i]]
+            idx = [i for i in range(40, 56) if v[i]]   # 41 load | 42 runs | 43 terms | 44 pixel loop + chains | 45 corner atomics | 47 tail
             line += "\n      stamps(us) " + " ".join("%d:%.2f" % (i, (v[i] - v[j]) / 100.0) for j, i in zip(idx, idx[1:]))
+            line += "\n      feeder wave 0 (us since stamp 44): " + " ".join("%d:%.2f" % (i, (v[i] - v[44]) / 100.0) for i in range(48, 53) if v[i])
     print(line)
