@@ -189,6 +189,11 @@ int air_colsum(const air_colsum_t* probs /*HOST array*/, int count, void* stream
  * acts [B,4R] receives sigmoid(i), tanh(j), sigmoid(f+1), sigmoid(o). */
 int air_lstm_gates_fwd(const float* gates_pre, const float* c_prev, float* acts,
                        float* c, float* h, int B, int R, void* stream);
+/* The first step of the loop: the LSTM starts from zero_state (air_model.py:540), so [x, h].kernel is the
+ * hoisted x.Wx alone -- no MatMul.  xw_slabs: `nslabs` split-K slabs [B,4R] of x.Wx (air_gemm ksplit);
+ * pre-activation = slab sum (in slab order) + bias, i.e. AIR_EPI_LSTM_FWD with a zero accumulator. */
+int air_lstm_first_step(const float* xw_slabs, int nslabs, const float* bias /*nullable*/, float* acts,
+                        float* c, float* h, int B, int R, void* stream);
 /* dgates [B,4R] (pre-activation grads), dc_prev [B,R]; dgsum (+)= dgates when given */
 int air_lstm_gates_bwd(const float* dh, const float* dc_in /*nullable*/, const float* acts,
                        const float* c_prev, const float* c, float* dgates, float* dc_prev,

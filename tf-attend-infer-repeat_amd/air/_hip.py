@@ -103,6 +103,7 @@ _SIGNATURES = {
     "air_wgrad_num_blocks": (C.c_int, [C.POINTER(Wgrad), C.c_int]),
     "air_wgrad_grouped": (C.c_int, [C.POINTER(Wgrad), C.c_int, C.c_int, _p, _p, _p]),
     "air_lstm_gates_fwd": (C.c_int, [_p, _p, _p, _p, _p, C.c_int, C.c_int, _p]),
+    "air_lstm_first_step": (C.c_int, [_p, C.c_int, _p, _p, _p, _p, C.c_int, C.c_int, _p]),
     "air_lstm_gates_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, C.c_int, C.c_int, C.c_int, _p]),
     "air_transformer_fwd": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "air_transformer_bwd": (C.c_int, [_p, _p, _p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),

@@ -417,7 +417,7 @@ class AIRModel:
                    nbytes=4 * (M * K + K * N + M * N * (1 + extra)) + (4 * N if bias is not None else 0) + extra_bytes,
                    flops=2 * M * N * K, kernel=kbuf.value.decode())
 
-    _KERNEL_OF = {"air_step_begin": "step_begin_kernel", "air_attend_fwd": "attend_fwd_kernel",
+    _KERNEL_OF = {"air_lstm_first_step": "lstm_first_step_kernel", "air_step_begin": "step_begin_kernel", "air_attend_fwd": "attend_fwd_kernel",
                   "air_attend_bwd": "attend_bwd_kernel", "air_write_fwd": "write_fwd_kernel",
                   "air_write_bwd": "write_bwd_kernel", "air_finalize": "finalize_kernel",
                   "air_grad_sqnorm": "grad_sqnorm_kernel", "air_adam_clip_step": "adam_clip_kernel"}
@@ -457,7 +457,11 @@ class AIRModel:
                                           extra_bytes=4 * (self.normals.numel() + self.uniforms.numel()))
         # the recurrence: N chained LSTM steps (the only sequential part of the loop -- the LSTM
         # sees the same image every step and nothing downstream feeds back into it, :286/:535)
-        for t in range(N):
+        # step 0 starts from zero_state (:540): h_0 . Wh = 0, the gates are x.Wx + b -- a pointwise launch
+        fwd.append(self._call("air_lstm_first_step", _ptr(self.xw), self._xw_slabs, _ptr(P["lstm_bias"]),
+                              _ptr(self.acts[0]), _ptr(self.c[1]), _ptr(self.h[1]), B, R,
+                              nbytes=4 * B * R * (4 * self._xw_slabs + 6) + 16 * R, tag="lstm_fwd0"))
+        for t in range(1, N):
             fwd.append(self._gemm(self.h[t], Wh, self.gates_pre, B, 4 * R, R, R, 4 * R, 4 * R,
                                   bias=P["lstm_bias"], addend=self.xw, ldadd=4 * R, addend_slabs=self._xw_slabs,
                                   epi=H.EPI_LSTM_FWD, p=(self.c[t],), q=(self.acts[t], self.c[t + 1], self.h[t + 1]),
@@ -593,6 +597,7 @@ class AIRModel:
             raise NotImplementedError("more than 12 weight matrices (deeper VAE) need a second grouped launch")
         arr = (H.Wgrad * len(probs))(*probs)
         keep.append(arr)
+        self._wgrad_arr = arr
         wbytes = sum(4 * (q.M * q.N + q.K * (q.M + q.N)) for q in probs)
         wflops = sum(2 * q.M * q.N * q.K for q in probs)
         self._wgrad_plain = self._call("air_wgrad_grouped", arr, len(probs), self._prec, None, None,
@@ -695,6 +700,8 @@ class AIRModel:
         weight-gradient launch then also publishes the global-norm partials and counts the step."""
         for i, op in enumerate(self._bwd):
             (self._write_bwd_fin if (i == 0 and fused_finalize) else op)(s)
+        # (tried: the VAE weight gradients as their own launch on a side stream beside attend_bwd ->
+        # dh_heads -> BPTT.  The big launch takes the CUs the latency-critical chain needs: 217 -> 257 us.)
         if for_update and self._world() == 1:
             self._wgrad_fused(s)
             return

@@ -29,6 +29,42 @@ __global__ __launch_bounds__(THREADS) void lstm_gates_fwd_kernel(
     h[idx] = tanhf(cn) * so;
 }
 
+// The FIRST step of the recurrence: h_0 = c_0 = 0 (zero_state, air_model.py:540), so [x, h].K reduces to
+// the hoisted x.Wx and no MatMul is needed.  Pre-activation = ((0 + slab_0) + slab_1 ...) + bias -- the
+// summation order of the fused GEMM epilogue (AIR_EPI_LSTM_FWD) with a zero accumulator, bit for bit.
+__global__ __launch_bounds__(THREADS) void lstm_first_step_kernel(
+    const float* __restrict__ slabs, int nslabs, long slab_stride, const float* __restrict__ bias,
+    float* __restrict__ acts, float* __restrict__ c, float* __restrict__ h, int B, int R)
+{
+    const int idx = blockIdx.x * THREADS + threadIdx.x;
+    if (idx >= B * R) return;
+    const int b = idx / R, u = idx % R;
+    // all 4 x 8 loads in flight before the first add (one memory round trip, not thirty-two)
+    float v[4][8], bj[4], g[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const size_t o = (size_t)b * 4 * R + j * R + u;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[j][k] = k < nslabs ? slabs[k * slab_stride + o] : 0.0f;
+        bj[j] = bias ? bias[j * R + u] : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += v[j][k];          // slabs past nslabs add +0.0f: the fused epilogue does the same
+        if (bias) s += bj[j];
+        g[j] = s;
+    }
+    const float si = air_sigmoid(g[0]), tj = tanhf(g[1]);
+    const float sf = air_sigmoid(g[2] + 1.0f), so = air_sigmoid(g[3]);
+    const float cn = 0.0f * sf + si * tj;
+    float* a = acts + (size_t)b * 4 * R;
+    a[u] = si; a[R + u] = tj; a[2 * R + u] = sf; a[3 * R + u] = so;
+    c[idx] = cn;
+    h[idx] = tanhf(cn) * so;
+}
+
 __global__ __launch_bounds__(THREADS) void lstm_gates_bwd_kernel(
     const float* __restrict__ dh, const float* __restrict__ dc_in, const float* __restrict__ acts,
     const float* __restrict__ c_prev, const float* __restrict__ c, float* __restrict__ dgates,
@@ -213,6 +249,16 @@ extern "C" int air_lstm_gates_fwd(const float* gates_pre, const float* c_prev, f
     if (!gates_pre || !c_prev || !acts || !c || !h || B <= 0 || R <= 0) return AIR_EINVAL;
     hipLaunchKernelGGL(lstm_gates_fwd_kernel, dim3((B * R + THREADS - 1) / THREADS), dim3(THREADS), 0,
                        air_stream(stream), gates_pre, c_prev, acts, c, h, B, R);
+    AIR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int air_lstm_first_step(const float* xw_slabs, int nslabs, const float* bias, float* acts,
+                                   float* c, float* h, int B, int R, void* stream) {
+    if (!xw_slabs || !acts || !c || !h || B <= 0 || R <= 0 || nslabs <= 0) return AIR_EINVAL;
+    if (nslabs > 8) return AIR_ELIMIT;
+    hipLaunchKernelGGL(lstm_first_step_kernel, dim3((B * R + THREADS - 1) / THREADS), dim3(THREADS), 0,
+                       air_stream(stream), xw_slabs, nslabs, (long)B * 4 * R, bias, acts, c, h, B, R);
     AIR_CHECK_LAUNCH();
     return 0;
 }

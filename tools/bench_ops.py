@@ -35,7 +35,7 @@ for op in ops:
     print("%-34s %7.2f us  %8.1f GB/s  %7.2f TF" % (op.name, t, op.nbytes / t * 1e-3, op.flops / t * 1e-6))
 print("sum %.1f us over %d ops" % (tot, len(ops)))
 # grouped wgrad subsets
-arr = m._keep[-1]
+arr = m._wgrad_arr
 n = len(arr)
 for name, idx in (("dWx only", [n - 1]), ("all but dWx", list(range(0, n - 1))), ("heads only", [n - 2]),
                   ("rec0+out", [2, n - 3])):
