@@ -551,3 +551,91 @@ def test_transformer_bwd_generic_matches_oracle(H, Hi, Wi, Ho, Wo):
     Ug, tg = Ut.clone().requires_grad_(True), tt.clone().requires_grad_(True)
     transformer(Ug, tg, (Ho, Wo)).backward(dt)
     assert torch.equal(Ug.grad, dU) and torch.equal(tg.grad.reshape(B, 6), dth)
+
+
+# ---- exported un-fused kernels vs the oracle directly (not only HIP-vs-HIP) ------------------------------
+
+def test_unfused_lstm_and_reparam_kernels_match_oracle(H):
+    """air_lstm_gates_fwd/bwd, air_lstm_first_step, air_reparam_fwd/bwd against oracle.lstm_cell / oracle.vae
+    arithmetic (BasicLSTMCell: i, j, f, o, forget bias 1.0 -- air_model.py:286; vae.py:22-24) and their
+    torch-autograd gradients."""
+    from oracle import air_oracle_torch as at  # noqa: F401
+    dev, lib = "cuda", H.lib()
+    rng = np.random.RandomState(21)
+    Bn, D, R, Z = 37, 19, 24, 50
+    x, h, c = (rng.randn(Bn, k).astype(np.float32) for k in (D, R, R))
+    K = (rng.randn(D + R, 4 * R) * 0.3).astype(np.float32)
+    b = (rng.randn(4 * R) * 0.1).astype(np.float32)
+    c_ref, h_ref = ao.lstm_cell(x, c, h, K, b)
+    pre = (np.concatenate([x, h], 1) @ K + b).astype(np.float32)
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), device=dev)  # noqa: E731
+    pre_d, c_d = t(pre), t(c)
+    acts, c1, h1 = torch.zeros(Bn, 4 * R, device=dev), torch.zeros(Bn, R, device=dev), torch.zeros(Bn, R, device=dev)
+    H.check(lib.air_lstm_gates_fwd(_p(pre_d), _p(c_d), _p(acts), _p(c1), _p(h1), Bn, R, _stream()))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(c1.cpu().numpy(), c_ref, rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(h1.cpu().numpy(), h_ref, rtol=2e-6, atol=2e-6)
+    # first step: zero state, pre-activation = sum of the x.Wx slabs (in slab order) + bias
+    slabs = (rng.randn(5, Bn, 4 * R) * 0.4).astype(np.float32)
+    s = np.zeros((Bn, 4 * R), np.float32)
+    for k in range(5):
+        s = s + slabs[k]
+    c0_ref, h0_ref = ao.lstm_cell(np.zeros((Bn, 1), np.float32), np.zeros((Bn, R), np.float32), np.zeros((Bn, R), np.float32),
+                                  np.zeros((1 + R, 4 * R), np.float32), np.zeros(4 * R, np.float32))
+    assert not c0_ref.any() and not h0_ref.any()                       # KAT: zero weights -> zero state
+    i_, j_, f_, o_ = np.split(s + b, 4, axis=1)
+    c_fs = ao.sigmoid(i_) * np.tanh(j_)
+    h_fs = np.tanh(c_fs) * ao.sigmoid(o_)
+    slabs_d, b_d = t(slabs), t(b)
+    H.check(lib.air_lstm_first_step(_p(slabs_d), 5, _p(b_d), _p(acts), _p(c1), _p(h1), Bn, R, _stream()))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(c1.cpu().numpy(), c_fs, rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(h1.cpu().numpy(), h_fs, rtol=2e-6, atol=2e-6)
+    # backward of the cell vs torch autograd of the same formulas
+    pre_t, c_t = torch.tensor(pre, dtype=torch.float64, requires_grad=True), torch.tensor(c, dtype=torch.float64, requires_grad=True)
+    ii, jj, ff, oo = torch.split(pre_t, R, dim=1)
+    cn = c_t * torch.sigmoid(ff + 1.0) + torch.sigmoid(ii) * torch.tanh(jj)
+    hn = torch.tanh(cn) * torch.sigmoid(oo)
+    dh, dc = rng.randn(Bn, R).astype(np.float32), rng.randn(Bn, R).astype(np.float32)
+    (hn * torch.tensor(dh, dtype=torch.float64) + cn * torch.tensor(dc, dtype=torch.float64)).sum().backward()
+    H.check(lib.air_lstm_gates_fwd(_p(pre_d), _p(c_d), _p(acts), _p(c1), _p(h1), Bn, R, _stream()))
+    dh_d, dc_d = t(dh), t(dc)
+    dg, dcp = torch.zeros(Bn, 4 * R, device=dev), torch.zeros(Bn, R, device=dev)
+    H.check(lib.air_lstm_gates_bwd(_p(dh_d), _p(dc_d), _p(acts), _p(c_d), _p(c1), _p(dg), _p(dcp), None, 0, Bn, R, _stream()))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(dg.cpu().numpy(), pre_t.grad.numpy(), rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(dcp.cpu().numpy(), c_t.grad.numpy(), rtol=2e-5, atol=2e-6)
+    # re-parameterisation: z = mean + eps * sqrt(exp(log_var))   (vae.py:22-24)
+    ml = (rng.randn(Bn, 2 * Z) * 0.5).astype(np.float32)
+    eps = rng.randn(Bn, Z).astype(np.float32)
+    z_ref = ml[:, :Z] + eps * np.sqrt(np.exp(ml[:, Z:]))
+    ml_d, eps_d, zs = t(ml), t(eps), torch.zeros(Bn, Z, device=dev)
+    H.check(lib.air_reparam_fwd(_p(ml_d), _p(eps_d), _p(zs), Bn, Z, _stream()))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(zs.cpu().numpy(), z_ref, rtol=2e-6, atol=2e-6)
+
+
+@pytest.mark.parametrize("sched", [
+    dict(init=10000.0, iters=3000, factor=0.1, min=1e-9, staircase=False, log=True),      # training.py:110-115
+    dict(init=1.0, iters=1000, factor=0.5, staircase=True),                                # staircase, no clamp, no log
+    dict(init=2.0, iters=500, factor=3.0, max=40.0, staircase=False),                      # growing, clamped from above
+    dict(init=5.0, iters=700, factor=0.2, min=0.3, max=2.0, staircase=True, log=True),     # everything at once
+])
+def test_annealing_schedule_variants_match_oracle(H, sched):
+    """_create_annealed_tensor (air_model.py:94-121): staircase / min / max / log in every combination,
+    evaluated on the device at several global steps vs oracle.annealed_value."""
+    dev = "cuda"
+    flags = (H.SCHED_STAIRCASE if sched.get("staircase") else 0) | (H.SCHED_HAS_MIN if "min" in sched else 0) | \
+            (H.SCHED_HAS_MAX if "max" in sched else 0) | (H.SCHED_LOG if sched.get("log") else 0)
+    arr = np.zeros(1, dtype=[("slot", "<i4"), ("flags", "<i4"), ("init", "<f4"), ("iters", "<f4"),
+                             ("factor", "<f4"), ("vmin", "<f4"), ("vmax", "<f4")])
+    arr[0] = (H.DYN_TEMPERATURE, flags, sched["init"], sched["iters"], sched["factor"], sched.get("min", 0.0), sched.get("max", 0.0))
+    tab = torch.from_numpy(arr.view(np.uint8).copy()).to(dev)
+    dyn = torch.zeros(H.DYN_COUNT, device=dev)
+    for step in (0, 1, 499, 500, 999, 1000, 2500, 12345, 40000):
+        ist = torch.tensor([step, 0, 0, 0], dtype=torch.int32, device=dev)
+        H.check(H.lib().air_step_begin(_p(tab), 1, _p(dyn), _p(ist), None, 0, None, 0, C.c_uint64(0), _stream()))
+        torch.cuda.synchronize()
+        ref = float(ao.annealed_value(sched, step))
+        got = float(dyn[H.DYN_TEMPERATURE])
+        assert abs(got - ref) <= 2e-5 * max(1.0, abs(ref)), (step, got, ref)

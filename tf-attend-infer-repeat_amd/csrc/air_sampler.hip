@@ -304,12 +304,15 @@ __global__ __launch_bounds__(THREADS) void attend_fwd_kernel(air_attend_fwd_t a)
     float pf[PF];
 #pragma unroll
     for (int k = 0; k < PF; ++k) { const int p = tid + k * THREADS; pf[k] = (whole && p < C * C) ? img[p] : 0.0f; }
-    float eps_s = 0.f, eps_x = 0.f, eps_y = 0.f, u_t = 0.f, u_prev[MAX_STEPS];
-    if (tid == 0) {
-        eps_s = a.eps_scale[row]; eps_x = a.eps_shift[2 * row]; eps_y = a.eps_shift[2 * row + 1]; u_t = a.u[row];
-#pragma unroll
-        for (int tp = 0; tp < MAX_STEPS; ++tp) u_prev[tp] = tp < t ? a.u[(size_t)tp * B + b] : 0.0f;
-    }
+    // the sampling / KL section below is spread over the lanes of wave 0: lanes 0..2 take the three Gaussian
+    // heads (scale, shift x, shift y), lane 3 the Concrete z_pres of this step, lanes 8.. the z_pres of the
+    // earlier steps (for the stopping sum); each lane fetches its own noise
+    float in_eps = 0.0f, in_u = 0.5f;
+    if (tid == 0) in_eps = a.eps_scale[row];
+    else if (tid == 1) in_eps = a.eps_shift[2 * row];
+    else if (tid == 2) in_eps = a.eps_shift[2 * row + 1];
+    else if (tid == 3) in_u = a.u[row];
+    else if (tid >= 8 && tid < 8 + t) in_u = a.u[(size_t)(tid - 8) * B + b];
     for (int j = tid; j < HT; j += THREADS) sh_hid[j] = a.hid[row * HT + j];
     for (int j = tid; j < 7 * a.wout_ld; j += THREADS) sh_wout[j] = a.wout[j];
     for (int j = tid; j < t * hs.wid[4]; j += THREADS) {
@@ -351,65 +354,62 @@ __global__ __launch_bounds__(THREADS) void attend_fwd_kernel(air_attend_fwd_t a)
     __syncthreads();
 
     AIR_STAMP(12);
-    if (tid == 0) {
+    if (tid < 64) {
         const float* dyn = a.dyn;
         const float T = dyn[AIR_DYN_TEMPERATURE], thr = dyn[AIR_DYN_STOP_THRESHOLD];
+        // lanes 0..2 -- scale :300-303, shift :317-320 (_sample_from_mvn :123-128) and their KL terms :441-477:
+        // one instruction stream, per-lane operands
+        const float mu = lane == 0 ? sh_out[0] : lane == 1 ? sh_out[2] : sh_out[3];
+        const float lv = lane == 0 ? sh_out[1] : lane == 1 ? sh_out[4] : sh_out[5];
+        const float var = expf(lv);
+        const float pre_act = mu + in_eps * sqrtf(var);
+        const float act = lane == 0 ? air_sigmoid(pre_act) : tanhf(pre_act);
+        const float term = lane == 0
+            ? gauss_kl_term(dyn[AIR_DYN_SCALE_PLV], lv, var, dyn[AIR_DYN_SCALE_PV], mu, dyn[AIR_DYN_SCALE_PM])
+            : gauss_kl_term(dyn[AIR_DYN_SHIFT_PLV], lv, var, dyn[AIR_DYN_SHIFT_PV], mu, dyn[AIR_DYN_SHIFT_PM]);
+        // lane 3 (this step) and lanes 8 + t' (earlier steps) -- Concrete sample :377-390, concrete.py:20-27
+        const float z_lo = sh_out[6];
+        const float lo = lane == 3 ? z_lo : (lane >= 8 && lane - 8 < t) ? sh_zlo[lane - 8] : 0.0f;
+        const float ypre_l = concrete_presigmoid(lo, in_u, T);
+        float z_l = air_sigmoid(ypre_l);
+        if (!a.train) z_l = rintf(z_l);                   // tf.round (half-to-even) :389-390
+        // concrete.py:30-43 (prior and posterior temperatures are both T :403-407); meaningful on lane 3
+        const float plo = dyn[AIR_DYN_PRIOR_LOG_ODDS];
+        const float yT = ypre_l * T;
+        const float log_prior = ((logf(T + AIR_EPS) - yT) + plo) - 2.0f * logf((1.0f + expf(-yT + plo)) + AIR_EPS);
+        const float log_post = ((logf(T + AIR_EPS) - yT) + lo) - 2.0f * logf((1.0f + expf(-yT + lo)) + AIR_EPS);
+        const float kl_z_l = log_post - log_prior;
+        // gather (uniform broadcasts)
+        const float s = __shfl(act, 0, 64), x = __shfl(act, 1, 64), y = __shfl(act, 2, 64);
+        const float kl_s = 0.5f * __shfl(term, 0, 64);
+        const float kl_h = 0.5f * (__shfl(term, 1, 64) + __shfl(term, 2, 64));
+        const float ypre = __shfl(ypre_l, 3, 64), z = __shfl(z_l, 3, 64), kl_z = __shfl(kl_z_l, 3, 64);
         // stopping sum on entry to step t (air_model.py:424): S += 1 - z_pres, in step order
         float S = 0.0f;
-#pragma unroll
-        for (int tp = 0; tp < MAX_STEPS; ++tp) {
-            if (tp < t) {
-                float zp = air_sigmoid(concrete_presigmoid(sh_zlo[tp], u_prev[tp], T));
-                if (!a.train) zp = rintf(zp);
-                S = S + (1.0f - zp);
-            }
-        }
-        const float mu_s = sh_out[0], lv_s = sh_out[1];
-        const float mu_x = sh_out[2], mu_y = sh_out[3], lv_x = sh_out[4], lv_y = sh_out[5];
-        const float z_lo = sh_out[6];
-        // scale :300-303, shift :317-320   (_sample_from_mvn :123-128)
-        const float var_s = expf(lv_s);
-        const float s = air_sigmoid(mu_s + eps_s * sqrtf(var_s));
-        const float var_x = expf(lv_x), var_y = expf(lv_y);
-        const float x = tanhf(mu_x + eps_x * sqrtf(var_x));
-        const float y = tanhf(mu_y + eps_y * sqrtf(var_y));
-        const float ypre = concrete_presigmoid(z_lo, u_t, T);
-        float z = air_sigmoid(ypre);
-        if (!a.train) z = rintf(z);                       // tf.round (half-to-even) :389-390
-        const float zprob = air_sigmoid(z_lo);
-        // concrete.py:30-43 (prior and posterior temperatures are both T :403-407)
-        const float plo = dyn[AIR_DYN_PRIOR_LOG_ODDS];
-        const float yT = ypre * T;
-        const float log_prior = ((logf(T + AIR_EPS) - yT) + plo) - 2.0f * logf((1.0f + expf(-yT + plo)) + AIR_EPS);
-        const float log_post = ((logf(T + AIR_EPS) - yT) + z_lo) - 2.0f * logf((1.0f + expf(-yT + z_lo)) + AIR_EPS);
-        const float kl_z = log_post - log_prior;
+        for (int tp = 0; tp < t; ++tp) S = S + (1.0f - __shfl(z_l, 8 + tp, 64));
         // stop logic :409-427
         const bool mask_prev = S < thr;
         S = S + (1.0f - z);
         const bool mask = S < thr;
-        // scale / shift KL :441-477
-        const float pv_s = dyn[AIR_DYN_SCALE_PV], pv_h = dyn[AIR_DYN_SHIFT_PV];
-        const float kl_s = 0.5f * gauss_kl_term(dyn[AIR_DYN_SCALE_PLV], lv_s, var_s, pv_s, mu_s, dyn[AIR_DYN_SCALE_PM]);
-        const float plv_h = dyn[AIR_DYN_SHIFT_PLV], pm_h = dyn[AIR_DYN_SHIFT_PM];
-        const float kl_h = 0.5f * (gauss_kl_term(plv_h, lv_x, var_x, pv_h, mu_x, pm_h) +
-                                   gauss_kl_term(plv_h, lv_y, var_y, pv_h, mu_y, pm_h));
-
-        float* o7 = a.out7 + row * AIR_OUT_STRIDE;
-        for (int o = 0; o < 7; ++o) o7[o] = sh_out[o];
-        o7[7] = 0.0f;
-        float* at = a.att + row * AIR_ATT_STRIDE;
-        at[AIR_ATT_S] = s; at[AIR_ATT_X] = x; at[AIR_ATT_Y] = y;
-        at[AIR_ATT_ZPRE] = ypre; at[AIR_ATT_Z] = z; at[AIR_ATT_ZPROB] = zprob;
-        at[AIR_ATT_KL_Z] = kl_z; at[AIR_ATT_KL_SCALE] = kl_s; at[AIR_ATT_KL_SHIFT] = kl_h;
-        at[AIR_ATT_KL_VAE] = 0.0f;
-        at[AIR_ATT_MASK_PREV] = mask_prev ? 1.0f : 0.0f;
-        at[AIR_ATT_MASK] = mask ? 1.0f : 0.0f;
-        // theta_recon :353-356
-        at[AIR_ATT_ST_BACK + 0] = 1.0f / s;
-        at[AIR_ATT_ST_BACK + 1] = (-x) / s;
-        at[AIR_ATT_ST_BACK + 2] = (-y) / s;
-        at[AIR_ATT_ST_BACK + 3] = 0.0f;
-        sh_sc[0] = s; sh_sc[1] = x; sh_sc[2] = y;
+        if (tid == 0) {
+            const float zprob = air_sigmoid(z_lo);
+            float* o7 = a.out7 + row * AIR_OUT_STRIDE;
+            for (int o = 0; o < 7; ++o) o7[o] = sh_out[o];
+            o7[7] = 0.0f;
+            float* at = a.att + row * AIR_ATT_STRIDE;
+            at[AIR_ATT_S] = s; at[AIR_ATT_X] = x; at[AIR_ATT_Y] = y;
+            at[AIR_ATT_ZPRE] = ypre; at[AIR_ATT_Z] = z; at[AIR_ATT_ZPROB] = zprob;
+            at[AIR_ATT_KL_Z] = kl_z; at[AIR_ATT_KL_SCALE] = kl_s; at[AIR_ATT_KL_SHIFT] = kl_h;
+            at[AIR_ATT_KL_VAE] = 0.0f;
+            at[AIR_ATT_MASK_PREV] = mask_prev ? 1.0f : 0.0f;
+            at[AIR_ATT_MASK] = mask ? 1.0f : 0.0f;
+            // theta_recon :353-356
+            at[AIR_ATT_ST_BACK + 0] = 1.0f / s;
+            at[AIR_ATT_ST_BACK + 1] = (-x) / s;
+            at[AIR_ATT_ST_BACK + 2] = (-y) / s;
+            at[AIR_ATT_ST_BACK + 3] = 0.0f;
+            sh_sc[0] = s; sh_sc[1] = x; sh_sc[2] = y;
+        }
     }
     __syncthreads();
 
