@@ -41,9 +41,13 @@ __device__ __forceinline__ float air_wave_sum(float v) {
 // Phase stamps of workgroup (0,0) for tools/phase_stamps.py (debug builds with -DAIR_STAMPS only;
 // the shipped library compiles them away).  wall_clock64(): 100 MHz constant counter.
 #ifdef AIR_STAMPS
-extern __device__ unsigned long long air_stamps_dev[64];
+static __device__ unsigned long long air_stamps_dev[64];       // one array per translation unit
+// reader of this translation unit's stamps (instantiate once per .hip that places stamps)
+#define AIR_STAMPS_READER(fn) extern "C" int fn(unsigned long long* out, int n) { \
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(air_stamps_dev), sizeof(unsigned long long) * (n < 64 ? n : 64)); }
 #define AIR_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) air_stamps_dev[i] = wall_clock64(); } while (0)
 #else
+#define AIR_STAMPS_READER(fn)
 #define AIR_STAMP(i) do { } while (0)
 #endif
 

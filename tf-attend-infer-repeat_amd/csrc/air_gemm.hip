@@ -25,7 +25,10 @@
 #include "air_common.h"
 #include "air_philox.h"
 #include <cstdlib>
+#include <type_traits>
 #include <cstdio>
+
+AIR_STAMPS_READER(air_debug_stamps_gemm)
 
 namespace {
 
@@ -71,21 +74,29 @@ struct Pre {
     float f[40];                                  // fused-epilogue operands (LSTM: 32 slab values + 4 bias + state)
 };
 
-template <int TM, int TN>
+// EPI >= 0: the epilogue is a COMPILE-TIME choice of the lean kernels; EPI < 0: a.epi at run time (fallback
+// kernels).  With a run-time choice every branch's loads meet at a control-flow join that needs their values
+// -- an s_waitcnt vmcnt(0) right behind them, i.e. a memory round trip of its own at kernel entry instead of
+// one that overlaps the operand panels'.  For the same reason optional operands are fetched through a
+// pointer SELECT (a.A stands in for an absent operand: always a valid address), never through a branch.
+template <int TM, int TN, int EPI>
 __device__ __forceinline__ void epilogue_prefetch(const Args& a, Pre<TM, TN>& pre, int m0, int n0, int lane, int wave) {
-    if (a.epi == AIR_EPI_GENERIC) {
+    const int E = EPI < 0 ? a.epi : EPI;
+    const float* const safe = a.A;
+    if (E == AIR_EPI_GENERIC) {
 #pragma unroll
         for (int k = 0; k < TM * TN; ++k) {
             const int it = wave + 4 * k;
             const int i = it / (TN * 4), j = (it >> 2) % TN, q = it & 3;
             const int m = m0 + i * 16 + (lane >> 4) * 4 + q;
             const int n = n0 + j * 16 + (lane & 15);
-            pre.bias[k] = 0.0f; pre.add[k] = 0.0f; pre.aux[k] = 0.0f;
-            if (m < a.M && n < a.N) {
-                if (a.bias) pre.bias[k] = a.bias[n];
-                if (a.addend && a.add_slabs == 1) pre.add[k] = a.addend[(size_t)m * a.ldadd + n];
-                if (a.aux) pre.aux[k] = a.aux[(size_t)m * a.ldaux + n];
-            }
+            const bool ok = m < a.M && n < a.N;
+            const bool hb = ok && a.bias, ha = ok && a.addend && a.add_slabs == 1, hx = ok && a.aux;
+            // raw values: the epilogue only reads an operand that exists (a select here would need the
+            // loaded value at once, i.e. a wait right behind the load)
+            pre.bias[k] = *(hb ? a.bias + n : safe);
+            pre.add[k] = *(ha ? a.addend + (size_t)m * a.ldadd + n : safe);
+            pre.aux[k] = *(hx ? a.aux + (size_t)m * a.ldaux + n : safe);
         }
         return;
     }
@@ -93,48 +104,52 @@ __device__ __forceinline__ void epilogue_prefetch(const Args& a, Pre<TM, TN>& pr
     const int m = m0 + (lane >> 4) * 4 + q;
     const int u = n0 + (lane & 15);
     const bool ok = (m < a.M) && (u < a.gwidth);
-    if (a.epi == AIR_EPI_LSTM_FWD) {
+    // p[off] when `have` (else an unrelated valid word: the epilogue applies the same `have` before use) --
+    // one unconditional load from a selected address, no select on the loaded value here
+    auto fetch = [&](bool have, const float* p, size_t off) __attribute__((always_inline)) { return *(have ? p + off : safe); };
+    if (E == AIR_EPI_LSTM_FWD) {
         const int R = a.gwidth;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = u + j * R;
 #pragma unroll
             for (int k = 0; k < 8; ++k)
-                pre.f[j * 8 + k] = (ok && k < a.add_slabs) ? a.addend[k * a.add_slab_stride + (size_t)m * a.ldadd + n] : 0.0f;
-            pre.f[32 + j] = (ok && a.bias) ? a.bias[n] : 0.0f;
+                pre.f[j * 8 + k] = fetch(ok && k < a.add_slabs, a.addend, k * a.add_slab_stride + (size_t)m * a.ldadd + n);
+            pre.f[32 + j] = fetch(ok && a.bias, a.bias, n);
         }
-        pre.f[36] = ok ? a.p0[(size_t)m * R + u] : 0.0f;
-    } else if (a.epi == AIR_EPI_REPARAM_FWD) {
+        pre.f[36] = fetch(ok, a.p0, (size_t)m * R + u);
+    } else if (E == AIR_EPI_REPARAM_FWD) {
         const int Z = a.gwidth;
-        pre.f[0] = (ok && a.bias) ? a.bias[u] : 0.0f;
-        pre.f[1] = (ok && a.bias) ? a.bias[Z + u] : 0.0f;
-        pre.f[2] = ok ? a.p0[(size_t)m * Z + u] : 0.0f;
-    } else if (a.epi == AIR_EPI_REPARAM_BWD) {
+        pre.f[0] = fetch(ok && a.bias, a.bias, u);
+        pre.f[1] = fetch(ok && a.bias, a.bias, Z + u);
+        pre.f[2] = fetch(ok, a.p0, (size_t)m * Z + u);
+    } else if (E == AIR_EPI_REPARAM_BWD) {
         const int Z = a.gwidth;
-        pre.f[0] = ok ? a.p0[(size_t)m * 2 * Z + u] : 0.0f;
-        pre.f[1] = ok ? a.p0[(size_t)m * 2 * Z + Z + u] : 0.0f;
-        pre.f[2] = ok ? a.p1[(size_t)m * Z + u] : 0.0f;
-        pre.f[3] = ok ? a.p2[(size_t)m * AIR_ATT_STRIDE + AIR_ATT_MASK] : 0.0f;
+        pre.f[0] = fetch(ok, a.p0, (size_t)m * 2 * Z + u);
+        pre.f[1] = fetch(ok, a.p0, (size_t)m * 2 * Z + Z + u);
+        pre.f[2] = fetch(ok, a.p1, (size_t)m * Z + u);
+        pre.f[3] = fetch(ok, a.p2, (size_t)m * AIR_ATT_STRIDE + AIR_ATT_MASK);
         pre.f[4] = a.p3[AIR_DYN_GRAD_SCALE]; pre.f[5] = a.p3[AIR_DYN_VAE_PV]; pre.f[6] = a.p3[AIR_DYN_VAE_PM];
-    } else if (a.epi == AIR_EPI_LSTM_BWD || a.epi == AIR_EPI_LSTM_BWD_TAIL) {
+    } else if (E == AIR_EPI_LSTM_BWD || E == AIR_EPI_LSTM_BWD_TAIL) {
         const int R = a.gwidth;
-        const int mm = m - (a.epi == AIR_EPI_LSTM_BWD_TAIL ? a.i0 : 0);      // row within the step's arrays
+        const int mm = m - (E == AIR_EPI_LSTM_BWD_TAIL ? a.i0 : 0);          // row within the step's arrays
         const bool okk = ok && mm >= 0;
-        const size_t idx = (size_t)mm * R + u;
+        const size_t idx = (size_t)(okk ? mm : 0) * R + u;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) pre.f[j] = okk ? a.p0[(size_t)mm * 4 * R + j * R + u] : 0.0f;
-        pre.f[4] = okk ? a.p1[idx] : 0.0f;
-        pre.f[5] = okk ? a.p2[idx] : 0.0f;
-        pre.f[6] = (okk && a.p3) ? a.p3[idx] : 0.0f;
-        pre.f[7] = (okk && a.addend) ? a.addend[(size_t)m * a.ldadd + u] : 0.0f;
+        for (int j = 0; j < 4; ++j) pre.f[j] = fetch(okk, a.p0, (size_t)(okk ? mm : 0) * 4 * R + j * R + u);
+        pre.f[4] = fetch(okk, a.p1, idx);
+        pre.f[5] = fetch(okk, a.p2, idx);
+        pre.f[6] = fetch(okk && a.p3, a.p3, idx);
+        pre.f[7] = fetch(okk && a.addend, a.addend, (size_t)m * a.ldadd + u);
     }
 }
 
 // Epilogue over the reduced tile values held in Red[(t*4 + q)*64 + lane] (t = i*TN + j).
-template <int TM, int TN>
+template <int TM, int TN, int EPI>
 __device__ __forceinline__ void epilogue(const Args& a, const Pre<TM, TN>& pre, const float* Red,
                                          int m0, int n0, int lane, int wave) {
-    if (a.epi == AIR_EPI_GENERIC) {
+    const int E = EPI < 0 ? a.epi : EPI;
+    if (E == AIR_EPI_GENERIC) {
 #pragma unroll
         for (int k = 0; k < TM * TN; ++k) {
             const int it = wave + 4 * k;
@@ -168,7 +183,7 @@ __device__ __forceinline__ void epilogue(const Args& a, const Pre<TM, TN>& pre, 
         float v[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) v[j] = Red[((i * TN + j) * 4 + q) * 64 + lane];
-        if (a.epi == AIR_EPI_LSTM_FWD) {
+        if (E == AIR_EPI_LSTM_FWD) {
             // BasicLSTMCell (air_model.py:286): gates = [x,h].K + b -> i, j, f, o; forget bias 1.0
             // p0 = c_prev [M,R]; addend slabs = hoisted x.Wx; q0 = acts [M,4R], q1 = c, q2 = h
             if (TN == 4 && TM == 1) {
@@ -178,7 +193,7 @@ __device__ __forceinline__ void epilogue(const Args& a, const Pre<TM, TN>& pre, 
                 for (int j = 0; j < 4; ++j) {
                     float s = v[j % TN];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) s += pre.f[j * 8 + k];       // fixed summation order
+                    for (int k = 0; k < 8; ++k) s += (k < a.add_slabs) ? pre.f[j * 8 + k] : 0.0f;   // fixed summation order
                     if (a.bias) s += pre.f[32 + j];
                     g[j] = s;
                 }
@@ -190,31 +205,32 @@ __device__ __forceinline__ void epilogue(const Args& a, const Pre<TM, TN>& pre, 
                 a.q1[(size_t)m * R + u] = cn;
                 a.q2[(size_t)m * R + u] = tanhf(cn) * so;
             }
-        } else if (a.epi == AIR_EPI_REPARAM_FWD) {
+        } else if (E == AIR_EPI_REPARAM_FWD) {
             // vae.py:16-24: mean | log_var (+bias), sample = mean + eps*sqrt(exp(lv))
             // C = ml [M,2Z]; p0 = eps [M,Z]; q0 = zs [M,Z]
             if (TN == 2) {
                 const int Z = a.gwidth;
-                const float mean = v[0] + pre.f[0];
-                const float lv = v[1 % TN] + pre.f[1];
+                const float mean = v[0] + (a.bias ? pre.f[0] : 0.0f);
+                const float lv = v[1 % TN] + (a.bias ? pre.f[1] : 0.0f);
                 a.C[(size_t)m * a.ldc + u] = mean;
                 a.C[(size_t)m * a.ldc + Z + u] = lv;
                 a.q0[(size_t)m * Z + u] = mean + pre.f[2] * sqrtf(expf(lv));
             }
-        } else if (a.epi == AIR_EPI_LSTM_BWD || a.epi == AIR_EPI_LSTM_BWD_TAIL) {
+        } else if (E == AIR_EPI_LSTM_BWD || E == AIR_EPI_LSTM_BWD_TAIL) {
             // v[0] (+ addend) = d loss / d h'.  p0 = acts, p1 = c_prev, p2 = c, p3 = dc_in (nullable)
             // q0 = dgates [M,4R], q1 = dc_prev [M,R], q2 = dgsum [M,4R] (nullable; i0 = accumulate)
             if (TM == 1) {
                 const int R = a.gwidth;
-                const bool tail = a.epi == AIR_EPI_LSTM_BWD_TAIL;
-                if (tail && m < a.i0) { a.C[(size_t)m * a.ldc + u] = v[0] + pre.f[7]; continue; }
+                const bool tail = E == AIR_EPI_LSTM_BWD_TAIL;
+                const float addv = a.addend ? pre.f[7] : 0.0f;
+                if (tail && m < a.i0) { a.C[(size_t)m * a.ldc + u] = v[0] + addv; continue; }
                 const int mrow = tail ? m - a.i0 : m;
                 const bool accumulate = tail ? false : (a.i0 != 0);
-                const float dhv = v[0] + pre.f[7];
+                const float dhv = v[0] + addv;
                 const float si = pre.f[0], tj = pre.f[1], sf = pre.f[2], so = pre.f[3];
                 const size_t idx = (size_t)mrow * R + u;
                 const float tc = tanhf(pre.f[5]);
-                const float dc = pre.f[6] + dhv * so * (1.0f - tc * tc);
+                const float dc = (a.p3 ? pre.f[6] : 0.0f) + dhv * so * (1.0f - tc * tc);
                 const float dgi = dc * tj * si * (1.0f - si);
                 const float dgj = dc * si * (1.0f - tj * tj);
                 const float dgf = dc * pre.f[4] * sf * (1.0f - sf);
@@ -228,7 +244,7 @@ __device__ __forceinline__ void epilogue(const Args& a, const Pre<TM, TN>& pre, 
                     else { ds[u] = dgi; ds[R + u] = dgj; ds[2 * R + u] = dgf; ds[3 * R + u] = dgo; }
                 }
             }
-        } else if (a.epi == AIR_EPI_REPARAM_BWD) {
+        } else if (E == AIR_EPI_REPARAM_BWD) {
             // v[0] = d loss / d z-sample.  p0 = ml [M,2Z], p1 = eps, p2 = att (mask), p3 = dyn; C = d_ml [M,2Z]
             const int Z = a.gwidth;
             const float klg = pre.f[3] * pre.f[4];
@@ -301,6 +317,7 @@ __host__ __device__ __forceinline__ bool aligned16(const void* p) { return (rein
 template <int TM, int TN, bool TA, bool TB>
 __global__ __launch_bounds__(THREADS) void gemm_f32_kernel(Args a)
 {
+    constexpr int EPI_ = -1;                               // fallback kernel: epilogue chosen at run time
     constexpr int BM = 16 * TM, BN = 16 * TN;
     constexpr int BKC = (TM * TN >= 4) ? 64 : 128;
     // transposing stores (NN-A, NT-B) want an odd stride; direct 16-byte stores want stride = 16 (mod 32)
@@ -336,7 +353,7 @@ __global__ __launch_bounds__(THREADS) void gemm_f32_kernel(Args a)
     const bool vecA = ((a.lda & 3) == 0) && aligned16(a.A);
     const bool vecB = ((a.ldb & 3) == 0) && aligned16(a.B) && ((a.gstride & 3) == 0);
     Pre<TM, TN> pre;
-    if (nslab == 1) epilogue_prefetch<TM, TN>(a, pre, m0, n0, lane, wave);
+    if (nslab == 1) epilogue_prefetch<TM, TN, EPI_>(a, pre, m0, n0, lane, wave);
 
     auto loadA = [&](int k0, int i) -> float4 {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -504,7 +521,7 @@ __global__ __launch_bounds__(THREADS) void gemm_f32_kernel(Args a)
         }
         return;
     }
-    epilogue<TM, TN>(a, pre, Red, m0, n0, lane, wave);
+    epilogue<TM, TN, EPI_>(a, pre, Red, m0, n0, lane, wave);
 }
 
 // ---------------------------------------------------------------------------
@@ -619,8 +636,8 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16_kernel(Args a)
         return;
     }
     Pre<TM, TN> pre;
-    epilogue_prefetch<TM, TN>(a, pre, m0, n0, lane, wave);
-    epilogue<TM, TN>(a, pre, Red, m0, n0, lane, wave);
+    epilogue_prefetch<TM, TN, -1>(a, pre, m0, n0, lane, wave);
+    epilogue<TM, TN, -1>(a, pre, Red, m0, n0, lane, wave);
 }
 
 
@@ -642,6 +659,8 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
     const f32x2_t v = {lo, hi};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
+// (tried: raw buffer loads with the hardware range check standing in for the EXEC-masked branches --
+// same results, no gain on the 16x16-tile kernels and 8.5 -> 11.7 us on the K = 2500 one)
 __device__ __forceinline__ float4 ldg16(const char* base, unsigned off, bool ok) {
     const float4 t = *reinterpret_cast<const float4*>(base + (ok ? off : 0u));
     return ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -653,8 +672,12 @@ __device__ __forceinline__ float2 ldg8(const char* base, unsigned off, bool ok) 
 }
 // 16 bytes as one load, or as two 8-byte loads when the operand is only 8-byte aligned
 // (row strides / column-group strides that are even but not multiples of 4: Z = 50)
-__device__ __forceinline__ float4 ldg16x(const char* base, unsigned off, bool ok_lo, bool ok_hi, bool half) {
-    if (!half) return ldg16(base, off, ok_lo);
+// HALF is a COMPILE-TIME choice: a run-time one puts every load in its own if/else whose join needs the
+// loaded value, i.e. an s_waitcnt vmcnt(0) behind each load -- the loads of a round then complete one
+// after the other instead of all being in flight (measured: 1.3 us of a 3.0 us kernel body).
+template <bool HALF>
+__device__ __forceinline__ float4 ldg16x(const char* base, unsigned off, bool ok_lo, bool ok_hi) {
+    if (!HALF) return ldg16(base, off, ok_lo);
     const float2 lo = ldg8(base, off, ok_lo), hi = ldg8(base, off + 8u, ok_hi);
     return make_float4(lo.x, lo.y, hi.x, hi.y);
 }
@@ -671,7 +694,7 @@ struct V2Cfg {
     static constexpr int BYTES = (R * IMG * 2 > RED) ? R * IMG * 2 : RED;
 };
 
-template <int TM, int TN, bool TB>
+template <int TM, int TN, bool TB, int EPI_>
 __global__ __launch_bounds__(THREADS) void gemm_bf16v2_kernel(Args a)
 {
     using Cfg = V2Cfg<TM, TN>;
@@ -695,6 +718,7 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16v2_kernel(Args a)
     const int kbeg = zslab * a.kslab;
     const int kend = min(a.K, kbeg + a.kslab);
 
+    AIR_STAMP(56);
     f32x4 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -702,7 +726,6 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16v2_kernel(Args a)
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     Pre<TM, TN> pre;
-    if (nslab == 1) epilogue_prefetch<TM, TN>(a, pre, m0, n0, lane, wave);
 
     const char* Ab = reinterpret_cast<const char*>(a.A);
     const char* Bb = reinterpret_cast<const char*>(a.B);
@@ -719,7 +742,8 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16v2_kernel(Args a)
     float4 vbk[TB ? TBK_N : 1][2];
     float4 vbn[TB ? 1 : TBN_N][8];
     // ---- every load of one round, issued back to back
-    auto issue_loads = [&](int kr) {
+    auto issue_loads_t = [&](int kr, auto ha_t, auto hb_t) __attribute__((always_inline)) {
+        constexpr bool HA = decltype(ha_t)::value, HB = decltype(hb_t)::value;
 #pragma unroll
         for (int i = 0; i < TA_N; ++i) {
             const int t = tid + THREADS * i;
@@ -727,8 +751,8 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16v2_kernel(Args a)
             const int gm = m0 + row, gk = kr + c * KB + g * 8;
             const bool okr = (t < R * BM * 8) && gm < a.M;
             const unsigned off = ((unsigned)gm * (unsigned)a.lda + (unsigned)gk) * 4u;
-            va[i][0] = ldg16x(Ab, off, okr && gk < kend, okr && gk + 2 < kend, a8);
-            va[i][1] = ldg16x(Ab, off + 16u, okr && gk + 4 < kend, okr && gk + 6 < kend, a8);
+            va[i][0] = ldg16x<HA>(Ab, off, okr && gk < kend, okr && gk + 2 < kend);
+            va[i][1] = ldg16x<HA>(Ab, off + 16u, okr && gk + 4 < kend, okr && gk + 6 < kend);
         }
         if (TB) {
 #pragma unroll
@@ -740,8 +764,8 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16v2_kernel(Args a)
                 const int gk = kr + c * KB + g * 8;
                 const bool okr = (t < R * BN * 8) && cg < a.gwidth && gn < a.N;
                 const unsigned off = ((unsigned)gn * (unsigned)a.ldb + (unsigned)gk) * 4u;
-                vbk[i][0] = ldg16x(Bb, off, okr && gk < kend, okr && gk + 2 < kend, b8);
-                vbk[i][1] = ldg16x(Bb, off + 16u, okr && gk + 4 < kend, okr && gk + 6 < kend, b8);
+                vbk[i][0] = ldg16x<HB>(Bb, off, okr && gk < kend, okr && gk + 2 < kend);
+                vbk[i][1] = ldg16x<HB>(Bb, off + 16u, okr && gk + 4 < kend, okr && gk + 6 < kend);
             }
         } else {
 #pragma unroll
@@ -756,14 +780,21 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16v2_kernel(Args a)
                 const unsigned off = ((unsigned)gk * (unsigned)a.ldb + (unsigned)gn) * 4u;
 #pragma unroll
                 for (int r = 0; r < 8; ++r)
-                    vbn[i][r] = ldg16x(Bb, off + (unsigned)r * ((unsigned)a.ldb * 4u), okc && gk + r < kend,
-                                       okh && gk + r < kend, b8);
+                    vbn[i][r] = ldg16x<HB>(Bb, off + (unsigned)r * ((unsigned)a.ldb * 4u), okc && gk + r < kend,
+                                           okh && gk + r < kend);
             }
         }
     };
     // software pipeline over rounds: the loads of round r+1 are issued right after the registers of
-    // round r were drained into LDS, so their latency runs under the barrier and the MFMAs of round r
+    // round r were drained into LDS, so their latency runs under the barrier and the MFMAs of round r.
+    // The whole K loop is instantiated per operand alignment and picked by ONE uniform branch, so that
+    // no control-flow join sits between a round's loads and their first use.
+    auto k_loop = [&](auto ha_t, auto hb_t) __attribute__((always_inline)) {
+    auto issue_loads = [&](int kr) __attribute__((always_inline)) { issue_loads_t(kr, ha_t, hb_t); };
     issue_loads(kbeg);
+    // the epilogue's operands ride behind the first round's panels (same memory round trip)
+    if (nslab == 1) epilogue_prefetch<TM, TN, EPI_>(a, pre, m0, n0, lane, wave);
+    AIR_STAMP(57);
     for (int kr = kbeg; kr < kend; kr += R * KB) {
         if (kr > kbeg) __syncthreads();                                   // images of the previous round consumed
         // ---- round to bf16 and store the images
@@ -806,6 +837,7 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16v2_kernel(Args a)
         }
         if (kr + R * KB < kend) issue_loads(kr + R * KB);
         __syncthreads();
+        AIR_STAMP(58);
         // ---- MFMAs: wave w owns images w, w+4, ... of the round
 #pragma unroll
         for (int cc = 0; cc < (R + 3) / 4; ++cc) {
@@ -834,8 +866,18 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16v2_kernel(Args a)
             }
         }
     }
+    };
+    {
+        using T_ = std::true_type; using F_ = std::false_type;
+        if (!a8 && !b8) k_loop(F_{}, F_{});
+        else if (!a8) k_loop(F_{}, T_{});
+        else if (!b8) k_loop(T_{}, F_{});
+        else k_loop(T_{}, T_{});
+    }
+    AIR_STAMP(59);
     __syncthreads();                                                      // Red aliases the images
     reduce_waves<TM, TN>(acc, Red, lane, wave);
+    AIR_STAMP(60);
     if (nslab > 1) {
         float* Cz = a.C + (size_t)zslab * a.slab_stride;
         for (int t = wave; t < TM * TN; t += 4) {
@@ -849,7 +891,8 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16v2_kernel(Args a)
         }
         return;
     }
-    epilogue<TM, TN>(a, pre, Red, m0, n0, lane, wave);
+    epilogue<TM, TN, EPI_>(a, pre, Red, m0, n0, lane, wave);
+    AIR_STAMP(61);
 }
 
 
@@ -868,7 +911,7 @@ struct F32V2Cfg {
     static constexpr int BYTES = (R * IMG > RED) ? R * IMG : RED;
 };
 
-template <int TM, int TN, bool TB>
+template <int TM, int TN, bool TB, int EPI_>
 __global__ __launch_bounds__(THREADS) void gemm_f32v2_kernel(Args a)
 {
     using Cfg = F32V2Cfg<TM, TN>;
@@ -899,7 +942,7 @@ __global__ __launch_bounds__(THREADS) void gemm_f32v2_kernel(Args a)
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     Pre<TM, TN> pre;
-    if (nslab == 1) epilogue_prefetch<TM, TN>(a, pre, m0, n0, lane, wave);
+    if (nslab == 1) epilogue_prefetch<TM, TN, EPI_>(a, pre, m0, n0, lane, wave);
 
     const char* Ab = reinterpret_cast<const char*>(a.A);
     const char* Bb = reinterpret_cast<const char*>(a.B);
@@ -916,7 +959,8 @@ __global__ __launch_bounds__(THREADS) void gemm_f32v2_kernel(Args a)
     float4 vbk[TB ? TBK_N : 1][2];
     float4 vbn[TB ? 1 : TBN_N][8];
     // ---- every load of one round, issued back to back
-    auto issue_loads = [&](int kr) {
+    auto issue_loads_t = [&](int kr, auto ha_t, auto hb_t) __attribute__((always_inline)) {
+        constexpr bool HA = decltype(ha_t)::value, HB = decltype(hb_t)::value;
 #pragma unroll
         for (int i = 0; i < TA_N; ++i) {
             const int t = tid + THREADS * i;
@@ -924,8 +968,8 @@ __global__ __launch_bounds__(THREADS) void gemm_f32v2_kernel(Args a)
             const int gm = m0 + row, gk = kr + c * KB + g * 8;
             const bool okr = (t < R * BM * 8) && gm < a.M;
             const unsigned off = ((unsigned)gm * (unsigned)a.lda + (unsigned)gk) * 4u;
-            va[i][0] = ldg16x(Ab, off, okr && gk < kend, okr && gk + 2 < kend, a8);
-            va[i][1] = ldg16x(Ab, off + 16u, okr && gk + 4 < kend, okr && gk + 6 < kend, a8);
+            va[i][0] = ldg16x<HA>(Ab, off, okr && gk < kend, okr && gk + 2 < kend);
+            va[i][1] = ldg16x<HA>(Ab, off + 16u, okr && gk + 4 < kend, okr && gk + 6 < kend);
         }
         if (TB) {
 #pragma unroll
@@ -937,8 +981,8 @@ __global__ __launch_bounds__(THREADS) void gemm_f32v2_kernel(Args a)
                 const int gk = kr + c * KB + g * 8;
                 const bool okr = (t < R * BN * 8) && cg < a.gwidth && gn < a.N;
                 const unsigned off = ((unsigned)gn * (unsigned)a.ldb + (unsigned)gk) * 4u;
-                vbk[i][0] = ldg16x(Bb, off, okr && gk < kend, okr && gk + 2 < kend, b8);
-                vbk[i][1] = ldg16x(Bb, off + 16u, okr && gk + 4 < kend, okr && gk + 6 < kend, b8);
+                vbk[i][0] = ldg16x<HB>(Bb, off, okr && gk < kend, okr && gk + 2 < kend);
+                vbk[i][1] = ldg16x<HB>(Bb, off + 16u, okr && gk + 4 < kend, okr && gk + 6 < kend);
             }
         } else {
 #pragma unroll
@@ -953,10 +997,18 @@ __global__ __launch_bounds__(THREADS) void gemm_f32v2_kernel(Args a)
                 const unsigned off = ((unsigned)gk * (unsigned)a.ldb + (unsigned)gn) * 4u;
 #pragma unroll
                 for (int r = 0; r < 8; ++r)
-                    vbn[i][r] = ldg16x(Bb, off + (unsigned)r * ((unsigned)a.ldb * 4u), okc && gk + r < kend,
-                                       okh && gk + r < kend, b8);
+                    vbn[i][r] = ldg16x<HB>(Bb, off + (unsigned)r * ((unsigned)a.ldb * 4u), okc && gk + r < kend,
+                                       okh && gk + r < kend);
             }
         }
+    };
+    // one uniform branch per round picks the straight-line variant for the operands' alignment
+    auto issue_loads = [&](int kr) __attribute__((always_inline)) {
+        using T_ = std::true_type; using F_ = std::false_type;
+        if (!a8 && !b8) issue_loads_t(kr, F_{}, F_{});
+        else if (!a8) issue_loads_t(kr, F_{}, T_{});
+        else if (!b8) issue_loads_t(kr, T_{}, F_{});
+        else issue_loads_t(kr, T_{}, T_{});
     };
     // (no software pipeline over rounds here: measured A/B it costs the fp32 kernel 15-20 % --
     // its rounds are MFMA-bound already, the early loads only lengthen the register live ranges)
@@ -1053,7 +1105,7 @@ __global__ __launch_bounds__(THREADS) void gemm_f32v2_kernel(Args a)
         }
         return;
     }
-    epilogue<TM, TN>(a, pre, Red, m0, n0, lane, wave);
+    epilogue<TM, TN, EPI_>(a, pre, Red, m0, n0, lane, wave);
 }
 
 
@@ -1077,23 +1129,54 @@ int launch(const air_gemm_t* g, const Args& a0, hipStream_t s) {
     }
     grid.z = (a.K + a.kslab - 1) / a.kslab + a.job_on;
     a.slab_stride = (long)a.M * a.ldc;
+    // the lean kernels are instantiated per epilogue; a fused epilogue exists for its one tile shape
+    // (resolve_tile) -- any other combination would be a dispatch bug
+    constexpr bool T14 = TM == 1 && TN == 4, T12 = TM == 1 && TN == 2, T11 = TM == 1 && TN == 1;
+    const int epi = a.epi;
+    const bool epi_ok = epi == AIR_EPI_GENERIC || (epi == AIR_EPI_LSTM_FWD && T14 && !TB) || (epi == AIR_EPI_REPARAM_FWD && T12 && !TB) ||
+                        ((epi == AIR_EPI_LSTM_BWD || epi == AIR_EPI_LSTM_BWD_TAIL || epi == AIR_EPI_REPARAM_BWD) && T11);
+    if (!epi_ok) return AIR_EINVAL;
+#define AIR_V2_LAUNCH(KERNEL, LDS)                                                                                     \
+    do {                                                                                                                \
+        if (epi == AIR_EPI_GENERIC) hipLaunchKernelGGL((KERNEL<TM, TN, TB, AIR_EPI_GENERIC>), grid, dim3(THREADS), LDS, s, a);      \
+        else if constexpr (T14 && !TB) hipLaunchKernelGGL((KERNEL<1, 4, false, AIR_EPI_LSTM_FWD>), grid, dim3(THREADS), LDS, s, a);   \
+        else if constexpr (T12 && !TB) hipLaunchKernelGGL((KERNEL<1, 2, false, AIR_EPI_REPARAM_FWD>), grid, dim3(THREADS), LDS, s, a); \
+        else if constexpr (T11) {                                                                                      \
+            if (epi == AIR_EPI_LSTM_BWD) hipLaunchKernelGGL((KERNEL<1, 1, TB, AIR_EPI_LSTM_BWD>), grid, dim3(THREADS), LDS, s, a);   \
+            else if (epi == AIR_EPI_LSTM_BWD_TAIL) hipLaunchKernelGGL((KERNEL<1, 1, TB, AIR_EPI_LSTM_BWD_TAIL>), grid, dim3(THREADS), LDS, s, a); \
+            else hipLaunchKernelGGL((KERNEL<1, 1, TB, AIR_EPI_REPARAM_BWD>), grid, dim3(THREADS), LDS, s, a);             \
+        }                                                                                                               \
+    } while (0)
     if (g->precision == 1) {
         const bool v2 = use_bf16_v2(a, TA, TB);
-        if (v2) hipLaunchKernelGGL((gemm_bf16v2_kernel<TM, TN, TB>), grid, dim3(THREADS), 0, s, a);
+        if (v2) AIR_V2_LAUNCH(gemm_bf16v2_kernel, 0);
         else hipLaunchKernelGGL((gemm_bf16_kernel<TM, TN, TA, TB>), grid, dim3(THREADS), 0, s, a);
     }
     else if (use_bf16_v2(a, TA, TB) && getenv("AIR_GEMM_F32_V1") == nullptr) {   // same operand requirements
         using Cfg = F32V2Cfg<TM, TN>;
-        static bool attr_set = false;
-        if (!attr_set && Cfg::BYTES > 48 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32v2_kernel<TM, TN, TB>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::BYTES);
-            if (e != hipSuccess) return (int)e;
-            attr_set = true;
+        if (Cfg::BYTES > 48 * 1024) {
+            // opt-in to the large dynamic LDS once per kernel function (all epilogue variants of this tile)
+            static bool attr_set = false;
+            if (!attr_set) {
+                const void* fns[] = {
+                    reinterpret_cast<const void*>(&gemm_f32v2_kernel<TM, TN, TB, AIR_EPI_GENERIC>),
+                    T14 && !TB ? reinterpret_cast<const void*>(&gemm_f32v2_kernel<1, 4, false, AIR_EPI_LSTM_FWD>) : nullptr,
+                    T12 && !TB ? reinterpret_cast<const void*>(&gemm_f32v2_kernel<1, 2, false, AIR_EPI_REPARAM_FWD>) : nullptr,
+                    T11 ? reinterpret_cast<const void*>(&gemm_f32v2_kernel<1, 1, TB, AIR_EPI_LSTM_BWD>) : nullptr,
+                    T11 ? reinterpret_cast<const void*>(&gemm_f32v2_kernel<1, 1, TB, AIR_EPI_LSTM_BWD_TAIL>) : nullptr,
+                    T11 ? reinterpret_cast<const void*>(&gemm_f32v2_kernel<1, 1, TB, AIR_EPI_REPARAM_BWD>) : nullptr};
+                for (const void* fn : fns)
+                    if (fn) {
+                        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::BYTES);
+                        if (e != hipSuccess) return (int)e;
+                    }
+                attr_set = true;
+            }
         }
-        hipLaunchKernelGGL((gemm_f32v2_kernel<TM, TN, TB>), grid, dim3(THREADS), Cfg::BYTES, s, a);
+        AIR_V2_LAUNCH(gemm_f32v2_kernel, Cfg::BYTES);
     } else
         hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, TA, TB>), grid, dim3(THREADS), 0, s, a);
+#undef AIR_V2_LAUNCH
     AIR_CHECK_LAUNCH();
     return 0;
 }
@@ -1162,9 +1245,9 @@ extern "C" int air_gemm_kernel_name(const air_gemm_t* g, char* buf, int n) {
     resolve_tile(g, tm, tn);
     const bool ta = g->transA != 0, tb = g->transB != 0;
     if (g->precision == 1 && use_bf16_v2(a, ta, tb))
-        snprintf(buf, n, "gemm_bf16v2_kernel<%d, %d, %s>", tm, tn, tb ? "true" : "false");
+        snprintf(buf, n, "gemm_bf16v2_kernel<%d, %d, %s, %d>", tm, tn, tb ? "true" : "false", g->epi);
     else if (g->precision == 0 && use_bf16_v2(a, ta, tb) && getenv("AIR_GEMM_F32_V1") == nullptr)
-        snprintf(buf, n, "gemm_f32v2_kernel<%d, %d, %s>", tm, tn, tb ? "true" : "false");
+        snprintf(buf, n, "gemm_f32v2_kernel<%d, %d, %s, %d>", tm, tn, tb ? "true" : "false", g->epi);
     else
         snprintf(buf, n, "gemm_%s_kernel<%d, %d, %s, %s>", g->precision == 1 ? "bf16" : "f32", tm, tn,
                  ta ? "true" : "false", tb ? "true" : "false");

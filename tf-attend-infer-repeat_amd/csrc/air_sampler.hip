@@ -16,12 +16,7 @@
 #include "air_common.h"
 #include <atomic>
 
-#ifdef AIR_STAMPS
-__device__ unsigned long long air_stamps_dev[64];
-extern "C" int air_debug_stamps(unsigned long long* out, int n) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(air_stamps_dev), sizeof(unsigned long long) * (n < 64 ? n : 64));
-}
-#endif
+AIR_STAMPS_READER(air_debug_stamps)
 
 namespace {
 

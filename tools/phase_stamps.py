@@ -13,8 +13,9 @@ subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-
 import torch
 from air import _hip as H
 H._LIB = H.load(out)
-H._LIB.air_debug_stamps.restype = C.c_int
-H._LIB.air_debug_stamps.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+for fn in ("air_debug_stamps", "air_debug_stamps_gemm"):
+    getattr(H._LIB, fn).restype = C.c_int
+    getattr(H._LIB, fn).argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 from bench import HP, ANNEAL, synthetic_canvases
 from air import air_model as am
 images, targets = synthetic_canvases(64, 50, 2, 1)
@@ -28,15 +29,15 @@ names = sys.argv[1:] or ["write_bwd", "compose", "attend_fwd", "attend_bwd"]
 ops = [m._begin] + m._fwd + m._bwd
 for want in names:
     for op in ops:
-        if want in op.name:
+        if want in op.name and not getattr(op, "_seen_%s" % want, False):
             buf = (C.c_ulonglong * 64)()
             for _ in range(3):
                 op(s)
             torch.cuda.synchronize()
-            H._LIB.air_debug_stamps(buf, 64)
+            base = {"write_bwd": 40, "attend_fwd": 10, "attend_bwd": 20, "compose": 30}.get(want, 56)
+            (H._LIB.air_debug_stamps_gemm if base == 56 else H._LIB.air_debug_stamps)(buf, 64)
             v = [int(x) for x in buf]
-            base = {"write_bwd": 0, "attend_fwd": 10, "attend_bwd": 20, "compose": 30}.get(want, 0)
-            idx = [i for i in range(base, base + 10) if v[i]]
+            idx = [i for i in range(base, base + (8 if base == 56 else 10)) if v[i]]
             d = ["%d:%.2f" % (i, (v[i] - v[j]) / 100.0) for j, i in zip(idx, idx[1:])]
             print("%-14s total %.2f us | deltas(us) %s" % (op.name, (v[idx[-1]] - v[idx[0]]) / 100.0 if idx else 0, " ".join(d)))
             break
