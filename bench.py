@@ -187,6 +187,8 @@ def launch_ranks(n):
     initialise it) and never execs; it exits non-zero if any rank fails."""
     import subprocess
     have = torch.cuda.device_count()
+    if os.environ.get("AIR_BENCH_SAME_DEVICE") == "1":
+        have = max(have, n) if have >= 1 else 0      # test mode: all ranks share cuda:0 (gloo backend)
     if have < n:
         sys.stderr.write("bench.py: --gpus %d requested but this node exposes %d GPU(s); refusing to report a "
                          "%d-GPU number from fewer devices\n" % (n, have, n))
@@ -233,10 +235,19 @@ def main():
                  % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks (tests/test_gpu_dp.py): the multi-rank flow on ONE device over gloo -- RCCL refuses two
+    # ranks on one GPU.  The numbers of such a run are not a scaling measurement and are labelled so.
+    same_device = os.environ.get("AIR_BENCH_SAME_DEVICE") == "1"
+    backend = os.environ.get("AIR_BENCH_BACKEND", "nccl")
+    if same_device:
+        local = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
         assert dist.get_world_size() == args.gpus
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
@@ -431,6 +442,8 @@ def main():
             line["allreduce"] = ar
         if world > 1:
             line["replicas_bit_identical"] = replicas_identical
+            if same_device or backend != "nccl":
+                line["test_mode"] = "ranks share one device over %s: NOT a scaling measurement" % backend
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

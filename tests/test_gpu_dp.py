@@ -138,3 +138,32 @@ def test_dp2_training_equals_full_batch_step(prec, graph, blank):
     print("dp2 %s graph=%s blank=%s: (loss, gnorm) rel per step %r, update rel-L2 %.3e" % (prec, graph, blank, report, rel))
     if blank:
         assert rel < (5e-3 if prec == "fp32" else 1e-1), rel
+
+
+def test_bench_multi_rank_flow_on_one_device(tmp_path):
+    """`python bench.py --gpus 2` end to end -- rank spawning, parameter sync, the [fwd+bwd graph] ->
+    all_reduce -> [clip+Adam graph] loop, max-over-ranks timing, the collective's own timing, ONE JSON
+    line from rank 0 -- with both ranks on the one leased GPU over gloo (a flow test: the line is
+    labelled as not a scaling measurement).  The same command without the test hooks must refuse to
+    run on a 1-GPU box."""
+    import json
+    import subprocess
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AIR_BENCH_SAME_DEVICE="1", AIR_BENCH_BACKEND="gloo")
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "12", "--warmup", "4"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 12 and d["config"]["global_batch"] == 128 and d["scaling"] == "weak"
+    assert d["replicas_bit_identical"] is True
+    assert d["value"] > 0 and abs(d["value"] - 128 * 12 / (d["ms_per_step"] * 12 * 1e-3)) / d["value"] < 1e-3
+    assert d["allreduce"]["bytes"] >= 4 * 4011643 and d["allreduce"]["bytes"] % 16 == 0 and d["allreduce"]["us"] > 0
+    assert "NOT a scaling measurement" in d["test_mode"]
+    if torch.cuda.device_count() < 2:
+        q = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "0"], cwd=root,
+                           capture_output=True, text=True, timeout=300)
+        assert q.returncode != 0 and "refusing" in q.stderr and not any(l.startswith("{") for l in q.stdout.splitlines())
