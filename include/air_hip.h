@@ -175,7 +175,9 @@ typedef struct {
  * gradient element each workgroup stored -- the tf.global_norm terms (air_model.py:673), handed to
  * air_adam_clip_step instead of a separate air_grad_sqnorm pass (single-GPU path; with data
  * parallelism the norm is taken after the all-reduce).  istate (nullable, only with sq_partials):
- * istate[GLOBAL_STEP] += 1, as air_grad_sqnorm does. */
+ * istate[GLOBAL_STEP] += 1, as air_grad_sqnorm does.  A plain problem may have dW == NULL when
+ * sq_partials is given: its tiles are computed and squared but not stored (the gradient is rebuilt
+ * from its factors by air_adam_clip_step_factored). */
 int air_wgrad_num_blocks(const air_wgrad_t* probs, int count);
 int air_wgrad_grouped(const air_wgrad_t* probs /*HOST array, <= 12*/, int count, int precision,
                       float* sq_partials, int32_t* istate, void* stream);
@@ -329,6 +331,19 @@ int air_adam_clip_step(float* params, const float* grads, float* m, float* v, in
                        float grad_prescale /* e.g. 1/world_size */, float beta1, float beta2,
                        float epsilon, uint16_t* bf16_shadow /*nullable*/, float* gnorm_out /*nullable*/,
                        void* stream);
+/* The same step with ONE gradient block taken from its factors instead of from `grads`:
+ * `factored` (HOST pointer, one plain problem, db NULL, ldc == N, N % 4 == 0) names a block
+ * dW = A^T.dY [M,N] that lies inside the flat buffer (dW points into `grads`; the matching ranges
+ * of params / m / v are updated).  Its workgroups rebuild the block tile by tile exactly as
+ * air_wgrad_grouped(precision) would have stored it, so params / m / v end bit-identical to the
+ * stored path; the grads range of the block is never read.  Pair it with an air_wgrad_grouped launch
+ * in which that problem has dW == NULL (sum of squares only).  Meant for the input-weight gradient
+ * of the LSTM, dWx = X^T.(sum_t dgates): rank <= B, 64 % of all gradient elements (air_model.py:286). */
+int air_adam_clip_step_factored(float* params, const float* grads, float* m, float* v, int64_t n,
+                                const air_wgrad_t* factored, int precision,
+                                const float* partials, int npartials, const float* dyn, const int32_t* istate,
+                                float grad_prescale, float beta1, float beta2, float epsilon,
+                                float* gnorm_out /*nullable*/, void* stream);
 
 #ifdef __cplusplus
 }

@@ -43,7 +43,7 @@ def _dump_report():
 
 
 def _make(am, B, train, seed_img=3, seed_noise=1, prec="fp32", scope=None, lo=-2.0, hp=HP, blank=False,
-          backward="exact"):
+          backward="exact", **ctor_kw):
     images, targets = blob_canvases(B, hp["canvas_size"], hp["max_digits"], seed=seed_img)
     noise = None
     if blank:
@@ -57,7 +57,7 @@ def _make(am, B, train, seed_img=3, seed_noise=1, prec="fp32", scope=None, lo=-2
         noise = ao.make_noise(hp, B, seed_noise)
     am.reset_default_graph()
     model = am.AIRModel(torch.tensor(images, device="cuda"), torch.tensor(targets, device="cuda"),
-                        cnn=False, train=train, scope=scope or "air", gemm_precision=prec, backward=backward, **hp)
+                        cnn=False, train=train, scope=scope or "air", gemm_precision=prec, backward=backward, **ctor_kw, **hp)
     model.load_state_dict(params)
     model.set_noise(noise)
     model.set_dynamic(z_pres_prior_log_odds=lo)
@@ -389,3 +389,28 @@ def test_inference_graph_replay_equals_eager(am):
     inf.forward()
     torch.cuda.synchronize()
     assert float(inf.loss) != l0
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_factored_input_weight_gradient_equals_stored_bit_for_bit(am, prec):
+    """input_weight_gradient="factored": training() never writes dWx = X^T.(sum_t dgates) to memory -- the
+    weight-gradient launch takes its norm, the Adam launch rebuilds its tiles.  Variables, both Adam slots, the global norm
+    and the loss must equal the run that stores every gradient, bit for bit, over several steps
+    (MatMul_grad of air_model.py:286's [x, h] kernel; clip + ApplyAdam :673-694)."""
+    D = HP["canvas_size"] ** 2
+    res = {}
+    for mode in ("stored", "factored"):
+        model, *_ = _make(am, 64, True, prec=prec, backward="reference", input_weight_gradient=mode)
+        model.store.grads.zero_()
+        for _ in range(3):
+            model.training()
+        torch.cuda.synchronize()
+        st = model.store
+        res[mode] = (st.params.clone(), st.m.clone(), st.v.clone(), float(st.gnorm), float(model.loss))
+        gx = model.gradients["rnn/kernel"][:D]
+        assert bool((gx != 0).any()) == (mode == "stored")        # factored: the block is never materialised
+        assert float(model.gradients["rnn/bias"].abs().max()) > 0  # ... but its bias gradient is
+        assert int(model.global_step) == 3
+    for a, b in zip(res["stored"][:3], res["factored"][:3]):
+        assert torch.equal(a, b)
+    assert res["stored"][3:] == res["factored"][3:]

@@ -120,6 +120,8 @@ _SIGNATURES = {
     "air_optim_num_partials": (C.c_int, [C.c_int64]),
     "air_grad_sqnorm": (C.c_int, [_p, C.c_int64, _p, _p, _p]),
     "air_adam_clip_step": (C.c_int, [_p, _p, _p, _p, C.c_int64, _p, C.c_int, _p, _p, _f, _f, _f, _f, _p, _p, _p]),
+    "air_adam_clip_step_factored": (C.c_int, [_p, _p, _p, _p, C.c_int64, C.POINTER(Wgrad), C.c_int, _p, C.c_int, _p, _p,
+                                              _f, _f, _f, _f, _p, _p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

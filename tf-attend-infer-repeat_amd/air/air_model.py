@@ -204,7 +204,8 @@ class AIRModel:
                  z_pres_prior_log_odds=-2.0, z_pres_temperature=1.0, stopping_threshold=0.99,
                  learning_rate=1e-3, gradient_clipping_norm=100.0, cnn=True, cnn_filters=8,
                  num_summary_images=60, train=False, reuse=False, scope="air",
-                 annealing_schedules=None, seed=0, gemm_precision=None, backward="reference", noise_seed=None):
+                 annealing_schedules=None, seed=0, gemm_precision=None, backward="reference", noise_seed=None,
+                 input_weight_gradient="stored"):
         if cnn:
             # reference :510-533; every caller passes cnn=False (training.py:108, demo.py:24)
             raise NotImplementedError("cnn=True front-end is outside the accelerated hot path; pass cnn=False")
@@ -295,6 +296,15 @@ class AIRModel:
         # (default: seed) keys the device Philox stream -- DP ranks pass different ones, otherwise
         # every shard would draw the same noise
         self._seed = (seed if noise_seed is None else noise_seed) + (0 if train else 7919)
+        # "stored" (default): every gradient is materialised.  "factored": the single-GPU train step never
+        # writes dWx = X^T.(sum_t dgates) (64 % of the gradient elements, rank <= B) to memory -- the
+        # weight-gradient launch takes its norm, the Adam launch rebuilds its tiles (bit-identical update);
+        # gradients["rnn/kernel"][:D] is then NOT refreshed by training().  Measured on MI355X: the 10 MB
+        # not written and not read are worth ~1 us in the weight-gradient launch, the tiles rebuilt inside
+        # Adam cost ~7 us (instruction-issue bound) -- a net loss at B = 64, kept as an option.
+        if input_weight_gradient not in ("factored", "stored"):
+            raise ValueError("input_weight_gradient must be 'factored' or 'stored'")
+        self._factor_dwx = input_weight_gradient == "factored"
         self._injected_noise = False
         self._graph = None
         self._dirty = True
@@ -427,6 +437,8 @@ class AIRModel:
         kernel = self._KERNEL_OF.get(name)
         if name == "air_wgrad_grouped":
             kernel = "wgrad_grouped_bf16_kernel" if self._prec else "wgrad_grouped_kernel"
+        if name == "air_adam_clip_step_factored":
+            kernel = "adam_factored_bf16_kernel" if self._prec else "adam_factored_kernel"
         return _Op(tag or name, lambda s, fn=fn, args=args, name=name: H.check(fn(*args, s), name),
                    nbytes=nbytes, flops=flops, kernel=kernel)
 
@@ -609,8 +621,19 @@ class AIRModel:
             H.check(self._wgrad_blocks, "air_wgrad_num_blocks")
         if st.partials.numel() < self._wgrad_blocks:
             raise NotImplementedError("weight-gradient launch of %d workgroups exceeds the partial-sum buffer" % self._wgrad_blocks)
-        self._wgrad_fused = self._call("air_wgrad_grouped", arr, len(probs), self._prec, _ptr(st.partials),
-                                       _ptr(st.istate), nbytes=wbytes, flops=wflops, tag="wgrad_grouped")
+        self._dwx_factors = None
+        if self._factor_dwx:
+            # same launch with dWx norm-only (its bias gradient is still stored); the factors go to Adam
+            fx = probs[-1]
+            probs_f = probs[:-1] + [H.Wgrad(fx.A, fx.dY, None, fx.db, fx.M, fx.N, fx.K, fx.lda, fx.ldb, fx.ldc, 0, 0, 0, 0)]
+            arr_f = (H.Wgrad * len(probs_f))(*probs_f)
+            self._dwx_factors = (H.Wgrad * 1)(H.Wgrad(fx.A, fx.dY, fx.dW, None, fx.M, fx.N, fx.K, fx.lda, fx.ldb, fx.ldc, 0, 0, 0, 0))
+            keep.extend([arr_f, self._dwx_factors])
+            self._wgrad_fused = self._call("air_wgrad_grouped", arr_f, len(probs_f), self._prec, _ptr(st.partials),
+                                           _ptr(st.istate), nbytes=wbytes - 4 * fx.M * fx.N, flops=wflops, tag="wgrad_grouped")
+        else:
+            self._wgrad_fused = self._call("air_wgrad_grouped", arr, len(probs), self._prec, _ptr(st.partials),
+                                           _ptr(st.istate), nbytes=wbytes, flops=wflops, tag="wgrad_grouped")
 
         self._sqnorm = self._call("air_grad_sqnorm", _ptr(st.grads), st.n, _ptr(st.partials), _ptr(st.istate),
                                   nbytes=4 * st.n, tag="grad_sqnorm")
@@ -687,9 +710,16 @@ class AIRModel:
             st = self.store
             fused = world == 1
             npart = self._wgrad_blocks if fused else self.lib.air_optim_num_partials(st.n)
-            adam = self._call("air_adam_clip_step", _ptr(st.params), _ptr(st.grads), _ptr(st.m), _ptr(st.v),
-                              st.n, _ptr(st.partials), npart, _ptr(self.dyn), _ptr(st.istate), 1.0 / world,
-                              0.9, 0.999, 1e-8, None, _ptr(st.gnorm), nbytes=28 * st.n, tag="adam_clip")
+            if fused and self._dwx_factors is not None:
+                fx = self._dwx_factors[0]
+                adam = self._call("air_adam_clip_step_factored", _ptr(st.params), _ptr(st.grads), _ptr(st.m), _ptr(st.v),
+                                  st.n, self._dwx_factors, self._prec, _ptr(st.partials), npart, _ptr(self.dyn),
+                                  _ptr(st.istate), 1.0, 0.9, 0.999, 1e-8, _ptr(st.gnorm),
+                                  nbytes=28 * st.n - 4 * fx.M * fx.N, flops=2 * fx.M * fx.N * fx.K, tag="adam_clip")
+            else:
+                adam = self._call("air_adam_clip_step", _ptr(st.params), _ptr(st.grads), _ptr(st.m), _ptr(st.v),
+                                  st.n, _ptr(st.partials), npart, _ptr(self.dyn), _ptr(st.istate), 1.0 / world,
+                                  0.9, 0.999, 1e-8, None, _ptr(st.gnorm), nbytes=28 * st.n, tag="adam_clip")
             # data parallel: the norm is that of the all-reduced gradient -> separate pass after the collective
             self._opt = [adam] if fused else [self._sqnorm, adam]
             self._opt_world = world

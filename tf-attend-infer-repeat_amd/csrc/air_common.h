@@ -97,3 +97,30 @@ __device__ __forceinline__ float air_block_sum_256(float v, float* red) {
     __syncthreads();
     return ((red[0] + red[1]) + red[2]) + red[3];
 }
+
+// clip_by_global_norm + ApplyAdam coefficients, identical in every workgroup: the partial sums are
+// re-reduced in one fixed order (air_model.py:673, TF 1.3 training_ops ApplyAdam).
+struct AirAdamCoef { float scale, lr_t, gnorm; };
+__device__ __forceinline__ AirAdamCoef air_adam_coef(const float* __restrict__ partials, int npartials,
+                                                     const float* __restrict__ dyn, const int32_t* __restrict__ istate,
+                                                     float prescale, float b1, float b2, float* red /* >= 4 floats of LDS */) {
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < npartials; i += 256) s += partials[i];
+    s = air_block_sum_256(s, red);
+    AirAdamCoef c;
+    c.gnorm = sqrtf(s) * prescale;                     // norm of the (pre-scaled, e.g. averaged) gradient
+    const float clip = dyn[AIR_DYN_CLIP_NORM];
+    // t * clip_norm * min(1/global_norm, 1/clip_norm); clip <= 0 disables clipping
+    c.scale = prescale * (clip > 0.0f ? clip * fminf(1.0f / c.gnorm, 1.0f / clip) : 1.0f);
+    const float t = (float)istate[AIR_IST_GLOBAL_STEP];     // already incremented (grad_sqnorm / fused wgrad)
+    c.lr_t = dyn[AIR_DYN_LEARNING_RATE] * sqrtf(1.0f - powf(b2, t)) / (1.0f - powf(b1, t));
+    return c;
+}
+// m += (g-m)(1-b1); v += (g^2-v)(1-b2); var -= lr_t*m/(sqrt(v)+eps)
+__device__ __forceinline__ void air_adam_update(float& p, float& m, float& v, float g, const AirAdamCoef& c,
+                                                float omb1, float omb2, float eps) {
+    const float gk = g * c.scale;
+    m = m + (gk - m) * omb1;
+    v = v + (gk * gk - v) * omb2;
+    p = p - (m * c.lr_t) / (sqrtf(v) + eps);
+}

@@ -43,17 +43,8 @@ __global__ __launch_bounds__(THREADS) void adam_clip_kernel(
     float prescale, float b1, float b2, float eps, uint16_t* __restrict__ shadow, float* __restrict__ gnorm_out)
 {
     __shared__ float red[4];
-    // every workgroup re-reduces the partials in the same fixed order: identical scale everywhere
-    float s = 0.0f;
-    for (int i = threadIdx.x; i < npartials; i += THREADS) s += partials[i];
-    s = air_block_sum_256(s, red);
-    const float gn = sqrtf(s) * prescale;              // norm of the (pre-scaled, e.g. averaged) gradient
-    const float clip = dyn[AIR_DYN_CLIP_NORM];
-    // t * clip_norm * min(1/global_norm, 1/clip_norm); clip <= 0 disables clipping
-    const float scale = prescale * (clip > 0.0f ? clip * fminf(1.0f / gn, 1.0f / clip) : 1.0f);
-    const float t = (float)istate[AIR_IST_GLOBAL_STEP];     // already incremented (grad_sqnorm / fused wgrad)
-    const float lr_t = dyn[AIR_DYN_LEARNING_RATE] * sqrtf(1.0f - powf(b2, t)) / (1.0f - powf(b1, t));
-    if (gnorm_out && blockIdx.x == 0 && threadIdx.x == 0) *gnorm_out = gn;
+    const AirAdamCoef cf = air_adam_coef(partials, npartials, dyn, istate, prescale, b1, b2, red);
+    if (gnorm_out && blockIdx.x == 0 && threadIdx.x == 0) *gnorm_out = cf.gnorm;
     const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
 
     const long n4 = n / 4;
@@ -66,12 +57,7 @@ __global__ __launch_bounds__(THREADS) void adam_clip_kernel(
         const float4 gg = g4[i];
         float* pa = &pp.x; float* ma = &mm.x; float* va = &vv.x; const float* ga = &gg.x;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float gk = ga[k] * scale;
-            ma[k] = ma[k] + (gk - ma[k]) * omb1;
-            va[k] = va[k] + (gk * gk - va[k]) * omb2;
-            pa[k] = pa[k] - (ma[k] * lr_t) / (sqrtf(va[k]) + eps);
-        }
+        for (int k = 0; k < 4; ++k) air_adam_update(pa[k], ma[k], va[k], ga[k], cf, omb1, omb2, eps);
         p4[i] = pp; m4[i] = mm; v4[i] = vv;
         if (shadow) {
             for (int k = 0; k < 4; ++k) {
@@ -83,11 +69,9 @@ __global__ __launch_bounds__(THREADS) void adam_clip_kernel(
     }
     if (blockIdx.x == 0 && threadIdx.x < (int)(n - n4 * 4)) {
         const long i = n4 * 4 + threadIdx.x;
-        const float gk = g[i] * scale;
-        const float mk = m[i] + (gk - m[i]) * omb1;
-        const float vk = v[i] + (gk * gk - v[i]) * omb2;
-        m[i] = mk; v[i] = vk;
-        p[i] = p[i] - (mk * lr_t) / (sqrtf(vk) + eps);
+        float pk = p[i], mk = m[i], vk = v[i];
+        air_adam_update(pk, mk, vk, g[i], cf, omb1, omb2, eps);
+        p[i] = pk; m[i] = mk; v[i] = vk;
         if (shadow) { uint32_t u = __float_as_uint(p[i]); u += 0x7fffu + ((u >> 16) & 1u); shadow[i] = (uint16_t)(u >> 16); }
     }
 }

@@ -12,6 +12,7 @@
 // separate reduction launch exists.  The ten problems of the step are
 // independent: one launch fills the chip instead of ten latency-bound ones.
 #include "air_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -28,20 +29,36 @@ struct Prob {
     int head_pack, Hs, Hh, Hz;
     int tiles_n, first_block;
 };
-struct Table { int count; int total_blocks; Prob p[MAXP]; };
+// first[i] = first workgroup of problem i (INT_MAX past `count`): kept apart from the descriptors so that
+// ONE wide scalar load fetches all of them and the owner is found without a chain of dependent loads
+struct Table { int count; int total_blocks; int first[MAXP]; Prob p[MAXP]; };
 
-__device__ __forceinline__ float4 load4(const float* base, int ld, int row, int col, int rows, int cols, bool vec) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < rows) {
-        const float* src = base + (size_t)row * ld + col;
-        if (vec && col + 3 < cols) v = *reinterpret_cast<const float4*>(src);
-        else {
-            if (col < cols) v.x = src[0];
-            if (col + 1 < cols) v.y = src[1];
-            if (col + 2 < cols) v.z = src[2];
-            if (col + 3 < cols) v.w = src[3];
-        }
-    }
+// One float4 of a row-major operand, zero outside [rows x cols], in two branch-free halves: fetch4
+// issues the load(s) with out-of-range accesses redirected to element 0, mask4 zeroes what was out of
+// range.  Callers issue ALL fetches of a batch before the first mask: a run-time branch around a
+// load (or a consumer right behind it) makes the compiler wait on the spot, which serialises the
+// 16-24 loads a thread should have in flight (12 us instead of 3 for the ragged-edge tiles).
+// VEC: base 16-byte aligned and ld % 4 == 0 -- a quad that starts inside a row then lies inside
+// the padded row, so the 16-byte load is issued even when its last columns are past `cols`.
+template <bool VEC>
+__device__ __forceinline__ float4 fetch4(const float* __restrict__ base, int ld, int row, int col, int rows, int cols) {
+    const bool okr = row < rows;
+    const unsigned at = (unsigned)row * (unsigned)ld + (unsigned)col;
+    if (VEC) return *reinterpret_cast<const float4*>(base + ((okr && col < cols) ? at : 0u));
+    float4 v;
+    v.x = base[(okr && col < cols) ? at : 0u];
+    v.y = base[(okr && col + 1 < cols) ? at + 1u : 0u];
+    v.z = base[(okr && col + 2 < cols) ? at + 2u : 0u];
+    v.w = base[(okr && col + 3 < cols) ? at + 3u : 0u];
+    return v;
+}
+__device__ __forceinline__ float4 mask4(float4 t, int row, int col, int rows, int cols) {
+    const bool okr = row < rows;
+    float4 v;
+    v.x = (okr && col < cols) ? t.x : 0.f;
+    v.y = (okr && col + 1 < cols) ? t.y : 0.f;
+    v.z = (okr && col + 2 < cols) ? t.z : 0.f;
+    v.w = (okr && col + 3 < cols) ? t.w : 0.f;
     return v;
 }
 
@@ -58,18 +75,11 @@ __device__ __forceinline__ void publish_sq(float sq, float* sq_partials, int32_t
     }
 }
 
-__global__ __launch_bounds__(THREADS) void wgrad_grouped_kernel(Table tab, float* __restrict__ sq_partials, int32_t* __restrict__ istate)
+// fp32 tile: the 64 x 64 block (m0, n0) of pr.A^T . pr.dY, left as 64 rows of LS floats at &As[0][0]
+// (barrier-synchronised).  Returns this thread's share of the squared bias gradient it stored.
+template <int NCH>      // chunks of 32 rows in flight per round trip (8: K <= 256 in one)
+__device__ __forceinline__ float tile_f32(const Prob& pr, int m0, int n0, float (*As)[KC * LS], float (*Bs)[KC * LS])
 {
-    __shared__ __attribute__((aligned(16))) float As[2][KC * LS];
-    __shared__ __attribute__((aligned(16))) float Bs[2][KC * LS];
-
-    // which problem / tile is this workgroup?
-    int pi = 0;
-    while (pi + 1 < tab.count && (int)blockIdx.x >= tab.p[pi + 1].first_block) ++pi;
-    const Prob& pr = tab.p[pi];
-    const int local = blockIdx.x - pr.first_block;
-    const int m0 = (local / pr.tiles_n) * BT, n0 = (local % pr.tiles_n) * BT;
-
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;        // this wave's quadrant
     const bool vecA = ((pr.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(pr.A) & 15) == 0);
@@ -78,28 +88,39 @@ __global__ __launch_bounds__(THREADS) void wgrad_grouped_kernel(Table tab, float
     // copy the problem descriptor out of the kernel-argument table once
     const float* __restrict__ Ap = pr.A;
     const float* __restrict__ Yp = pr.dY;
-    const int M = pr.M, N = pr.N, K = pr.K, lda = pr.lda, ldb = pr.ldb, ldc = pr.ldc;
-    float* dW = pr.dW;
+    const int M = pr.M, N = pr.N, K = pr.K, lda = pr.lda, ldb = pr.ldb;
     float* db = pr.db;
     const int head_pack = pr.head_pack;
 
     // staging map: 32 rows x 16 float4 columns = 512 float4 per operand chunk, 2 per thread
     const int srow = tid >> 4, scol = (tid & 15) * 4;             // rows srow and srow + 16
-    constexpr int NCH = 8;                                        // chunks in flight: K <= 256 in one round trip
     float4 ra[NCH][2], rb[NCH][2];
-    auto fetch = [&](int set, int k0) {
+    auto fetch = [&](int set, int k0, auto vec_t) __attribute__((always_inline)) {
+        constexpr bool V = decltype(vec_t)::value;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int k = k0 + srow + 16 * h;
-            ra[set][h] = load4(Ap, lda, k, m0 + scol, K, M, vecA);
-            rb[set][h] = load4(Yp, ldb, k, n0 + scol, K, N, vecB);
+            ra[set][h] = fetch4<V>(Ap, lda, k, m0 + scol, K, M);
+            rb[set][h] = fetch4<V>(Yp, ldb, k, n0 + scol, K, N);
         }
     };
-    auto stage = [&](int set, int buf) {
+    // interior tile, whole chunks: nothing to clamp or mask
+    const bool plain = vecA && vecB && m0 + BT <= M && n0 + BT <= N && (K % KC) == 0;
+    auto fetch_plain = [&](int set, int k0) __attribute__((always_inline)) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            *reinterpret_cast<float4*>(&As[buf][(srow + 16 * h) * LS + scol]) = ra[set][h];
-            *reinterpret_cast<float4*>(&Bs[buf][(srow + 16 * h) * LS + scol]) = rb[set][h];
+            const unsigned k = (unsigned)(k0 + srow + 16 * h);
+            ra[set][h] = *reinterpret_cast<const float4*>(Ap + (k * (unsigned)lda + (unsigned)(m0 + scol)));
+            rb[set][h] = *reinterpret_cast<const float4*>(Yp + (k * (unsigned)ldb + (unsigned)(n0 + scol)));
+        }
+    };
+    auto stage = [&](int set, int buf, int k0, auto plain_t) __attribute__((always_inline)) {
+        constexpr bool PL = decltype(plain_t)::value;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = k0 + srow + 16 * h;
+            *reinterpret_cast<float4*>(&As[buf][(srow + 16 * h) * LS + scol]) = PL ? ra[set][h] : mask4(ra[set][h], k, m0 + scol, K, M);
+            *reinterpret_cast<float4*>(&Bs[buf][(srow + 16 * h) * LS + scol]) = PL ? rb[set][h] : mask4(rb[set][h], k, n0 + scol, K, N);
         }
     };
 
@@ -139,20 +160,40 @@ __global__ __launch_bounds__(THREADS) void wgrad_grouped_kernel(Table tab, float
     // reading before it passed the barrier of iteration c.
     for (int ks0 = 0; ks0 < K; ks0 += NCH * KC) {
         if (ks0 > 0) __syncthreads();
+        if (plain) {                            // ONE uniform branch around the whole batch of loads
 #pragma unroll
-        for (int c = 0; c < NCH; ++c)
-            if (ks0 + c * KC < K) fetch(c, ks0 + c * KC);
+            for (int c = 0; c < NCH; ++c)
+                if (ks0 + c * KC < K) fetch_plain(c, ks0 + c * KC);
+        } else if (vecA && vecB) {
 #pragma unroll
-        for (int c = 0; c < NCH; ++c)
-            if (ks0 + c * KC < K) {
-                stage(c, c & 1);
-                __syncthreads();
-                compute(c & 1);
-            }
+            for (int c = 0; c < NCH; ++c)
+                if (ks0 + c * KC < K) fetch(c, ks0 + c * KC, std::true_type{});
+        } else {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+                if (ks0 + c * KC < K) fetch(c, ks0 + c * KC, std::false_type{});
+        }
+        if (plain) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+                if (ks0 + c * KC < K) {
+                    stage(c, c & 1, ks0 + c * KC, std::true_type{});
+                    __syncthreads();
+                    compute(c & 1);
+                }
+        } else {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+                if (ks0 + c * KC < K) {
+                    stage(c, c & 1, ks0 + c * KC, std::false_type{});
+                    __syncthreads();
+                    compute(c & 1);
+                }
+        }
     }
 
-    // epilogue: C/D map row = (lane>>4)*4 + q, col = lane&15.  The tile goes through LDS so that
-    // every store instruction writes whole 256-byte rows (full cache lines).
+    // C/D map row = (lane>>4)*4 + q, col = lane&15.  The tile goes through LDS so that every store
+    // instruction of the epilogue touches whole 256-byte rows (full cache lines).
     __syncthreads();
     float* Ct = &As[0][0];                      // 64 x LS floats = 20 KB: spans As[0..1]
 #pragma unroll
@@ -163,25 +204,39 @@ __global__ __launch_bounds__(THREADS) void wgrad_grouped_kernel(Table tab, float
             for (int q = 0; q < 4; ++q)
                 Ct[(wm + i * 16 + (lane >> 4) * 4 + q) * LS + wn + j * 16 + (lane & 15)] = acc[i][j][q];
     __syncthreads();
-    float sq = 0.0f;
-    if (!head_pack) {
+    float bias_sq = 0.0f;
+    if (do_bias) {
+        if (!head_pack) { if (n0 + lane < N) { db[n0 + lane] = colsum; bias_sq = colsum * colsum; } }
+        else if (lane < 7) { db[lane] = colsum; bias_sq = colsum * colsum; }
+    }
+    return bias_sq;
+}
+
+// Epilogue of the weight-gradient kernels: the tile in Ct goes to pr.dW (whole rows per store
+// instruction) and its sum of squares to the caller.  pr.dW == NULL: nothing is stored, only the
+// sum of squares is taken (a gradient that air_adam_clip_step_factored rebuilds from its factors).
+__device__ __forceinline__ float store_tile(const Prob& pr, int m0, int n0, const float* Ct, float sq)
+{
+    const int tid = threadIdx.x;
+    const int M = pr.M, N = pr.N, ldc = pr.ldc;
+    float* dW = pr.dW;
+    if (!pr.head_pack) {
         const bool vecC = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(dW) & 15) == 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = (tid >> 4) + 16 * r, col = (tid & 15) * 4;
             const int m = m0 + row, n = n0 + col;
             if (m >= M) continue;
-            const float4 v = *reinterpret_cast<const float4*>(&Ct[row * LS + col]);
+            const float4 t = *reinterpret_cast<const float4*>(&Ct[row * LS + col]);
             float* dst = dW + (size_t)m * ldc + n;
-            if (vecC && n + 3 < N) { *reinterpret_cast<float4*>(dst) = v; sq += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w); }
+            if (vecC && n + 3 < N) { if (dW) *reinterpret_cast<float4*>(dst) = t; sq += (t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w); }
             else {
-                if (n < N) { dst[0] = v.x; sq += v.x * v.x; }
-                if (n + 1 < N) { dst[1] = v.y; sq += v.y * v.y; }
-                if (n + 2 < N) { dst[2] = v.z; sq += v.z * v.z; }
-                if (n + 3 < N) { dst[3] = v.w; sq += v.w * v.w; }
+                if (n < N) { if (dW) dst[0] = t.x; sq += t.x * t.x; }
+                if (n + 1 < N) { if (dW) dst[1] = t.y; sq += t.y * t.y; }
+                if (n + 2 < N) { if (dW) dst[2] = t.z; sq += t.z * t.z; }
+                if (n + 3 < N) { if (dW) dst[3] = t.w; sq += t.w * t.w; }
             }
         }
-        if (do_bias && n0 + lane < N) { db[n0 + lane] = colsum; sq += colsum * colsum; }
     } else {
         // head output units (air_model.py:294-316, 376): A = d_out7 [K,8], dY = hid [K,HT];
         // unit o only owns the hidden segment of its head: dW = wout[o][n - off], db = bout[o] = sum_k d_out7[k][o]
@@ -192,13 +247,33 @@ __global__ __launch_bounds__(THREADS) void wgrad_grouped_kernel(Table tab, float
             int off = 0;
             for (int h = 0; h < head[o]; ++h) off += wid[h];
             if (m0 == 0 && n < N && n >= off && n < off + wid[head[o]]) {
-                const float v = Ct[o * LS + col];
-                dW[(size_t)o * ldc + (n - off)] = v;
-                sq += v * v;
+                const float t = Ct[o * LS + col];
+                dW[(size_t)o * ldc + (n - off)] = t;
+                sq += t * t;
             }
         }
-        if (do_bias && lane < 7) { db[lane] = colsum; sq += colsum * colsum; }
     }
+    return sq;
+}
+
+__device__ __forceinline__ const Prob& find_tile(const Table& tab, int block, int& m0, int& n0) {
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < MAXP; ++i) pi += (block >= tab.first[i]) ? 1 : 0;
+    const Prob& pr = tab.p[pi];
+    const int local = block - pr.first_block;
+    m0 = (local / pr.tiles_n) * BT; n0 = (local % pr.tiles_n) * BT;
+    return pr;
+}
+
+__global__ __launch_bounds__(THREADS) void wgrad_grouped_kernel(Table tab, float* __restrict__ sq_partials, int32_t* __restrict__ istate)
+{
+    __shared__ __attribute__((aligned(16))) float As[2][KC * LS];
+    __shared__ __attribute__((aligned(16))) float Bs[2][KC * LS];
+    int m0, n0;
+    const Prob& pr = find_tile(tab, blockIdx.x, m0, n0);
+    const float bias_sq = tile_f32<6>(pr, m0, n0, As, Bs);      // K = 192 (3 steps x 64 images) in one round trip
+    const float sq = store_tile(pr, m0, n0, &As[0][0], 0.0f) + bias_sq;
     if (sq_partials) publish_sq(sq, sq_partials, istate);
 }
 
@@ -220,30 +295,23 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 constexpr int KB = 64;          // rows per LDS image
-constexpr int NIMG = 3;         // images resident per round: K <= 192 needs one round
+constexpr int NIMG_W = 3;       // images resident per round in the weight-gradient kernel: K <= 192 needs one round
 
 __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
     const f32x2_t v = {lo, hi};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void wgrad_grouped_bf16_kernel(Table tab, float* __restrict__ sq_partials, int32_t* __restrict__ istate)
+// bf16 tile: as tile_f32, operands rounded to bf16; Img = [operand][image][column][k] shorts of LDS,
+// the fp32 tile is left at its start (64 rows of LS floats, barrier-synchronised).
+template <int NIMG>     // LDS images (64 rows each) resident per round; Img holds max(2 * NIMG * 8 KB, 20 KB)
+__device__ __forceinline__ float tile_bf16(const Prob& pr, int m0, int n0, unsigned short* Img)
 {
-    // [operand][image][column 0..63][k 0..63] bf16 = 2 x 3 x 8 KB; reused as the fp32 output tile
-    __shared__ __attribute__((aligned(16))) unsigned short Img[2 * NIMG * BT * KB];
-
-    int pi = 0;
-    while (pi + 1 < tab.count && (int)blockIdx.x >= tab.p[pi + 1].first_block) ++pi;
-    const Prob& pr = tab.p[pi];
-    const int local = blockIdx.x - pr.first_block;
-    const int m0 = (local / pr.tiles_n) * BT, n0 = (local % pr.tiles_n) * BT;
-
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
     const float* __restrict__ Ap = pr.A;
     const float* __restrict__ Yp = pr.dY;
-    const int M = pr.M, N = pr.N, K = pr.K, lda = pr.lda, ldb = pr.ldb, ldc = pr.ldc;
-    float* dW = pr.dW;
+    const int M = pr.M, N = pr.N, K = pr.K, lda = pr.lda, ldb = pr.ldb;
     float* db = pr.db;
     const int head_pack = pr.head_pack;
 
@@ -253,7 +321,6 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
     const int ld = op ? ldb : lda, cols = op ? N : M, c0 = (op ? n0 : m0) + 4 * q;
     const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
     unsigned short* img = Img + (size_t)op * NIMG * BT * KB;
-    const bool full = vec && ((op ? n0 : m0) + BT <= cols);      // wave-uniform (op is)
     const bool bias_block = (db != nullptr) && (head_pack ? (n0 == 0) : (m0 == 0));
     const bool bias_thread = bias_block && (op == (head_pack ? 0 : 1));
     float csum[4] = {0.f, 0.f, 0.f, 0.f};
@@ -264,30 +331,46 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    AIR_STAMP(1);
     for (int kr = 0; kr < K; kr += NIMG * KB) {
         if (kr > 0) __syncthreads();                     // every wave is done reading the previous images
         float4 v[NIMG][8];
-        if (full) {
-            // interior tile: uniform base + 32-bit byte offsets, rows past K read as zero
+        // wave-uniform choices, each ONE branch around the whole batch of loads
+        const bool inside = (op ? n0 : m0) + BT <= cols;                  // no ragged column edge
+        if (vec && inside && (K % KB) == 0) {
+            // interior tile, whole images: uniform base + 32-bit byte offsets, nothing to mask
             const char* base = reinterpret_cast<const char*>(src);
-            const unsigned off0 = ((unsigned)(kr + g * 8) * (unsigned)ld + (unsigned)c0) * 4u;
+            const unsigned step = (unsigned)ld * 4u;
+            const unsigned off0 = (unsigned)(kr + g * 8) * step + (unsigned)c0 * 4u;
 #pragma unroll
             for (int c = 0; c < NIMG; ++c)
                 if (kr + c * KB < K) {
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        const bool ok = kr + c * KB + g * 8 + r < K;
-                        const unsigned off = off0 + (unsigned)(c * KB + r) * ((unsigned)ld * 4u);
-                        const float4 t = *reinterpret_cast<const float4*>(base + (ok ? off : 0u));
-                        v[c][r] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
-                    }
+                    for (int r = 0; r < 8; ++r)
+                        v[c][r] = *reinterpret_cast<const float4*>(base + (off0 + (unsigned)(c * KB + r) * step));
+                }
+        } else if (vec) {
+#pragma unroll
+            for (int c = 0; c < NIMG; ++c)
+                if (kr + c * KB < K) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[c][r] = fetch4<true>(src, ld, kr + c * KB + g * 8 + r, c0, K, cols);
                 }
         } else {
 #pragma unroll
             for (int c = 0; c < NIMG; ++c)
                 if (kr + c * KB < K) {
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) v[c][r] = load4(src, ld, kr + c * KB + g * 8 + r, c0, K, cols, vec);
+                    for (int r = 0; r < 8; ++r) v[c][r] = fetch4<false>(src, ld, kr + c * KB + g * 8 + r, c0, K, cols);
+                }
+        }
+        AIR_STAMP(2);
+        if (!(vec && inside && (K % KB) == 0)) {
+#pragma unroll
+            for (int c = 0; c < NIMG; ++c)
+                if (kr + c * KB < K) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[c][r] = mask4(v[c][r], kr + c * KB + g * 8 + r, c0, K, cols);
                 }
         }
 #pragma unroll
@@ -307,7 +390,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
                     *reinterpret_cast<uint4*>(&img[(size_t)c * BT * KB + col * KB + ((g ^ (col & 7)) << 3)]) = w;
                 }
             }
+        AIR_STAMP(3);
         __syncthreads();
+        AIR_STAMP(4);
 #pragma unroll
         for (int c = 0; c < NIMG; ++c)
             if (kr + c * KB < K) {
@@ -356,6 +441,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
     }
 
     // epilogue through LDS: whole 256-byte rows per store instruction
+    AIR_STAMP(5);
     __syncthreads();
     float* Ct = reinterpret_cast<float*>(Img);           // 64 x LS floats = 20 KB <= 48 KB
 #pragma unroll
@@ -366,77 +452,188 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
             for (int qq = 0; qq < 4; ++qq)
                 Ct[(wm + i * 16 + (lane >> 4) * 4 + qq) * LS + wn + j * 16 + (lane & 15)] = acc[i][j][qq];
     __syncthreads();
-    if (!head_pack) {
-        const bool vecC = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(dW) & 15) == 0);
+    return sq;
+}
+
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void wgrad_grouped_bf16_kernel(Table tab, float* __restrict__ sq_partials, int32_t* __restrict__ istate)
+{
+    // [operand][image][column 0..63][k 0..63] bf16 = 2 x 3 x 8 KB; reused as the fp32 output tile
+    __shared__ __attribute__((aligned(16))) unsigned short Img[2 * NIMG_W * BT * KB];
+    int m0, n0;
+    const Prob& pr = find_tile(tab, blockIdx.x, m0, n0);
+    AIR_STAMP(0);
+    const float bias_sq = tile_bf16<NIMG_W>(pr, m0, n0, Img);
+    AIR_STAMP(6);
+    const float sq = store_tile(pr, m0, n0, reinterpret_cast<const float*>(Img), bias_sq);
+    AIR_STAMP(7);
+    if (sq_partials) publish_sq(sq, sq_partials, istate);
+    AIR_STAMP(8);
+}
+
+// ---------------------------------------------------------------------------
+// clip + Adam with ONE gradient taken from its factors instead of from memory.
+// dWx = X^T . (sum_t dgates) has rank <= B and is 64 % of all gradient elements
+// (air_model.py:286: the [x, h] kernel's x rows): the weight-gradient launch
+// only takes its sum of squares (dW == NULL above), and the workgroups here that
+// own its 64 x 64 blocks rebuild each block with the same tile function (so the
+// values are the ones a stored gradient would hold) and apply ApplyAdam to the
+// matching block of var / m / v.  The other workgroups stream the rest of the flat
+// buffer as adam_clip_kernel does.  -10 MB written, -10 MB read per step.
+// ---------------------------------------------------------------------------
+struct AdamFac {
+    float* p; const float* g; float* m; float* v; long n;
+    long roff, rlen;                   // region [roff, roff + rlen) of the flat buffers = the factored M x N block
+    const float* partials; int npartials; const float* dyn; const int32_t* istate;
+    float prescale, b1, b2, eps; float* gnorm_out; int tile_blocks;
+};
+
+template <int PREC>
+__device__ __forceinline__ void adam_factored_body(const Prob& pr, const AdamFac& a, unsigned char* smem)
+{
+    __shared__ float red[4];
+    const float omb1 = 1.0f - a.b1, omb2 = 1.0f - a.b2, eps = a.eps;
+    const int tid = threadIdx.x;
+
+    if ((int)blockIdx.x < a.tile_blocks) {
+        const int m0 = ((int)blockIdx.x / pr.tiles_n) * BT, n0 = ((int)blockIdx.x % pr.tiles_n) * BT;
+        const int M = pr.M, N = pr.N;                      // ldc == N, N % 4 == 0 (checked on the host)
+        float* P = a.p + a.roff; float* Mo = a.m + a.roff; float* V = a.v + a.roff;
+        // var / m / v of this block are requested first: they arrive while the tile is rebuilt
+        float4 pp[4], mm[4], vv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + (tid >> 4) + 16 * r, n = n0 + (tid & 15) * 4;
+            const size_t i = (m < M && n < N) ? (size_t)m * N + n : 0;
+            pp[r] = *reinterpret_cast<const float4*>(P + i);
+            mm[r] = *reinterpret_cast<const float4*>(Mo + i);
+            vv[r] = *reinterpret_cast<const float4*>(V + i);
+        }
+        const AirAdamCoef cf = air_adam_coef(a.partials, a.npartials, a.dyn, a.istate, a.prescale, a.b1, a.b2, red);
+        if (a.gnorm_out && blockIdx.x == 0 && tid == 0) *a.gnorm_out = cf.gnorm;
+        if (PREC) tile_bf16<1>(pr, m0, n0, reinterpret_cast<unsigned short*>(smem));
+        else tile_f32<2>(pr, m0, n0, reinterpret_cast<float (*)[KC * LS]>(smem), reinterpret_cast<float (*)[KC * LS]>(smem) + 2);
+        const float* Ct = reinterpret_cast<const float*>(smem);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = (tid >> 4) + 16 * r, col = (tid & 15) * 4;
             const int m = m0 + row, n = n0 + col;
-            if (m >= M) continue;
-            const float4 t = *reinterpret_cast<const float4*>(&Ct[row * LS + col]);
-            float* dst = dW + (size_t)m * ldc + n;
-            if (vecC && n + 3 < N) { *reinterpret_cast<float4*>(dst) = t; sq += (t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w); }
-            else {
-                if (n < N) { dst[0] = t.x; sq += t.x * t.x; }
-                if (n + 1 < N) { dst[1] = t.y; sq += t.y * t.y; }
-                if (n + 2 < N) { dst[2] = t.z; sq += t.z * t.z; }
-                if (n + 3 < N) { dst[3] = t.w; sq += t.w * t.w; }
-            }
+            if (m >= M || n >= N) continue;
+            const float4 gg = *reinterpret_cast<const float4*>(&Ct[row * LS + col]);
+            const size_t i = (size_t)m * N + n;
+            float* pa = &pp[r].x; float* ma = &mm[r].x; float* va = &vv[r].x; const float* ga = &gg.x;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) air_adam_update(pa[k], ma[k], va[k], ga[k], cf, omb1, omb2, eps);
+            *reinterpret_cast<float4*>(P + i) = pp[r]; *reinterpret_cast<float4*>(Mo + i) = mm[r]; *reinterpret_cast<float4*>(V + i) = vv[r];
         }
-    } else {
-        const int wid[5] = {pr.Hs, pr.Hs, pr.Hh, pr.Hh, pr.Hz};
-        const int head[7] = {0, 1, 2, 2, 3, 3, 4};
-        for (int it = tid; it < 7 * BT; it += THREADS) {
-            const int o = it / BT, col = it % BT, n = n0 + col;
-            int off = 0;
-            for (int h = 0; h < head[o]; ++h) off += wid[h];
-            if (m0 == 0 && n < N && n >= off && n < off + wid[head[o]]) {
-                const float t = Ct[o * LS + col];
-                dW[(size_t)o * ldc + (n - off)] = t;
-                sq += t * t;
-            }
-        }
+        return;
     }
-    if (sq_partials) publish_sq(sq, sq_partials, istate);
+    // everything outside the region: the flat stream of adam_clip_kernel with the region skipped
+    const AirAdamCoef cf = air_adam_coef(a.partials, a.npartials, a.dyn, a.istate, a.prescale, a.b1, a.b2, red);
+    const long bid = (long)blockIdx.x - a.tile_blocks, nb = (long)gridDim.x - a.tile_blocks;
+    const long n4 = a.n / 4, roff4 = a.roff / 4, rlen4 = a.rlen / 4, plain4 = n4 - rlen4;
+    float4* p4 = reinterpret_cast<float4*>(a.p);
+    const float4* g4 = reinterpret_cast<const float4*>(a.g);
+    float4* m4 = reinterpret_cast<float4*>(a.m);
+    float4* v4 = reinterpret_cast<float4*>(a.v);
+    for (long j = bid * THREADS + tid; j < plain4; j += nb * THREADS) {
+        const long i = j < roff4 ? j : j + rlen4;
+        float4 pp = p4[i], mm = m4[i], vv = v4[i];
+        const float4 gg = g4[i];
+        float* pa = &pp.x; float* ma = &mm.x; float* va = &vv.x; const float* ga = &gg.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) air_adam_update(pa[k], ma[k], va[k], ga[k], cf, omb1, omb2, eps);
+        p4[i] = pp; m4[i] = mm; v4[i] = vv;
+    }
+    if (bid == 0 && tid < (int)(a.n - n4 * 4)) {           // the region is 4-aligned, so the tail is outside it
+        const long i = n4 * 4 + tid;
+        float pk = a.p[i], mk = a.m[i], vk = a.v[i];
+        air_adam_update(pk, mk, vk, a.g[i], cf, omb1, omb2, eps);
+        a.p[i] = pk; a.m[i] = mk; a.v[i] = vk;
+    }
+}
+
+__global__ __launch_bounds__(THREADS) void adam_factored_kernel(Prob pr, AdamFac a)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * KC * LS * sizeof(float)];
+    adam_factored_body<0>(pr, a, smem);
+}
+__global__ __launch_bounds__(THREADS) void adam_factored_bf16_kernel(Prob pr, AdamFac a)
+{
+    // one 64-row image per operand (16 KB: the contraction is over B rows) or the 20 KB fp32 tile
+    __shared__ __attribute__((aligned(16))) unsigned char smem[BT * LS * sizeof(float)];
+    adam_factored_body<1>(pr, a, smem);
 }
 
 }  // namespace
 
-static int fill_table(const air_wgrad_t* probs, int count, Table& tab) {
+AIR_STAMPS_READER(air_debug_stamps_wgrad)
+
+static int fill_table(const air_wgrad_t* probs, int count, Table& tab, bool allow_null_dw) {
     if (!probs || count <= 0) return AIR_EINVAL;
     if (count > MAXP) return AIR_ELIMIT;
     tab.count = count;
     int blocks = 0;
     for (int i = 0; i < count; ++i) {
         const air_wgrad_t& g = probs[i];
-        if (!g.A || !g.dY || !g.dW || g.M <= 0 || g.N <= 0 || g.K <= 0) return AIR_EINVAL;
+        if (!g.A || !g.dY || g.M <= 0 || g.N <= 0 || g.K <= 0) return AIR_EINVAL;
+        if (!g.dW && (g.head_pack || !allow_null_dw)) return AIR_EINVAL;     // norm-only problems: plain layout, and only with sq_partials
         Prob& p = tab.p[i];
         p.A = g.A; p.dY = g.dY; p.dW = g.dW; p.db = g.db;
         p.M = g.M; p.N = g.N; p.K = g.K; p.lda = g.lda; p.ldb = g.ldb; p.ldc = g.ldc;
         p.head_pack = g.head_pack; p.Hs = g.Hs; p.Hh = g.Hh; p.Hz = g.Hz;
         p.tiles_n = (g.N + BT - 1) / BT;
         p.first_block = blocks;
+        tab.first[i] = blocks;
         blocks += p.tiles_n * ((g.M + BT - 1) / BT);
     }
-    for (int i = count; i < MAXP; ++i) tab.p[i] = tab.p[0];
+    for (int i = count; i < MAXP; ++i) { tab.p[i] = tab.p[0]; tab.first[i] = 0x7fffffff; }
     tab.total_blocks = blocks;
     return 0;
 }
 
 extern "C" int air_wgrad_num_blocks(const air_wgrad_t* probs, int count) {
     Table tab;
-    const int rc = fill_table(probs, count, tab);
+    const int rc = fill_table(probs, count, tab, true);
     return rc ? rc : tab.total_blocks;
 }
 
 extern "C" int air_wgrad_grouped(const air_wgrad_t* probs, int count, int precision,
                                  float* sq_partials, int32_t* istate, void* stream) {
     Table tab;
-    const int rc = fill_table(probs, count, tab);
+    const int rc = fill_table(probs, count, tab, sq_partials != nullptr);
     if (rc) return rc;
     if (precision != 0 && precision != 1) return AIR_EINVAL;
     if (precision == 1) hipLaunchKernelGGL(wgrad_grouped_bf16_kernel, dim3(tab.total_blocks), dim3(THREADS), 0, air_stream(stream), tab, sq_partials, istate);
     else hipLaunchKernelGGL(wgrad_grouped_kernel, dim3(tab.total_blocks), dim3(THREADS), 0, air_stream(stream), tab, sq_partials, istate);
+    AIR_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int air_adam_clip_step_factored(float* params, const float* grads, float* m, float* v, int64_t n,
+                                           const air_wgrad_t* factored, int precision,
+                                           const float* partials, int npartials, const float* dyn, const int32_t* istate,
+                                           float grad_prescale, float beta1, float beta2, float epsilon,
+                                           float* gnorm_out, void* stream) {
+    if (!params || !grads || !m || !v || !partials || npartials <= 0 || !dyn || !istate || n <= 0 || !factored) return AIR_EINVAL;
+    if ((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)m | (uintptr_t)v) & 15) != 0) return AIR_EALIGN;
+    if (precision != 0 && precision != 1) return AIR_EINVAL;
+    Table tab;
+    const int rc = fill_table(factored, 1, tab, false);
+    if (rc) return rc;
+    const air_wgrad_t& f = *factored;
+    if (f.head_pack || f.db || f.ldc != f.N) return AIR_EINVAL;
+    if ((f.N & 3) != 0) return AIR_EALIGN;
+    const long roff = (long)(f.dW - grads), rlen = (long)f.M * f.N;
+    if (f.dW < grads || roff + rlen > n) return AIR_EINVAL;      // the block must lie inside the flat buffer
+    if ((roff & 3) != 0) return AIR_EALIGN;
+    long plain = ((n - rlen) / 4 + THREADS - 1) / THREADS;
+    if (plain < 1) plain = 1;
+    if (plain > 2048) plain = 2048;
+    AdamFac a{params, grads, m, v, (long)n, roff, rlen, partials, npartials, dyn, istate,
+              grad_prescale, beta1, beta2, epsilon, gnorm_out, tab.total_blocks};
+    const dim3 grid((unsigned)(tab.total_blocks + plain));
+    if (precision == 1) hipLaunchKernelGGL(adam_factored_bf16_kernel, grid, dim3(THREADS), 0, air_stream(stream), tab.p[0], a);
+    else hipLaunchKernelGGL(adam_factored_kernel, grid, dim3(THREADS), 0, air_stream(stream), tab.p[0], a);
     AIR_CHECK_LAUNCH();
     return 0;
 }

@@ -13,7 +13,7 @@ subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-
 import torch
 from air import _hip as H
 H._LIB = H.load(out)
-for fn in ("air_debug_stamps", "air_debug_stamps_gemm"):
+for fn in ("air_debug_stamps", "air_debug_stamps_gemm", "air_debug_stamps_wgrad"):
     getattr(H._LIB, fn).restype = C.c_int
     getattr(H._LIB, fn).argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 from bench import HP, ANNEAL, synthetic_canvases
@@ -26,7 +26,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 s = m._stream()
 names = sys.argv[1:] or ["write_bwd", "compose", "attend_fwd", "attend_bwd"]
-ops = [m._begin] + m._fwd + m._bwd
+ops = [m._begin] + m._fwd + m._bwd + [m._wgrad_fused]
 for want in names:
     for op in ops:
         if want in op.name and not getattr(op, "_seen_%s" % want, False):
@@ -34,8 +34,8 @@ for want in names:
             for _ in range(3):
                 op(s)
             torch.cuda.synchronize()
-            base = {"write_bwd": 40, "attend_fwd": 10, "attend_bwd": 20, "compose": 30}.get(want, 56)
-            (H._LIB.air_debug_stamps_gemm if base == 56 else H._LIB.air_debug_stamps)(buf, 64)
+            base = {"write_bwd": 40, "attend_fwd": 10, "attend_bwd": 20, "compose": 30, "wgrad": 0}.get(want, 56)
+            {56: H._LIB.air_debug_stamps_gemm, 0: H._LIB.air_debug_stamps_wgrad}.get(base, H._LIB.air_debug_stamps)(buf, 64)
             v = [int(x) for x in buf]
             idx = [i for i in range(base, base + (8 if base == 56 else 10)) if v[i]]
             d = ["%d:%.2f" % (i, (v[i] - v[j]) / 100.0) for j, i in zip(idx, idx[1:])]
