@@ -304,6 +304,34 @@ typedef struct {
 } air_write_bwd_t;
 int air_write_bwd(const air_write_bwd_t* a, void* stream);
 
+/* ---- VAE bottleneck, one launch per direction (vae.py:16-34) ------------------
+ * Forward = the last recognition product and the first generative layer:
+ *   ml [M,2Z] = X [M,K1].Wml [K1,2Z] + bml  (mean | log-variance, vae.py:16-20)
+ *   z  [M,Z]  = mean + eps * sqrt(exp(lv))                          (vae.py:22-24)
+ *   g  [M,H]  = softplus(z.Wg [Z,H] + bg)                           (vae.py:26-30)
+ * i.e. air_gemm(AIR_EPI_REPARAM_FWD) followed by air_gemm(bias, AIR_ACT_SOFTPLUS) without the second
+ * launch and without z's round trip through memory.  Operands are rounded to bf16 for the MFMAs
+ * (as air_gemm precision 1 does), accumulation is fp32.
+ * Backward = their data gradients:
+ *   d_z = dG [M,H].Wg^T; d_ml [M,2Z] as AIR_EPI_REPARAM_BWD writes it (ml, eps, att mask, dyn);
+ *   d_x [M,K1] = (d_ml.Wml^T) * softplus'(x)    (x = the saved activation X, AIR_GRAD_SOFTPLUS)
+ * Limits: K1 == 256 (forward) / H == 256 (backward), Z <= 64 and even, 16-byte aligned operands;
+ * AIR_ELIMIT / AIR_EALIGN otherwise (callers fall back to the two air_gemm launches). */
+typedef struct {
+    const float* X; const float* Wml; const float* bml; const float* eps; const float* Wg; const float* bg;
+    float* ml; float* z; float* g;
+    int32_t M, K1, Z, H, ldx;
+} air_bottleneck_fwd_t;
+typedef struct {
+    const float* dG; const float* Wg; const float* ml; const float* eps;
+    const float* att;                    /* [M, AIR_ATT_STRIDE]: AIR_ATT_MASK gates the KL gradient */
+    const float* dyn; const float* Wml; const float* x;
+    float* d_ml; float* d_x;
+    int32_t M, K1, Z, H;
+} air_bottleneck_bwd_t;
+int air_vae_bottleneck_fwd(const air_bottleneck_fwd_t* a, void* stream);
+int air_vae_bottleneck_bwd(const air_bottleneck_bwd_t* a, void* stream);
+
 /* ---- reconstruction loss (air_model.py:580-593) + its gradient ---------------- */
 int air_bce_fwd_bwd(const float* images, const float* run_recon, const float* dyn,
                     float* recon /*clipped [B,D]*/, float* rec_loss /*[B]*/,

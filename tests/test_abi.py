@@ -56,14 +56,17 @@ def test_struct_layout_matches_c(H, tmp_path):
                     'printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(air_gemm_t), offsetof(air_gemm_t, bias),'
                     'offsetof(air_gemm_t, aux), offsetof(air_gemm_t, precision), offsetof(air_gemm_t, p0), offsetof(air_gemm_t, q2), sizeof(air_schedule_t),'
                     'sizeof(air_attend_fwd_t), offsetof(air_attend_fwd_t, B), sizeof(air_attend_bwd_t),'
-                    'sizeof(air_write_fwd_t), sizeof(air_write_bwd_t)); printf("%zu\\n", sizeof(air_colsum_t)); return 0;}')
+                    'sizeof(air_write_fwd_t), sizeof(air_write_bwd_t)); printf("%zu %zu %zu %zu %zu\\n", sizeof(air_colsum_t),'
+                    'sizeof(air_bottleneck_fwd_t), offsetof(air_bottleneck_fwd_t, ldx), sizeof(air_bottleneck_bwd_t), offsetof(air_bottleneck_bwd_t, H));'
+                    'return 0;}')
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
     out = subprocess.check_output([str(exe)]).decode().split()
     got = [int(x) for x in out]
     exp = [C.sizeof(H.Gemm), H.Gemm.bias.offset, H.Gemm.aux.offset, H.Gemm.precision.offset, H.Gemm.p0.offset, H.Gemm.q2.offset,
            C.sizeof(H.Schedule), C.sizeof(H.AttendFwd), H.AttendFwd.B.offset, C.sizeof(H.AttendBwd),
-           C.sizeof(H.WriteFwd), C.sizeof(H.WriteBwd), C.sizeof(H.Colsum)]
+           C.sizeof(H.WriteFwd), C.sizeof(H.WriteBwd), C.sizeof(H.Colsum),
+           C.sizeof(H.BottleneckFwd), H.BottleneckFwd.ldx.offset, C.sizeof(H.BottleneckBwd), H.BottleneckBwd.H.offset]
     assert got == exp, (got, exp)
 
 
@@ -76,6 +79,8 @@ def test_argument_errors_without_gpu(H):
     assert lib.air_lstm_gates_fwd(None, None, None, None, None, 4, 4, None) == -1
     assert lib.air_grad_sqnorm(None, 10, None, None, None) == -1
     assert lib.air_colsum(None, 0, None) == -1
+    assert lib.air_vae_bottleneck_fwd(C.byref(H.BottleneckFwd()), None) == -1
+    assert lib.air_vae_bottleneck_bwd(None, None) == -1
     assert lib.air_adam_clip_step_factored(None, None, None, None, 16, None, 1, None, 1, None, None, 1.0, 0.9, 0.999, 1e-8,
                                            None, None) == -1
     # a factored block must lie inside the flat buffer, be plain (no head packing, no bias) and 4-aligned

@@ -639,3 +639,104 @@ def test_annealing_schedule_variants_match_oracle(H, sched):
         ref = float(ao.annealed_value(sched, step))
         got = float(dyn[H.DYN_TEMPERATURE])
         assert abs(got - ref) <= 2e-5 * max(1.0, abs(ref)), (step, got, ref)
+
+
+def _softplus_tf(x):
+    x = np.asarray(x, np.float64)
+    return np.where(x > 13.942384719848633, x, np.where(x < -13.942384719848633, np.exp(x), np.log1p(np.exp(x))))
+
+
+@pytest.mark.parametrize("M,Hd,Z", [(192, 256, 50), (37, 192, 50), (16, 256, 64), (5, 64, 2)])
+def test_vae_bottleneck_forward_matches_the_formulas(H, M, Hd, Z):
+    """air_vae_bottleneck_fwd = vae.py:16-30 in one launch: mean | log-variance, the reparameterised
+    sample and the first generative layer.  Reference: float64 on bf16-rounded GEMM operands."""
+    rng = np.random.RandomState(3)
+    K1 = 256
+    X = rng.uniform(0, 2, (M, K1)).astype(np.float32)
+    Wml = rng.uniform(-0.1, 0.1, (K1, 2 * Z)).astype(np.float32)
+    bml = rng.uniform(-0.1, 0.1, 2 * Z).astype(np.float32)
+    eps = rng.randn(M, Z).astype(np.float32)
+    Wg = rng.uniform(-0.3, 0.3, (Z, Hd)).astype(np.float32)
+    bg = rng.uniform(-0.1, 0.1, Hd).astype(np.float32)
+    t = {k: torch.tensor(v, device="cuda") for k, v in dict(X=X, Wml=Wml, bml=bml, eps=eps, Wg=Wg, bg=bg).items()}
+    ml = torch.full((M, 2 * Z), float("nan"), device="cuda")
+    z = torch.full((M, Z), float("nan"), device="cuda")
+    g = torch.full((M, Hd), float("nan"), device="cuda")
+    a = H.BottleneckFwd(_p(t["X"]), _p(t["Wml"]), _p(t["bml"]), _p(t["eps"]), _p(t["Wg"]), _p(t["bg"]), _p(ml), _p(z), _p(g),
+                        M, K1, Z, Hd, K1)
+    H.check(H.lib().air_vae_bottleneck_fwd(C.byref(a), _stream()))
+    torch.cuda.synchronize()
+    ml_ref = _bf16_round(X).astype(np.float64) @ _bf16_round(Wml).astype(np.float64) + bml
+    z_ref = ml_ref[:, :Z] + eps * np.sqrt(np.exp(ml_ref[:, Z:]))
+    assert np.abs(ml.cpu().numpy() - ml_ref).max() < 2e-5
+    assert np.abs(z.cpu().numpy() - z_ref).max() < 2e-5
+    # the second product sees the sample the kernel made (rounded to bf16 as the MFMA operand is)
+    g_ref = _softplus_tf(_bf16_round(z.cpu().numpy()).astype(np.float64) @ _bf16_round(Wg).astype(np.float64) + bg)
+    assert np.abs(g.cpu().numpy() - g_ref).max() < 2e-5
+    # and equals the two-launch path it replaces
+    ml2, z2, g2 = torch.empty_like(ml), torch.empty_like(z), torch.empty_like(g)
+    g1 = _gemm_struct(H, t["X"], t["Wml"], ml2, M, 2 * Z, K1, K1, 2 * Z, 2 * Z, 1, bias=t["bml"], epi=H.EPI_REPARAM_FWD,
+                      p0=t["eps"], q0=z2)
+    H.check(H.lib().air_gemm(C.byref(g1), _stream()))
+    g2s = _gemm_struct(H, z2, t["Wg"], g2, M, Hd, Z, Z, Hd, Hd, 1, bias=t["bg"], act=H.ACT_SOFTPLUS)
+    H.check(H.lib().air_gemm(C.byref(g2s), _stream()))
+    torch.cuda.synchronize()
+    assert (ml - ml2).abs().max() < 1e-5 and (z - z2).abs().max() < 1e-5 and (g - g2).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("M,K1,Z", [(192, 256, 50), (37, 200, 50), (16, 64, 64), (5, 256, 2)])
+def test_vae_bottleneck_backward_matches_the_formulas(H, M, K1, Z):
+    """air_vae_bottleneck_bwd: d_z = dG.Wg^T, the reparameterisation + KL gradients (vae.py:22-24,
+    air_model.py:386-392, masked by the step's stopping mask), d_x = (d_ml.Wml^T) * softplus'(x)."""
+    rng = np.random.RandomState(4)
+    Hd = 256
+    dG = rng.randn(M, Hd).astype(np.float32) * 0.1
+    Wg = rng.uniform(-0.3, 0.3, (Z, Hd)).astype(np.float32)
+    ml = rng.uniform(-1, 1, (M, 2 * Z)).astype(np.float32)
+    eps = rng.randn(M, Z).astype(np.float32)
+    att = np.zeros((M, H.ATT_STRIDE), np.float32)
+    att[:, H.ATT_MASK] = rng.randint(0, 2, M)
+    dyn = np.zeros(32, np.float32)
+    dyn[H.DYN_GRAD_SCALE], dyn[H.DYN_VAE_PV], dyn[H.DYN_VAE_PM] = 1.0 / 64, 0.8, 0.1
+    Wml = rng.uniform(-0.1, 0.1, (K1, 2 * Z)).astype(np.float32)
+    x = rng.uniform(0.01, 2, (M, K1)).astype(np.float32)
+    t = {k: torch.tensor(v, device="cuda") for k, v in dict(dG=dG, Wg=Wg, ml=ml, eps=eps, att=att, dyn=dyn, Wml=Wml, x=x).items()}
+    d_ml = torch.full((M, 2 * Z), float("nan"), device="cuda")
+    d_x = torch.full((M, K1), float("nan"), device="cuda")
+    a = H.BottleneckBwd(_p(t["dG"]), _p(t["Wg"]), _p(t["ml"]), _p(t["eps"]), _p(t["att"]), _p(t["dyn"]), _p(t["Wml"]), _p(t["x"]),
+                        _p(d_ml), _p(d_x), M, K1, Z, Hd)
+    H.check(H.lib().air_vae_bottleneck_bwd(C.byref(a), _stream()))
+    torch.cuda.synchronize()
+    dz = _bf16_round(dG).astype(np.float64) @ _bf16_round(Wg).astype(np.float64).T
+    klg = att[:, H.ATT_MASK:H.ATT_MASK + 1].astype(np.float64) * dyn[H.DYN_GRAD_SCALE]
+    var = np.exp(ml[:, Z:].astype(np.float64))
+    dmean = dz + klg * (ml[:, :Z] - dyn[H.DYN_VAE_PM]) / dyn[H.DYN_VAE_PV]
+    dlv = dz * eps * 0.5 * np.sqrt(var) + klg * 0.5 * (var / dyn[H.DYN_VAE_PV] - 1.0)
+    ref = np.concatenate([dmean, dlv], 1)
+    got = d_ml.cpu().numpy()
+    assert np.abs(got - ref).max() < 2e-5
+    dx_ref = (_bf16_round(got).astype(np.float64) @ _bf16_round(Wml).astype(np.float64).T) * (1.0 - np.exp(-x.astype(np.float64)))
+    assert np.abs(d_x.cpu().numpy() - dx_ref).max() < 2e-5
+    # the two-launch path it replaces
+    d_ml2, d_x2 = torch.empty_like(d_ml), torch.empty_like(d_x)
+    g1 = _gemm_struct(H, t["dG"], t["Wg"], d_ml2, M, Z, Hd, Hd, Hd, 2 * Z, 1, transB=1, epi=H.EPI_REPARAM_BWD,
+                      p0=t["ml"], p1=t["eps"], p2=t["att"], p3=t["dyn"])
+    H.check(H.lib().air_gemm(C.byref(g1), _stream()))
+    g2 = _gemm_struct(H, d_ml2, t["Wml"], d_x2, M, K1, 2 * Z, 2 * Z, 2 * Z, K1, 1, transB=1, aux=t["x"], ldaux=K1,
+                      actgrad=H.GRAD_SOFTPLUS)
+    H.check(H.lib().air_gemm(C.byref(g2), _stream()))
+    torch.cuda.synchronize()
+    # (d_ml differs in the last fp32 bits between the two accumulation orders; where that flips its bf16
+    # rounding as the second product's operand, d_x moves by one bf16 ulp of d_ml times a weight)
+    assert (d_ml - d_ml2).abs().max() < 1e-5 and (d_x - d_x2).abs().max() < 3e-4
+
+
+def test_vae_bottleneck_limits(H):
+    a = H.BottleneckFwd()
+    buf = torch.zeros(1024, device="cuda")
+    for f in ("X", "Wml", "bml", "eps", "Wg", "bg", "ml", "z", "g"):
+        setattr(a, f, buf.data_ptr())
+    a.M, a.K1, a.Z, a.H, a.ldx = 4, 128, 50, 256, 128
+    assert H.lib().air_vae_bottleneck_fwd(C.byref(a), _stream()) == -2          # K1 != 256: callers fall back
+    a.K1, a.ldx, a.Z = 256, 256, 51
+    assert H.lib().air_vae_bottleneck_fwd(C.byref(a), _stream()) == -3          # odd Z

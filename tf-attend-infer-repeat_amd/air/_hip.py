@@ -93,6 +93,16 @@ class WriteBwd(C.Structure):
                 ("fin_loss_item", _p), ("fin_targets", _p), ("fin_digits", _p), ("fin_scalars", _p)]
 
 
+class BottleneckFwd(C.Structure):
+    _fields_ = [("X", _p), ("Wml", _p), ("bml", _p), ("eps", _p), ("Wg", _p), ("bg", _p), ("ml", _p), ("z", _p), ("g", _p),
+                ("M", _i), ("K1", _i), ("Z", _i), ("H", _i), ("ldx", _i)]
+
+
+class BottleneckBwd(C.Structure):
+    _fields_ = [("dG", _p), ("Wg", _p), ("ml", _p), ("eps", _p), ("att", _p), ("dyn", _p), ("Wml", _p), ("x", _p),
+                ("d_ml", _p), ("d_x", _p), ("M", _i), ("K1", _i), ("Z", _i), ("H", _i)]
+
+
 _SIGNATURES = {
     "air_abi_version": (C.c_int, []),
     "air_strerror": (C.c_char_p, [C.c_int]),
@@ -119,6 +129,8 @@ _SIGNATURES = {
     "air_step_begin": (C.c_int, [_p, C.c_int, _p, _p, _p, C.c_int64, _p, C.c_int64, C.c_uint64, _p]),
     "air_optim_num_partials": (C.c_int, [C.c_int64]),
     "air_grad_sqnorm": (C.c_int, [_p, C.c_int64, _p, _p, _p]),
+    "air_vae_bottleneck_fwd": (C.c_int, [C.POINTER(BottleneckFwd), _p]),
+    "air_vae_bottleneck_bwd": (C.c_int, [C.POINTER(BottleneckBwd), _p]),
     "air_adam_clip_step": (C.c_int, [_p, _p, _p, _p, C.c_int64, _p, C.c_int, _p, _p, _f, _f, _f, _f, _p, _p, _p]),
     "air_adam_clip_step_factored": (C.c_int, [_p, _p, _p, _p, C.c_int64, C.POINTER(Wgrad), C.c_int, _p, C.c_int, _p, _p,
                                               _f, _f, _f, _f, _p, _p]),

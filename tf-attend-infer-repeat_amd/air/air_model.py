@@ -430,7 +430,8 @@ class AIRModel:
     _KERNEL_OF = {"air_lstm_first_step": "lstm_first_step_kernel", "air_step_begin": "step_begin_kernel", "air_attend_fwd": "attend_fwd_kernel",
                   "air_attend_bwd": "attend_bwd_kernel", "air_write_fwd": "write_fwd_kernel",
                   "air_write_bwd": "write_bwd_kernel", "air_finalize": "finalize_kernel",
-                  "air_grad_sqnorm": "grad_sqnorm_kernel", "air_adam_clip_step": "adam_clip_kernel"}
+                  "air_grad_sqnorm": "grad_sqnorm_kernel", "air_adam_clip_step": "adam_clip_kernel",
+                  "air_vae_bottleneck_fwd": "bottleneck_fwd_kernel<256>", "air_vae_bottleneck_bwd": "bottleneck_bwd_kernel<256>"}
 
     def _call(self, name, *args, nbytes=0, flops=0, tag=None):
         fn = getattr(self.lib, name)
@@ -492,11 +493,27 @@ class AIRModel:
             fwd.append(self._gemm(x, P["rec%d_w" % i], self.rec_act[i], NB, u, k, k, u, u,
                                   bias=P["rec%d_b" % i], act=H.ACT_SOFTPLUS, tag="vae_rec"))
             x, k = self.rec_act[i], u
-        fwd.append(self._gemm(x, P["ml_w"], self.ml, NB, 2 * Z, k, k, 2 * Z, 2 * Z, bias=P["ml_b"],
-                              epi=H.EPI_REPARAM_FWD, p=(self.eps_z,), q=(self.zs,),
-                              extra_bytes=8 * NB * Z, tag="ml_reparam"))
-        x, k = self.zs, Z
-        for i, u in enumerate(gen_u):
+        # the bottleneck (last recognition product -> reparameterised sample -> first generative layer) is
+        # ONE launch where the fused kernel's limits hold (bf16 operands; vae.py:16-30); else two GEMMs
+        nofuse = os.environ.get("AIR_NO_BOTTLENECK_FUSION") == "1"
+        fuse_f = (self._prec == 1 and not nofuse and len(gen_u) >= 1 and k == 256 and Z <= 64 and Z % 2 == 0
+                  and gen_u[0] % 4 == 0)
+        first_gen = 0
+        if fuse_f:
+            bf = H.BottleneckFwd(_ptr(x), _ptr(P["ml_w"]), _ptr(P["ml_b"]), _ptr(self.eps_z), _ptr(P["gen0_w"]),
+                                 _ptr(P["gen0_b"]), _ptr(self.ml), _ptr(self.zs), _ptr(self.gen_act[0]), NB, k, Z, gen_u[0], k)
+            keep.append(bf)
+            fwd.append(self._call("air_vae_bottleneck_fwd", C.byref(bf),
+                                  nbytes=4 * (NB * (k + 4 * Z + gen_u[0]) + k * 2 * Z + Z * gen_u[0]),
+                                  flops=2 * NB * (k * 2 * Z + Z * gen_u[0]), tag="vae_bottleneck"))
+            x, k, first_gen = self.gen_act[0], gen_u[0], 1
+        else:
+            fwd.append(self._gemm(x, P["ml_w"], self.ml, NB, 2 * Z, k, k, 2 * Z, 2 * Z, bias=P["ml_b"],
+                                  epi=H.EPI_REPARAM_FWD, p=(self.eps_z,), q=(self.zs,),
+                                  extra_bytes=8 * NB * Z, tag="ml_reparam"))
+            x, k = self.zs, Z
+        for i in range(first_gen, len(gen_u)):
+            u = gen_u[i]
             fwd.append(self._gemm(x, P["gen%d_w" % i], self.gen_act[i], NB, u, k, k, u, u,
                                   bias=P["gen%d_b" % i], act=H.ACT_SOFTPLUS, tag="vae_gen"))
             x, k = self.gen_act[i], u
@@ -542,11 +559,25 @@ class AIRModel:
             bwd.append(self._gemm(dy, P[wname], self.d_gen[i], NB, u, n_out, n_out, n_out, u, tb=1,
                                   aux=self.gen_act[i], ldaux=u, actgrad=H.GRAD_SOFTPLUS, tag="dgrad_gen"))
             dy, n_out, wname = self.d_gen[i], u, "gen%d_w" % i
-        bwd.append(self._gemm(dy, P[wname], self.d_ml, NB, Z, n_out, n_out, n_out, 2 * Z, tb=1,
-                              epi=H.EPI_REPARAM_BWD, p=(self.ml, self.eps_z, self.att, self.dyn),
-                              extra_bytes=16 * NB * Z, tag="dz_reparam"))
-        dy, n_out, wname = self.d_ml, 2 * Z, "ml_w"
-        for i in reversed(range(len(rec_u))):
+        fuse_b = (self._prec == 1 and not nofuse and len(gen_u) >= 1 and len(rec_u) >= 1 and gen_u[0] == 256
+                  and Z <= 64 and Z % 2 == 0)
+        last_rec = len(rec_u)
+        if fuse_b:
+            # d_gen[0] -> d_z -> (d_mean | d_lv) -> d_rec[last] in ONE launch (vae.py:22-24 and the KL, backwards)
+            bb = H.BottleneckBwd(_ptr(dy), _ptr(P["gen0_w"]), _ptr(self.ml), _ptr(self.eps_z), _ptr(self.att), _ptr(self.dyn),
+                                 _ptr(P["ml_w"]), _ptr(self.rec_act[-1]), _ptr(self.d_ml), _ptr(self.d_rec[-1]),
+                                 NB, rec_u[-1], Z, gen_u[0])
+            keep.append(bb)
+            bwd.append(self._call("air_vae_bottleneck_bwd", C.byref(bb),
+                                  nbytes=4 * (NB * (gen_u[0] + 5 * Z + 2 * rec_u[-1]) + Z * gen_u[0] + rec_u[-1] * 2 * Z),
+                                  flops=2 * NB * (gen_u[0] * Z + 2 * Z * rec_u[-1]), tag="vae_bottleneck_bwd"))
+            dy, n_out, wname, last_rec = self.d_rec[-1], rec_u[-1], "rec%d_w" % (len(rec_u) - 1), len(rec_u) - 1
+        else:
+            bwd.append(self._gemm(dy, P[wname], self.d_ml, NB, Z, n_out, n_out, n_out, 2 * Z, tb=1,
+                                  epi=H.EPI_REPARAM_BWD, p=(self.ml, self.eps_z, self.att, self.dyn),
+                                  extra_bytes=16 * NB * Z, tag="dz_reparam"))
+            dy, n_out, wname = self.d_ml, 2 * Z, "ml_w"
+        for i in reversed(range(last_rec)):
             u = rec_u[i]
             bwd.append(self._gemm(dy, P[wname], self.d_rec[i], NB, u, n_out, n_out, n_out, u, tb=1,
                                   aux=self.rec_act[i], ldaux=u, actgrad=H.GRAD_SOFTPLUS, tag="dgrad_rec"))

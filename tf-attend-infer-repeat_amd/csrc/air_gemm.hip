@@ -732,7 +732,9 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16v2_kernel(Args a)
     const bool a8 = !(((a.lda & 3) == 0) && aligned16(a.A) && ((a.K & 3) == 0));
     const bool b8 = !(((a.ldb & 3) == 0) && aligned16(a.B) &&
                       (TB ? ((a.K & 3) == 0) : (((a.N & 3) == 0) && ((a.gstride & 3) == 0) && ((a.gwidth & 3) == 0))));
-    // tasks of one round.  k-contiguous operand (A, and B when TB): task = (image, row, k-run g) = 2 float4;
+    // tasks of one round.  k-contiguous operand (A, and B when TB): task = (image, row, 16-byte chunk of the row's
+    // 64 k) -- consecutive lanes read consecutive 16 bytes, so every load instruction covers whole cache lines
+    // (a lane that read one k-run of 8 as two float4 left every second 16 bytes of its lines to the other load);
     // NN B: task = (image, column quad, k-run g) = the same 4 columns of 8 consecutive rows = 8 float4.
     constexpr int TA_N = (R * BM * 8 + THREADS - 1) / THREADS;           // A tasks per thread
     constexpr int TBK_N = (R * BN * 8 + THREADS - 1) / THREADS;          // NT-B tasks per thread
@@ -745,27 +747,25 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16v2_kernel(Args a)
     auto issue_loads_t = [&](int kr, auto ha_t, auto hb_t) __attribute__((always_inline)) {
         constexpr bool HA = decltype(ha_t)::value, HB = decltype(hb_t)::value;
 #pragma unroll
-        for (int i = 0; i < TA_N; ++i) {
-            const int t = tid + THREADS * i;
-            const int c = t / (BM * 8), row = (t / 8) % BM, g = t & 7;
-            const int gm = m0 + row, gk = kr + c * KB + g * 8;
-            const bool okr = (t < R * BM * 8) && gm < a.M;
+        for (int i = 0; i < 2 * TA_N; ++i) {
+            const int u = tid + THREADS * i;
+            const int c = u / (BM * 16), row = (u / 16) % BM, hh = u & 15;
+            const int gm = m0 + row, gk = kr + c * KB + hh * 4;
+            const bool okr = (u < R * BM * 16) && gm < a.M;
             const unsigned off = ((unsigned)gm * (unsigned)a.lda + (unsigned)gk) * 4u;
-            va[i][0] = ldg16x<HA>(Ab, off, okr && gk < kend, okr && gk + 2 < kend);
-            va[i][1] = ldg16x<HA>(Ab, off + 16u, okr && gk + 4 < kend, okr && gk + 6 < kend);
+            va[i >> 1][i & 1] = ldg16x<HA>(Ab, off, okr && gk < kend, okr && gk + 2 < kend);
         }
         if (TB) {
 #pragma unroll
-            for (int i = 0; i < TBK_N; ++i) {
-                const int t = tid + THREADS * i;
-                const int c = t / (BN * 8), col = (t / 8) % BN, g = t & 7;
+            for (int i = 0; i < 2 * TBK_N; ++i) {
+                const int u = tid + THREADS * i;
+                const int c = u / (BN * 16), col = (u / 16) % BN, hh = u & 15;
                 const int j = col >> 4, cc = col & 15;
                 const int gn = n0 + j * a.gstride + cc, cg = n0 + cc + (a.gstride == 16 ? j * 16 : 0);
-                const int gk = kr + c * KB + g * 8;
-                const bool okr = (t < R * BN * 8) && cg < a.gwidth && gn < a.N;
+                const int gk = kr + c * KB + hh * 4;
+                const bool okr = (u < R * BN * 16) && cg < a.gwidth && gn < a.N;
                 const unsigned off = ((unsigned)gn * (unsigned)a.ldb + (unsigned)gk) * 4u;
-                vbk[i][0] = ldg16x<HB>(Bb, off, okr && gk < kend, okr && gk + 2 < kend);
-                vbk[i][1] = ldg16x<HB>(Bb, off + 16u, okr && gk + 4 < kend, okr && gk + 6 < kend);
+                vbk[i >> 1][i & 1] = ldg16x<HB>(Bb, off, okr && gk < kend, okr && gk + 2 < kend);
             }
         } else {
 #pragma unroll
@@ -799,23 +799,26 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16v2_kernel(Args a)
         if (kr > kbeg) __syncthreads();                                   // images of the previous round consumed
         // ---- round to bf16 and store the images
 #pragma unroll
-        for (int i = 0; i < TA_N; ++i) {
-            const int t = tid + THREADS * i;
-            const int c = t / (BM * 8), row = (t / 8) % BM, g = t & 7;
-            uint4 w;
-            w.x = pack_bf16(va[i][0].x, va[i][0].y); w.y = pack_bf16(va[i][0].z, va[i][0].w);
-            w.z = pack_bf16(va[i][1].x, va[i][1].y); w.w = pack_bf16(va[i][1].z, va[i][1].w);
-            if (t < R * BM * 8) *reinterpret_cast<uint4*>(&ImgA[(c * BM + row) * KB + ((g ^ (row & 7)) << 3)]) = w;
+        for (int i = 0; i < 2 * TA_N; ++i) {
+            const int u = tid + THREADS * i;
+            const int c = u / (BM * 16), row = (u / 16) % BM, hh = u & 15;
+            const float4& x = va[i >> 1][i & 1];
+            uint2 w;
+            w.x = pack_bf16(x.x, x.y); w.y = pack_bf16(x.z, x.w);
+            // half of the swizzled 16-byte slot of k-run hh >> 1
+            if (u < R * BM * 16)
+                *reinterpret_cast<uint2*>(&ImgA[(c * BM + row) * KB + (((hh >> 1) ^ (row & 7)) << 3) + (hh & 1) * 4]) = w;
         }
         if (TB) {
 #pragma unroll
-            for (int i = 0; i < TBK_N; ++i) {
-                const int t = tid + THREADS * i;
-                const int c = t / (BN * 8), col = (t / 8) % BN, g = t & 7;
-                uint4 w;
-                w.x = pack_bf16(vbk[i][0].x, vbk[i][0].y); w.y = pack_bf16(vbk[i][0].z, vbk[i][0].w);
-                w.z = pack_bf16(vbk[i][1].x, vbk[i][1].y); w.w = pack_bf16(vbk[i][1].z, vbk[i][1].w);
-                if (t < R * BN * 8) *reinterpret_cast<uint4*>(&ImgB[(c * BN + col) * KB + ((g ^ (col & 7)) << 3)]) = w;
+            for (int i = 0; i < 2 * TBK_N; ++i) {
+                const int u = tid + THREADS * i;
+                const int c = u / (BN * 16), col = (u / 16) % BN, hh = u & 15;
+                const float4& x = vbk[i >> 1][i & 1];
+                uint2 w;
+                w.x = pack_bf16(x.x, x.y); w.y = pack_bf16(x.z, x.w);
+                if (u < R * BN * 16)
+                    *reinterpret_cast<uint2*>(&ImgB[(c * BN + col) * KB + (((hh >> 1) ^ (col & 7)) << 3) + (hh & 1) * 4]) = w;
             }
         } else {
 #pragma unroll
@@ -1187,7 +1190,9 @@ void resolve_tile(const air_gemm_t* g, int& tm, int& tn) {
     else if (g->epi == AIR_EPI_REPARAM_FWD) { tm = 1; tn = 2; }
     else if (g->epi != AIR_EPI_GENERIC) { tm = 1; tn = 1; }
     if (tm == 0 || tn == 0) {
-        // at these sizes wall time ~ one workgroup's latency: prefer many small workgroups
+        // at these sizes wall time ~ one workgroup's latency: prefer many small workgroups.  (Tried: the tile
+        // that minimises the operand-panel bytes of the busiest CU -- 16x32 for N = 512, 32x32 for N = 784.
+        // Slower: 0.205 -> 0.218 ms per step; the 16x16 tiles win although some CUs then run 2-3 of them.)
         const long t11 = (long)((g->M + 15) / 16) * ((g->N + 15) / 16);
         if (t11 <= 1024) { tm = 1; tn = 1; }
         else if (t11 <= 4096) { tm = 2; tn = 2; }
