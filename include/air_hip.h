@@ -303,6 +303,8 @@ typedef struct {
     float* fin_scalars;
 } air_write_bwd_t;
 int air_write_bwd(const air_write_bwd_t* a, void* stream);
+/* the kernel function air_write_bwd dispatches this descriptor to, as rocprofv3 prints it (profiling tools) */
+int air_write_bwd_kernel_name(const air_write_bwd_t* a, char* buf, int n);
 
 /* ---- VAE bottleneck, one launch per direction (vae.py:16-34) ------------------
  * Forward = the last recognition product and the first generative layer:

@@ -129,6 +129,7 @@ _SIGNATURES = {
     "air_step_begin": (C.c_int, [_p, C.c_int, _p, _p, _p, C.c_int64, _p, C.c_int64, C.c_uint64, _p]),
     "air_optim_num_partials": (C.c_int, [C.c_int64]),
     "air_grad_sqnorm": (C.c_int, [_p, C.c_int64, _p, _p, _p]),
+    "air_write_bwd_kernel_name": (C.c_int, [C.POINTER(WriteBwd), C.c_char_p, C.c_int]),
     "air_vae_bottleneck_fwd": (C.c_int, [C.POINTER(BottleneckFwd), _p]),
     "air_vae_bottleneck_bwd": (C.c_int, [C.POINTER(BottleneckBwd), _p]),
     "air_adam_clip_step": (C.c_int, [_p, _p, _p, _p, C.c_int64, _p, C.c_int, _p, _p, _f, _f, _f, _f, _p, _p, _p]),

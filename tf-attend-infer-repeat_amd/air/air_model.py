@@ -550,8 +550,11 @@ class AIRModel:
                          _ptr(self.d_sxyw), B, N, Cc, w, lit, _ptr(self._loss_item), _ptr(self.target_num_digits),
                          _ptr(self.run_digits), _ptr(self.scalars))
         keep += [wb, wbf]
+        kbuf = C.create_string_buffer(96)
+        H.check(self.lib.air_write_bwd_kernel_name(C.byref(wb), kbuf, 96), "air_write_bwd_kernel_name")
         bwd.append(self._call("air_write_bwd", C.byref(wb), nbytes=NB * ((D + 2 * d) * 4 + 32), tag="write_bwd"))
         self._write_bwd_fin = self._call("air_write_bwd", C.byref(wbf), nbytes=NB * ((D + 2 * d) * 4 + 32), tag="write_bwd")
+        bwd[-1].kernel = self._write_bwd_fin.kernel = kbuf.value.decode()
         # decoder data-grads over all N*B rows: dX = dY . W^T, times softplus'(saved activation)
         dy, n_out, wname = self.d_genpre, d, "out_w"
         for i in reversed(range(len(gen_u))):

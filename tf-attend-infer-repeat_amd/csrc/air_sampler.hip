@@ -14,6 +14,7 @@
 // the exact adjoint in separable form (R_y^T g R_x) as a deterministic gather:
 // no atomics anywhere.
 #include "air_common.h"
+#include <cstdio>
 #include <atomic>
 
 AIR_STAMPS_READER(air_debug_stamps)
@@ -1379,6 +1380,15 @@ extern "C" int air_write_fwd(const air_write_fwd_t* a, void* stream) {
     if (rc) return rc;
     hipLaunchKernelGGL(write_fwd_kernel, dim3(a->B), dim3(CF_THREADS), lds, air_stream(stream), *a);
     AIR_CHECK_LAUNCH();
+    return 0;
+}
+
+/* name of the kernel function air_write_bwd dispatches this descriptor to, as rocprofv3 prints it */
+extern "C" int air_write_bwd_kernel_name(const air_write_bwd_t* a, char* buf, int n) {
+    if (!a || !buf || n <= 0 || a->C < 2 || a->w < 2) return AIR_EINVAL;
+    if (a->literal == 2)
+        snprintf(buf, n, "write_bwd_graph_kernel<%s>", write_bwd_graph_smem(a->C, a->w, true) <= 80 * 1024 ? "true" : "false");
+    else snprintf(buf, n, "write_bwd_kernel");
     return 0;
 }
 
