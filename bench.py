@@ -220,7 +220,7 @@ def main():
     ap.add_argument("--workload", default="configs[1]", choices=["configs[1]", "configs[3]"],
                     help="configs[1]: 50x50, N=3, b=64 (the metric); configs[3]: stress, 128x128, 0-4 objects, N=5, b=256")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--graph-steps", type=int, default=4, help="train steps captured per hipGraph replay (1 GPU)")
+    ap.add_argument("--graph-steps", type=int, default=20, help="train steps captured per hipGraph replay (1 GPU), at most")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary blocks (fp32 step, stress config, inference)")
@@ -268,7 +268,8 @@ def main():
     gsteps = 1
     if not args.no_graph:
         if world == 1:
-            gsteps = next(g for g in (args.graph_steps, 4, 2, 1) if g >= 1 and args.steps % g == 0)
+            # the largest divisor of the step count up to --graph-steps: exactly args.steps steps are timed
+            gsteps = max(g for g in range(1, max(1, args.graph_steps) + 1) if args.steps % g == 0)
         model.capture_graph(steps=gsteps)
 
     def sync():
