@@ -369,9 +369,9 @@ class AIRModel:
         self.run_digits = torch.zeros(B, dtype=torch.int32, device=dv)
         self.c = f(N + 1, B, R); self.h = f(N + 1, B, R)         # [0] stays zero (zero_state :540)
 
-        # split-K slabs of the hoisted x.Wx: 4 at D = 2500 (measured 0.1977 -> 0.1968 ms per step against 8: the
-        # LSTM epilogues sum the slabs), 8 for the long contraction of the large canvases
-        self._xw_ksplit, self._xw_tile = (4 if D <= 4096 else 8), (2, 2)
+        # the hoisted x.Wx: 4 split-K slabs (the LSTM epilogues sum them); 32x32 tiles at D = 2500 (0.1977 ->
+        # 0.1968 ms per step against 8 slabs), 64x32 for the 128x128 canvases (0.923 -> 0.898 ms) -- measured sweeps
+        self._xw_ksplit, self._xw_tile = 4, ((2, 2) if D <= 4096 else (4, 2))
         if os.environ.get("AIR_XW_TILE"):                    # tuning hook: "tm,tn,ksplit" (ksplit <= 8 slabs)
             tm_, tn_, ks_ = (int(v) for v in os.environ["AIR_XW_TILE"].split(","))
             self._xw_ksplit, self._xw_tile = ks_, (tm_, tn_)

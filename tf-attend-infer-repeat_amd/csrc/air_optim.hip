@@ -125,7 +125,7 @@ extern "C" int air_adam_clip_step(float* params, const float* grads, float* m, f
     if ((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)m | (uintptr_t)v) & 15) != 0) return AIR_EALIGN;
     long blocks = (n / 4 + THREADS - 1) / THREADS;
     if (blocks < 1) blocks = 1;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 2048) blocks = 2048;        // (512 .. 8192 measured: 20.3 .. 23.8 us in isolation, no difference inside the step)
     hipLaunchKernelGGL(adam_clip_kernel, dim3((int)blocks), dim3(THREADS), 0, air_stream(stream),
                        params, grads, m, v, (long)n, partials, npartials, dyn, istate, grad_prescale, beta1, beta2,
                        epsilon, bf16_shadow, gnorm_out);
