@@ -218,13 +218,14 @@ __global__ __launch_bounds__(THREADS) void bottleneck_bwd_kernel(BwdArgs a)
         vg[i] = fetch16(a.Wg, row < Z, (size_t)row * H + c4 * 4);
     }
     // Wml [K1, 2Z]: rows j0 .. j0+63, k = 2Z contiguous
-    const int NQ = (Z2 + 3) >> 2;                 // float4 per row
-    constexpr int NM = 8;                         // 64 rows x <= 32 quads / 256 threads
+    const int NQ = (Z2 + 3) >> 2;                 // float4 per row, <= 32
+    const unsigned inv_nq = ((1u << 20) + NQ - 1) / NQ;   // t / NQ == (t * inv_nq) >> 20 for t < 2048, NQ <= 32
+    constexpr int NM = 8;                         // 64 rows x <= 32 quads / 256 threads, densely packed: t -> (row t / NQ, quad t % NQ)
     float4 vm[NM];
 #pragma unroll
     for (int i = 0; i < NM; ++i) {
         const int t = tid + THREADS * i;
-        const int row = t / NQ, c4 = t - row * NQ;
+        const int row = (int)(((unsigned)t * inv_nq) >> 20), c4 = t - row * NQ;
         vm[i] = fetch16(a.Wml, row < 64 && j0 + row < K1, (size_t)(j0 + row) * Z2 + c4 * 4);
     }
     const int u = wave * 16 + (lane & 15);
@@ -266,12 +267,11 @@ __global__ __launch_bounds__(THREADS) void bottleneck_bwd_kernel(BwdArgs a)
 #pragma unroll
     for (int i = 0; i < NM; ++i) {
         const int t = tid + THREADS * i;
-        const int row = t / NQ, c4 = t - row * NQ;
+        const int row = (int)(((unsigned)t * inv_nq) >> 20), c4 = t - row * NQ;
         if (row >= 64) continue;
-        const float4 x = zero_unless(j0 + row < K1, vm[i]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (c4 * 4 + j < Z2) B2[row * L2 + c4 * 4 + j] = bf16_of(comp(x, j));
+        const float4 x = zero_unless(j0 + row < K1, vm[i]);       // 2Z % 4 == 0 (Z even): whole quads
+        uint2 w; w.x = pack_bf16(x.x, x.y); w.y = pack_bf16(x.z, x.w);
+        *reinterpret_cast<uint2*>(&B2[row * L2 + c4 * 4]) = w;
     }
 
     // ---- first product: d_z for the units of this wave ----------------------------------------------------

@@ -1239,8 +1239,11 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
         __syncthreads();
         AIR_STAMP(43);
         theta_loop(WB_THREADS);
+        AIR_STAMP(48);
         chains(0, 4);
+        AIR_STAMP(49);
         publish();
+        AIR_STAMP(39);
         __syncthreads();
         AIR_STAMP(44);
         if (wave < 4) feed_corner(wave, 0, 4);

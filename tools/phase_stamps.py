@@ -37,7 +37,8 @@ for want in names:
             base = {"write_bwd": 40, "attend_fwd": 10, "attend_bwd": 20, "compose": 30, "wgrad": 0}.get(want, 56)
             {56: H._LIB.air_debug_stamps_gemm, 0: H._LIB.air_debug_stamps_wgrad}.get(base, H._LIB.air_debug_stamps)(buf, 64)
             v = [int(x) for x in buf]
-            idx = [i for i in range(base, base + (8 if base == 56 else 10)) if v[i]]
+            idx = [i for i in range(base - (1 if base == 40 else 0), base + (8 if base == 56 else 10)) if v[i]]
+            idx.sort(key=lambda i: v[i])
             d = ["%d:%.2f" % (i, (v[i] - v[j]) / 100.0) for j, i in zip(idx, idx[1:])]
             print("%-14s total %.2f us | deltas(us) %s" % (op.name, (v[idx[-1]] - v[idx[0]]) / 100.0 if idx else 0, " ".join(d)))
             break
