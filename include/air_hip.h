@@ -122,7 +122,12 @@ enum {
     /* rows [0, i0): plain store of acc into C; rows [i0, M): AIR_EPI_LSTM_BWD of the LAST time step
      * (no d c' from a later step, q2 is stored not accumulated), with p0..p2 / q0..q2 indexed by
      * (row - i0).  Lets the GEMM that produces d h' of all steps also start the BPTT chain. */
-    AIR_EPI_LSTM_BWD_TAIL = 5
+    AIR_EPI_LSTM_BWD_TAIL = 5,
+    /* The FIRST step of the recurrence in the GEMM that hoists x.Wx (zero_state, air_model.py:540: h_0 = c_0 = 0,
+     * so [x, h].kernel = x.Wx): N = 4R; C [M,4R] receives the raw product (the addend of the later steps,
+     * one slab), and q0 = acts, q1 = c, q2 = h of step 0 from acc + bias.  16-column tiles of four units x
+     * four gates (untransposed operands, no split-K, no addend). */
+    AIR_EPI_LSTM_FWD0 = 6
 };
 /* air_step_begin's work as a descriptor, so that a GEMM launch can carry it (air_gemm_t.step_job) */
 typedef struct {

@@ -740,3 +740,36 @@ def test_vae_bottleneck_limits(H):
     assert H.lib().air_vae_bottleneck_fwd(C.byref(a), _stream()) == -2          # K1 != 256: callers fall back
     a.K1, a.ldx, a.Z = 256, 256, 51
     assert H.lib().air_vae_bottleneck_fwd(C.byref(a), _stream()) == -3          # odd Z
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("M,R,K", [(64, 256, 2500), (37, 12, 300), (16, 4, 64)])
+def test_gemm_first_lstm_step_epilogue_matches_product_plus_pointwise_step(H, prec, M, R, K):
+    """AIR_EPI_LSTM_FWD0: the hoisted x.Wx and, from zero state, the first BasicLSTMCell step in one launch
+    (air_model.py:286, :540) == air_gemm (plain) followed by air_lstm_first_step; the gates against the
+    float64 formulas on the operands as the MFMAs see them."""
+    rng = np.random.RandomState(11)
+    X = rng.uniform(0, 1, (M, K)).astype(np.float32)
+    W = rng.uniform(-0.05, 0.05, (K, 4 * R)).astype(np.float32)
+    b = rng.uniform(-0.5, 0.5, 4 * R).astype(np.float32)
+    Xt, Wt, bt = (torch.tensor(v, device="cuda") for v in (X, W, b))
+    xw = torch.full((M, 4 * R), float("nan"), device="cuda")
+    acts = torch.full((M, 4 * R), float("nan"), device="cuda")
+    c, h = torch.full((M, R), float("nan"), device="cuda"), torch.full((M, R), float("nan"), device="cuda")
+    g = _gemm_struct(H, Xt, Wt, xw, M, 4 * R, K, K, 4 * R, 4 * R, prec, bias=bt, epi=H.EPI_LSTM_FWD0, q0=acts, q1=c, q2=h)
+    H.check(H.lib().air_gemm(C.byref(g), _stream()))
+    torch.cuda.synchronize()
+    rd = (lambda v: _bf16_round(v)) if prec else (lambda v: np.asarray(v, np.float64))
+    ref = rd(X) @ rd(W)
+    assert np.abs(xw.cpu().numpy() - ref).max() < (2e-6 if prec == 0 else 2e-5) * np.sqrt(K)
+    pre = xw.cpu().numpy().astype(np.float64) + b
+    sig = lambda v: 1.0 / (1.0 + np.exp(-v))
+    si, tj, sf, so = sig(pre[:, :R]), np.tanh(pre[:, R:2 * R]), sig(pre[:, 2 * R:3 * R] + 1.0), sig(pre[:, 3 * R:])
+    np.testing.assert_allclose(acts.cpu().numpy(), np.concatenate([si, tj, sf, so], 1), atol=2e-6)
+    np.testing.assert_allclose(c.cpu().numpy(), si * tj, atol=2e-6)
+    np.testing.assert_allclose(h.cpu().numpy(), np.tanh(si * tj) * so, atol=2e-6)
+    # the two launches it replaces, fed the same product: bit-identical gates
+    acts2, c2, h2 = torch.empty_like(acts), torch.empty_like(c), torch.empty_like(h)
+    H.check(H.lib().air_lstm_first_step(_p(xw), 1, _p(bt), _p(acts2), _p(c2), _p(h2), M, R, _stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(acts, acts2) and torch.equal(c, c2) and torch.equal(h, h2)

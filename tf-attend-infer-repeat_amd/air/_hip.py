@@ -25,7 +25,7 @@ ATT_KL_Z, ATT_KL_SCALE, ATT_KL_SHIFT, ATT_KL_VAE, ATT_MASK_PREV, ATT_MASK, ATT_S
 ATT_STRIDE, OUT_STRIDE = 16, 8
 ACT_NONE, ACT_RELU, ACT_SOFTPLUS, ACT_SIGMOID_NOISE = 0, 1, 2, 3
 GRAD_NONE, GRAD_RELU, GRAD_SOFTPLUS = 0, 1, 2
-EPI_GENERIC, EPI_LSTM_FWD, EPI_REPARAM_FWD, EPI_LSTM_BWD, EPI_REPARAM_BWD, EPI_LSTM_BWD_TAIL = 0, 1, 2, 3, 4, 5
+EPI_GENERIC, EPI_LSTM_FWD, EPI_REPARAM_FWD, EPI_LSTM_BWD, EPI_REPARAM_BWD, EPI_LSTM_BWD_TAIL, EPI_LSTM_FWD0 = 0, 1, 2, 3, 4, 5, 6
 SCHED_STAIRCASE, SCHED_HAS_MIN, SCHED_HAS_MAX, SCHED_LOG = 1, 2, 4, 8
 
 _p = C.c_void_p

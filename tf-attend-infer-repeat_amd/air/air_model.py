@@ -375,8 +375,14 @@ class AIRModel:
         if os.environ.get("AIR_XW_TILE"):                    # tuning hook: "tm,tn,ksplit" (ksplit <= 8 slabs)
             tm_, tn_, ks_ = (int(v) for v in os.environ["AIR_XW_TILE"].split(","))
             self._xw_ksplit, self._xw_tile = ks_, (tm_, tn_)
-        self._xw_slabs = self.lib.air_gemm_slabs(D, self._xw_ksplit)
-        self.xw = f(self._xw_slabs, B, 4 * R)            # split-K slabs of the hoisted x.Wx
+        # AIR_STEP0_FUSION=1: ONE launch computes x.Wx (no split-K) and, in its epilogue, the first LSTM step (zero
+        # state: no h.Wh) -- AIR_EPI_LSTM_FWD0.  Measured slower and therefore off: its tiles are four units x four
+        # gates, i.e. 16-byte row segments of Wx (one eighth of every cache line fetched), 16.0 us against
+        # 7.8 + 3.4 us for the split-K product + the pointwise first step (0.198 vs 0.194-0.195 ms per step).
+        self._fuse_step0 = (os.environ.get("AIR_STEP0_FUSION") == "1" and R % 4 == 0 and D % 2 == 0
+                            and not os.environ.get("AIR_XW_TILE"))
+        self._xw_slabs = 1 if self._fuse_step0 else self.lib.air_gemm_slabs(D, self._xw_ksplit)
+        self.xw = f(self._xw_slabs, B, 4 * R)            # x.Wx (split-K slabs when not fused)
         self.gates_pre = f(B, 4 * R)
         self.acts = f(N, B, 4 * R)
         self.hid = f(N, B, HT)
@@ -460,22 +466,32 @@ class AIRModel:
         NB = N * B
         fwd = []
         # hoisted x.W_x (the reference recomputes it every step, :286); split-K slabs
-        fwd.append(self._gemm(imgs, Wx, self.xw, B, 4 * R, D, D, 4 * R, 4 * R, ksplit=self._xw_ksplit,
-                              tile=self._xw_tile, tag="xWx"))
-        # the same launch carrying the step prologue (schedules + Philox noise) as an extra plane of
-        # workgroups: x.Wx reads neither, so the train step needs no prologue launch of its own
         job = H.StepJob(_ptr(self.sched), self._nsched, _ptr(self.dyn), _ptr(st.istate),
                         _ptr(self.normals), self.normals.numel(), _ptr(self.uniforms), self.uniforms.numel(),
                         self._seed)
-        self._xwx_with_begin = self._gemm(imgs, Wx, self.xw, B, 4 * R, D, D, 4 * R, 4 * R, ksplit=self._xw_ksplit,
-                                          tile=self._xw_tile, tag="xWx+step_begin", step_job=job,
-                                          extra_bytes=4 * (self.normals.numel() + self.uniforms.numel()))
-        # the recurrence: N chained LSTM steps (the only sequential part of the loop -- the LSTM
+        noise_bytes = 4 * (self.normals.numel() + self.uniforms.numel())
+        if self._fuse_step0:
+            # the first step rides in the x.Wx launch: h_0 = c_0 = 0 (zero_state, :540), so its gates are x.Wx + b
+            step0 = dict(bias=P["lstm_bias"], epi=H.EPI_LSTM_FWD0, q=(self.acts[0], self.c[1], self.h[1]),
+                         extra_bytes=4 * B * R * 6)
+            fwd.append(self._gemm(imgs, Wx, self.xw, B, 4 * R, D, D, 4 * R, 4 * R, tag="xWx+lstm0", **step0))
+            step0["extra_bytes"] += noise_bytes
+            self._xwx_with_begin = self._gemm(imgs, Wx, self.xw, B, 4 * R, D, D, 4 * R, 4 * R,
+                                              tag="xWx+lstm0+step_begin", step_job=job, **step0)
+        else:
+            fwd.append(self._gemm(imgs, Wx, self.xw, B, 4 * R, D, D, 4 * R, 4 * R, ksplit=self._xw_ksplit,
+                                  tile=self._xw_tile, tag="xWx"))
+            # the same launch carrying the step prologue (schedules + Philox noise) as an extra plane of
+            # workgroups: x.Wx reads neither, so the train step needs no prologue launch of its own
+            self._xwx_with_begin = self._gemm(imgs, Wx, self.xw, B, 4 * R, D, D, 4 * R, 4 * R, ksplit=self._xw_ksplit,
+                                              tile=self._xw_tile, tag="xWx+step_begin", step_job=job,
+                                              extra_bytes=noise_bytes)
+            # step 0 starts from zero_state (:540): h_0 . Wh = 0, the gates are x.Wx + b -- a pointwise launch
+            fwd.append(self._call("air_lstm_first_step", _ptr(self.xw), self._xw_slabs, _ptr(P["lstm_bias"]),
+                                  _ptr(self.acts[0]), _ptr(self.c[1]), _ptr(self.h[1]), B, R,
+                                  nbytes=4 * B * R * (4 * self._xw_slabs + 6) + 16 * R, tag="lstm_fwd0"))
+        # the recurrence: the remaining LSTM steps, chained (the only sequential part of the loop -- the LSTM
         # sees the same image every step and nothing downstream feeds back into it, :286/:535)
-        # step 0 starts from zero_state (:540): h_0 . Wh = 0, the gates are x.Wx + b -- a pointwise launch
-        fwd.append(self._call("air_lstm_first_step", _ptr(self.xw), self._xw_slabs, _ptr(P["lstm_bias"]),
-                              _ptr(self.acts[0]), _ptr(self.c[1]), _ptr(self.h[1]), B, R,
-                              nbytes=4 * B * R * (4 * self._xw_slabs + 6) + 16 * R, tag="lstm_fwd0"))
         for t in range(1, N):
             fwd.append(self._gemm(self.h[t], Wh, self.gates_pre, B, 4 * R, R, R, 4 * R, 4 * R,
                                   bias=P["lstm_bias"], addend=self.xw, ldadd=4 * R, addend_slabs=self._xw_slabs,

@@ -118,6 +118,11 @@ __device__ __forceinline__ void epilogue_prefetch(const Args& a, Pre<TM, TN>& pr
             pre.f[32 + j] = fetch(ok && a.bias, a.bias, n);
         }
         pre.f[36] = fetch(ok, a.p0, (size_t)m * R + u);
+    } else if (E == AIR_EPI_LSTM_FWD0) {
+        // item of lane L (wave 0): row L >> 2, unit n0 + (L & 3); only the bias is needed (zero state, no addend)
+        const int R = a.gwidth, uu = n0 + (lane & 3);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pre.f[j] = fetch(a.bias && uu < R, a.bias, j * R + uu);
     } else if (E == AIR_EPI_REPARAM_FWD) {
         const int Z = a.gwidth;
         pre.f[0] = fetch(ok && a.bias, a.bias, u);
@@ -171,6 +176,35 @@ __device__ __forceinline__ void epilogue(const Args& a, const Pre<TM, TN>& pre, 
             float* c = a.C + (size_t)m * a.ldc + n;
             if (a.accumulate) v += *c;
             *c = v;
+        }
+        return;
+    }
+    if (E == AIR_EPI_LSTM_FWD0) {
+        // tile columns: gate (col >> 2) of unit n0 + (col & 3).  Every wave stores one accumulator row set of the
+        // raw x.Wx; wave 0 then takes the 64 (row, unit) items: BasicLSTMCell from zero state (air_model.py:286, :540)
+        const int R = a.gwidth;
+        {
+            const int m = m0 + (lane >> 4) * 4 + wave, col = lane & 15, u = n0 + (col & 3);
+            if (m < a.M && u < R) a.C[(size_t)m * a.ldc + (col >> 2) * R + u] = Red[wave * 64 + lane];
+        }
+        if (wave == 0) {
+            const int r = lane >> 2, m = m0 + r, u = n0 + (lane & 3);
+            if (m < a.M && u < R) {
+                float g[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float s = Red[(r & 3) * 64 + (r >> 2) * 16 + j * 4 + (lane & 3)];
+                    if (a.bias) s += pre.f[j];
+                    g[j] = s;
+                }
+                const float si = air_sigmoid(g[0]), tj = tanhf(g[1]);
+                const float sf = air_sigmoid(g[2] + 1.0f), so = air_sigmoid(g[3]);
+                const float cn = 0.0f * sf + si * tj;
+                float* ac = a.q0 + (size_t)m * 4 * R;
+                ac[u] = si; ac[R + u] = tj; ac[2 * R + u] = sf; ac[3 * R + u] = so;
+                a.q1[(size_t)m * R + u] = cn;
+                a.q2[(size_t)m * R + u] = tanhf(cn) * so;
+            }
         }
         return;
     }
@@ -714,7 +748,7 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16v2_kernel(Args a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int tile_m, tile_n;
     xcd_tile(tile_m, tile_n);
-    const int m0 = tile_m * BM, n0 = tile_n * BN / TN * (a.gstride == 16 ? TN : 1);
+    const int m0 = tile_m * BM, n0 = EPI_ == AIR_EPI_LSTM_FWD0 ? tile_n * 4 : tile_n * BN / TN * (a.gstride == 16 ? TN : 1);
     const int kbeg = zslab * a.kslab;
     const int kend = min(a.K, kbeg + a.kslab);
 
@@ -773,7 +807,9 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16v2_kernel(Args a)
                 const int t = tid + THREADS * i;
                 const int c = t / (BN * 2), q = (t / 8) % (BN / 4), g = t & 7;
                 const int col = q * 4, j = col >> 4, cc = col & 15;
-                const int gn = n0 + j * a.gstride + cc, cg = n0 + cc + (a.gstride == 16 ? j * 16 : 0);
+                // (LSTM_FWD0: column quad q = gate q of the four units n0 .. n0+3)
+                const int gn = EPI_ == AIR_EPI_LSTM_FWD0 ? n0 + q * a.gstride : n0 + j * a.gstride + cc;
+                const int cg = EPI_ == AIR_EPI_LSTM_FWD0 ? n0 : n0 + cc + (a.gstride == 16 ? j * 16 : 0);
                 const int gk = kr + c * KB + g * 8;
                 const bool okc = (t < R * BN * 2) && cg < a.gwidth && gn < a.N;
                 const bool okh = okc && cg + 2 < a.gwidth && gn + 2 < a.N;     // upper half of the column quad
@@ -934,7 +970,7 @@ __global__ __launch_bounds__(THREADS) void gemm_f32v2_kernel(Args a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int tile_m, tile_n;
     xcd_tile(tile_m, tile_n);
-    const int m0 = tile_m * BM, n0 = tile_n * BN / TN * (a.gstride == 16 ? TN : 1);
+    const int m0 = tile_m * BM, n0 = EPI_ == AIR_EPI_LSTM_FWD0 ? tile_n * 4 : tile_n * BN / TN * (a.gstride == 16 ? TN : 1);
     const int kbeg = zslab * a.kslab;
     const int kend = min(a.K, kbeg + a.kslab);
 
@@ -993,7 +1029,9 @@ __global__ __launch_bounds__(THREADS) void gemm_f32v2_kernel(Args a)
                 const int t = tid + THREADS * i;
                 const int c = t / (BN * 2), q = (t / 8) % (BN / 4), g = t & 7;
                 const int col = q * 4, j = col >> 4, cc = col & 15;
-                const int gn = n0 + j * a.gstride + cc, cg = n0 + cc + (a.gstride == 16 ? j * 16 : 0);
+                // (LSTM_FWD0: column quad q = gate q of the four units n0 .. n0+3)
+                const int gn = EPI_ == AIR_EPI_LSTM_FWD0 ? n0 + q * a.gstride : n0 + j * a.gstride + cc;
+                const int cg = EPI_ == AIR_EPI_LSTM_FWD0 ? n0 : n0 + cc + (a.gstride == 16 ? j * 16 : 0);
                 const int gk = kr + c * KB + g * 8;
                 const bool okc = (t < R * BN * 2) && cg < a.gwidth && gn < a.N;
                 const bool okh = okc && cg + 2 < a.gwidth && gn + 2 < a.N;     // upper half of the column quad
@@ -1120,7 +1158,8 @@ int launch(const air_gemm_t* g, const Args& a0, hipStream_t s) {
     constexpr int BM = 16 * TM, BN = 16 * TN;
     const bool grouped = a.gstride != 16;
     const int ncols = grouped ? a.gwidth : a.N;
-    dim3 grid((ncols + (grouped ? 16 : BN) - 1) / (grouped ? 16 : BN), (a.M + BM - 1) / BM, 1);
+    const int tile_cols = a.epi == AIR_EPI_LSTM_FWD0 ? 4 : (grouped ? 16 : BN);      // units (grouped) or columns per tile
+    dim3 grid((ncols + tile_cols - 1) / tile_cols, (a.M + BM - 1) / BM, 1);
     const int ks = g->ksplit > 1 ? g->ksplit : 1;
     a.kslab = ((a.K + ks - 1) / ks + 3) & ~3;
     if (a.job_on) {
@@ -1137,14 +1176,18 @@ int launch(const air_gemm_t* g, const Args& a0, hipStream_t s) {
     constexpr bool T14 = TM == 1 && TN == 4, T12 = TM == 1 && TN == 2, T11 = TM == 1 && TN == 1;
     const int epi = a.epi;
     const bool epi_ok = epi == AIR_EPI_GENERIC || (epi == AIR_EPI_LSTM_FWD && T14 && !TB) || (epi == AIR_EPI_REPARAM_FWD && T12 && !TB) ||
+                        (epi == AIR_EPI_LSTM_FWD0 && T11 && !TB && !TA) ||
                         ((epi == AIR_EPI_LSTM_BWD || epi == AIR_EPI_LSTM_BWD_TAIL || epi == AIR_EPI_REPARAM_BWD) && T11);
     if (!epi_ok) return AIR_EINVAL;
+    // the four-unit column map of LSTM_FWD0 only exists in the lean kernels
+    if (epi == AIR_EPI_LSTM_FWD0 && (!use_bf16_v2(a, TA, TB) || (g->precision == 0 && getenv("AIR_GEMM_F32_V1") != nullptr))) return AIR_EALIGN;
 #define AIR_V2_LAUNCH(KERNEL, LDS)                                                                                     \
     do {                                                                                                                \
         if (epi == AIR_EPI_GENERIC) hipLaunchKernelGGL((KERNEL<TM, TN, TB, AIR_EPI_GENERIC>), grid, dim3(THREADS), LDS, s, a);      \
         else if constexpr (T14 && !TB) hipLaunchKernelGGL((KERNEL<1, 4, false, AIR_EPI_LSTM_FWD>), grid, dim3(THREADS), LDS, s, a);   \
         else if constexpr (T12 && !TB) hipLaunchKernelGGL((KERNEL<1, 2, false, AIR_EPI_REPARAM_FWD>), grid, dim3(THREADS), LDS, s, a); \
         else if constexpr (T11) {                                                                                      \
+            if constexpr (!TB) { if (epi == AIR_EPI_LSTM_FWD0) { hipLaunchKernelGGL((KERNEL<1, 1, false, AIR_EPI_LSTM_FWD0>), grid, dim3(THREADS), LDS, s, a); break; } } \
             if (epi == AIR_EPI_LSTM_BWD) hipLaunchKernelGGL((KERNEL<1, 1, TB, AIR_EPI_LSTM_BWD>), grid, dim3(THREADS), LDS, s, a);   \
             else if (epi == AIR_EPI_LSTM_BWD_TAIL) hipLaunchKernelGGL((KERNEL<1, 1, TB, AIR_EPI_LSTM_BWD_TAIL>), grid, dim3(THREADS), LDS, s, a); \
             else hipLaunchKernelGGL((KERNEL<1, 1, TB, AIR_EPI_REPARAM_BWD>), grid, dim3(THREADS), LDS, s, a);             \
@@ -1167,7 +1210,8 @@ int launch(const air_gemm_t* g, const Args& a0, hipStream_t s) {
                     T12 && !TB ? reinterpret_cast<const void*>(&gemm_f32v2_kernel<1, 2, false, AIR_EPI_REPARAM_FWD>) : nullptr,
                     T11 ? reinterpret_cast<const void*>(&gemm_f32v2_kernel<1, 1, TB, AIR_EPI_LSTM_BWD>) : nullptr,
                     T11 ? reinterpret_cast<const void*>(&gemm_f32v2_kernel<1, 1, TB, AIR_EPI_LSTM_BWD_TAIL>) : nullptr,
-                    T11 ? reinterpret_cast<const void*>(&gemm_f32v2_kernel<1, 1, TB, AIR_EPI_REPARAM_BWD>) : nullptr};
+                    T11 ? reinterpret_cast<const void*>(&gemm_f32v2_kernel<1, 1, TB, AIR_EPI_REPARAM_BWD>) : nullptr,
+                    T11 && !TB ? reinterpret_cast<const void*>(&gemm_f32v2_kernel<1, 1, false, AIR_EPI_LSTM_FWD0>) : nullptr};
                 for (const void* fn : fns)
                     if (fn) {
                         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::BYTES);
@@ -1188,6 +1232,7 @@ void resolve_tile(const air_gemm_t* g, int& tm, int& tn) {
     tm = g->tile_m; tn = g->tile_n;
     if (g->epi == AIR_EPI_LSTM_FWD) { tm = 1; tn = 4; }
     else if (g->epi == AIR_EPI_REPARAM_FWD) { tm = 1; tn = 2; }
+    else if (g->epi == AIR_EPI_LSTM_FWD0) { tm = 1; tn = 1; }
     else if (g->epi != AIR_EPI_GENERIC) { tm = 1; tn = 1; }
     if (tm == 0 || tn == 0) {
         // at these sizes wall time ~ one workgroup's latency: prefer many small workgroups.  (Tried: the tile
@@ -1265,7 +1310,7 @@ static int fill_args(const air_gemm_t* g, Args& a) {
     if (g->precision != 0 && g->precision != 1) return AIR_EINVAL;
     if ((g->act == AIR_ACT_SIGMOID_NOISE || g->actgrad != AIR_GRAD_NONE) && !g->aux) return AIR_EINVAL;
     if (g->transA && g->transB) return AIR_EINVAL;     // never needed on this path
-    if (g->epi < AIR_EPI_GENERIC || g->epi > AIR_EPI_LSTM_BWD_TAIL) return AIR_EINVAL;
+    if (g->epi < AIR_EPI_GENERIC || g->epi > AIR_EPI_LSTM_FWD0) return AIR_EINVAL;
     if (g->ksplit > 1 && g->epi != AIR_EPI_GENERIC) return AIR_EINVAL;
     if (g->addend_slabs > 8) return AIR_ELIMIT;
     a.A = g->A; a.B = g->B; a.C = g->C;
@@ -1293,6 +1338,9 @@ static int fill_args(const air_gemm_t* g, Args& a) {
     switch (g->epi) {
         case AIR_EPI_LSTM_FWD:      // N = 4R gate columns, groups of R
             if (g->transA || g->transB || (g->N & 3) || !g->p0 || !g->q0 || !g->q1 || !g->q2) return AIR_EINVAL;
+            a.gstride = g->N / 4; a.gwidth = g->N / 4; break;
+        case AIR_EPI_LSTM_FWD0:     // N = 4R, tiles of four units x four gates; plain operands, lean kernels only
+            if (g->transA || g->transB || (g->N & 15) || g->addend || !g->q0 || !g->q1 || !g->q2) return AIR_EINVAL;
             a.gstride = g->N / 4; a.gwidth = g->N / 4; break;
         case AIR_EPI_REPARAM_FWD:   // N = 2Z (mean | log_var)
             if (g->transA || g->transB || (g->N & 1) || !g->p0 || !g->q0) return AIR_EINVAL;
