@@ -1,5 +1,7 @@
-"""Times air_adam_clip_step vs air_adam_clip_step_factored in isolation (GPU box):
-  python tools/exp/adam_factored_bench.py [-DFLAG ...]"""
+"""Times air_adam_clip_step vs air_adam_clip_step_factored in isolation (GPU box), 200 back-to-back launches each:
+  python tools/exp/adam_factored_bench.py [-DFLAG ...]      (-D flags rebuild the library into /tmp first)
+Measured (MI355X, n = 4.01 M, factored block 2500 x 1024, B = 64): stored 20-21 us, factored 27-29 us; with the
+tile workgroups' tile rebuild compiled out 16.5 us, with only the tile workgroups running 19 us."""
 import ctypes as C, glob, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 PKG = os.path.join(ROOT, "tf-attend-infer-repeat_amd")

@@ -1,4 +1,6 @@
-"""Times the grouped weight-gradient launch of the b=64 train step in parts (GPU box)."""
+"""Times the grouped weight-gradient launch of the b=64 train step in parts (GPU box): all problems, all but
+dWx, dWx stored / norm-only, and every problem alone.  Measured (bf16): all 14.0 us, all but dWx 11.2 us, dWx
+stored 7.9 / norm-only 6.7 us, any single K = 192 problem (4 .. 104 workgroups) 7-8.6 us."""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tf-attend-infer-repeat_amd"))
