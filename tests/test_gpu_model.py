@@ -418,3 +418,23 @@ def test_factored_input_weight_gradient_equals_stored_bit_for_bit(am, prec):
     for a, b in zip(res["stored"][:3], res["factored"][:3]):
         assert torch.equal(a, b)
     assert res["stored"][3:] == res["factored"][3:]
+
+
+def test_first_lstm_step_in_the_xwx_launch_matches_the_default_path(am, monkeypatch):
+    """AIR_STEP0_FUSION=1 (x.Wx un-split with the zero-state first LSTM step in its epilogue, AIR_EPI_LSTM_FWD0)
+    gives the same forward as the default split-K product + pointwise first step, up to the summation order
+    of the K = 2500 contraction."""
+    outs = {}
+    for fused in (False, True):
+        if fused:
+            monkeypatch.setenv("AIR_STEP0_FUSION", "1")
+        else:
+            monkeypatch.delenv("AIR_STEP0_FUSION", raising=False)
+        model, *_ = _make(am, 16, True, blank=True)
+        assert model._fuse_step0 == fused
+        model.forward()
+        torch.cuda.synchronize()
+        outs[fused] = (model.h.clone(), model.c.clone(), model.acts.clone(), float(model.loss))
+    for a, b in zip(outs[False][:3], outs[True][:3]):
+        assert (a - b).abs().max() < 2e-5
+    assert abs(outs[False][3] - outs[True][3]) / abs(outs[False][3]) < 1e-5
