@@ -421,6 +421,11 @@ class AIRModel:
               epi=H.EPI_GENERIC, tile=(0, 0), ksplit=0, addend_slabs=0, i0=0, p=(), q=(), extra_bytes=0, step_job=None):
         p = list(p) + [None] * (4 - len(p))
         q = list(q) + [None] * (3 - len(q))
+        if epi == H.EPI_GENERIC and tile == (0, 0) and os.environ.get("AIR_EXP_TILES"):      # tuning hook: "N:tm,tn;N:tm,tn"
+            for item in os.environ["AIR_EXP_TILES"].split(";"):
+                n_, t_ = item.split(":")
+                if int(n_) == N:
+                    tile = tuple(int(v) for v in t_.split(","))
         g = H.Gemm(_ptr(A), _ptr(Bm), _ptr(Cm), M, N, K, lda, ldb, ldc, ta, tb, _ptr(bias), _ptr(addend), ldadd,
                    _ptr(aux), ldaux, aux_scale, act, actgrad, accumulate, self._prec,
                    epi, tile[0], tile[1], ksplit, addend_slabs, i0,
