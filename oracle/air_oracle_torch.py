@@ -35,6 +35,22 @@ class _Bf16MatMul(torch.autograd.Function):
         return _r(g) @ _r(b).t(), _r(a).t() @ _r(g)
 
 
+class _HeadOutMatMul(torch.autograd.Function):
+    """The 7 head output units on the device's bf16 path: forward and data gradient are exact fp32
+    (computed inside attend_fwd / attend_bwd, not by a GEMM); only their weight gradient goes through the
+    grouped bf16 weight-gradient launch (both operands rounded)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return a @ b
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        return g @ b.t(), _r(a).t() @ _r(g)
+
+
 def _r(x):
     return x.to(torch.bfloat16).to(x.dtype)
 
@@ -46,8 +62,11 @@ def _mm(a, b):
     return _Bf16MatMul.apply(a, b) if MATMUL_MODE == "bf16" else a @ b
 
 
-def _fc(x, W, b, act=None):
-    y = _mm(x, W) + b
+def _fc(x, W, b, act=None, head_out=False):
+    if head_out and MATMUL_MODE == "bf16":
+        y = _HeadOutMatMul.apply(x, W) + b
+    else:
+        y = _mm(x, W) + b
     if act == "relu":
         return torch.relu(y)
     if act == "softplus":
@@ -134,7 +153,7 @@ def air_forward(params, images, targets, noise, hp, train=True, z_pres_prior_log
 
     def head(outputs, name):
         hid = _fc(outputs, params[name + "/hidden/weights"], params[name + "/hidden/biases"], "relu")
-        return _fc(hid, params[name + "/output/weights"], params[name + "/output/biases"])
+        return _fc(hid, params[name + "/output/weights"], params[name + "/output/biases"], head_out=True)
 
     for t in range(N):
         g = _mm(torch.cat([images, h], dim=1), params["rnn/kernel"]) + params["rnn/bias"]

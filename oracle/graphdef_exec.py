@@ -381,6 +381,18 @@ def _k_dynamic_stitch(n, *xs):
     return out
 
 
+def apply_adam(var, m, v, b1p, b2p, lr, b1, b2, eps, g):
+    """tensorflow/core/kernels/training_ops.cc ApplyAdam (use_nesterov = False):
+         alpha = lr * sqrt(1 - beta2_power) / (1 - beta1_power)
+         m += (g - m) * (1 - beta1); v += (g*g - v) * (1 - beta2); var -= (m * alpha) / (sqrt(v) + eps)
+    Returns (var, m, v) after the update."""
+    T = var.dtype.type
+    alpha = lr * np.sqrt(T(1) - b2p) / (T(1) - b1p)
+    m2 = m + (g - m) * (T(1) - b1)
+    v2 = v + (g * g - v) * (T(1) - b2)
+    return var - (m2 * alpha) / (np.sqrt(v2) + eps), m2, v2
+
+
 OPS.update({"LinSpace": _k_linspace, "AddN": _k_addn, "UnsortedSegmentSum": _k_unsorted_segment_sum,
             "StridedSlice": _k_strided_slice, "StridedSliceGrad": _k_strided_slice_grad,
             "ConcatOffset": _k_concat_offset, "DynamicStitch": _k_dynamic_stitch})
@@ -564,15 +576,8 @@ class Executor:
             dst = n.a("DstT")
             return np.asarray(x).astype(self.fd if dst == DT_FLOAT else _DT[dst])
         if op == "ApplyAdam":
-            # tensorflow/core/kernels/training_ops.cc ApplyAdam (use_nesterov = False):
-            #   alpha = lr * sqrt(1 - beta2_power) / (1 - beta1_power)
-            #   m += (g - m) * (1 - beta1); v += (g*g - v) * (1 - beta2); var -= (m * alpha) / (sqrt(v) + eps)
             var, m, v, b1p, b2p, lr, b1, b2, eps, g = (self._in(n, k, it) for k in range(10))
-            T = var.dtype.type
-            alpha = lr * np.sqrt(T(1) - b2p) / (T(1) - b1p)
-            m2 = m + (g - m) * (T(1) - b1)
-            v2 = v + (g * g - v) * (T(1) - b2)
-            new = var - (m2 * alpha) / (np.sqrt(v2) + eps)
+            new, m2, v2 = apply_adam(var, m, v, b1p, b2p, lr, b1, b2, eps, g)
             self.assigned[n.inputs[0][0]] = dict(var=new, m=m2, v=v2, grad=g)
             return new
         if op == "AssignAdd":

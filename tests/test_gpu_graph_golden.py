@@ -137,7 +137,17 @@ def test_exact_backward_and_adam_match_graph_fp64(gold):
 
 def test_reference_backward_carries_the_graphs_residue(gold):
     """backward="reference": same order of magnitude per variable as the graph's own fp32 backward
-    (|g| 1.6e6 against 1.1e3 exact at initialisation), far above what the exact adjoint gives."""
+    (|g| 1.6e6 against 1.1e3 exact at initialisation), far above what the exact adjoint gives.
+
+    Why only a magnitude band (0.2-5x per tensor) and not element-wise equality: the residue is
+    ulp(partial sum ~1e11) of a cancellation, so a last-ulp difference in ANY upstream expf / logf / GEMM
+    accumulation reshuffles it completely -- two correct fp32 evaluations of the same graph disagree
+    element-wise.  The band is acceptable ONLY because the two kernels that create and consume the residue
+    are teacher-forced on the graph's own tensors and compared exactly: air_write_bwd(literal=2) bit for
+    bit against the graph's UnsortedSegmentSum output (test_write_bwd_reproduces_the_graphs_scatter_bit_for_bit,
+    and at every canvas regime vs the graph-pinned oracle in
+    test_gpu_kernels.py::test_write_bwd_graph_order_matches_oracle_all_canvas_sizes), air_attend_bwd(literal=2)
+    <= 1e-4 against AddN_27..32 (test_attend_bwd_matches_graph_head_gradients)."""
     m, _, _ = _model(64, True, gold["train0/z_pres_prior_log_odds"], backward="reference")
     m.training()
     torch.cuda.synchronize()

@@ -773,3 +773,143 @@ def test_gemm_first_lstm_step_epilogue_matches_product_plus_pointwise_step(H, pr
     H.check(H.lib().air_lstm_first_step(_p(xw), 1, _p(bt), _p(acts2), _p(c2), _p(h2), M, R, _stream()))
     torch.cuda.synchronize()
     assert torch.equal(acts, acts2) and torch.equal(c, c2) and torch.equal(h, h2)
+
+
+# ---- graph-order sampler backward at every canvas regime (small: all taps resident; large: per-tap staging) ----
+
+def _write_theta(s, x, y):
+    """theta_recon of air_model.py:353-356 in the kernel's fp32 op order: [[1/s, 0, -x/s], [0, 1/s, -y/s]]."""
+    one = np.float32(1.0)
+    th = np.zeros((len(s), 2, 3), np.float32)
+    th[:, 0, 0] = th[:, 1, 1] = one / s
+    th[:, 0, 2], th[:, 1, 2] = (-x) / s, (-y) / s
+    return th
+
+
+@pytest.mark.parametrize("Cc,w,N,B", [(50, 28, 3, 6), (71, 28, 2, 5), (128, 28, 5, 4), (128, 20, 2, 3)])
+def test_write_bwd_graph_order_matches_oracle_all_canvas_sizes(H, Cc, w, N, B):
+    """air_write_bwd(literal=2) -- the default backward="reference" -- against oracle.transformer_backward
+    (pinned to the reference's executed graph, transformer.py:56-117 under tf.gradients) on random inputs.
+    C = 50 takes write_bwd_graph_kernel<true> (all four taps' terms resident), C >= 63 the per-tap staged
+    <false> variant that every large canvas (BASELINE configs[3]: 128x128, N = 5) runs.  d_gen_pre (the
+    UnsortedSegmentSum result times SigmoidGrad) BIT FOR BIT, residue included; theta / z legs <= 2e-5."""
+    name = C.create_string_buffer(96)
+    rng = np.random.RandomState(Cc * 3 + w + N)
+    s = rng.uniform(0.12, 0.6, (N, B)).astype(np.float32)
+    x = rng.uniform(-0.8, 0.8, (N, B)).astype(np.float32)
+    y = rng.uniform(-0.8, 0.8, (N, B)).astype(np.float32)
+    s[0, 0], x[0, 0], y[0, 0] = 0.3, -0.95, 0.9            # glimpse in a canvas corner: one corner slot owns most pixels
+    z = rng.uniform(0.05, 1.0, (N, B)).astype(np.float32)
+    mask = np.ones((N, B), np.float32)
+    mask[N - 1, B - 1] = 0.0                              # a stopped item: Select(active, ., 0)
+    att = np.zeros((N, B, H.ATT_STRIDE), np.float32)
+    att[:, :, H.ATT_S], att[:, :, H.ATT_X], att[:, :, H.ATT_Y], att[:, :, H.ATT_Z] = s, x, y, z
+    att[:, :, H.ATT_MASK] = mask
+    # d loss / d reconstruction with the poles of the Bernoulli ELBO (1e9 / B at unexplained ink)
+    g = (rng.randn(B, Cc * Cc) * np.where(rng.uniform(size=(B, Cc * Cc)) < 0.08, 1e7, 1e-2)).astype(np.float32)
+    vrec = rng.uniform(0.01, 0.99, (N, B, w * w)).astype(np.float32)
+    att_d, g_d, v_d = (torch.tensor(v, device="cuda") for v in (att, g, vrec))
+    dgen = torch.full((N, B, w * w), 7.0, device="cuda")
+    dsx = torch.full((N, B, 4), 7.0, device="cuda")
+    wb = H.WriteBwd(_p(g_d), _p(v_d), _p(att_d), _p(dgen), _p(dsx), B, N, Cc, w, 2, None, None, None, None)
+    H.check(H.lib().air_write_bwd_kernel_name(C.byref(wb), name, 96))
+    assert name.value.decode() == "write_bwd_graph_kernel<%s>" % ("true" if Cc <= 62 else "false")
+    H.check(H.lib().air_write_bwd(C.byref(wb), _stream()), "air_write_bwd")
+    torch.cuda.synchronize()
+    dgen, dsx = dgen.cpu().numpy(), dsx.cpu().numpy()
+    residue = 0.0
+    for t in range(N):
+        th = _write_theta(s[t], x[t], y[t])
+        U = vrec[t].reshape(B, w, w)
+        d_out = (z[t][:, None] * g).reshape(B, Cc, Cc)                        # canvas/mul_grad: z * Select_grad
+        dU, dth = ao.transformer_backward(U, th, (Cc, Cc), d_out)
+        ref = ((dU.reshape(B, -1) * vrec[t]) * (np.float32(1.0) - vrec[t])).astype(np.float32)   # SigmoidGrad
+        patch = ao.transformer(U, th, (Cc, Cc)).reshape(B, -1).astype(np.float64)
+        for b in range(B):
+            if mask[t, b] == 0.0:
+                assert not dgen[t, b].any() and not dsx[t, b].any()
+                continue
+            assert np.array_equal(dgen[t, b], ref[b]), (t, b, float(np.abs(dgen[t, b] - ref[b]).max()))
+            residue = max(residue, float(np.abs(ref[b]).max()))
+            sb, xb, yb = np.float64(s[t, b]), np.float64(x[t, b]), np.float64(y[t, b])
+            d00, d02, d11, d12 = (np.float64(dth[b, 0, 0]), np.float64(dth[b, 0, 2]),
+                                  np.float64(dth[b, 1, 1]), np.float64(dth[b, 1, 2]))
+            want = np.array([-(d00 + d11) / sb ** 2 + (d02 * xb + d12 * yb) / sb ** 2, -d02 / sb, -d12 / sb,
+                             float((g[b].astype(np.float64) * patch[b]).sum())])
+            terms = np.array([abs(d00) / sb ** 2 + abs(d11) / sb ** 2 + abs(d02 * xb) / sb ** 2 + abs(d12 * yb) / sb ** 2,
+                              abs(d02) / sb, abs(d12) / sb, float(np.abs(g[b].astype(np.float64) * patch[b]).sum())])
+            # fixed-order block reductions over C*C pixels vs numpy's matmul: relative to the summed magnitudes
+            assert (np.abs(dsx[t, b] - want) <= 2e-5 * np.maximum(terms, 1e-30) + 2e-5 * np.abs(want)).all(), \
+                (t, b, dsx[t, b], want)
+    assert residue > 1.0          # the out-of-range residue is present in what was compared
+
+
+@pytest.mark.parametrize("Cc,w", [(50, 28), (128, 28), (97, 20)])
+def test_attend_bwd_graph_order_read_gradient_matches_oracle(H, Cc, w):
+    """air_attend_bwd(literal=2) at small and large canvases (C = 128 takes the bounding-box staging): the
+    read transformer's gradient wrt theta = [[s,0,x],[0,s,y]] (air_model.py:324-333) from
+    oracle.transformer_backward in the graph's op order, pushed through the sampling (sigmoid / tanh of
+    mean + eps*sd, :300-303, :317-320), the Gaussian KLs and the Concrete z_pres (concrete.py:20-43) in fp64."""
+    rng = np.random.RandomState(Cc + w)
+    N, B, Hs, Hh, Hz = 2, 5, 64, 64, 64
+    HT = 2 * Hs + 2 * Hh + Hz
+    canvas = rng.uniform(0, 1, (B, Cc * Cc)).astype(np.float32)
+    o7 = (rng.randn(N, B, H.OUT_STRIDE) * 0.5).astype(np.float32)
+    e_s, e_h = rng.randn(N, B, 1).astype(np.float32), rng.randn(N, B, 2).astype(np.float32)
+    sd = lambda lv: np.sqrt(np.exp(lv.astype(np.float64)))  # noqa: E731
+    s = 1.0 / (1.0 + np.exp(-(o7[..., 0] + e_s[..., 0] * sd(o7[..., 1]))))
+    xs = np.tanh(o7[..., 2] + e_h[..., 0] * sd(o7[..., 4]))
+    ys = np.tanh(o7[..., 3] + e_h[..., 1] * sd(o7[..., 5]))
+    s, xs, ys = (v.astype(np.float32) for v in (s, xs, ys))
+    u = rng.uniform(0.05, 0.95, (N, B))
+    T, plo, gsc = 1.0, -2.0, 1.0 / 64
+    ypre = ((o7[..., 6] + np.log(u) - np.log(1 - u)) / T).astype(np.float32)
+    zz = (1.0 / (1.0 + np.exp(-ypre.astype(np.float64)))).astype(np.float32)
+    att = np.zeros((N, B, H.ATT_STRIDE), np.float32)
+    att[..., H.ATT_S], att[..., H.ATT_X], att[..., H.ATT_Y] = s, xs, ys
+    att[..., H.ATT_Z], att[..., H.ATT_ZPRE] = zz, ypre
+    att[..., H.ATT_MASK], att[..., H.ATT_MASK_PREV] = 1.0, 1.0
+    att[1, 0, H.ATT_MASK] = 0.0
+    d_win = rng.randn(N, B, w * w).astype(np.float32)
+    d_sxyw = rng.randn(N, B, 4).astype(np.float32)
+    dyn = np.zeros(H.DYN_COUNT, np.float32)
+    dyn[H.DYN_PRIOR_LOG_ODDS], dyn[H.DYN_TEMPERATURE], dyn[H.DYN_STOP_THRESHOLD] = plo, T, 0.99
+    dyn[H.DYN_SCALE_PM], dyn[H.DYN_SCALE_PV], dyn[H.DYN_SHIFT_PM], dyn[H.DYN_SHIFT_PV] = -1.0, 0.1, 0.0, 1.0
+    dyn[H.DYN_VAE_PM], dyn[H.DYN_VAE_PV], dyn[H.DYN_GRAD_SCALE] = 0.0, 1.0, gsc
+    t_ = lambda a: torch.tensor(np.ascontiguousarray(a), device="cuda")  # noqa: E731
+    hid, wout = torch.ones(N, B, HT, device="cuda"), torch.zeros(7, 64, device="cuda")
+    d_hid, d_out7 = torch.zeros(N, B, HT, device="cuda"), torch.zeros(N, B, H.OUT_STRIDE, device="cuda")
+    cv, es_d, eh_d, dyn_d, o7_d, att_d, dw_d, ds_d = (t_(v) for v in (canvas, e_s, e_h, dyn, o7, att, d_win, d_sxyw))
+    ab = H.AttendBwd(_p(hid), _p(wout), _p(cv), _p(es_d), _p(eh_d), _p(dyn_d), _p(o7_d), _p(att_d),
+                     _p(dw_d), _p(ds_d), _p(d_hid), _p(d_out7), B, N, Cc, w, Hs, Hh, Hz, 64, 2)
+    H.check(H.lib().air_attend_bwd(C.byref(ab), _stream()), "air_attend_bwd")
+    torch.cuda.synchronize()
+    got = d_out7.cpu().numpy().astype(np.float64)
+    for t in range(N):
+        th = np.zeros((B, 2, 3), np.float32)
+        th[:, 0, 0] = th[:, 1, 1] = s[t]
+        th[:, 0, 2], th[:, 1, 2] = xs[t], ys[t]
+        _, dth = ao.transformer_backward(canvas.reshape(B, Cc, Cc), th, (w, w), d_win[t].reshape(B, w, w))
+        dth = dth.astype(np.float64)
+        d_s = dth[:, 0, 0] + dth[:, 1, 1] + d_sxyw[t, :, 0]
+        d_x, d_y, d_z = dth[:, 0, 2] + d_sxyw[t, :, 1], dth[:, 1, 2] + d_sxyw[t, :, 2], d_sxyw[t, :, 3].astype(np.float64)
+        S, X, Y = (v[t].astype(np.float64) for v in (s, xs, ys))
+        klg = att[t, :, H.ATT_MASK].astype(np.float64) * gsc
+        da_s, da_x, da_y = d_s * S * (1 - S), d_x * (1 - X * X), d_y * (1 - Y * Y)
+        o = o7[t].astype(np.float64)
+        sds, sdx, sdy = sd(o7[t, :, 1]), sd(o7[t, :, 4]), sd(o7[t, :, 5])
+        ref = np.zeros((B, 7))
+        ref[:, 0] = da_s + klg * (o[:, 0] + 1.0) / 0.1
+        ref[:, 1] = da_s * e_s[t, :, 0] * 0.5 * sds + klg * 0.5 * (sds * sds / 0.1 - 1.0)
+        ref[:, 2] = da_x + klg * o[:, 2]
+        ref[:, 3] = da_y + klg * o[:, 3]
+        ref[:, 4] = da_x * e_h[t, :, 0] * 0.5 * sdx + klg * 0.5 * (sdx * sdx - 1.0)
+        ref[:, 5] = da_y * e_h[t, :, 1] * 0.5 * sdy + klg * 0.5 * (sdy * sdy - 1.0)
+        yp, Z_ = ypre[t].astype(np.float64), zz[t].astype(np.float64)
+        eq, ep = np.exp(-yp * T + o[:, 6]), np.exp(-yp * T + plo)
+        rq, rp = eq / (1 + eq + 1e-9), ep / (1 + ep + 1e-9)
+        dkl = att[t, :, H.ATT_MASK_PREV].astype(np.float64) * gsc
+        ref[:, 6] = (d_z * Z_ * (1 - Z_) + dkl * 2 * T * (rq - rp)) / T + dkl * (1 - 2 * rq)
+        for k in range(7):
+            scale = max(np.abs(ref[:, k]).max(), 1e-6)
+            assert np.abs(got[t, :, k] - ref[:, k]).max() <= 1e-4 * scale, (t, k, got[t, :, k], ref[:, k])

@@ -115,7 +115,7 @@ def test_golden_fixture(am, golden_dir):
         assert abs(float(model.loss) - float(g[tag + "/loss"])) / abs(float(g[tag + "/loss"])) <= 1e-2
 
 
-def _grad_check(am, B, prec, tol, emulate_bf16=False, blank=False, tag=""):
+def _grad_check(am, B, prec, tol, emulate_bf16=False, blank=False, tag="", loose=("z_pres", "rnn")):
     model, images, targets, params, noise = _make(am, B, True, prec=prec, blank=blank)
     # run forward+backward only (no optimizer): use the programs directly
     s = model._stream()
@@ -144,7 +144,7 @@ def _grad_check(am, B, prec, tol, emulate_bf16=False, blank=False, tag=""):
     if blank:
         rep.pop("rnn/kernel")       # x == 0: only the recurrent rows carry gradient; covered by rnn/bias
     if tol is not None:
-        bad = {k: v for k, v in rep.items() if v > (tol * 10 if k.startswith(("z_pres", "rnn")) else tol)}
+        bad = {k: v for k, v in rep.items() if v > (tol * 10 if loose and k.startswith(loose) else tol)}
         assert not bad, bad
     return model, grads
 
@@ -157,12 +157,18 @@ def test_gradients_fp32(am, B, tol):
 
 
 def test_gradients_bf16(am):
-    """bf16-operand GEMMs (fwd, dgrad, wgrad).  The Bernoulli ELBO has poles at r -> 0 under
-    ink and r -> 1 off ink (d log(r + 1e-9), d log(1 - r + 1e-9)); at initialisation a few
-    such pixels dominate the gradient, so the ~1e-3 perturbation bf16 makes to the canvas
-    changes it by O(1) relative to ANY other evaluation (reported, not asserted).  The bf16
-    backward is asserted in the smooth regime: blank canvases, z_pres ~ 0.55."""
+    """bf16-operand GEMMs (fwd, dgrad, wgrad), the arithmetic bench.py runs.  The Bernoulli ELBO has
+    poles at r -> 0 under ink and r -> 1 off ink (d log(r + 1e-9), d log(1 - r + 1e-9)); at
+    initialisation a few such pixels dominate the gradient, so the ~1e-3 perturbation bf16 makes to the
+    canvas changes it by O(1) relative to an evaluation with exact products (measured 0.5-1.1 on the
+    where-heads: reported, not asserted).  Against the fp64 twin that rounds the SAME GEMM operands to
+    bf16 (oracle/air_oracle_torch.MATMUL_MODE = "bf16": every MatMul and both of its gradient MatMuls,
+    the seven head output units exact as attend_fwd/attend_bwd compute them) the inked gradients ARE
+    assertable: per-tensor relative L2 <= 1e-2 on all 36 variables (measured <= 4.7e-3), and <= 5e-4 in
+    the smooth regime (blank canvases, z_pres ~ 0.55; measured <= 1.4e-4)."""
     _grad_check(am, 64, "bf16", None, tag="_inked")
+    _grad_check(am, 64, "bf16", 1e-2, emulate_bf16=True, tag="_inked", loose=())
+    _grad_check(am, 64, "bf16", 5e-4, emulate_bf16=True, blank=True, tag="_blank", loose=())
     _grad_check(am, 64, "bf16", 5e-2, blank=True, tag="_blank")
     _grad_check(am, 64, "fp32", 1e-3, blank=True, tag="_blank")
 
@@ -200,7 +206,7 @@ def test_train_step_matches_oracle_update(am):
         d_got = (got - torch.as_tensor(params[k])).double()
         err = float((d_got - d_ref).norm() / max(d_ref.norm(), 1e-12))
         worst = max(worst, err)
-        assert err < 5e-2, (k, err)      # sign-like first step: tiny-gradient entries may flip
+        assert err < 1e-3, (k, err)      # measured worst 7.6e-5 (the first Adam step is sign-like: ~lr per entry)
     REPORT["adam_delta_worst_rel"] = worst
     o32 = ao.air_forward(params, images, targets, noise, HP, True, -2.0)
     assert abs(float(model.loss) - float(o32["loss"])) / abs(float(o32["loss"])) < 1e-2
