@@ -25,7 +25,9 @@
 extern "C" {
 #endif
 
-#define AIR_ABI_VERSION 1
+/* 2: air_gemm_t / air_wgrad_t carry bf16 twins; `literal` of the sampler backward: 0 exact, 1 per-tap order, 2 the
+ * reference graph's order (version 1 headers of round 1 called the per-tap order "reference") */
+#define AIR_ABI_VERSION 2
 
 #define AIR_EINVAL   (-1)   /* bad dimension / null pointer            */
 #define AIR_ELIMIT   (-2)   /* size exceeds what the kernel supports    */
@@ -158,12 +160,25 @@ typedef struct {
      * an extra plane of workgroups of THIS launch.  Only for a GEMM that reads neither the noise nor
      * dyn (the hoisted x.Wx): the train step then has no separate prologue launch. */
     const air_step_job_t* step_job;
+    /* bf16 TWINS (precision 1 only; each nullable).  A twin is the RNE-rounded bf16 copy of an fp32 array with the
+     * same shape and leading dimension -- exactly what the kernel would have produced on the operand's way into
+     * LDS, so results are bit-identical with and without them.  A16 / B16: twins of A / B; when B16 (and A16, or an
+     * fp32 A) are given and aligned to 16 bytes the operands are read as bf16 (half the bytes through the CU,
+     * no conversion; row-major weights through the LDS transpose read).  C16 / q0_16 / q2_16: twins the epilogue
+     * writes next to C / q0 / q2 for the next consumer (q2_16 of AIR_EPI_LSTM_BWD: pass it with the LAST
+     * accumulation into q2 only). */
+    const uint16_t* A16; const uint16_t* B16;
+    uint16_t* C16; uint16_t* q0_16; uint16_t* q2_16;
 } air_gemm_t;
 /* number of K-slabs a ksplit request produces for contraction depth K */
 int air_gemm_slabs(int K, int ksplit);
 int air_gemm(const air_gemm_t* g, void* stream);
 /* name of the kernel function `g` dispatches to, as rocprofv3 prints it (profiling aid) */
 int air_gemm_kernel_name(const air_gemm_t* g, char* buf, int n);
+
+/* dst[i] = bf16(src[i]), round to nearest even: the twin of an array whose producer could not write it (the flat
+ * variable buffer after a host-side load -- air_adam_clip_step keeps its shadow fresh afterwards). */
+int air_bf16_twin(const float* src, uint16_t* dst, int64_t n, void* stream);
 
 /* ---- grouped weight gradients: every dW = A^T . dY (+ db = column sums of dY) of the
  * step in ONE launch (MatMul_grad / BiasAdd_grad nodes of all variables; weights are shared
@@ -200,7 +215,7 @@ int air_lstm_gates_fwd(const float* gates_pre, const float* c_prev, float* acts,
  * hoisted x.Wx alone -- no MatMul.  xw_slabs: `nslabs` split-K slabs [B,4R] of x.Wx (air_gemm ksplit);
  * pre-activation = slab sum (in slab order) + bias, i.e. AIR_EPI_LSTM_FWD with a zero accumulator. */
 int air_lstm_first_step(const float* xw_slabs, int nslabs, const float* bias /*nullable*/, float* acts,
-                        float* c, float* h, int B, int R, void* stream);
+                        float* c, float* h, uint16_t* h16 /*bf16 twin of h, nullable*/, int B, int R, void* stream);
 /* dgates [B,4R] (pre-activation grads), dc_prev [B,R]; dgsum (+)= dgates when given */
 int air_lstm_gates_bwd(const float* dh, const float* dc_in /*nullable*/, const float* acts,
                        const float* c_prev, const float* c, float* dgates, float* dc_prev,
@@ -239,6 +254,7 @@ typedef struct {
     float* att;                          /* [N,B,AIR_ATT_STRIDE]            */
     float* window;                       /* [N,B,w*w]                       */
     int32_t B, N, C, w, Hs, Hh, Hz, wout_ld, train;
+    uint16_t* window16;                  /* bf16 twin of window (nullable): A operand of the first recognition GEMM */
 } air_attend_fwd_t;
 int air_attend_fwd(const air_attend_fwd_t* a, void* stream);
 
@@ -258,6 +274,7 @@ typedef struct {
                                                concatenated Gather gradients (the graph's single UnsortedSegmentSum) --
                                                keeps the out-of-range rounding residue, bit-identical to the executed graph.
                                             1: per-tap partial sums added ((d+c)+b)+a (a much smaller residue)        */
+    uint16_t* d_hid16;                   /* bf16 twin of d_hid (nullable)   */
 } air_attend_bwd_t;
 int air_attend_bwd(const air_attend_bwd_t* a, void* stream);
 
@@ -306,6 +323,7 @@ typedef struct {
      * fin_scalars == NULL disables; loss_item is the [B] output of air_write_fwd */
     const float* fin_loss_item; const int32_t* fin_targets; const int32_t* fin_digits;
     float* fin_scalars;
+    uint16_t* d_gen_pre16;               /* bf16 twin of d_gen_pre (nullable) */
 } air_write_bwd_t;
 int air_write_bwd(const air_write_bwd_t* a, void* stream);
 /* the kernel function air_write_bwd dispatches this descriptor to, as rocprofv3 prints it (profiling tools) */
@@ -328,6 +346,7 @@ typedef struct {
     const float* X; const float* Wml; const float* bml; const float* eps; const float* Wg; const float* bg;
     float* ml; float* z; float* g;
     int32_t M, K1, Z, H, ldx;
+    uint16_t* z16; uint16_t* g16;        /* bf16 twins of z / g written next to them (nullable) */
 } air_bottleneck_fwd_t;
 typedef struct {
     const float* dG; const float* Wg; const float* ml; const float* eps;
@@ -335,6 +354,7 @@ typedef struct {
     const float* dyn; const float* Wml; const float* x;
     float* d_ml; float* d_x;
     int32_t M, K1, Z, H;
+    uint16_t* d_ml16; uint16_t* d_x16;   /* bf16 twins of d_ml / d_x written next to them (nullable) */
 } air_bottleneck_bwd_t;
 int air_vae_bottleneck_fwd(const air_bottleneck_fwd_t* a, void* stream);
 int air_vae_bottleneck_bwd(const air_bottleneck_bwd_t* a, void* stream);

@@ -587,7 +587,7 @@ def test_unfused_lstm_and_reparam_kernels_match_oracle(H):
     c_fs = ao.sigmoid(i_) * np.tanh(j_)
     h_fs = np.tanh(c_fs) * ao.sigmoid(o_)
     slabs_d, b_d = t(slabs), t(b)
-    H.check(lib.air_lstm_first_step(_p(slabs_d), 5, _p(b_d), _p(acts), _p(c1), _p(h1), Bn, R, _stream()))
+    H.check(lib.air_lstm_first_step(_p(slabs_d), 5, _p(b_d), _p(acts), _p(c1), _p(h1), None, Bn, R, _stream()))
     torch.cuda.synchronize()
     np.testing.assert_allclose(c1.cpu().numpy(), c_fs, rtol=2e-6, atol=2e-6)
     np.testing.assert_allclose(h1.cpu().numpy(), h_fs, rtol=2e-6, atol=2e-6)
@@ -770,7 +770,7 @@ def test_gemm_first_lstm_step_epilogue_matches_product_plus_pointwise_step(H, pr
     np.testing.assert_allclose(h.cpu().numpy(), np.tanh(si * tj) * so, atol=2e-6)
     # the two launches it replaces, fed the same product: bit-identical gates
     acts2, c2, h2 = torch.empty_like(acts), torch.empty_like(c), torch.empty_like(h)
-    H.check(H.lib().air_lstm_first_step(_p(xw), 1, _p(bt), _p(acts2), _p(c2), _p(h2), M, R, _stream()))
+    H.check(H.lib().air_lstm_first_step(_p(xw), 1, _p(bt), _p(acts2), _p(c2), _p(h2), None, M, R, _stream()))
     torch.cuda.synchronize()
     assert torch.equal(acts, acts2) and torch.equal(c, c2) and torch.equal(h, h2)
 
@@ -913,3 +913,175 @@ def test_attend_bwd_graph_order_read_gradient_matches_oracle(H, Cc, w):
         for k in range(7):
             scale = max(np.abs(ref[:, k]).max(), 1e-6)
             assert np.abs(got[t, :, k] - ref[:, k]).max() <= 1e-4 * scale, (t, k, got[t, :, k], ref[:, k])
+
+
+# ---- bf16 twins: operands read as bf16 (written by the producer / by Adam) -- bit-identical to rounding on the way into LDS ----
+
+def _bf16_twin(H, t):
+    """RNE bf16 twin of a device fp32 tensor through the ABI's own converter (as int16 storage)."""
+    tw = torch.empty(t.shape, dtype=torch.int16, device=t.device)
+    H.check(H.lib().air_bf16_twin(_p(t), _p(tw), t.numel(), _stream()))
+    return tw
+
+
+def _kernel_name(H, g):
+    buf = C.create_string_buffer(128)
+    H.check(H.lib().air_gemm_kernel_name(C.byref(g), buf, 128))
+    return buf.value.decode()
+
+
+def test_bf16_twin_converter_is_rne(H):
+    rng = np.random.RandomState(3)
+    x = np.concatenate([rng.randn(4099).astype(np.float32) * 10.0 ** rng.randint(-6, 6, 4099),
+                        np.array([0.0, -0.0, 1.0, 1.00390625, 1.01171875, -3.0e38, 1e-40], np.float32)]).astype(np.float32)
+    xt = torch.tensor(x, device="cuda")
+    tw = _bf16_twin(H, xt)
+    torch.cuda.synchronize()
+    assert torch.equal(tw.view(torch.bfloat16), xt.to(torch.bfloat16))
+
+
+TWIN_GEMMS = [
+    # (M, N, K, transB, tile) -- the train step's shapes (Cfg-A and the 128x128 stress batch) + multi-round depths
+    (192, 320, 256, 0, (0, 0)), (192, 512, 784, 0, (0, 0)), (192, 256, 512, 0, (0, 0)), (192, 784, 512, 0, (0, 0)),
+    (192, 512, 784, 1, (0, 0)), (192, 256, 512, 1, (0, 0)), (192, 784, 512, 1, (0, 0)), (192, 256, 320, 1, (0, 0)),
+    (64, 256, 1024, 1, (1, 1)), (1280, 512, 784, 0, (0, 0)), (1280, 784, 512, 1, (0, 0)), (1280, 512, 256, 1, (2, 2)),
+    (50, 96, 2048, 0, (1, 1)), (50, 96, 2048, 1, (1, 1)), (37, 200, 1160, 0, (2, 2)),
+]
+
+
+@pytest.mark.parametrize("M,N,K,tb,tile", TWIN_GEMMS)
+def test_gemm_bf16_twins_bit_identical(H, M, N, K, tb, tile):
+    """air_gemm(precision=1) with bf16 twins of both operands (air_gemm_t.A16 / B16) against the same call
+    without them (fp32 operands rounded on their way into LDS): the same RNE rounding, the same k order
+    and reduction, so C is BIT-IDENTICAL; the twin C16 the epilogue writes is bf16(C)."""
+    rng = np.random.RandomState(M + N + K + tb)
+    A = torch.tensor(rng.uniform(-1, 1, (M, K)).astype(np.float32), device="cuda")
+    B = torch.tensor(rng.uniform(-1, 1, (N, K) if tb else (K, N)).astype(np.float32), device="cuda")
+    bias = torch.tensor(rng.uniform(-1, 1, N).astype(np.float32), device="cuda")
+    aux = torch.tensor(rng.uniform(0.1, 2, (M, N)).astype(np.float32), device="cuda")
+    A16, B16 = _bf16_twin(H, A), _bf16_twin(H, B)
+    outs = []
+    for twins in (False, True):
+        Ct = torch.full((M, N), float("nan"), device="cuda")
+        C16 = torch.zeros((M, N), dtype=torch.int16, device="cuda")
+        kw = dict(transB=tb, tile_m=tile[0], tile_n=tile[1], bias=bias, act=H.ACT_SOFTPLUS, C16=C16)
+        if tb:
+            kw = dict(transB=1, tile_m=tile[0], tile_n=tile[1], aux=aux, ldaux=N, actgrad=H.GRAD_SOFTPLUS, C16=C16)
+        if twins:
+            kw.update(A16=A16, B16=B16)
+        g = _gemm_struct(H, A, B, Ct, M, N, K, K, B.shape[1], N, 1, **kw)
+        name = _kernel_name(H, g)
+        assert name.startswith("gemm_bf16tw_kernel" if twins else "gemm_bf16v2_kernel"), name
+        H.check(H.lib().air_gemm(C.byref(g), _stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(C16.view(torch.bfloat16), Ct.to(torch.bfloat16))
+        outs.append(Ct)
+    assert torch.equal(outs[0], outs[1])
+    ref = _ref_gemm(A.cpu().numpy(), B.cpu().numpy(), 0, tb, 1)
+    if not tb:
+        ref = np.log1p(np.exp(ref + bias.cpu().numpy().astype(np.float64)))
+    else:
+        ref = ref * (1.0 - np.exp(-aux.cpu().numpy().astype(np.float64)))
+    assert np.abs(outs[1].cpu().numpy() - ref).max() / np.sqrt(K) < 2e-5
+
+
+def test_gemm_bf16_twins_fp32_a_split_k_bit_identical(H):
+    """The hoisted x.Wx: fp32 image batch (the caller's tensor) x bf16 shadow of Wx, split-K slabs."""
+    rng = np.random.RandomState(12)
+    for M, N, K, ks, tile in ((64, 1024, 2500, 4, (2, 2)), (256, 1024, 16384, 4, (4, 2))):
+        A = torch.tensor(rng.uniform(0, 1, (M, K)).astype(np.float32), device="cuda")
+        B = torch.tensor(rng.uniform(-0.05, 0.05, (K, N)).astype(np.float32), device="cuda")
+        B16 = _bf16_twin(H, B)
+        S = H.lib().air_gemm_slabs(K, ks)
+        outs = []
+        for twins in (False, True):
+            Ct = torch.full((S, M, N), float("nan"), device="cuda")
+            kw = dict(ksplit=ks, tile_m=tile[0], tile_n=tile[1])
+            if twins:
+                kw["B16"] = B16
+            g = _gemm_struct(H, A, B, Ct, M, N, K, K, N, N, 1, **kw)
+            assert _kernel_name(H, g).startswith("gemm_bf16tw_kernel" if twins else "gemm_bf16v2_kernel")
+            H.check(H.lib().air_gemm(C.byref(g), _stream()))
+            torch.cuda.synchronize()
+            outs.append(Ct)
+        assert torch.equal(outs[0], outs[1]), (M, N, K)
+
+
+def test_gemm_bf16_twins_fused_lstm_epilogues_bit_identical(H):
+    """AIR_EPI_LSTM_FWD / LSTM_BWD / LSTM_BWD_TAIL on twin operands: every output bit-identical to the
+    fp32-operand launch, and the twins they write (h, dgates, the final running sum) are bf16 of the fp32 outputs."""
+    dev, lib = "cuda", H.lib()
+    rng = np.random.RandomState(13)
+    Bn, R, HT = 64, 256, 320
+    f = lambda *s: torch.tensor(rng.uniform(-1, 1, s).astype(np.float32), device=dev)  # noqa: E731
+    i16 = lambda *s: torch.zeros(*s, dtype=torch.int16, device=dev)  # noqa: E731
+    h, Wh, bias, c_prev, slabs = f(Bn, R), f(R, 4 * R) * 0.1, f(4 * R) * 0.1, f(Bn, R), f(4, Bn, 4 * R) * 0.3
+    res = []
+    for twins in (False, True):
+        acts, c1, h1, dummy, h16 = f(Bn, 4 * R), f(Bn, R), f(Bn, R), f(Bn, 4 * R), i16(Bn, R)
+        kw = dict(bias=bias, addend=slabs, ldadd=4 * R, addend_slabs=4, epi=H.EPI_LSTM_FWD, p0=c_prev, q0=acts, q1=c1, q2=h1, q2_16=h16)
+        if twins:
+            kw.update(A16=_bf16_twin(H, h), B16=_bf16_twin(H, Wh))
+        g = _gemm_struct(H, h, Wh, dummy, Bn, 4 * R, R, R, 4 * R, 4 * R, 1, **kw)
+        assert ("tw_kernel" in _kernel_name(H, g)) == twins
+        H.check(lib.air_gemm(C.byref(g), _stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(h16.view(torch.bfloat16), h1.to(torch.bfloat16))
+        res.append((acts, c1, h1))
+    for a0, a1 in zip(*res):
+        assert torch.equal(a0, a1)
+    acts0, c0 = res[0][0], res[0][1]
+    # BPTT step: dgates[t+1] . Wh^T (+ heads' d h) -> LSTM cell backward; running sum accumulated
+    dgn, dh_heads, dc_in, ds_init = f(Bn, 4 * R), f(Bn, R), f(Bn, R), f(Bn, 4 * R)
+    res = []
+    for twins in (False, True):
+        dh, dg, dcp, ds = f(Bn, R), f(Bn, 4 * R), f(Bn, R), ds_init.clone()
+        dg16, ds16 = i16(Bn, 4 * R), i16(Bn, 4 * R)
+        kw = dict(transB=1, addend=dh_heads, ldadd=R, epi=H.EPI_LSTM_BWD, p0=acts0, p1=c_prev, p2=c0, p3=dc_in,
+                  q0=dg, q1=dcp, q2=ds, i0=1, q0_16=dg16, q2_16=ds16)
+        if twins:
+            kw.update(A16=_bf16_twin(H, dgn), B16=_bf16_twin(H, Wh))
+        g = _gemm_struct(H, dgn, Wh, dh, Bn, R, 4 * R, 4 * R, 4 * R, R, 1, **kw)
+        assert ("tw_kernel" in _kernel_name(H, g)) == twins
+        H.check(lib.air_gemm(C.byref(g), _stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(dg16.view(torch.bfloat16), dg.to(torch.bfloat16))
+        assert torch.equal(ds16.view(torch.bfloat16), ds.to(torch.bfloat16))
+        res.append((dg, dcp, ds))
+    for a0, a1 in zip(*res):
+        assert torch.equal(a0, a1)
+    # heads' d h of all steps, the last step's rows straight through the cell backward
+    NB, tl = 3 * Bn, 2 * Bn
+    d_hid, Whid = f(NB, HT), f(R, HT) * 0.1
+    res = []
+    for twins in (False, True):
+        dhh, dg, dcp, ds = f(NB, R), f(Bn, 4 * R), f(Bn, R), f(Bn, 4 * R)
+        dg16 = i16(Bn, 4 * R)
+        kw = dict(transB=1, epi=H.EPI_LSTM_BWD_TAIL, i0=tl, p0=acts0, p1=c_prev, p2=c0, q0=dg, q1=dcp, q2=ds, q0_16=dg16)
+        if twins:
+            kw.update(A16=_bf16_twin(H, d_hid), B16=_bf16_twin(H, Whid))
+        g = _gemm_struct(H, d_hid, Whid, dhh, NB, R, HT, HT, HT, R, 1, **kw)
+        assert ("tw_kernel" in _kernel_name(H, g)) == twins
+        H.check(lib.air_gemm(C.byref(g), _stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(dg16.view(torch.bfloat16), dg.to(torch.bfloat16))
+        res.append((dhh[:tl].clone(), dg, dcp, ds))
+    for a0, a1 in zip(*res):
+        assert torch.equal(a0, a1)
+
+
+def test_gemm_ragged_shapes_keep_the_fp32_operand_kernels(H):
+    """Twins given but the shape is not made of whole 16-byte bf16 pieces (K % 8, ld % 8, N % 8): the call
+    silently takes the fp32-operand kernels -- same results, and it still writes the C16 twin."""
+    rng = np.random.RandomState(14)
+    for M, N, K, tb in ((40, 100, 50, 0), (40, 50, 100, 1), (33, 64, 36, 0), (33, 36, 64, 1)):
+        A = torch.tensor(rng.uniform(-1, 1, (M, K)).astype(np.float32), device="cuda")
+        B = torch.tensor(rng.uniform(-1, 1, (N, K) if tb else (K, N)).astype(np.float32), device="cuda")
+        Ct, C16 = torch.zeros(M, N, device="cuda"), torch.zeros(M, N, dtype=torch.int16, device="cuda")
+        g = _gemm_struct(H, A, B, Ct, M, N, K, K, B.shape[1], N, 1, transB=tb, A16=_bf16_twin(H, A), B16=_bf16_twin(H, B), C16=C16)
+        ragged = (K % 8 != 0) or (not tb and N % 8 != 0)
+        assert ("tw_kernel" in _kernel_name(H, g)) == (not ragged), (M, N, K, tb)
+        H.check(H.lib().air_gemm(C.byref(g), _stream()))
+        torch.cuda.synchronize()
+        assert np.abs(Ct.cpu().numpy() - _ref_gemm(A.cpu().numpy(), B.cpu().numpy(), 0, tb, 1)).max() / np.sqrt(K) < 2e-5
+        assert torch.equal(C16.view(torch.bfloat16), Ct.to(torch.bfloat16))

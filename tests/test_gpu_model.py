@@ -444,3 +444,59 @@ def test_first_lstm_step_in_the_xwx_launch_matches_the_default_path(am, monkeypa
     for a, b in zip(outs[False][:3], outs[True][:3]):
         assert (a - b).abs().max() < 2e-5
     assert abs(outs[False][3] - outs[True][3]) / abs(outs[False][3]) < 1e-5
+
+
+@pytest.mark.parametrize("hp_over,B", [({}, 64), (dict(canvas_size=128, max_steps=5, max_digits=4), 32)])
+def test_bf16_twins_are_bit_identical_to_fp32_operands(am, hp_over, B):
+    """bf16_twins=True (default on the bf16 path): every GEMM / weight-gradient operand is read from a bf16
+    twin its producer (or Adam, for the variables) wrote.  The twin is the RNE rounding the fp32-operand
+    kernels apply on the way into LDS, so forward outputs, all 36 gradients, both Adam slots, the
+    variables and the global norm after several train steps equal the bf16_twins=False run BIT FOR BIT --
+    at the bench configuration and at the 128x128 stress configuration (other tiles, several rounds)."""
+    hp = dict(HP, **hp_over)
+    res = {}
+    for tw in (False, True):
+        model, *_ = _make(am, B, True, prec="bf16", backward="reference", hp=hp, bf16_twins=tw)
+        assert model._twins == tw
+        names = {op.kernel for op in model.train_step_ops()}
+        assert any("gemm_bf16tw_kernel" in n for n in names) == tw, names
+        for _ in range(3):
+            model.training()
+        torch.cuda.synchronize()
+        st = model.store
+        res[tw] = dict(params=st.params.clone(), m=st.m.clone(), v=st.v.clone(), grads=st.grads.clone(),
+                       gnorm=st.gnorm.clone(), recon=model.reconstruction.clone(), att=model.att.clone(),
+                       ml=model.ml.clone(), vrec=model.vrec.clone(), h=model.h.clone())
+        if tw:
+            # the shadow Adam maintains IS bf16(variables); activation twins are bf16 of their fp32 arrays
+            assert torch.equal(st.params16.view(torch.bfloat16), st.params.to(torch.bfloat16))
+            assert torch.equal(model.h16.view(torch.bfloat16), model.h.to(torch.bfloat16))
+            assert torch.equal(model.window16.view(torch.bfloat16), model.window.to(torch.bfloat16))
+            assert torch.equal(model.d_hid16.view(torch.bfloat16), model.d_hid.to(torch.bfloat16))
+            assert torch.equal(model.dgsum16.view(torch.bfloat16), model.dgsum.to(torch.bfloat16))
+            assert torch.equal(model.dgates16.view(torch.bfloat16), model.dgates.to(torch.bfloat16))
+            assert torch.equal(model.d_genpre16.view(torch.bfloat16), model.d_genpre.to(torch.bfloat16))
+    for k in res[False]:
+        assert torch.equal(res[False][k], res[True][k]), k
+
+
+def test_bf16_shadow_follows_host_side_changes_of_the_variables(am):
+    """load_state_dict / initialize / sync mark the bf16 shadow stale; the next forward re-derives it (one
+    air_bf16_twin launch) also when a captured graph is replayed."""
+    model, images, targets, params, noise = _make(am, 16, False, prec="bf16")
+    model.use_device_rng()
+    model.capture_graph()
+    model.forward()
+    l0 = float(model.loss)
+    p2 = {k: (v * 0.5 if v.ndim == 2 else v) for k, v in params.items()}
+    model.load_state_dict(p2)
+    assert model.store.shadow_stale
+    model.forward()
+    torch.cuda.synchronize()
+    assert not model.store.shadow_stale
+    assert torch.equal(model.store.params16.view(torch.bfloat16), model.store.params.to(torch.bfloat16))
+    ref, *_ = _make(am, 16, False, prec="bf16", bf16_twins=False)
+    ref.use_device_rng()
+    ref.load_state_dict(p2)
+    ref.forward()
+    assert float(model.loss) == float(ref.loss) and float(model.loss) != l0

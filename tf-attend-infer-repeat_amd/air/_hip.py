@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AIR_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "libair_hip.so")   # override: A/B builds in tools/
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # enums (keep in sync with include/air_hip.h)
 DYN_PRIOR_LOG_ODDS, DYN_TEMPERATURE, DYN_STOP_THRESHOLD, DYN_LEARNING_RATE, DYN_CLIP_NORM = 0, 1, 2, 3, 4
@@ -52,7 +52,8 @@ class Gemm(C.Structure):
                 ("aux_scale", _f), ("act", _i), ("actgrad", _i), ("accumulate", _i), ("precision", _i),
                 ("epi", _i), ("tile_m", _i), ("tile_n", _i), ("ksplit", _i), ("addend_slabs", _i), ("i0", _i),
                 ("p0", _p), ("p1", _p), ("p2", _p), ("p3", _p), ("q0", _p), ("q1", _p), ("q2", _p),
-                ("step_job", C.POINTER(StepJob))]
+                ("step_job", C.POINTER(StepJob)),
+                ("A16", _p), ("B16", _p), ("C16", _p), ("q0_16", _p), ("q2_16", _p)]
 
 
 class Colsum(C.Structure):
@@ -70,7 +71,7 @@ class AttendFwd(C.Structure):
                 ("eps_scale", _p), ("eps_shift", _p), ("u", _p), ("dyn", _p),
                 ("out7", _p), ("att", _p), ("window", _p),
                 ("B", _i), ("N", _i), ("C", _i), ("w", _i), ("Hs", _i), ("Hh", _i), ("Hz", _i),
-                ("wout_ld", _i), ("train", _i)]
+                ("wout_ld", _i), ("train", _i), ("window16", _p)]
 
 
 class AttendBwd(C.Structure):
@@ -78,7 +79,7 @@ class AttendBwd(C.Structure):
                 ("dyn", _p), ("out7", _p), ("att", _p), ("d_window", _p), ("d_sxy_write", _p),
                 ("d_hid", _p), ("d_out7", _p),
                 ("B", _i), ("N", _i), ("C", _i), ("w", _i), ("Hs", _i), ("Hh", _i), ("Hz", _i), ("wout_ld", _i),
-                ("literal", _i)]
+                ("literal", _i), ("d_hid16", _p)]
 
 
 class WriteFwd(C.Structure):
@@ -90,17 +91,17 @@ class WriteFwd(C.Structure):
 class WriteBwd(C.Structure):
     _fields_ = [("d_recon", _p), ("vrec", _p), ("att", _p), ("d_gen_pre", _p), ("d_sxy_write", _p),
                 ("B", _i), ("N", _i), ("C", _i), ("w", _i), ("literal", _i),
-                ("fin_loss_item", _p), ("fin_targets", _p), ("fin_digits", _p), ("fin_scalars", _p)]
+                ("fin_loss_item", _p), ("fin_targets", _p), ("fin_digits", _p), ("fin_scalars", _p), ("d_gen_pre16", _p)]
 
 
 class BottleneckFwd(C.Structure):
     _fields_ = [("X", _p), ("Wml", _p), ("bml", _p), ("eps", _p), ("Wg", _p), ("bg", _p), ("ml", _p), ("z", _p), ("g", _p),
-                ("M", _i), ("K1", _i), ("Z", _i), ("H", _i), ("ldx", _i)]
+                ("M", _i), ("K1", _i), ("Z", _i), ("H", _i), ("ldx", _i), ("z16", _p), ("g16", _p)]
 
 
 class BottleneckBwd(C.Structure):
     _fields_ = [("dG", _p), ("Wg", _p), ("ml", _p), ("eps", _p), ("att", _p), ("dyn", _p), ("Wml", _p), ("x", _p),
-                ("d_ml", _p), ("d_x", _p), ("M", _i), ("K1", _i), ("Z", _i), ("H", _i)]
+                ("d_ml", _p), ("d_x", _p), ("M", _i), ("K1", _i), ("Z", _i), ("H", _i), ("d_ml16", _p), ("d_x16", _p)]
 
 
 _SIGNATURES = {
@@ -109,11 +110,12 @@ _SIGNATURES = {
     "air_gemm": (C.c_int, [C.POINTER(Gemm), _p]),
     "air_gemm_kernel_name": (C.c_int, [C.POINTER(Gemm), C.c_char_p, C.c_int]),
     "air_gemm_slabs": (C.c_int, [C.c_int, C.c_int]),
+    "air_bf16_twin": (C.c_int, [_p, _p, C.c_int64, _p]),
     "air_colsum": (C.c_int, [C.POINTER(Colsum), C.c_int, _p]),
     "air_wgrad_num_blocks": (C.c_int, [C.POINTER(Wgrad), C.c_int]),
     "air_wgrad_grouped": (C.c_int, [C.POINTER(Wgrad), C.c_int, C.c_int, _p, _p, _p]),
     "air_lstm_gates_fwd": (C.c_int, [_p, _p, _p, _p, _p, C.c_int, C.c_int, _p]),
-    "air_lstm_first_step": (C.c_int, [_p, C.c_int, _p, _p, _p, _p, C.c_int, C.c_int, _p]),
+    "air_lstm_first_step": (C.c_int, [_p, C.c_int, _p, _p, _p, _p, _p, C.c_int, C.c_int, _p]),
     "air_lstm_gates_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, C.c_int, C.c_int, C.c_int, _p]),
     "air_transformer_fwd": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "air_transformer_bwd": (C.c_int, [_p, _p, _p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),

@@ -45,8 +45,8 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
-def _align4(n):
-    return (n + 3) & ~3
+def _align8(n):
+    return (n + 7) & ~7
 
 
 class VariableStore:
@@ -91,8 +91,8 @@ class VariableStore:
         off = 0
         for k, shp in fused.items():
             self.offsets[k] = off
-            off += _align4(int(np.prod(shp)))
-        self.n = off                                        # multiple of 4
+            off += _align8(int(np.prod(shp)))               # every tensor 32-byte aligned in fp32, 16-byte in the bf16 shadow
+        self.n = off                                        # multiple of 8
         # +4 tail floats: loss / accuracy ride along in the gradient all-reduce
         self.params = torch.zeros(self.n, dtype=torch.float32, device=device)
         self.grads = torch.zeros(self.n + 4, dtype=torch.float32, device=device)
@@ -103,11 +103,19 @@ class VariableStore:
         self.partials = torch.zeros(max(H.lib().air_optim_num_partials(self.n), 16384), dtype=torch.float32, device=device)
         self.gnorm = torch.zeros(1, dtype=torch.float32, device=device)
         self.synced_world = 1            # world size the replicas were last made identical for (AIRModel.sync_parameters)
+        # bf16 shadow of the whole flat variable buffer (same offsets): the weight operand of every bf16 GEMM.
+        # Adam rewrites it with the variables (air_adam_clip_step's bf16_shadow); any host-side change of the
+        # variables (initialize / load_state_dict / sync / checkpoint load) marks it stale and the next
+        # forward() / training() re-derives it with one air_bf16_twin launch.  Code that writes into
+        # `variables[...]` views directly must call touch().
+        self.params16 = torch.zeros(self.n, dtype=torch.int16, device=device)
+        self.shadow_stale = True
 
         def views(buf):
             return OrderedDict((k, buf[self.offsets[k]:self.offsets[k] + int(np.prod(s))].view(*s))
                                for k, s in fused.items())
         self.P, self.G = views(self.params), views(self.grads)
+        self.P16 = views(self.params16)
 
         # TF-named views (air-model.index names, relative to scope "<scope>/rnn/")
         def named(V):
@@ -152,6 +160,17 @@ class VariableStore:
                 limit = math.sqrt(6.0 / (v.shape[0] + v.shape[1]))
                 v.copy_(torch.from_numpy(rng.uniform(-limit, limit, size=tuple(v.shape)).astype(np.float32)))
         self.m.zero_(); self.v.zero_(); self.grads.zero_(); self.istate.zero_()
+        self.shadow_stale = True
+
+    def touch(self):
+        """The variables were changed from the host side: the bf16 shadow has to be re-derived."""
+        self.shadow_stale = True
+
+    def refresh_shadow(self, stream=None):
+        if stream is None:
+            stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        H.check(H.lib().air_bf16_twin(_ptr(self.params), _ptr(self.params16), self.n, stream), "air_bf16_twin")
+        self.shadow_stale = False
 
     def state_dict(self):
         sd = OrderedDict((k, v.detach().cpu().contiguous().clone()) for k, v in self.variables.items())
@@ -169,6 +188,7 @@ class VariableStore:
             self.istate[H.IST_GLOBAL_STEP] = int(sd["global_step"])
         if "_adam_m" in sd:
             self.m.copy_(torch.as_tensor(sd["_adam_m"])); self.v.copy_(torch.as_tensor(sd["_adam_v"]))
+        self.shadow_stale = True
 
 
 _ANNEALABLE = {
@@ -205,7 +225,7 @@ class AIRModel:
                  learning_rate=1e-3, gradient_clipping_norm=100.0, cnn=True, cnn_filters=8,
                  num_summary_images=60, train=False, reuse=False, scope="air",
                  annealing_schedules=None, seed=0, gemm_precision=None, backward="reference", noise_seed=None,
-                 input_weight_gradient="stored"):
+                 input_weight_gradient="stored", bf16_twins=None):
         if cnn:
             # reference :510-533; every caller passes cnn=False (training.py:108, demo.py:24)
             raise NotImplementedError("cnn=True front-end is outside the accelerated hot path; pass cnn=False")
@@ -263,6 +283,12 @@ class AIRModel:
         self.backward = backward
         self._literal = {"reference": 2, "taps": 1, "exact": 0}[backward]
         self._prec = 1 if prec == "bf16" else 0
+        # bf16 path: every GEMM operand also exists as a bf16 twin in memory (written by the producing kernel /
+        # by Adam), so the GEMMs read 2-byte operands and convert nothing -- bit-identical results (the twin IS
+        # the rounding the fp32-operand kernels apply on the way into LDS).  bf16_twins=False keeps fp32 operands.
+        if bf16_twins is None:
+            bf16_twins = os.environ.get("AIR_BF16_TWINS", "1") != "0"
+        self._twins = bool(bf16_twins) and self._prec == 1
 
         dev = input_images.device
         if tuple(input_images.shape) != (self.batch_size, canvas_size * canvas_size) or \
@@ -305,6 +331,8 @@ class AIRModel:
         if input_weight_gradient not in ("factored", "stored"):
             raise ValueError("input_weight_gradient must be 'factored' or 'stored'")
         self._factor_dwx = input_weight_gradient == "factored"
+        if self._factor_dwx:
+            self._twins = False      # air_adam_clip_step_factored does not maintain the bf16 shadow of the variables
         self._injected_noise = False
         self._graph = None
         self._dirty = True
@@ -399,6 +427,22 @@ class AIRModel:
         self._loss_item = f(B)
         self.scalars = self.store.grads[self.store.n:self.store.n + 4] if self.train else f(4)
 
+        tw = self._twins
+        h16 = lambda *s: (torch.zeros(*s, dtype=torch.int16, device=dv) if tw else None)  # noqa: E731
+        self.h16 = h16(N + 1, B, R)                     # [0] stays zero like h[0]
+        self.hid16 = h16(N, B, HT)
+        self.window16 = h16(N, B, d)
+        self.rec_act16 = [h16(N, B, u) for u in self.vae_recognition_units]
+        self.zs16 = h16(N, B, Z)
+        self.gen_act16 = [h16(N, B, u) for u in self.vae_generative_units]
+        if self.train:
+            self.d_genpre16 = h16(N, B, d)
+            self.d_gen16 = [h16(N, B, u) for u in self.vae_generative_units]
+            self.d_ml16 = h16(N, B, 2 * Z)
+            self.d_rec16 = [h16(N, B, u) for u in self.vae_recognition_units]
+            self.d_hid16 = h16(N, B, HT)
+            self.dgates16 = h16(N, B, 4 * R)
+            self.dgsum16 = h16(B, 4 * R)
         if self.train:
             self.d_recon = f(B, D)
             self.d_genpre = f(N, B, d)
@@ -418,7 +462,8 @@ class AIRModel:
     # ------------------------------------------------------------- launch lists
     def _gemm(self, A, Bm, Cm, M, N, K, lda, ldb, ldc, ta=0, tb=0, bias=None, addend=None, ldadd=0,
               aux=None, ldaux=0, aux_scale=0.0, act=H.ACT_NONE, actgrad=H.GRAD_NONE, accumulate=0, tag="gemm",
-              epi=H.EPI_GENERIC, tile=(0, 0), ksplit=0, addend_slabs=0, i0=0, p=(), q=(), extra_bytes=0, step_job=None):
+              epi=H.EPI_GENERIC, tile=(0, 0), ksplit=0, addend_slabs=0, i0=0, p=(), q=(), extra_bytes=0, step_job=None,
+              A16=None, B16=None, C16=None, q0_16=None, q2_16=None):
         p = list(p) + [None] * (4 - len(p))
         q = list(q) + [None] * (3 - len(q))
         if epi == H.EPI_GENERIC and tile == (0, 0) and os.environ.get("AIR_EXP_TILES"):      # tuning hook: "N:tm,tn;N:tm,tn"
@@ -430,14 +475,16 @@ class AIRModel:
                    _ptr(aux), ldaux, aux_scale, act, actgrad, accumulate, self._prec,
                    epi, tile[0], tile[1], ksplit, addend_slabs, i0,
                    _ptr(p[0]), _ptr(p[1]), _ptr(p[2]), _ptr(p[3]), _ptr(q[0]), _ptr(q[1]), _ptr(q[2]),
-                   C.pointer(step_job) if step_job is not None else None)
+                   C.pointer(step_job) if step_job is not None else None,
+                   _ptr(A16), _ptr(B16), _ptr(C16), _ptr(q0_16), _ptr(q2_16))
         fn = self.lib.air_gemm
         kbuf = C.create_string_buffer(96)
         H.check(self.lib.air_gemm_kernel_name(C.byref(g), kbuf, 96), "air_gemm_kernel_name")
         extra = (addend is not None) * max(1, addend_slabs) + (aux is not None) + (1 if accumulate else 0)
         return _Op("%s[%dx%dx%d%s]" % (tag, M, N, K, "t" if ta else ("n" + ("t" if tb else "n"))),
                    lambda s, g=g, fn=fn, keep=step_job: H.check(fn(C.byref(g), s), "air_gemm"),
-                   nbytes=4 * (M * K + K * N + M * N * (1 + extra)) + (4 * N if bias is not None else 0) + extra_bytes,
+                   nbytes=(2 if A16 is not None else 4) * M * K + (2 if B16 is not None else 4) * K * N
+                   + 4 * M * N * (1 + extra) + (2 * M * N if C16 is not None else 0) + (4 * N if bias is not None else 0) + extra_bytes,
                    flops=2 * M * N * K, kernel=kbuf.value.decode())
 
     _KERNEL_OF = {"air_lstm_first_step": "lstm_first_step_kernel", "air_step_begin": "step_begin_kernel", "air_attend_fwd": "attend_fwd_kernel",
@@ -465,6 +512,12 @@ class AIRModel:
         Cc, w = self.canvas_size, self.windows_size
         rec_u, gen_u = list(self.vae_recognition_units), list(self.vae_generative_units)
         Wx, Wh = P["lstm_kernel"][:D], P["lstm_kernel"][D:]
+        # bf16 twins (None when off): T(name) = shadow of a fused variable; activations carry their own twin buffers
+        tw = self._twins
+        P16 = st.P16
+        T = (lambda k: P16[k]) if tw else (lambda k: None)  # noqa: E731
+        Wx16, Wh16 = (P16["lstm_kernel"][:D], P16["lstm_kernel"][D:]) if tw else (None, None)
+        o16 = lambda t, i=None: (None if t is None else (t if i is None else t[i]))  # noqa: E731
         imgs = self.input_images
         keep = self._keep = []          # ctypes structs referenced by the closures
 
@@ -478,22 +531,22 @@ class AIRModel:
         if self._fuse_step0:
             # the first step rides in the x.Wx launch: h_0 = c_0 = 0 (zero_state, :540), so its gates are x.Wx + b
             step0 = dict(bias=P["lstm_bias"], epi=H.EPI_LSTM_FWD0, q=(self.acts[0], self.c[1], self.h[1]),
-                         extra_bytes=4 * B * R * 6)
+                         extra_bytes=4 * B * R * 6, q2_16=o16(self.h16, 1))
             fwd.append(self._gemm(imgs, Wx, self.xw, B, 4 * R, D, D, 4 * R, 4 * R, tag="xWx+lstm0", **step0))
             step0["extra_bytes"] += noise_bytes
             self._xwx_with_begin = self._gemm(imgs, Wx, self.xw, B, 4 * R, D, D, 4 * R, 4 * R,
                                               tag="xWx+lstm0+step_begin", step_job=job, **step0)
         else:
             fwd.append(self._gemm(imgs, Wx, self.xw, B, 4 * R, D, D, 4 * R, 4 * R, ksplit=self._xw_ksplit,
-                                  tile=self._xw_tile, tag="xWx"))
+                                  tile=self._xw_tile, tag="xWx", B16=Wx16))
             # the same launch carrying the step prologue (schedules + Philox noise) as an extra plane of
             # workgroups: x.Wx reads neither, so the train step needs no prologue launch of its own
             self._xwx_with_begin = self._gemm(imgs, Wx, self.xw, B, 4 * R, D, D, 4 * R, 4 * R, ksplit=self._xw_ksplit,
                                               tile=self._xw_tile, tag="xWx+step_begin", step_job=job,
-                                              extra_bytes=noise_bytes)
+                                              extra_bytes=noise_bytes, B16=Wx16)
             # step 0 starts from zero_state (:540): h_0 . Wh = 0, the gates are x.Wx + b -- a pointwise launch
             fwd.append(self._call("air_lstm_first_step", _ptr(self.xw), self._xw_slabs, _ptr(P["lstm_bias"]),
-                                  _ptr(self.acts[0]), _ptr(self.c[1]), _ptr(self.h[1]), B, R,
+                                  _ptr(self.acts[0]), _ptr(self.c[1]), _ptr(self.h[1]), _ptr(o16(self.h16, 1)), B, R,
                                   nbytes=4 * B * R * (4 * self._xw_slabs + 6) + 16 * R, tag="lstm_fwd0"))
         # the recurrence: the remaining LSTM steps, chained (the only sequential part of the loop -- the LSTM
         # sees the same image every step and nothing downstream feeds back into it, :286/:535)
@@ -501,21 +554,23 @@ class AIRModel:
             fwd.append(self._gemm(self.h[t], Wh, self.gates_pre, B, 4 * R, R, R, 4 * R, 4 * R,
                                   bias=P["lstm_bias"], addend=self.xw, ldadd=4 * R, addend_slabs=self._xw_slabs,
                                   epi=H.EPI_LSTM_FWD, p=(self.c[t],), q=(self.acts[t], self.c[t + 1], self.h[t + 1]),
-                                  extra_bytes=4 * B * R * 7, tag="lstm_fwd"))
+                                  extra_bytes=4 * B * R * 7, tag="lstm_fwd",
+                                  A16=o16(self.h16, t), B16=Wh16, q2_16=o16(self.h16, t + 1)))
         # everything else runs ONCE over all N*B (step, image) rows
         fwd.append(self._gemm(self.h[1], P["whid"], self.hid, NB, HT, R, R, HT, HT, bias=P["bhid"],
-                              act=H.ACT_RELU, tag="heads_hid"))
+                              act=H.ACT_RELU, tag="heads_hid", A16=o16(self.h16, 1), B16=T("whid"), C16=self.hid16))
         a = H.AttendFwd(_ptr(self.hid), _ptr(P["wout"]), _ptr(P["bout"]), _ptr(imgs),
                         _ptr(self.eps_scale), _ptr(self.eps_shift), _ptr(self.u), _ptr(self.dyn),
                         _ptr(self.out7), _ptr(self.att), _ptr(self.window),
-                        B, N, Cc, w, Hs, Hh, Hz, Hmax, 1 if self.train else 0)
+                        B, N, Cc, w, Hs, Hh, Hz, Hmax, 1 if self.train else 0, _ptr(self.window16))
         keep.append(a)
         fwd.append(self._call("air_attend_fwd", C.byref(a), nbytes=NB * ((D + d + HT) * 4 + 12), tag="attend_fwd"))
-        x, k = self.window, d
+        x, x16, k = self.window, self.window16, d
         for i, u in enumerate(rec_u):
             fwd.append(self._gemm(x, P["rec%d_w" % i], self.rec_act[i], NB, u, k, k, u, u,
-                                  bias=P["rec%d_b" % i], act=H.ACT_SOFTPLUS, tag="vae_rec"))
-            x, k = self.rec_act[i], u
+                                  bias=P["rec%d_b" % i], act=H.ACT_SOFTPLUS, tag="vae_rec",
+                                  A16=x16, B16=T("rec%d_w" % i), C16=self.rec_act16[i]))
+            x, x16, k = self.rec_act[i], self.rec_act16[i], u
         # the bottleneck (last recognition product -> reparameterised sample -> first generative layer) is
         # ONE launch where the fused kernel's limits hold (bf16 operands; vae.py:16-30); else two GEMMs
         nofuse = os.environ.get("AIR_NO_BOTTLENECK_FUSION") == "1"
@@ -524,25 +579,27 @@ class AIRModel:
         first_gen = 0
         if fuse_f:
             bf = H.BottleneckFwd(_ptr(x), _ptr(P["ml_w"]), _ptr(P["ml_b"]), _ptr(self.eps_z), _ptr(P["gen0_w"]),
-                                 _ptr(P["gen0_b"]), _ptr(self.ml), _ptr(self.zs), _ptr(self.gen_act[0]), NB, k, Z, gen_u[0], k)
+                                 _ptr(P["gen0_b"]), _ptr(self.ml), _ptr(self.zs), _ptr(self.gen_act[0]), NB, k, Z, gen_u[0], k,
+                                 _ptr(self.zs16), _ptr(self.gen_act16[0]))
             keep.append(bf)
             fwd.append(self._call("air_vae_bottleneck_fwd", C.byref(bf),
                                   nbytes=4 * (NB * (k + 4 * Z + gen_u[0]) + k * 2 * Z + Z * gen_u[0]),
                                   flops=2 * NB * (k * 2 * Z + Z * gen_u[0]), tag="vae_bottleneck"))
-            x, k, first_gen = self.gen_act[0], gen_u[0], 1
+            x, x16, k, first_gen = self.gen_act[0], self.gen_act16[0], gen_u[0], 1
         else:
             fwd.append(self._gemm(x, P["ml_w"], self.ml, NB, 2 * Z, k, k, 2 * Z, 2 * Z, bias=P["ml_b"],
                                   epi=H.EPI_REPARAM_FWD, p=(self.eps_z,), q=(self.zs,),
-                                  extra_bytes=8 * NB * Z, tag="ml_reparam"))
-            x, k = self.zs, Z
+                                  extra_bytes=8 * NB * Z, tag="ml_reparam", q0_16=self.zs16))
+            x, x16, k = self.zs, self.zs16, Z
         for i in range(first_gen, len(gen_u)):
             u = gen_u[i]
             fwd.append(self._gemm(x, P["gen%d_w" % i], self.gen_act[i], NB, u, k, k, u, u,
-                                  bias=P["gen%d_b" % i], act=H.ACT_SOFTPLUS, tag="vae_gen"))
-            x, k = self.gen_act[i], u
+                                  bias=P["gen%d_b" % i], act=H.ACT_SOFTPLUS, tag="vae_gen",
+                                  A16=x16, B16=T("gen%d_w" % i), C16=self.gen_act16[i]))
+            x, x16, k = self.gen_act[i], self.gen_act16[i], u
         fwd.append(self._gemm(x, P["out_w"], self.vrec, NB, d, k, k, d, d, bias=P["out_b"],
                               act=H.ACT_SIGMOID_NOISE, aux=self.eps_x, ldaux=d,
-                              aux_scale=float(self.vae_likelihood_std), tag="vae_out"))
+                              aux_scale=float(self.vae_likelihood_std), tag="vae_out", A16=x16, B16=T("out_w")))
         wf = H.WriteFwd(_ptr(self.vrec), _ptr(self.ml), _ptr(imgs), _ptr(self.dyn), _ptr(self.att),
                         _ptr(self._recon), _ptr(self._rec_loss), _ptr(self.d_recon if self.train else None),
                         _ptr(self.run_loss), _ptr(self.run_digits), _ptr(self._loss_item), B, N, Cc, w, Z)
@@ -568,10 +625,10 @@ class AIRModel:
         bwd = []
         lit = self._literal
         wb = H.WriteBwd(_ptr(self.d_recon), _ptr(self.vrec), _ptr(self.att), _ptr(self.d_genpre),
-                        _ptr(self.d_sxyw), B, N, Cc, w, lit, None, None, None, None)
+                        _ptr(self.d_sxyw), B, N, Cc, w, lit, None, None, None, None, _ptr(self.d_genpre16))
         wbf = H.WriteBwd(_ptr(self.d_recon), _ptr(self.vrec), _ptr(self.att), _ptr(self.d_genpre),
                          _ptr(self.d_sxyw), B, N, Cc, w, lit, _ptr(self._loss_item), _ptr(self.target_num_digits),
-                         _ptr(self.run_digits), _ptr(self.scalars))
+                         _ptr(self.run_digits), _ptr(self.scalars), _ptr(self.d_genpre16))
         keep += [wb, wbf]
         kbuf = C.create_string_buffer(96)
         H.check(self.lib.air_write_bwd_kernel_name(C.byref(wb), kbuf, 96), "air_write_bwd_kernel_name")
@@ -579,12 +636,13 @@ class AIRModel:
         self._write_bwd_fin = self._call("air_write_bwd", C.byref(wbf), nbytes=NB * ((D + 2 * d) * 4 + 32), tag="write_bwd")
         bwd[-1].kernel = self._write_bwd_fin.kernel = kbuf.value.decode()
         # decoder data-grads over all N*B rows: dX = dY . W^T, times softplus'(saved activation)
-        dy, n_out, wname = self.d_genpre, d, "out_w"
+        dy, dy16, n_out, wname = self.d_genpre, self.d_genpre16, d, "out_w"
         for i in reversed(range(len(gen_u))):
             u = gen_u[i]
             bwd.append(self._gemm(dy, P[wname], self.d_gen[i], NB, u, n_out, n_out, n_out, u, tb=1,
-                                  aux=self.gen_act[i], ldaux=u, actgrad=H.GRAD_SOFTPLUS, tag="dgrad_gen"))
-            dy, n_out, wname = self.d_gen[i], u, "gen%d_w" % i
+                                  aux=self.gen_act[i], ldaux=u, actgrad=H.GRAD_SOFTPLUS, tag="dgrad_gen",
+                                  A16=dy16, B16=T(wname), C16=self.d_gen16[i]))
+            dy, dy16, n_out, wname = self.d_gen[i], self.d_gen16[i], u, "gen%d_w" % i
         fuse_b = (self._prec == 1 and not nofuse and len(gen_u) >= 1 and len(rec_u) >= 1 and gen_u[0] == 256
                   and Z <= 64 and Z % 2 == 0)
         last_rec = len(rec_u)
@@ -592,27 +650,30 @@ class AIRModel:
             # d_gen[0] -> d_z -> (d_mean | d_lv) -> d_rec[last] in ONE launch (vae.py:22-24 and the KL, backwards)
             bb = H.BottleneckBwd(_ptr(dy), _ptr(P["gen0_w"]), _ptr(self.ml), _ptr(self.eps_z), _ptr(self.att), _ptr(self.dyn),
                                  _ptr(P["ml_w"]), _ptr(self.rec_act[-1]), _ptr(self.d_ml), _ptr(self.d_rec[-1]),
-                                 NB, rec_u[-1], Z, gen_u[0])
+                                 NB, rec_u[-1], Z, gen_u[0], _ptr(self.d_ml16), _ptr(self.d_rec16[-1]))
             keep.append(bb)
             bwd.append(self._call("air_vae_bottleneck_bwd", C.byref(bb),
                                   nbytes=4 * (NB * (gen_u[0] + 5 * Z + 2 * rec_u[-1]) + Z * gen_u[0] + rec_u[-1] * 2 * Z),
                                   flops=2 * NB * (gen_u[0] * Z + 2 * Z * rec_u[-1]), tag="vae_bottleneck_bwd"))
-            dy, n_out, wname, last_rec = self.d_rec[-1], rec_u[-1], "rec%d_w" % (len(rec_u) - 1), len(rec_u) - 1
+            dy, dy16, n_out, wname, last_rec = (self.d_rec[-1], self.d_rec16[-1], rec_u[-1], "rec%d_w" % (len(rec_u) - 1),
+                                                len(rec_u) - 1)
         else:
             bwd.append(self._gemm(dy, P[wname], self.d_ml, NB, Z, n_out, n_out, n_out, 2 * Z, tb=1,
                                   epi=H.EPI_REPARAM_BWD, p=(self.ml, self.eps_z, self.att, self.dyn),
-                                  extra_bytes=16 * NB * Z, tag="dz_reparam"))
-            dy, n_out, wname = self.d_ml, 2 * Z, "ml_w"
+                                  extra_bytes=16 * NB * Z, tag="dz_reparam", C16=self.d_ml16))
+            dy, dy16, n_out, wname = self.d_ml, self.d_ml16, 2 * Z, "ml_w"
         for i in reversed(range(last_rec)):
             u = rec_u[i]
             bwd.append(self._gemm(dy, P[wname], self.d_rec[i], NB, u, n_out, n_out, n_out, u, tb=1,
-                                  aux=self.rec_act[i], ldaux=u, actgrad=H.GRAD_SOFTPLUS, tag="dgrad_rec"))
-            dy, n_out, wname = self.d_rec[i], u, "rec%d_w" % i
-        bwd.append(self._gemm(dy, P[wname], self.d_window, NB, d, n_out, n_out, n_out, d, tb=1, tag="dgrad_win"))
+                                  aux=self.rec_act[i], ldaux=u, actgrad=H.GRAD_SOFTPLUS, tag="dgrad_rec",
+                                  A16=dy16, B16=T(wname), C16=self.d_rec16[i]))
+            dy, dy16, n_out, wname = self.d_rec[i], self.d_rec16[i], u, "rec%d_w" % i
+        bwd.append(self._gemm(dy, P[wname], self.d_window, NB, d, n_out, n_out, n_out, d, tb=1, tag="dgrad_win",
+                              A16=dy16, B16=T(wname)))
         ab = H.AttendBwd(_ptr(self.hid), _ptr(P["wout"]), _ptr(imgs), _ptr(self.eps_scale),
                          _ptr(self.eps_shift), _ptr(self.dyn), _ptr(self.out7), _ptr(self.att),
                          _ptr(self.d_window), _ptr(self.d_sxyw), _ptr(self.d_hid), _ptr(self.d_out7),
-                         B, N, Cc, w, Hs, Hh, Hz, Hmax, lit)
+                         B, N, Cc, w, Hs, Hh, Hz, Hmax, lit, _ptr(self.d_hid16))
         keep.append(ab)
         bwd.append(self._call("air_attend_bwd", C.byref(ab), nbytes=NB * ((D + d + 2 * HT) * 4 + 64), tag="attend_bwd"))
         # heads' contribution to d loss / d h'[t] for every step
@@ -622,7 +683,8 @@ class AIRModel:
                               epi=H.EPI_LSTM_BWD_TAIL, i0=tl * B,
                               p=(self.acts[tl], self.c[tl], self.c[tl + 1]),
                               q=(self.dgates[tl], self.dc[tl % 2], self.dgsum),
-                              extra_bytes=4 * B * R * 15, tag="dh_heads"))
+                              extra_bytes=4 * B * R * 15, tag="dh_heads", A16=self.d_hid16, B16=T("whid"),
+                              q0_16=o16(self.dgates16, tl), q2_16=(self.dgsum16 if N == 1 else None)))
         # back-propagation through time: the only sequential part of the backward
         for t in reversed(range(N)):
             last = (t == N - 1)
@@ -635,7 +697,9 @@ class AIRModel:
                                       addend=self.dh_heads[t], ldadd=R, epi=H.EPI_LSTM_BWD,
                                       p=(self.acts[t], self.c[t], self.c[t + 1], dc_nxt),
                                       q=(self.dgates[t], dc_cur, self.dgsum), i0=1,
-                                      extra_bytes=4 * B * R * 15, tag="bptt_lstm_bwd"))
+                                      extra_bytes=4 * B * R * 15, tag="bptt_lstm_bwd",
+                                      A16=o16(self.dgates16, t + 1), B16=Wh16, q0_16=o16(self.dgates16, t),
+                                      q2_16=(self.dgsum16 if t == 0 else None)))
         self._bwd = bwd
 
         # weight + bias grads of all variables: ONE grouped launch (weights are shared across the
@@ -722,7 +786,13 @@ class AIRModel:
             self.dyn[_ANNEALABLE[k]] = float(v)
         self._dirty = True
 
+    def _fresh_shadow(self):
+        """bf16 shadow of the variables, re-derived (outside any captured graph) after a host-side change"""
+        if self._twins and self.store.shadow_stale:
+            self.store.refresh_shadow(self._stream())
+
     def _run_forward(self, s, finalize=True):
+        self._fresh_shadow()
         if self._injected_noise or os.environ.get("AIR_SEPARATE_STEP_BEGIN") == "1":
             (self._begin_sched_only if self._injected_noise else self._begin)(s)
             for op in self._fwd:
@@ -736,6 +806,7 @@ class AIRModel:
 
     def forward(self):
         """Evaluates the model on the current contents of the input buffers."""
+        self._fresh_shadow()
         if self._graph is not None and not self.train and not self._injected_noise:
             self._graph[0].replay()
         else:
@@ -759,6 +830,7 @@ class AIRModel:
             for buf in (st.params, st.m, st.v, st.istate):
                 torch.distributed.broadcast(buf, src)
         self.store.synced_world = world
+        self.store.touch()
         self._dirty = True
 
     def _optimizer_ops(self):
@@ -776,7 +848,8 @@ class AIRModel:
             else:
                 adam = self._call("air_adam_clip_step", _ptr(st.params), _ptr(st.grads), _ptr(st.m), _ptr(st.v),
                                   st.n, _ptr(st.partials), npart, _ptr(self.dyn), _ptr(st.istate), 1.0 / world,
-                                  0.9, 0.999, 1e-8, None, _ptr(st.gnorm), nbytes=28 * st.n, tag="adam_clip")
+                                  0.9, 0.999, 1e-8, _ptr(st.params16) if self._twins else None, _ptr(st.gnorm),
+                                  nbytes=(30 if self._twins else 28) * st.n, tag="adam_clip")
             # data parallel: the norm is that of the all-reduced gradient -> separate pass after the collective
             self._opt = [adam] if fused else [self._sqnorm, adam]
             self._opt_world = world
@@ -822,6 +895,7 @@ class AIRModel:
         world = self._world()
         if self.store.synced_world != world:
             self.sync_parameters()
+        self._fresh_shadow()
         if steps < 1 or (steps > 1 and world > 1):
             raise ValueError("multi-step graphs need world_size 1")
         self._graph_steps = steps
@@ -852,6 +926,7 @@ class AIRModel:
         return self
 
     def _capture_forward_graph(self):
+        self._fresh_shadow()
         """train=False models (the demo / evaluation call, demo/model_wrapper.py:19-30): the whole
         forward -- schedules + noise, hoisted x.Wx, N x (LSTM, heads, read, VAE), compose, batch means --
         as ONE hipGraph; forward() then is a single replay."""
@@ -882,6 +957,7 @@ class AIRModel:
         world = self._world()
         if self.store.synced_world != world:
             self.sync_parameters()
+        self._fresh_shadow()
         if self._graph is not None and not eager:
             ga, gb = self._graph
             ga.replay()
@@ -978,6 +1054,7 @@ class AIRModel:
                 st.adam_v[k].copy_(torch.from_numpy(np.asarray(sd[k + "/Adam_1"], np.float32)).reshape(v.shape))
         if "global_step" in sd:
             st.istate[H.IST_GLOBAL_STEP] = int(sd["global_step"])
+        st.touch()
         self._dirty = True
         return self
 

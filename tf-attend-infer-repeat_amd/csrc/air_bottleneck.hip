@@ -13,6 +13,7 @@
 // Operand images in LDS are [row or column][k] bf16 with a row stride of K + 8 elements: consecutive rows
 // shift by 16 bytes, so the 16-lane ds_read_b128 fragment groups are bank-conflict free without a swizzle.
 #include "air_common.h"
+#include <atomic>
 
 namespace {
 
@@ -48,6 +49,7 @@ struct FwdArgs {
     const float* X; const float* Wml; const float* bml; const float* eps; const float* Wg; const float* bg;
     float* ml; float* z; float* g;
     int M, Z, H, ldx;
+    unsigned short* z16; unsigned short* g16;      // bf16 twins of z / g (nullable)
 };
 
 // K1 = width of X (the last recognition layer), compile-time
@@ -162,6 +164,7 @@ __global__ __launch_bounds__(THREADS) void bottleneck_fwd_kernel(FwdArgs a)
             a.ml[(size_t)m * Z2 + u] = mean;
             a.ml[(size_t)m * Z2 + Z + u] = lv;
             a.z[(size_t)m * Z + u] = zz;
+            if (a.z16) a.z16[(size_t)m * Z + u] = bf16_of(zz);
         }
         A2[row * L2 + u] = (uok && m < M) ? bf16_of(zz) : (unsigned short)0;
     }
@@ -175,7 +178,11 @@ __global__ __launch_bounds__(THREADS) void bottleneck_fwd_kernel(FwdArgs a)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int m = m0 + (lane >> 4) * 4 + q;
-        if (m < M && n < H) a.g[(size_t)m * H + n] = air_softplus(ag[q] + b_g);
+        if (m < M && n < H) {
+            const float gv = air_softplus(ag[q] + b_g);
+            a.g[(size_t)m * H + n] = gv;
+            if (a.g16) a.g16[(size_t)m * H + n] = bf16_of(gv);
+        }
     }
 }
 
@@ -184,6 +191,7 @@ struct BwdArgs {
     const float* Wml; const float* x;
     float* d_ml; float* d_x;
     int M, Z, K1;
+    unsigned short* d_ml16; unsigned short* d_x16; // bf16 twins of d_ml / d_x (nullable)
 };
 
 // H = width of dG (the first generative layer), compile-time
@@ -290,7 +298,10 @@ __global__ __launch_bounds__(THREADS) void bottleneck_bwd_kernel(BwdArgs a)
         const float dmean = d + klg * (e_mean[q] - pm) / pv;
         const float dlv = d * e_eps[q] * 0.5f * sd + klg * 0.5f * (var / pv - 1.0f);
         if (uok && m < M) {
-            if (blockIdx.y == 0) { a.d_ml[(size_t)m * Z2 + u] = dmean; a.d_ml[(size_t)m * Z2 + Z + u] = dlv; }
+            if (blockIdx.y == 0) {
+                a.d_ml[(size_t)m * Z2 + u] = dmean; a.d_ml[(size_t)m * Z2 + Z + u] = dlv;
+                if (a.d_ml16) { a.d_ml16[(size_t)m * Z2 + u] = bf16_of(dmean); a.d_ml16[(size_t)m * Z2 + Z + u] = bf16_of(dlv); }
+            }
             A2[row * L2 + u] = bf16_of(dmean);
             A2[row * L2 + Z + u] = bf16_of(dlv);
         }
@@ -305,18 +316,33 @@ __global__ __launch_bounds__(THREADS) void bottleneck_bwd_kernel(BwdArgs a)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int m = m0 + (lane >> 4) * 4 + q;
-        if (m < M && jn < K1) a.d_x[(size_t)m * K1 + jn] = ax[q] * (1.0f - expf(-e_x[q]));
+        if (m < M && jn < K1) {
+            const float dxv = ax[q] * (1.0f - expf(-e_x[q]));
+            a.d_x[(size_t)m * K1 + jn] = dxv;
+            if (a.d_x16) a.d_x16[(size_t)m * K1 + jn] = bf16_of(dxv);
+        }
     }
 }
 
+// opt-in to > 48 KB of dynamic LDS once per (kernel function, device); hipFuncSetAttribute is a host-side driver
+// call and must not sit on every launch (in particular not inside stream capture)
 template <typename K>
 int grant_lds(K kernel, size_t bytes) {
-    static bool granted = false;                 // one flag per kernel instantiation
+    struct Slot { std::atomic<const void*> fn; std::atomic<int> dev; };
+    static Slot granted[16];
     if (bytes > 160 * 1024) return AIR_ELIMIT;
-    if (granted) return 0;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const void* fn = reinterpret_cast<const void*>(kernel);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    int free_slot = -1;
+    for (int i = 0; i < 16; ++i) {
+        const void* g = granted[i].fn.load(std::memory_order_acquire);
+        if (g == fn && granted[i].dev.load(std::memory_order_relaxed) == dev) return 0;
+        if (!g && free_slot < 0) free_slot = i;
+    }
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
-    granted = true;
+    if (free_slot >= 0) { granted[free_slot].dev.store(dev, std::memory_order_relaxed); granted[free_slot].fn.store(fn, std::memory_order_release); }
     return 0;
 }
 
@@ -333,7 +359,7 @@ extern "C" int air_vae_bottleneck_fwd(const air_bottleneck_fwd_t* a, void* strea
     const size_t lds = sizeof(unsigned short) * ((16 + 128) * (K1 + PAD) + (16 + 64) * (64 + PAD));
     const int rc = grant_lds(bottleneck_fwd_kernel<K1>, lds);
     if (rc) return rc;
-    FwdArgs k{a->X, a->Wml, a->bml, a->eps, a->Wg, a->bg, a->ml, a->z, a->g, a->M, a->Z, a->H, a->ldx};
+    FwdArgs k{a->X, a->Wml, a->bml, a->eps, a->Wg, a->bg, a->ml, a->z, a->g, a->M, a->Z, a->H, a->ldx, a->z16, a->g16};
     hipLaunchKernelGGL(bottleneck_fwd_kernel<K1>, dim3((a->M + 15) / 16, (a->H + 63) / 64), dim3(THREADS), lds, air_stream(stream), k);
     AIR_CHECK_LAUNCH();
     return 0;
@@ -348,7 +374,7 @@ extern "C" int air_vae_bottleneck_bwd(const air_bottleneck_bwd_t* a, void* strea
     const size_t lds = sizeof(unsigned short) * ((16 + 64) * (H + PAD) + (16 + 64) * (128 + PAD));
     const int rc = grant_lds(bottleneck_bwd_kernel<H>, lds);
     if (rc) return rc;
-    BwdArgs k{a->dG, a->Wg, a->ml, a->eps, a->att, a->dyn, a->Wml, a->x, a->d_ml, a->d_x, a->M, a->Z, a->K1};
+    BwdArgs k{a->dG, a->Wg, a->ml, a->eps, a->att, a->dyn, a->Wml, a->x, a->d_ml, a->d_x, a->M, a->Z, a->K1, a->d_ml16, a->d_x16};
     hipLaunchKernelGGL(bottleneck_bwd_kernel<H>, dim3((a->M + 15) / 16, (a->K1 + 63) / 64), dim3(THREADS), lds, air_stream(stream), k);
     AIR_CHECK_LAUNCH();
     return 0;

@@ -31,6 +31,16 @@ __device__ __forceinline__ float air_softplus(float x) {
     return logf(expf(x) + 1.0f);
 }
 
+// two fp32 -> packed bf16 pair / one value, round to nearest even (v_cvt_pk_bf16_f32): the rounding every
+// bf16-operand kernel applies, so a twin written by a producer is what its consumer would have made itself
+typedef __bf16 air_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float air_f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned air_pack_bf16(float lo, float hi) {
+    const air_f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, air_bf16x2_t));
+}
+__device__ __forceinline__ unsigned short air_bf16_of(float v) { return (unsigned short)(air_pack_bf16(v, 0.0f) & 0xffffu); }
+
 // wave64 butterfly sum: every lane ends with the total
 __device__ __forceinline__ float air_wave_sum(float v) {
 #pragma unroll

@@ -1,0 +1,356 @@
+// bf16-TWIN operand GEMM (precision 1 when the caller supplies bf16 twins of the operands).
+//
+// The fp32-operand kernel of air_gemm.hip (gemm_bf16v2_kernel) rounds both operand panels to bf16 on
+// their way into LDS: every workgroup pulls 4-byte elements through its CU's L1 and spends most of its
+// VALU instructions on v_cvt_pk_bf16_f32 and on transposing row-major weights into k-contiguous
+// fragments.  Here the operands ARE bf16 in memory -- the producing epilogue / the Adam step wrote an
+// RNE-rounded twin next to every fp32 array (air_gemm_t.A16 / B16) -- so
+//   * a k-contiguous operand (activations; weights of a data-gradient GEMM, transB) is copied
+//     global -> VGPR -> LDS in 16-byte pieces of 8 k, one ds_write_b128 into the same XOR-swizzled
+//     [row][64 k] image the fp32-operand kernel builds: half the bytes, half the load instructions,
+//     no conversion;
+//   * an n-contiguous operand (row-major [K,N] weights of a forward GEMM) is copied AS IT LIES into a
+//     [64 k][BN] image (lane-linear 16-byte stores, conflict free) and its MFMA fragments are read
+//     with gfx950's transpose read ds_read_b64_tr_b16: each 16-lane group fetches a [4 k][16 n] block
+//     and every lane receives the 4 k of its own column (semantics and bank behaviour measured in
+//     tools/exp/tr_read.hip) -- two of them give the 8 consecutive k v_mfma_f32_16x16x32_bf16 wants.
+//     No VALU instruction touches the operand;
+//   * the number of 64-deep images per round R is a template parameter picked from K, so a K = 256
+//     product does not issue (masked) loads for images it does not have, and K <= 1024 is ONE round.
+// The rounding is the RNE the other kernel applies on the way into LDS, accumulation order over k,
+// cross-wave reduction and epilogues are shared code (air_gemm_common.h): results are bit-identical to
+// the fp32-operand bf16 path (tests/test_gpu_kernels.py::test_gemm_bf16_twins_bit_identical).
+// A may stay fp32 (AF32: the hoisted x.Wx reads the caller's fp32 image batch).
+#include "air_gemm_common.h"
+#include <atomic>
+#include <cstdlib>
+#include <cstdio>
+
+using namespace airg;
+
+namespace {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint4 ldg16u(const char* base, unsigned off, bool ok) {
+    const uint4 t = *reinterpret_cast<const uint4*>(base + (ok ? off : 0u));
+    return ok ? t : make_uint4(0u, 0u, 0u, 0u);
+}
+__device__ __forceinline__ float4 ldg16f(const char* base, unsigned off, bool ok) {
+    const float4 t = *reinterpret_cast<const float4*>(base + (ok ? off : 0u));
+    return ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+template <int TM, int TN, int R>
+struct TwCfg {
+    static constexpr int BM = 16 * TM, BN = 16 * TN, KB = 64;
+    static constexpr int IMG = (BM + BN) * KB * 2;                       // bytes per image pair
+    static constexpr int RED = 3 * TM * TN * 4 * 64 * 4;                 // bytes of the cross-wave reduction
+    static constexpr int BYTES = (R * IMG > RED) ? R * IMG : RED;
+};
+
+template <int TM, int TN, bool TB, int EPI_, bool AF32, int R>
+__global__ __launch_bounds__(THREADS) void gemm_bf16tw_kernel(Args a)
+{
+    using Cfg = TwCfg<TM, TN, R>;
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, KB = Cfg::KB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char Lds[];   // Cfg::BYTES
+    unsigned short* ImgA = reinterpret_cast<unsigned short*>(Lds);       // [R][BM][64], 16-byte slots swizzled by row
+    unsigned short* ImgB = ImgA + R * BM * KB;                           // TB: [R][BN][64] swizzled; else [R][64][BN]
+    float* Red = reinterpret_cast<float*>(Lds);
+
+    if ((int)blockIdx.z < a.job_on) {                    // block-uniform: the prologue's planes of workgroups (dispatched first)
+        const long plane = (long)gridDim.x * gridDim.y;
+        air_step_job_run(a.job, blockIdx.z * plane + (long)blockIdx.y * gridDim.x + blockIdx.x, plane * a.job_on);
+        return;
+    }
+    const int nslab = (int)gridDim.z - a.job_on;
+    const int zslab = (int)blockIdx.z - a.job_on;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int tile_m, tile_n;
+    xcd_tile(tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN / TN * (a.gstride == 16 ? TN : 1);
+    const int kbeg = zslab * a.kslab;
+    const int kend = min(a.K, kbeg + a.kslab);
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    Pre<TM, TN> pre;
+
+    const char* Ab = AF32 ? reinterpret_cast<const char*>(a.A) : reinterpret_cast<const char*>(a.A16);
+    const char* Bb = reinterpret_cast<const char*>(a.B16);
+    // tasks of one round, 16 bytes each.  k-contiguous bf16 operand: (image, row, slot g of 8 k) -- eight
+    // consecutive lanes read one whole 128-byte row of an image.  fp32 A: (image, row, 4 k), rounded on the
+    // way into LDS as the fp32-operand kernel does.  n-contiguous B: (image, k, 8 columns).
+    constexpr int TA_N = AF32 ? (R * BM * 16 + THREADS - 1) / THREADS : (R * BM * 8 + THREADS - 1) / THREADS;
+    constexpr int TBK_N = (R * BN * 8 + THREADS - 1) / THREADS;
+    constexpr int TBN_N = (R * KB * (BN / 8) + THREADS - 1) / THREADS;
+    uint4 va[AF32 ? 1 : TA_N];
+    float4 vaf[AF32 ? TA_N : 1];
+    uint4 vb[TB ? TBK_N : TBN_N];
+
+    auto issue_loads = [&](int kr) __attribute__((always_inline)) {
+        if (AF32) {
+#pragma unroll
+            for (int i = 0; i < TA_N; ++i) {
+                const int u = tid + THREADS * i;
+                const int c = u / (BM * 16), row = (u / 16) % BM, hh = u & 15;
+                const int gm = m0 + row, gk = kr + c * KB + hh * 4;
+                const bool ok = (u < R * BM * 16) && gm < a.M && gk < kend;
+                vaf[i] = ldg16f(Ab, ((unsigned)gm * (unsigned)a.lda + (unsigned)gk) * 4u, ok);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TA_N; ++i) {
+                const int u = tid + THREADS * i;
+                const int c = u / (BM * 8), row = (u / 8) % BM, g = u & 7;
+                const int gm = m0 + row, gk = kr + c * KB + g * 8;
+                const bool ok = (u < R * BM * 8) && gm < a.M && gk < kend;
+                va[i] = ldg16u(Ab, ((unsigned)gm * (unsigned)a.lda + (unsigned)gk) * 2u, ok);
+            }
+        }
+        if (TB) {
+#pragma unroll
+            for (int i = 0; i < TBK_N; ++i) {
+                const int u = tid + THREADS * i;
+                const int c = u / (BN * 8), col = (u / 8) % BN, g = u & 7;
+                const int j = col >> 4, cc = col & 15;
+                const int gn = n0 + j * a.gstride + cc, cg = n0 + cc + (a.gstride == 16 ? j * 16 : 0);
+                const int gk = kr + c * KB + g * 8;
+                const bool ok = (u < R * BN * 8) && cg < a.gwidth && gn < a.N && gk < kend;
+                vb[i] = ldg16u(Bb, ((unsigned)gn * (unsigned)a.ldb + (unsigned)gk) * 2u, ok);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TBN_N; ++i) {
+                const int t = tid + THREADS * i;
+                const int c = t / (KB * (BN / 8)), k = (t / (BN / 8)) % KB, h = t % (BN / 8);
+                const int col = h * 8, j = col >> 4, cc = col & 15;
+                const int gn = n0 + j * a.gstride + cc, cg = n0 + cc + (a.gstride == 16 ? j * 16 : 0);
+                const int gk = kr + c * KB + k;
+                const bool ok = (t < R * KB * (BN / 8)) && cg < a.gwidth && gn < a.N && gk < kend;
+                vb[i] = ldg16u(Bb, ((unsigned)gk * (unsigned)a.ldb + (unsigned)gn) * 2u, ok);
+            }
+        }
+    };
+
+    issue_loads(kbeg);
+    // the epilogue's operands ride behind the first round's panels (same memory round trip)
+    if (nslab == 1) epilogue_prefetch<TM, TN, EPI_>(a, pre, m0, n0, lane, wave);
+    for (int kr = kbeg; kr < kend; kr += R * KB) {
+        if (kr > kbeg) __syncthreads();                                   // images of the previous round consumed
+        if (AF32) {
+#pragma unroll
+            for (int i = 0; i < TA_N; ++i) {
+                const int u = tid + THREADS * i;
+                const int c = u / (BM * 16), row = (u / 16) % BM, hh = u & 15;
+                uint2 w;
+                w.x = pack_bf16(vaf[i].x, vaf[i].y); w.y = pack_bf16(vaf[i].z, vaf[i].w);
+                if (u < R * BM * 16)
+                    *reinterpret_cast<uint2*>(&ImgA[(c * BM + row) * KB + (((hh >> 1) ^ (row & 7)) << 3) + (hh & 1) * 4]) = w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TA_N; ++i) {
+                const int u = tid + THREADS * i;
+                const int c = u / (BM * 8), row = (u / 8) % BM, g = u & 7;
+                if (u < R * BM * 8) *reinterpret_cast<uint4*>(&ImgA[(c * BM + row) * KB + ((g ^ (row & 7)) << 3)]) = va[i];
+            }
+        }
+        if (TB) {
+#pragma unroll
+            for (int i = 0; i < TBK_N; ++i) {
+                const int u = tid + THREADS * i;
+                const int c = u / (BN * 8), col = (u / 8) % BN, g = u & 7;
+                if (u < R * BN * 8) *reinterpret_cast<uint4*>(&ImgB[(c * BN + col) * KB + ((g ^ (col & 7)) << 3)]) = vb[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TBN_N; ++i) {
+                const int t = tid + THREADS * i;
+                if (t < R * KB * (BN / 8)) *reinterpret_cast<uint4*>(&ImgB[t * 8]) = vb[i];      // [c][k][BN]: lane-linear
+            }
+        }
+        if (kr + R * KB < kend) issue_loads(kr + R * KB);
+        __syncthreads();
+        // ---- MFMAs: wave w owns the images whose index within the slab is w (mod 4), whatever R is
+        const int cfirst = (wave - ((kr - kbeg) / KB)) & 3;
+#pragma unroll
+        for (int cc = 0; cc < (R + 3) / 4; ++cc) {
+            const int c = cfirst + 4 * cc;
+            if (c < R && kr + c * KB < kend) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int slot = ks * 4 + (lane >> 4);
+                    bf16x8 av[TM], bv[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const int row = i * 16 + (lane & 15);
+                        av[i] = *reinterpret_cast<const bf16x8*>(&ImgA[(c * BM + row) * KB + ((slot ^ (row & 7)) << 3)]);
+                    }
+                    if (TB) {
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            const int col = j * 16 + (lane & 15);
+                            bv[j] = *reinterpret_cast<const bf16x8*>(&ImgB[(c * BN + col) * KB + ((slot ^ (col & 7)) << 3)]);
+                        }
+                    } else {
+                        // transpose read: lane i of a 16-lane group hands in the address of row 8g + i/4 (+4),
+                        // column quad i%4 of the [k][16] block; it receives k = 8g .. 8g+3 (+4) of column i
+                        const int il = lane & 15;
+                        const unsigned short* blk = &ImgB[(c * KB + ks * 32 + (lane >> 4) * 8 + (il >> 2)) * BN + (il & 3) * 4];
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+                            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(blk + j * 16));
+                            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(blk + j * 16 + 4 * BN));
+                            bv[j] = bf16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+    }
+    __syncthreads();                                                      // Red aliases the images
+    reduce_waves<TM, TN>(acc, Red, lane, wave);
+    if (nslab > 1) {
+        float* Cz = a.C + (size_t)zslab * a.slab_stride;
+        for (int t = wave; t < TM * TN; t += 4) {
+            const int i = t / TN, j = t % TN;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = m0 + i * 16 + (lane >> 4) * 4 + q;
+                const int n = n0 + j * 16 + (lane & 15);
+                if (m < a.M && n < a.N) Cz[(size_t)m * a.ldc + n] = Red[(t * 4 + q) * 64 + lane];
+            }
+        }
+        return;
+    }
+    epilogue<TM, TN, EPI_>(a, pre, Red, m0, n0, lane, wave);
+}
+
+// opt-in to > 48 KB of dynamic LDS once per (kernel function, device)
+int grant_lds(const void* fn, int bytes) {
+    if (bytes <= 48 * 1024) return 0;
+    struct Slot { std::atomic<const void*> fn; std::atomic<int> dev; };
+    static Slot granted[128];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    int free_slot = -1;
+    for (int i = 0; i < 128; ++i) {
+        const void* g = granted[i].fn.load(std::memory_order_acquire);
+        if (g == fn && granted[i].dev.load(std::memory_order_relaxed) == dev) return 0;
+        if (!g && free_slot < 0) free_slot = i;
+    }
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    if (free_slot >= 0) { granted[free_slot].dev.store(dev, std::memory_order_relaxed); granted[free_slot].fn.store(fn, std::memory_order_release); }
+    return 0;
+}
+
+template <int TM, int TN, bool TB, int EPI_, bool AF32, int R>
+int launch_one(const Args& a, dim3 grid, hipStream_t s) {
+    using Cfg = TwCfg<TM, TN, R>;
+    auto kern = gemm_bf16tw_kernel<TM, TN, TB, EPI_, AF32, R>;
+    const int rc = grant_lds(reinterpret_cast<const void*>(kern), Cfg::BYTES);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, grid, dim3(THREADS), Cfg::BYTES, s, a);
+    AIR_CHECK_LAUNCH();
+    return 0;
+}
+
+int images_of(const Args& a) { return (a.kslab + 63) / 64; }
+
+}  // namespace
+
+namespace airg {
+
+// Which (tile, epilogue, layout) combinations exist as twin kernels, and with how many images per round.
+// Returns R (> 0) or 0 when this descriptor has to take the fp32-operand kernels.
+int twin_rounds(const Args& a, int tm, int tn, bool ta, bool tb) {
+    if (ta || !a.B16 || getenv("AIR_GEMM_NO_TWINS") != nullptr) return 0;
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const bool af32 = a.A16 == nullptr;
+    // whole 16-byte pieces only: the ragged shapes keep the fp32-operand kernels
+    if (af32) { if (!al16(a.A) || (a.lda & 3) || (a.K & 3) || (a.kslab & 3)) return 0; }
+    else if (!al16(a.A16) || (a.lda & 7) || (a.K & 7) || (a.kslab & 7)) return 0;
+    if (!al16(a.B16) || (a.ldb & 7)) return 0;
+    if (tb) { if ((a.K & 7) || (a.kslab & 7)) return 0; }
+    else if ((a.N & 7) || (a.gstride & 7) || (a.gwidth & 7)) return 0;
+    const int nimg = images_of(a);
+    const int e = a.epi;
+    if (tm == 1 && tn == 1) {
+        if (af32) return 0;
+        if (e == AIR_EPI_GENERIC || ((e == AIR_EPI_LSTM_BWD || e == AIR_EPI_LSTM_BWD_TAIL) && tb)) return nimg <= 4 ? 4 : (nimg <= 8 ? 8 : 16);
+        return 0;
+    }
+    if (tm == 1 && tn == 4) return (!af32 && !tb && e == AIR_EPI_LSTM_FWD) ? 4 : 0;
+    if (tm == 2 && tn == 2) return e == AIR_EPI_GENERIC ? (af32 ? (tb ? 0 : 8) : (nimg <= 4 ? 4 : 8)) : 0;
+    if (tm == 4 && tn == 2) return (e == AIR_EPI_GENERIC && !tb) ? 4 : 0;
+    return 0;
+}
+
+int twin_launch(const Args& a, int tm, int tn, bool tb, dim3 grid, hipStream_t s) {
+    const int r = twin_rounds(a, tm, tn, false, tb);
+    const bool af32 = a.A16 == nullptr;
+    const int e = a.epi;
+#define TW(TM_, TN_, TB_, EPI__, AF_, R_) return launch_one<TM_, TN_, TB_, EPI__, AF_, R_>(a, grid, s)
+    if (tm == 1 && tn == 1) {
+        if (e == AIR_EPI_GENERIC) {
+            if (tb) { if (r == 4) TW(1, 1, true, AIR_EPI_GENERIC, false, 4); if (r == 8) TW(1, 1, true, AIR_EPI_GENERIC, false, 8); TW(1, 1, true, AIR_EPI_GENERIC, false, 16); }
+            if (r == 4) TW(1, 1, false, AIR_EPI_GENERIC, false, 4); if (r == 8) TW(1, 1, false, AIR_EPI_GENERIC, false, 8); TW(1, 1, false, AIR_EPI_GENERIC, false, 16);
+        }
+        if (e == AIR_EPI_LSTM_BWD) { if (r == 4) TW(1, 1, true, AIR_EPI_LSTM_BWD, false, 4); if (r == 8) TW(1, 1, true, AIR_EPI_LSTM_BWD, false, 8); TW(1, 1, true, AIR_EPI_LSTM_BWD, false, 16); }
+        if (e == AIR_EPI_LSTM_BWD_TAIL) { if (r == 4) TW(1, 1, true, AIR_EPI_LSTM_BWD_TAIL, false, 4); if (r == 8) TW(1, 1, true, AIR_EPI_LSTM_BWD_TAIL, false, 8); TW(1, 1, true, AIR_EPI_LSTM_BWD_TAIL, false, 16); }
+    }
+    if (tm == 1 && tn == 4) TW(1, 4, false, AIR_EPI_LSTM_FWD, false, 4);
+    if (tm == 2 && tn == 2) {
+        if (af32) TW(2, 2, false, AIR_EPI_GENERIC, true, 8);
+        if (tb) { if (r == 4) TW(2, 2, true, AIR_EPI_GENERIC, false, 4); TW(2, 2, true, AIR_EPI_GENERIC, false, 8); }
+        if (r == 4) TW(2, 2, false, AIR_EPI_GENERIC, false, 4); TW(2, 2, false, AIR_EPI_GENERIC, false, 8);
+    }
+    if (tm == 4 && tn == 2) { if (af32) TW(4, 2, false, AIR_EPI_GENERIC, true, 4); TW(4, 2, false, AIR_EPI_GENERIC, false, 4); }
+#undef TW
+    return AIR_EINVAL;
+}
+
+void twin_kernel_name(const Args& a, int tm, int tn, bool tb, char* buf, int n) {
+    snprintf(buf, n, "gemm_bf16tw_kernel<%d, %d, %s, %d, %s, %d>", tm, tn, tb ? "true" : "false", a.epi,
+             a.A16 == nullptr ? "true" : "false", twin_rounds(a, tm, tn, false, tb));
+}
+
+}  // namespace airg
+
+namespace {
+
+// fp32 -> bf16 (RNE) copy: the twin of an array its producer could not write (variables after a
+// host-side load; Adam keeps the shadow fresh afterwards)
+__global__ __launch_bounds__(256) void bf16_twin_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, long n) {
+    const long n4 = n / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(src)[i];
+        reinterpret_cast<uint2*>(dst)[i] = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - n4 * 4)) dst[n4 * 4 + threadIdx.x] = bf16_of(src[n4 * 4 + threadIdx.x]);
+}
+
+}  // namespace
+
+extern "C" int air_bf16_twin(const float* src, uint16_t* dst, int64_t n, void* stream) {
+    if (!src || !dst || n <= 0) return AIR_EINVAL;
+    if (((reinterpret_cast<uintptr_t>(src) & 15) != 0) || ((reinterpret_cast<uintptr_t>(dst) & 7) != 0)) return AIR_EALIGN;
+    long blocks = (n / 4 + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    hipLaunchKernelGGL(bf16_twin_kernel, dim3((unsigned)blocks), dim3(256), 0, air_stream(stream), src, dst, (long)n);
+    AIR_CHECK_LAUNCH();
+    return 0;
+}

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(THREADS) void lstm_gates_fwd_kernel(
 // summation order of the fused GEMM epilogue (AIR_EPI_LSTM_FWD) with a zero accumulator, bit for bit.
 __global__ __launch_bounds__(THREADS) void lstm_first_step_kernel(
     const float* __restrict__ slabs, int nslabs, long slab_stride, const float* __restrict__ bias,
-    float* __restrict__ acts, float* __restrict__ c, float* __restrict__ h, int B, int R)
+    float* __restrict__ acts, float* __restrict__ c, float* __restrict__ h, unsigned short* __restrict__ h16, int B, int R)
 {
     const int idx = blockIdx.x * THREADS + threadIdx.x;
     if (idx >= B * R) return;
@@ -62,7 +62,9 @@ __global__ __launch_bounds__(THREADS) void lstm_first_step_kernel(
     float* a = acts + (size_t)b * 4 * R;
     a[u] = si; a[R + u] = tj; a[2 * R + u] = sf; a[3 * R + u] = so;
     c[idx] = cn;
-    h[idx] = tanhf(cn) * so;
+    const float hn = tanhf(cn) * so;
+    h[idx] = hn;
+    if (h16) h16[idx] = air_bf16_of(hn);
 }
 
 __global__ __launch_bounds__(THREADS) void lstm_gates_bwd_kernel(
@@ -254,11 +256,11 @@ extern "C" int air_lstm_gates_fwd(const float* gates_pre, const float* c_prev, f
 }
 
 extern "C" int air_lstm_first_step(const float* xw_slabs, int nslabs, const float* bias, float* acts,
-                                   float* c, float* h, int B, int R, void* stream) {
+                                   float* c, float* h, uint16_t* h16, int B, int R, void* stream) {
     if (!xw_slabs || !acts || !c || !h || B <= 0 || R <= 0 || nslabs <= 0) return AIR_EINVAL;
     if (nslabs > 8) return AIR_ELIMIT;
     hipLaunchKernelGGL(lstm_first_step_kernel, dim3((B * R + THREADS - 1) / THREADS), dim3(THREADS), 0,
-                       air_stream(stream), xw_slabs, nslabs, (long)B * 4 * R, bias, acts, c, h, B, R);
+                       air_stream(stream), xw_slabs, nslabs, (long)B * 4 * R, bias, acts, c, h, h16, B, R);
     AIR_CHECK_LAUNCH();
     return 0;
 }

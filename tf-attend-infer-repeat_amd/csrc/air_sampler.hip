@@ -431,11 +431,14 @@ __global__ __launch_bounds__(THREADS) void attend_fwd_kernel(air_attend_fwd_t a)
     }
     AIR_STAMP(14);
     float* win = a.window + row * w * w;
+    unsigned short* win16 = a.window16 ? a.window16 + row * w * w : nullptr;      // bf16 twin: A operand of the first recognition GEMM
     for (int p = tid; p < w * w; p += THREADS) {
         const int i = p / w, j = p % w;
         const Tap tx = sh_tx[j], ty = sh_ty[i];
         const int r0 = (ty.i0 - ylo) * bw - xlo, r1 = (ty.i1 - ylo) * bw - xlo;
-        win[p] = bilinear4(tx, ty, sh_img[r0 + tx.i0], sh_img[r1 + tx.i0], sh_img[r0 + tx.i1], sh_img[r1 + tx.i1]);
+        const float v = bilinear4(tx, ty, sh_img[r0 + tx.i0], sh_img[r1 + tx.i0], sh_img[r0 + tx.i1], sh_img[r1 + tx.i1]);
+        win[p] = v;
+        if (win16) win16[p] = air_bf16_of(v);
     }
     AIR_STAMP(15);
 }
@@ -579,7 +582,9 @@ __global__ __launch_bounds__(THREADS) void attend_bwd_kernel(air_attend_bwd_t a)
         float v = 0.0f;
         for (int o = 0; o < 7; ++o)
             if (kOutHead[o] == h) v += sh_d[o] * a.wout[o * a.wout_ld + jj];
-        a.d_hid[row * HT + j] = (a.hid[row * HT + j] > 0.0f) ? v : 0.0f;
+        const float dv = (a.hid[row * HT + j] > 0.0f) ? v : 0.0f;
+        a.d_hid[row * HT + j] = dv;
+        if (a.d_hid16) a.d_hid16[row * HT + j] = air_bf16_of(dv);
     }
 }
 
@@ -734,9 +739,10 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_kernel(air_write_bwd_t a
     }
     const float* at = a.att + row * AIR_ATT_STRIDE;
     float* dgen = a.d_gen_pre + row * w * w;
+    unsigned short* dgen16 = a.d_gen_pre16 ? a.d_gen_pre16 + row * w * w : nullptr;
     float* dsx = a.d_sxy_write + row * 4;
     if (at[AIR_ATT_MASK] == 0.0f) {                        // where(active, ., 0): no gradient
-        for (int p = tid; p < w * w; p += WB_THREADS) dgen[p] = 0.0f;
+        for (int p = tid; p < w * w; p += WB_THREADS) { dgen[p] = 0.0f; if (dgen16) dgen16[p] = 0; }
         if (tid < 4) dsx[tid] = 0.0f;
         return;
     }
@@ -944,7 +950,9 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_kernel(air_write_bwd_t a
             du = ((sh_S[3 * ss + it] + sh_S[2 * ss + it]) + sh_S[ss + it]) + sh_S[it];
         }
         const float r = sh_win[it];
-        dgen[it] = du * (r * (1.0f - r));
+        const float dgv = du * (r * (1.0f - r));
+        dgen[it] = dgv;
+        if (dgen16) dgen16[it] = air_bf16_of(dgv);
     }
     AIR_STAMP(6);
 }
@@ -1035,9 +1043,10 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
     AIR_STAMP(40);
     const float* at = a.att + row * AIR_ATT_STRIDE;
     float* dgen = a.d_gen_pre + row * w * w;
+    unsigned short* dgen16 = a.d_gen_pre16 ? a.d_gen_pre16 + row * w * w : nullptr;
     float* dsx = a.d_sxy_write + row * 4;
     if (at[AIR_ATT_MASK] == 0.0f) {                        // Select(active, ., 0): no gradient
-        for (int p = tid; p < w * w; p += WB_THREADS) dgen[p] = 0.0f;
+        for (int p = tid; p < w * w; p += WB_THREADS) { dgen[p] = 0.0f; if (dgen16) dgen16[p] = 0; }
         if (tid < 4) dsx[tid] = 0.0f;
         return;
     }
@@ -1229,7 +1238,9 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
         if (lane == 0) { float* r = sh_red + wave * 8; r[0] = d00; r[1] = d02; r[2] = d11; r[3] = d12; r[4] = dz; }
         if (is_slot && !corner) {
             const float r = sh_win[tid];
-            dgen[tid] = (acc * r) * (1.0f - r);              // SigmoidGrad of vae.py:39-41: dy * y * (1 - y)
+            const float dgv = (acc * r) * (1.0f - r);        // SigmoidGrad of vae.py:39-41: dy * y * (1 - y)
+            dgen[tid] = dgv;
+            if (dgen16) dgen16[tid] = air_bf16_of(dgv);
         }
     };
     if (ALLPH) {
@@ -1263,7 +1274,9 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
     AIR_STAMP(45);
     if (corner) {
         const float r = sh_win[tid];
-        dgen[tid] = (sh_acc[(sp ? 2 : 0) + (sq ? 1 : 0)] * r) * (1.0f - r);
+        const float dgv = (sh_acc[(sp ? 2 : 0) + (sq ? 1 : 0)] * r) * (1.0f - r);
+        dgen[tid] = dgv;
+        if (dgen16) dgen16[tid] = air_bf16_of(dgv);
     }
     if (tid < 64) {
         // lanes 0..4 each combine one quantity over the waves; lane 0 collects them by shuffle
