@@ -135,6 +135,7 @@ enum {
 typedef struct {
     const air_schedule_t* sched /*device*/; int32_t nsched; float* dyn; const int32_t* istate;
     float* normals; int64_t n_normal; float* uniforms; int64_t n_uniform; uint64_t seed;
+    const float* twin_src; uint16_t* twin_dst; int64_t twin_n;   /* see air_step_begin */
 } air_step_job_t;
 typedef struct {
     const float* A; const float* B; float* C;
@@ -189,6 +190,10 @@ typedef struct {
     const float* A; const float* dY; float* dW; float* db /*nullable*/;
     int32_t M, N, K, lda, ldb, ldc;
     int32_t head_pack, Hs, Hh, Hz;
+    /* bf16 twins of A / dY (precision 1, nullable, same leading dimensions; see air_gemm_t): a problem that has both
+     * (8-byte aligned, lda/ldb/M/N multiples of 4, not head_pack) reads its operands as bf16 -- bit-identical dW.
+     * db is always summed from the fp32 dY. */
+    const uint16_t* A16; const uint16_t* dY16;
 } air_wgrad_t;
 /* precision: 0 = fp32 MFMA (exact fp32 products), 1 = operands rounded to bf16, fp32 accumulate.
  * sq_partials (nullable): [air_wgrad_num_blocks()] floats receiving the sum of squares of every
@@ -371,10 +376,13 @@ int air_finalize(const float* run_loss, const float* rec_loss, const int32_t* ta
 /* ---- step prologue: annealing schedules + Philox noise ------------------------
  * Evaluates `nsched` schedules at istate[GLOBAL_STEP] into dyn, and fills
  * normals[n_normal] ~ N(0,1), uniforms[n_uniform] ~ U[0,1) from
- * Philox4x32-10(key = seed, counter = (index, global_step + call_salt)). */
+ * Philox4x32-10(key = seed, counter = (index, global_step + call_salt)).  Optionally also writes
+ * twin_dst[i] = bf16(twin_src[i]), i < twin_n: the bf16 twin of the image batch (the caller's fp32 tensor; it has no
+ * producing kernel of ours) that the input-weight gradient reads at the end of the step (air_wgrad_t.A16). */
 int air_step_begin(const air_schedule_t* sched /*device*/, int nsched, float* dyn,
                    const int32_t* istate, float* normals, int64_t n_normal,
-                   float* uniforms, int64_t n_uniform, uint64_t seed, void* stream);
+                   float* uniforms, int64_t n_uniform, uint64_t seed,
+                   const float* twin_src /*nullable*/, uint16_t* twin_dst, int64_t twin_n, void* stream);
 
 /* ---- optimizer (air_model.py:651-694): clip_by_global_norm + TF1.3 ApplyAdam --
  * partials: scratch [>= air_optim_num_partials(n)] floats.

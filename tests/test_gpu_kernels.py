@@ -247,7 +247,7 @@ def test_step_begin_schedule_and_noise(H):
     for step in (0, 3000, 39000):
         ist = torch.tensor([step, 0, 0, 0], dtype=torch.int32, device=dev)
         H.check(H.lib().air_step_begin(_p(sched), 1, _p(dyn), _p(ist), _p(normals), nn, _p(unif), nu,
-                                       C.c_uint64(1234), _stream()))
+                                       C.c_uint64(1234), None, None, 0, _stream()))
         torch.cuda.synchronize()
         ref = ao.annealed_value(ao.TRAINING_ANNEALING["z_pres_prior_log_odds"], step)
         assert abs(float(dyn[H.DYN_PRIOR_LOG_ODDS]) - float(ref)) < 2e-3, (step, float(dyn[0]), ref)
@@ -259,7 +259,7 @@ def test_step_begin_schedule_and_noise(H):
     assert not torch.equal(outs[0], outs[1])         # stream advances with global_step
     ist = torch.tensor([39000, 0, 0, 0], dtype=torch.int32, device=dev)
     H.check(H.lib().air_step_begin(_p(sched), 1, _p(dyn), _p(ist), _p(normals), nn, _p(unif), nu,
-                                   C.c_uint64(1234), _stream()))
+                                   C.c_uint64(1234), None, None, 0, _stream()))
     torch.cuda.synchronize()
     assert torch.equal(normals, outs[2])             # and is reproducible
 
@@ -634,7 +634,7 @@ def test_annealing_schedule_variants_match_oracle(H, sched):
     dyn = torch.zeros(H.DYN_COUNT, device=dev)
     for step in (0, 1, 499, 500, 999, 1000, 2500, 12345, 40000):
         ist = torch.tensor([step, 0, 0, 0], dtype=torch.int32, device=dev)
-        H.check(H.lib().air_step_begin(_p(tab), 1, _p(dyn), _p(ist), None, 0, None, 0, C.c_uint64(0), _stream()))
+        H.check(H.lib().air_step_begin(_p(tab), 1, _p(dyn), _p(ist), None, 0, None, 0, C.c_uint64(0), None, None, 0, _stream()))
         torch.cuda.synchronize()
         ref = float(ao.annealed_value(sched, step))
         got = float(dyn[H.DYN_TEMPERATURE])
@@ -1085,3 +1085,38 @@ def test_gemm_ragged_shapes_keep_the_fp32_operand_kernels(H):
         torch.cuda.synchronize()
         assert np.abs(Ct.cpu().numpy() - _ref_gemm(A.cpu().numpy(), B.cpu().numpy(), 0, tb, 1)).max() / np.sqrt(K) < 2e-5
         assert torch.equal(C16.view(torch.bfloat16), Ct.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("shapes", WGRAD_CASES + [[(256, 1024, 1280), (2500, 1024, 256)]])
+def test_wgrad_grouped_bf16_twins_bit_identical(H, shapes):
+    """air_wgrad_grouped(precision=1) with bf16 twins of A and dY (air_wgrad_t.A16 / dY16) against the same
+    launch without them: dW, db and the global-norm partials BIT-IDENTICAL.  Covers 16-byte rows (ld % 8 == 0),
+    8-byte rows (M = 2500, N = 100), problems whose twins are unusable (M = 50, M = 70, N = 33: ld % 4 != 0 --
+    they silently take the fp32 operands) and several rounds of images (K = 200, 1280)."""
+    dev = "cuda"
+    rng = np.random.RandomState(len(shapes))
+    outs = []
+    ops = []
+    for (M, N, K) in shapes:
+        At = torch.tensor(rng.randn(K, M).astype(np.float32), device=dev)
+        Yt = torch.tensor((rng.randn(K, N) * 10.0 ** rng.randint(-2, 3, (K, 1))).astype(np.float32), device=dev)
+        ops.append((At, Yt, _bf16_twin(H, At), _bf16_twin(H, Yt)))
+    for twins in (False, True):
+        keep, probs = [], []
+        for (M, N, K), (At, Yt, A16, Y16) in zip(shapes, ops):
+            Wt, bt = torch.full((M, N), float("nan"), device=dev), torch.full((N,), float("nan"), device=dev)
+            keep += [Wt, bt]
+            probs.append(H.Wgrad(_p(At), _p(Yt), _p(Wt), _p(bt), M, N, K, M, N, N, 0, 0, 0, 0,
+                                 _p(A16) if twins else None, _p(Y16) if twins else None))
+        arr = (H.Wgrad * len(probs))(*probs)
+        nblk = H.lib().air_wgrad_num_blocks(arr, len(probs))
+        part = torch.full((nblk,), float("nan"), device=dev)
+        ist = torch.zeros(8, dtype=torch.int32, device=dev)
+        H.check(H.lib().air_wgrad_grouped(arr, len(probs), 1, _p(part), _p(ist), _stream()), "air_wgrad_grouped")
+        torch.cuda.synchronize()
+        outs.append(keep + [part])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    for (M, N, K), (At, Yt, _, _), Wt in zip(shapes, ops, outs[1][0::2]):
+        ref = _bf16_round(At.cpu().numpy()).T @ _bf16_round(Yt.cpu().numpy())
+        assert np.abs(Wt.cpu().numpy() - ref).max() <= 1e-5 * np.sqrt(K) * 4 * np.abs(ref).max()

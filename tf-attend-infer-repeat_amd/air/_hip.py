@@ -41,7 +41,7 @@ class Schedule(C.Structure):
 class StepJob(C.Structure):
     _fields_ = [("sched", _p), ("nsched", _i), ("dyn", _p), ("istate", _p),
                 ("normals", _p), ("n_normal", C.c_int64), ("uniforms", _p), ("n_uniform", C.c_int64),
-                ("seed", C.c_uint64)]
+                ("seed", C.c_uint64), ("twin_src", _p), ("twin_dst", _p), ("twin_n", C.c_int64)]
 
 
 class Gemm(C.Structure):
@@ -63,7 +63,7 @@ class Colsum(C.Structure):
 class Wgrad(C.Structure):
     _fields_ = [("A", _p), ("dY", _p), ("dW", _p), ("db", _p),
                 ("M", _i), ("N", _i), ("K", _i), ("lda", _i), ("ldb", _i), ("ldc", _i),
-                ("head_pack", _i), ("Hs", _i), ("Hh", _i), ("Hz", _i)]
+                ("head_pack", _i), ("Hs", _i), ("Hh", _i), ("Hz", _i), ("A16", _p), ("dY16", _p)]
 
 
 class AttendFwd(C.Structure):
@@ -128,7 +128,7 @@ _SIGNATURES = {
     "air_write_bwd": (C.c_int, [C.POINTER(WriteBwd), _p]),
     "air_bce_fwd_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, C.c_int, C.c_int, _p]),
     "air_finalize": (C.c_int, [_p, _p, _p, _p, _p, _p, C.c_int, _p]),
-    "air_step_begin": (C.c_int, [_p, C.c_int, _p, _p, _p, C.c_int64, _p, C.c_int64, C.c_uint64, _p]),
+    "air_step_begin": (C.c_int, [_p, C.c_int, _p, _p, _p, C.c_int64, _p, C.c_int64, C.c_uint64, _p, _p, C.c_int64, _p]),
     "air_optim_num_partials": (C.c_int, [C.c_int64]),
     "air_grad_sqnorm": (C.c_int, [_p, C.c_int64, _p, _p, _p]),
     "air_write_bwd_kernel_name": (C.c_int, [C.POINTER(WriteBwd), C.c_char_p, C.c_int]),

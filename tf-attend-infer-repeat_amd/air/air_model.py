@@ -435,6 +435,7 @@ class AIRModel:
         self.rec_act16 = [h16(N, B, u) for u in self.vae_recognition_units]
         self.zs16 = h16(N, B, Z)
         self.gen_act16 = [h16(N, B, u) for u in self.vae_generative_units]
+        self.images16 = None
         if self.train:
             self.d_genpre16 = h16(N, B, d)
             self.d_gen16 = [h16(N, B, u) for u in self.vae_generative_units]
@@ -443,6 +444,8 @@ class AIRModel:
             self.d_hid16 = h16(N, B, HT)
             self.dgates16 = h16(N, B, 4 * R)
             self.dgsum16 = h16(B, 4 * R)
+            # twin of the image batch (the caller's fp32 tensor): written by the step prologue, read by the input-weight gradient
+            self.images16 = h16(B, D)
         if self.train:
             self.d_recon = f(B, D)
             self.d_genpre = f(N, B, d)
@@ -526,7 +529,8 @@ class AIRModel:
         # hoisted x.W_x (the reference recomputes it every step, :286); split-K slabs
         job = H.StepJob(_ptr(self.sched), self._nsched, _ptr(self.dyn), _ptr(st.istate),
                         _ptr(self.normals), self.normals.numel(), _ptr(self.uniforms), self.uniforms.numel(),
-                        self._seed)
+                        self._seed, _ptr(imgs if self.images16 is not None else None), _ptr(self.images16),
+                        imgs.numel() if self.images16 is not None else 0)
         noise_bytes = 4 * (self.normals.numel() + self.uniforms.numel())
         if self._fuse_step0:
             # the first step rides in the x.Wx launch: h_0 = c_0 = 0 (zero_state, :540), so its gates are x.Wx + b
@@ -611,13 +615,14 @@ class AIRModel:
                                     _ptr(self.target_num_digits), _ptr(self.run_digits), _ptr(self._loss_item),
                                     _ptr(self.scalars), B)
         self._fwd = fwd
+        twin_job = ((_ptr(imgs), _ptr(self.images16), imgs.numel()) if self.images16 is not None else (None, None, 0))
         self._begin = self._call(
             "air_step_begin", _ptr(self.sched), self._nsched, _ptr(self.dyn), _ptr(st.istate),
             _ptr(self.normals), self.normals.numel(), _ptr(self.uniforms), self.uniforms.numel(),
-            C.c_uint64(self._seed))
+            C.c_uint64(self._seed), *twin_job)
         self._begin_sched_only = self._call(
             "air_step_begin", _ptr(self.sched), self._nsched, _ptr(self.dyn), _ptr(st.istate),
-            None, 0, None, 0, C.c_uint64(self._seed))
+            None, 0, None, 0, C.c_uint64(self._seed), *twin_job)
         if not self.train:
             self._bwd, self._opt, self._wgrad_plain = [], [], None
             return
@@ -707,31 +712,31 @@ class AIRModel:
         Gx, Gh = G["lstm_kernel"][:D], G["lstm_kernel"][D:]
         probs = []
 
-        def wg(A, dY, dW, db, M, Nn, K):
-            probs.append(H.Wgrad(_ptr(A), _ptr(dY), _ptr(dW), _ptr(db), M, Nn, K, M, Nn, Nn, 0, 0, 0, 0))
-        wg(self.h[0], self.dgates, Gh, None, R, 4 * R, NB)
-        wg(self.h[1], self.d_hid, G["whid"], G["bhid"], R, HT, NB)
-        x, k = self.window, d
+        def wg(A, dY, dW, db, M, Nn, K, A16=None, dY16=None):
+            probs.append(H.Wgrad(_ptr(A), _ptr(dY), _ptr(dW), _ptr(db), M, Nn, K, M, Nn, Nn, 0, 0, 0, 0, _ptr(A16), _ptr(dY16)))
+        wg(self.h[0], self.dgates, Gh, None, R, 4 * R, NB, o16(self.h16, 0), self.dgates16)
+        wg(self.h[1], self.d_hid, G["whid"], G["bhid"], R, HT, NB, o16(self.h16, 1), self.d_hid16)
+        x, x16, k = self.window, self.window16, d
         for i, u in enumerate(rec_u):
-            wg(x, self.d_rec[i], G["rec%d_w" % i], G["rec%d_b" % i], k, u, NB)
-            x, k = self.rec_act[i], u
-        wg(x, self.d_ml, G["ml_w"], G["ml_b"], k, 2 * Z, NB)
-        x, k = self.zs, Z
+            wg(x, self.d_rec[i], G["rec%d_w" % i], G["rec%d_b" % i], k, u, NB, x16, self.d_rec16[i])
+            x, x16, k = self.rec_act[i], self.rec_act16[i], u
+        wg(x, self.d_ml, G["ml_w"], G["ml_b"], k, 2 * Z, NB, x16, self.d_ml16)
+        x, x16, k = self.zs, self.zs16, Z
         for i, u in enumerate(gen_u):
-            wg(x, self.d_gen[i], G["gen%d_w" % i], G["gen%d_b" % i], k, u, NB)
-            x, k = self.gen_act[i], u
-        wg(x, self.d_genpre, G["out_w"], G["out_b"], k, d, NB)
+            wg(x, self.d_gen[i], G["gen%d_w" % i], G["gen%d_b" % i], k, u, NB, x16, self.d_gen16[i])
+            x, x16, k = self.gen_act[i], self.gen_act16[i], u
+        wg(x, self.d_genpre, G["out_w"], G["out_b"], k, d, NB, x16, self.d_genpre16)
         probs.append(H.Wgrad(_ptr(self.d_out7), _ptr(self.hid), _ptr(G["wout"]), _ptr(G["bout"]),
                              H.OUT_STRIDE, HT, NB, H.OUT_STRIDE, HT, Hmax, 1, Hs, Hh, Hz))
         # the input-weight gradient contracts over B rows only (sum_t dgates): its many light
         # workgroups go LAST so that they fill the tail of the launch behind the K = N*B ones
-        wg(imgs, self.dgsum, Gx, G["lstm_bias"], D, 4 * R, B)
+        wg(imgs, self.dgsum, Gx, G["lstm_bias"], D, 4 * R, B, self.images16, self.dgsum16)
         if len(probs) > 12:
             raise NotImplementedError("more than 12 weight matrices (deeper VAE) need a second grouped launch")
         arr = (H.Wgrad * len(probs))(*probs)
         keep.append(arr)
         self._wgrad_arr = arr
-        wbytes = sum(4 * (q.M * q.N + q.K * (q.M + q.N)) for q in probs)
+        wbytes = sum(4 * q.M * q.N + (2 if (q.A16 and q.dY16) else 4) * q.K * (q.M + q.N) for q in probs)
         wflops = sum(2 * q.M * q.N * q.K for q in probs)
         self._wgrad_plain = self._call("air_wgrad_grouped", arr, len(probs), self._prec, None, None,
                                        nbytes=wbytes, flops=wflops, tag="wgrad_grouped")

@@ -860,7 +860,7 @@ int launch(const air_gemm_t* g, const Args& a0, hipStream_t s) {
     a.kslab = ((a.K + ks - 1) / ks + 3) & ~3;
     if (a.job_on) {
         // enough planes for ~1 quad of noise per thread (the prologue then ends well inside the GEMM)
-        const long quads = (a.job.n_normal + 3) / 4 + (a.job.n_uniform + 3) / 4;
+        const long quads = (a.job.n_normal + 3) / 4 + (a.job.n_uniform + 3) / 4 + (a.job.twin_n + 3) / 4;
         const long plane = (long)grid.x * grid.y * THREADS;
         long planes = (quads + plane - 1) / plane;
         a.job_on = (int)(planes < 1 ? 1 : (planes > 16 ? 16 : planes));
@@ -1036,8 +1036,10 @@ static int fill_args(const air_gemm_t* g, Args& a) {
         if (!j.dyn || !j.istate || j.nsched < 0 || j.nsched > THREADS || (j.nsched > 0 && !j.sched)) return AIR_EINVAL;
         if (j.n_normal < 0 || j.n_uniform < 0 || (j.n_normal > 0 && !j.normals) || (j.n_uniform > 0 && !j.uniforms)) return AIR_EINVAL;
         a.job_on = 1;
+        if (j.twin_n < 0 || (j.twin_n > 0 && (!j.twin_src || !j.twin_dst))) return AIR_EINVAL;
+        if (j.twin_n > 0 && (!aligned16(j.twin_src) || (reinterpret_cast<uintptr_t>(j.twin_dst) & 7) != 0)) return AIR_EALIGN;
         a.job = AirStepJob{j.sched, j.nsched, j.dyn, j.istate, j.normals, (long)j.n_normal, j.uniforms, (long)j.n_uniform,
-                           (uint32_t)(j.seed & 0xffffffffu), (uint32_t)(j.seed >> 32)};
+                           (uint32_t)(j.seed & 0xffffffffu), (uint32_t)(j.seed >> 32), j.twin_src, j.twin_dst, (long)j.twin_n};
     }
     switch (g->epi) {
         case AIR_EPI_LSTM_FWD:      // N = 4R gate columns, groups of R

@@ -86,15 +86,17 @@ extern "C" const char* air_strerror(int code) {
 
 extern "C" int air_step_begin(const air_schedule_t* sched, int nsched, float* dyn, const int32_t* istate,
                               float* normals, int64_t n_normal, float* uniforms, int64_t n_uniform,
-                              uint64_t seed, void* stream) {
+                              uint64_t seed, const float* twin_src, uint16_t* twin_dst, int64_t twin_n, void* stream) {
     if (!dyn || !istate || nsched < 0 || nsched > THREADS || (nsched > 0 && !sched)) return AIR_EINVAL;
     if (n_normal < 0 || n_uniform < 0 || (n_normal > 0 && !normals) || (n_uniform > 0 && !uniforms)) return AIR_EINVAL;
-    const long quads = (n_normal + 3) / 4 + (n_uniform + 3) / 4;
+    if (twin_n < 0 || (twin_n > 0 && (!twin_src || !twin_dst))) return AIR_EINVAL;
+    if (twin_n > 0 && ((((uintptr_t)twin_src) & 15) != 0 || (((uintptr_t)twin_dst) & 7) != 0)) return AIR_EALIGN;
+    const long quads = (n_normal + 3) / 4 + (n_uniform + 3) / 4 + (twin_n + 3) / 4;
     long blocks = (quads + THREADS - 1) / THREADS;
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;
     AirStepJob job{sched, nsched, dyn, istate, normals, (long)n_normal, uniforms, (long)n_uniform,
-                   (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32)};
+                   (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), twin_src, twin_dst, (long)twin_n};
     hipLaunchKernelGGL(step_begin_kernel, dim3((int)blocks), dim3(THREADS), 0, air_stream(stream), job);
     AIR_CHECK_LAUNCH();
     return 0;

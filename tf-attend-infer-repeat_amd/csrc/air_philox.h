@@ -7,6 +7,9 @@
 struct AirStepJob {
     const air_schedule_t* sched; int nsched; float* dyn; const int32_t* istate;
     float* normals; long n_normal; float* uniforms; long n_uniform; uint32_t seed_lo, seed_hi;
+    // optional: twin_dst[i] = bf16(twin_src[i]) for i < twin_n -- the bf16 twin of the image batch (the caller's
+    // fp32 tensor), read by the input-weight gradient at the end of the step
+    const float* twin_src; unsigned short* twin_dst; long twin_n;
 };
 
 __device__ __forceinline__ void air_philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
@@ -44,8 +47,17 @@ __device__ __forceinline__ void air_step_job_run(const AirStepJob& j, long wg, l
         const air_schedule_t s = j.sched[threadIdx.x];
         j.dyn[s.slot] = air_eval_schedule(s, step);
     }
-    const long quads_n = (j.n_normal + 3) / 4, quads_u = (j.n_uniform + 3) / 4;
-    for (long q = wg * 256 + threadIdx.x; q < quads_n + quads_u; q += nwg * 256) {
+    const long quads_n = (j.n_normal + 3) / 4, quads_u = (j.n_uniform + 3) / 4, quads_t = (j.twin_n + 3) / 4;
+    for (long q = wg * 256 + threadIdx.x; q < quads_n + quads_u + quads_t; q += nwg * 256) {
+        if (q >= quads_n + quads_u) {
+            const long base = (q - quads_n - quads_u) * 4;
+            if (base + 3 < j.twin_n) {
+                const float4 v = *reinterpret_cast<const float4*>(j.twin_src + base);
+                *reinterpret_cast<uint2*>(j.twin_dst + base) = make_uint2(air_pack_bf16(v.x, v.y), air_pack_bf16(v.z, v.w));
+            } else
+                for (int k = 0; k < 4; ++k) if (base + k < j.twin_n) j.twin_dst[base + k] = air_bf16_of(j.twin_src[base + k]);
+            continue;
+        }
         uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)step, 0x41495221u};
         air_philox4x32_10(c, j.seed_lo, j.seed_hi);
         float v[4];

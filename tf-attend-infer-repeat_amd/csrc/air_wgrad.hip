@@ -25,6 +25,7 @@ constexpr int MAXP = 12;
 
 struct Prob {
     const float* A; const float* dY; float* dW; float* db;
+    const unsigned short* A16; const unsigned short* dY16;      // bf16 twins of A / dY (nullable): see tile_bf16_tw
     int M, N, K, lda, ldb, ldc;
     int head_pack, Hs, Hh, Hz;
     int tiles_n, first_block;
@@ -455,6 +456,189 @@ __device__ __forceinline__ float tile_bf16(const Prob& pr, int m0, int n0, unsig
     return sq;
 }
 
+// bf16-TWIN tile: both operands are read from the bf16 twins their producers wrote (air_wgrad_t.A16 / dY16).
+// K is the slow axis of both, i.e. both are "n-contiguous" for the MFMA: a 64-row image of an operand is
+// copied as it lies into a [k][64 columns] LDS image (16- or 8-byte pieces, lane-linear rows of 128 bytes,
+// no conversion, no register transpose) and the MFMA fragments -- 8 consecutive k per lane -- come out of
+// gfx950's transpose read ds_read_b64_tr_b16 (tools/exp/tr_read.hip; the same scheme as the forward GEMM's
+// row-major weights, air_gemm_bf16.hip).  Same bf16 values, same k order per wave as tile_bf16: the tile is
+// bit-identical.  The bias gradient still comes from the fp32 dY (column sums before rounding, in tile_bf16's
+// order) -- only the m0 == 0 tiles pay those loads.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ bool twin_ok(const Prob& pr) {
+    auto a8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; };
+    return pr.A16 && pr.dY16 && !pr.head_pack && a8(pr.A16) && a8(pr.dY16) && (pr.lda & 3) == 0 && (pr.ldb & 3) == 0 &&
+           (pr.M & 3) == 0 && (pr.N & 3) == 0;
+}
+
+template <int NIMG>
+__device__ __forceinline__ float tile_bf16_tw(const Prob& pr, int m0, int n0, unsigned short* Img)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int M = pr.M, N = pr.N, K = pr.K, lda = pr.lda, ldb = pr.ldb;
+    float* db = pr.db;
+    const char* Ab = reinterpret_cast<const char*>(pr.A16);
+    const char* Yb = reinterpret_cast<const char*>(pr.dY16);
+    unsigned short* ImgA = Img;                              // [NIMG][64 k][64 m]
+    unsigned short* ImgB = Img + NIMG * KB * BT;             // [NIMG][64 k][64 n]
+    // 16-byte pieces when rows start 16-byte aligned (ld % 8 == 0), else 8-byte pieces (ld % 4 == 0)
+    const bool a16 = (lda & 7) == 0 && (reinterpret_cast<uintptr_t>(pr.A16) & 15) == 0 && (M & 7) == 0;
+    const bool b16 = (ldb & 7) == 0 && (reinterpret_cast<uintptr_t>(pr.dY16) & 15) == 0 && (N & 7) == 0;
+    const bool bias_block = (db != nullptr) && (m0 == 0);
+    // the bias threads' fp32 view of dY: g = k-run (8 rows), q = column quad -- tile_bf16's staging role of operand dY
+    const int bg = tid & 7, bq = (tid & 127) >> 3;
+    const bool bias_thread = bias_block && tid >= 128;
+    float csum[4] = {0.f, 0.f, 0.f, 0.f};
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int T8 = NIMG * KB * 16 / THREADS;             // 8-byte pieces per thread per operand (two of them = one 16-byte piece)
+    for (int kr = 0; kr < K; kr += NIMG * KB) {
+        if (kr > 0) __syncthreads();
+        uint2 ra[T8], rb[T8];
+        // ---- all operand loads of the round, one wave-uniform branch per operand
+        if (a16) {
+#pragma unroll
+            for (int i = 0; i < T8 / 2; ++i) {
+                const int t = tid + THREADS * i, k = kr + (t >> 3), col = m0 + (t & 7) * 8;
+                const bool ok = k < K && col < M;
+                const uint4 x = *reinterpret_cast<const uint4*>(Ab + (ok ? ((unsigned)k * (unsigned)lda + (unsigned)col) * 2u : 0u));
+                ra[2 * i] = ok ? make_uint2(x.x, x.y) : make_uint2(0u, 0u);
+                ra[2 * i + 1] = ok ? make_uint2(x.z, x.w) : make_uint2(0u, 0u);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < T8; ++i) {
+                const int t = tid + THREADS * i, k = kr + (t >> 4), col = m0 + (t & 15) * 4;
+                const bool ok = k < K && col < M;
+                const uint2 x = *reinterpret_cast<const uint2*>(Ab + (ok ? ((unsigned)k * (unsigned)lda + (unsigned)col) * 2u : 0u));
+                ra[i] = ok ? x : make_uint2(0u, 0u);
+            }
+        }
+        if (b16) {
+#pragma unroll
+            for (int i = 0; i < T8 / 2; ++i) {
+                const int t = tid + THREADS * i, k = kr + (t >> 3), col = n0 + (t & 7) * 8;
+                const bool ok = k < K && col < N;
+                const uint4 x = *reinterpret_cast<const uint4*>(Yb + (ok ? ((unsigned)k * (unsigned)ldb + (unsigned)col) * 2u : 0u));
+                rb[2 * i] = ok ? make_uint2(x.x, x.y) : make_uint2(0u, 0u);
+                rb[2 * i + 1] = ok ? make_uint2(x.z, x.w) : make_uint2(0u, 0u);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < T8; ++i) {
+                const int t = tid + THREADS * i, k = kr + (t >> 4), col = n0 + (t & 15) * 4;
+                const bool ok = k < K && col < N;
+                const uint2 x = *reinterpret_cast<const uint2*>(Yb + (ok ? ((unsigned)k * (unsigned)ldb + (unsigned)col) * 2u : 0u));
+                rb[i] = ok ? x : make_uint2(0u, 0u);
+            }
+        }
+        // ---- straight into the [k][64] images (lane-linear rows)
+        if (a16) {
+#pragma unroll
+            for (int i = 0; i < T8 / 2; ++i)
+                *reinterpret_cast<uint4*>(&ImgA[(tid + THREADS * i) * 8]) = make_uint4(ra[2 * i].x, ra[2 * i].y, ra[2 * i + 1].x, ra[2 * i + 1].y);
+        } else {
+#pragma unroll
+            for (int i = 0; i < T8; ++i) *reinterpret_cast<uint2*>(&ImgA[(tid + THREADS * i) * 4]) = ra[i];
+        }
+        if (b16) {
+#pragma unroll
+            for (int i = 0; i < T8 / 2; ++i)
+                *reinterpret_cast<uint4*>(&ImgB[(tid + THREADS * i) * 8]) = make_uint4(rb[2 * i].x, rb[2 * i].y, rb[2 * i + 1].x, rb[2 * i + 1].y);
+        } else {
+#pragma unroll
+            for (int i = 0; i < T8; ++i) *reinterpret_cast<uint2*>(&ImgB[(tid + THREADS * i) * 4]) = rb[i];
+        }
+        __syncthreads();
+        // ---- MFMAs: fragments through the transpose read (lane i of a 16-lane group hands in row 8g + i/4 (+4), column quad i%4)
+        const int il = lane & 15;
+#pragma unroll
+        for (int c = 0; c < NIMG; ++c)
+            if (kr + c * KB < K) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int krow = c * KB + ks * 32 + (lane >> 4) * 8 + (il >> 2);
+                    const unsigned short* pa = &ImgA[krow * BT + wm + (il & 3) * 4];
+                    const unsigned short* pb = &ImgB[krow * BT + wn + (il & 3) * 4];
+                    bf16x8 av[2], bv[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pa + i * 16));
+                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pa + i * 16 + 4 * BT));
+                        av[i] = bf16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pb + j * 16));
+                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pb + j * 16 + 4 * BT));
+                        bv[j] = bf16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        if (bias_thread) {
+            // fp32 column sums of dY (m0 == 0 tiles only) in tile_bf16's order: per k-run g the rows g*8 + r of image c
+            // (c-major); the xor-tree over g follows the last round.  One image at a time: 8 loads in flight, few registers
+            // (these tiles are the first of their problem, not the tail of the launch).
+            const bool vec = ((ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(pr.dY) & 15) == 0);
+#pragma unroll 1
+            for (int c = 0; c < NIMG; ++c)
+                if (kr + c * KB < K) {
+                    float4 v[8];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r)
+                        v[r] = vec ? fetch4<true>(pr.dY, ldb, kr + c * KB + bg * 8 + r, n0 + 4 * bq, K, N)
+                                   : fetch4<false>(pr.dY, ldb, kr + c * KB + bg * 8 + r, n0 + 4 * bq, K, N);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const float4 t = mask4(v[r], kr + c * KB + bg * 8 + r, n0 + 4 * bq, K, N);
+                        csum[0] += t.x; csum[1] += t.y; csum[2] += t.z; csum[3] += t.w;
+                    }
+                }
+        }
+    }
+
+    float sq = 0.0f;
+    if (bias_block) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s = csum[j];
+            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+            csum[j] = s;
+        }
+        if (bias_thread && bg == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = 4 * bq + j;
+                if (n0 + col < N) { db[n0 + col] = csum[j]; sq += csum[j] * csum[j]; }
+            }
+        }
+    }
+    __syncthreads();
+    float* Ct = reinterpret_cast<float*>(Img);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+                Ct[(wm + i * 16 + (lane >> 4) * 4 + qq) * LS + wn + j * 16 + (lane & 15)] = acc[i][j][qq];
+    __syncthreads();
+    return sq;
+}
+
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void wgrad_grouped_bf16_kernel(Table tab, float* __restrict__ sq_partials, int32_t* __restrict__ istate)
 {
     // [operand][image][column 0..63][k 0..63] bf16 = 2 x 3 x 8 KB; reused as the fp32 output tile
@@ -462,7 +646,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
     int m0, n0;
     const Prob& pr = find_tile(tab, blockIdx.x, m0, n0);
     AIR_STAMP(0);
-    const float bias_sq = tile_bf16<NIMG_W>(pr, m0, n0, Img);
+    // block-uniform: operands from their bf16 twins where the problem supplies usable ones
+    const float bias_sq = twin_ok(pr) ? tile_bf16_tw<NIMG_W>(pr, m0, n0, Img) : tile_bf16<NIMG_W>(pr, m0, n0, Img);
     AIR_STAMP(6);
     const float sq = store_tile(pr, m0, n0, reinterpret_cast<const float*>(Img), bias_sq);
     AIR_STAMP(7);
@@ -579,6 +764,7 @@ static int fill_table(const air_wgrad_t* probs, int count, Table& tab, bool allo
         if (!g.dW && (g.head_pack || !allow_null_dw)) return AIR_EINVAL;     // norm-only problems: plain layout, and only with sq_partials
         Prob& p = tab.p[i];
         p.A = g.A; p.dY = g.dY; p.dW = g.dW; p.db = g.db;
+        p.A16 = g.A16; p.dY16 = g.dY16;
         p.M = g.M; p.N = g.N; p.K = g.K; p.lda = g.lda; p.ldb = g.ldb; p.ldc = g.ldc;
         p.head_pack = g.head_pack; p.Hs = g.Hs; p.Hh = g.Hh; p.Hz = g.Hz;
         p.tiles_n = (g.N + BT - 1) / BT;
