@@ -136,6 +136,13 @@ typedef struct {
     const air_schedule_t* sched /*device*/; int32_t nsched; float* dyn; const int32_t* istate;
     float* normals; int64_t n_normal; float* uniforms; int64_t n_uniform; uint64_t seed;
     const float* twin_src; uint16_t* twin_dst; int64_t twin_n;   /* see air_step_begin */
+    /* optional (ad_n > 0, a multiple of 4; pointers 16-byte aligned): a deferred slice of the PREVIOUS step's
+     * air_adam_clip_step -- elements [0, ad_n) of the given (already advanced) params / grads / m / v pointers and of the
+     * bf16 shadow are updated by the carrying launch's extra workgroups with the coefficients the main Adam launch
+     * recorded in ad_coef (air_adam_clip_step_blocks' coef_out).  Only for variables that no kernel up to and including
+     * the carrying one reads: the forward of the next step needs each variable only from its own layer on. */
+    float* ad_params; const float* ad_grads; float* ad_m; float* ad_v; uint16_t* ad_shadow; int64_t ad_n;
+    const float* ad_coef; float ad_beta1, ad_beta2, ad_epsilon;
 } air_step_job_t;
 typedef struct {
     const float* A; const float* B; float* C;
@@ -150,7 +157,7 @@ typedef struct {
     int32_t accumulate;            /* C += result                        */
     int32_t precision;             /* 0 fp32, 1 bf16                     */
     int32_t epi;                   /* AIR_EPI_*                          */
-    int32_t tile_m, tile_n;        /* output tile in units of 16 (0 = auto): (1,1)(1,2)(1,4)(2,2)(2,4)(4,1)(4,2) */
+    int32_t tile_m, tile_n;        /* output tile in units of 16 (0 = auto): (1,1)(1,2)(1,4)(2,2)(2,4)(4,1)(4,2)(4,4) */
     int32_t ksplit;                /* > 1: split K over grid.z; C receives `air_gemm_slabs()` slabs of
                                       [M,ldc] (plain stores, generic epilogue skipped)            */
     int32_t addend_slabs;          /* addend is that many [M,ldadd] slabs (0/1 = one)            */
@@ -232,10 +239,14 @@ int air_lstm_gates_bwd(const float* dh, const float* dc_in /*nullable*/, const f
 int air_transformer_fwd(const float* U, const float* theta, float* out,
                         int B, int Hi, int Wi, int Ho, int Wo, void* stream);
 /* its gradient (what tf.gradients builds for transformer.py:56-171): d_U [B,Hi,Wi] and / or d_theta [B,2,3]
- * (either may be NULL) from d_out [B,Ho,Wo], in the reference graph's op order -- AddN order for the
- * coordinate gradients; d_U through ONE fp32 accumulator per input pixel that receives the a-, b-, c-,
- * d-tap terms in output-pixel order (the graph's single UnsortedSegmentSum over the concatenated Gather
- * gradients).  Hi*Wi <= ~20 000 (U and d_U of one image live in LDS). */
+ * (either may be NULL) from d_out [B,Ho,Wo].
+ *   d_U: ONE fp32 accumulator per input pixel that receives the a-, b-, c-, d-tap terms in output-pixel order -- the
+ *        graph's single UnsortedSegmentSum over the concatenated Gather gradients -- BIT-IDENTICAL to the executed
+ *        reference graph (oracle.transformer_backward, tests/test_gpu_kernels.py).
+ *   d_theta: per output pixel the graph's AddN order for the coordinate gradients; the contraction over the output
+ *        pixels with (x_t, y_t, 1) (MatMul_grad) is a per-thread strided sum followed by a fixed-order block reduction,
+ *        i.e. it matches the graph up to the reduction order of that one sum: tested to 2e-5 of the largest element.
+ * Hi*Wi <= ~20 000 (U and d_U of one image live in LDS). */
 int air_transformer_bwd(const float* U, const float* theta, const float* d_out, float* d_U, float* d_theta,
                         int B, int Hi, int Wi, int Ho, int Wo, void* stream);
 
@@ -394,6 +405,16 @@ int air_adam_clip_step(float* params, const float* grads, float* m, float* v, in
                        float grad_prescale /* e.g. 1/world_size */, float beta1, float beta2,
                        float epsilon, uint16_t* bf16_shadow /*nullable*/, float* gnorm_out /*nullable*/,
                        void* stream);
+/* The same update over a sub-range of the flat buffers (the pointers are advanced by the caller, `partials` still hold the
+ * norm of the WHOLE gradient) on at most `max_blocks` workgroups (0 = as many as fill the chip): a NARROW launch that a
+ * long train step graph can defer (see air_step_job_t.ad_*): every kernel of the forward only needs its own variables
+ * updated. */
+int air_adam_clip_step_blocks(float* params, const float* grads, float* m, float* v, int64_t n,
+                              const float* partials, int npartials, const float* dyn, const int32_t* istate,
+                              float grad_prescale, float beta1, float beta2, float epsilon,
+                              uint16_t* bf16_shadow /*nullable*/, float* gnorm_out /*nullable*/, int max_blocks,
+                              float* coef_out /*nullable: [4] floats receiving (clip scale, lr_t, global norm) for deferred slices*/,
+                              void* stream);
 /* The same step with ONE gradient block taken from its factors instead of from `grads`:
  * `factored` (HOST pointer, one plain problem, db NULL, ldc == N, N % 4 == 0) names a block
  * dW = A^T.dY [M,N] that lies inside the flat buffer (dW points into `grads`; the matching ranges

@@ -124,3 +124,44 @@ def test_product_does_not_import_oracle():
                 assert "oracle" not in txt.replace("no oracle", ""), os.path.join(dp, fn)
                 assert "/root/reference" not in txt or fn.endswith(".py") and "import" not in \
                     [ln for ln in txt.splitlines() if "/root/reference" in ln][0]
+
+
+def test_gemm_dispatch_is_pinned_per_shape(H):
+    """Which kernel family an air_gemm descriptor reaches (air_gemm_kernel_name is host-only code, no launch):
+      * bf16 twins supplied, whole 16-byte pieces          -> gemm_bf16tw_kernel (air_gemm_bf16.hip)
+      * fp32 operands, even K / leading dimensions, row-major A  -> the lean kernels gemm_bf16v2 / gemm_f32v2
+      * transposed A, or an odd K / leading dimension / 4-byte-aligned operand -> the general fallback kernels
+        gemm_bf16_kernel / gemm_f32_kernel (air_gemm.hip; the only users are ragged test shapes and the transA form
+        of the ABI -- no launch of the train step at any BASELINE configuration reaches them)."""
+    lib = H.lib()
+    buf = C.create_string_buffer(128)
+
+    def name(M, N, K, ta=0, tb=0, prec=1, lda=None, ldb=None, twins=False, a_off=0, epi=0, tile=(0, 0)):
+        g = H.Gemm()
+        base = 1 << 20
+        g.A, g.B, g.C = base + a_off, base * 2, base * 3
+        g.M, g.N, g.K = M, N, K
+        g.lda = lda if lda is not None else (M if ta else K)
+        g.ldb = ldb if ldb is not None else (K if tb else N)
+        g.ldc, g.transA, g.transB, g.precision, g.epi = N, ta, tb, prec, epi
+        g.tile_m, g.tile_n = tile
+        if twins:
+            g.A16, g.B16 = base * 4, base * 5
+        assert lib.air_gemm_kernel_name(C.byref(g), buf, 128) == 0
+        return buf.value.decode()
+
+    # the train step's shapes (Cfg-A and the stress batch): twins -> twin kernels, otherwise the lean ones
+    for M, N, K, tb in ((192, 320, 256, 0), (192, 512, 784, 0), (192, 784, 512, 1), (64, 256, 1024, 1), (1280, 512, 784, 0)):
+        assert name(M, N, K, tb=tb, twins=True).startswith("gemm_bf16tw_kernel<")
+        assert name(M, N, K, tb=tb).startswith("gemm_bf16v2_kernel<")
+        assert name(M, N, K, tb=tb, prec=0).startswith("gemm_f32v2_kernel<")
+    # even-but-not-multiple-of-4 dimensions (Z = 50): still the lean kernels (8-byte loads)
+    assert name(192, 100, 256).startswith("gemm_bf16v2_kernel<") and name(192, 256, 50).startswith("gemm_bf16v2_kernel<")
+    assert name(192, 100, 256, twins=True).startswith("gemm_bf16v2_kernel<")          # N % 8 != 0: twins unusable
+    assert name(192, 256, 50, twins=True).startswith("gemm_bf16v2_kernel<")           # K % 8 != 0
+    # the general fallback kernels: transposed A, odd K, odd leading dimension, 4-byte aligned operand
+    for kw in (dict(ta=1), dict(K=333), dict(lda=257), dict(a_off=4)):
+        args = dict(M=70, N=150, K=256)
+        args.update(kw)
+        n1, n0 = name(**args), name(prec=0, **args)
+        assert n1.startswith("gemm_bf16_kernel<") and n0.startswith("gemm_f32_kernel<"), (kw, n1, n0)

@@ -45,10 +45,10 @@ def _inputs(blank):
     return images, targets, noise, ao.init_params(HP, 0)
 
 
-def _run(am, images, targets, noise, params, prec, graph, init_seed):
+def _run(am, images, targets, noise, params, prec, graph, init_seed, exchange="flat", steps=STEPS):
     am.reset_default_graph()
     m = am.AIRModel(torch.tensor(images, device="cuda"), torch.tensor(targets, device="cuda"), cnn=False,
-                    train=True, scope="air", gemm_precision=prec, seed=init_seed, **HP)
+                    train=True, scope="air", gemm_precision=prec, seed=init_seed, dp_exchange=exchange, **HP)
     if params is not None:
         m.load_state_dict(params)
     m.set_noise(noise)
@@ -56,14 +56,14 @@ def _run(am, images, targets, noise, params, prec, graph, init_seed):
     if graph:
         m.capture_graph()
     out = []
-    for _ in range(STEPS):
+    for _ in range(steps):
         m.training()
         torch.cuda.synchronize()
         out.append((float(m.loss), float(m.accuracy), float(m.store.gnorm[0])))
     return m, out
 
 
-def _worker(rank, world, port, prec, graph, blank, q):
+def _worker(rank, world, port, prec, graph, blank, q, exchange="flat", steps=STEPS):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -75,8 +75,8 @@ def _worker(rank, world, port, prec, graph, blank, q):
     # rank 1 deliberately STARTS from different variables (seed) and only rank 0 loads the common
     # ones: sync_parameters() (called by training()/capture_graph()) must make the replicas identical
     m, out = _run(am, images[sl], targets[sl], {k: v[:, sl] for k, v in noise.items()},
-                  params if rank == 0 else None, prec, graph, init_seed=100 + rank)
-    q.put((rank, out, m.store.params.cpu().numpy(), int(m.global_step), m.store.m.cpu().numpy()))
+                  params if rank == 0 else None, prec, graph, init_seed=100 + rank, exchange=exchange, steps=steps)
+    q.put((rank, out, m.store.params.cpu().numpy(), int(m.global_step), m.store.m.cpu().numpy(), m.store.grads.cpu().numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -94,7 +94,7 @@ def test_dp2_training_equals_full_batch_step(prec, graph, blank):
         p.start()
     got = {}
     for _ in range(2):
-        r, out, par, step, mom = q.get(timeout=600)
+        r, out, par, step, mom, _ = q.get(timeout=600)
         got[r] = (out, par, step, mom)
     for p in procs:
         p.join(timeout=120)
@@ -138,6 +138,54 @@ def test_dp2_training_equals_full_batch_step(prec, graph, blank):
     print("dp2 %s graph=%s blank=%s: (loss, gnorm) rel per step %r, update rel-L2 %.3e" % (prec, graph, blank, report, rel))
     if blank:
         assert rel < (5e-3 if prec == "fp32" else 1e-1), rel
+
+
+def _dp2(prec, graph, blank, exchange, steps):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, prec, graph, blank, q, exchange, steps)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        r, out, par, step, mom, grads = q.get(timeout=600)
+        got[r] = dict(out=out, params=par, step=step, m=mom, grads=grads)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return got
+
+
+@pytest.mark.parametrize("prec,graph", [("fp32", True), ("bf16", True), ("bf16", False)])
+def test_dp2_factor_exchange_equals_flat_all_reduce(prec, graph):
+    """dp_exchange="factors": the LSTM input-weight gradient dWx = X^T.(sum_t dgates) (64 % of the gradient
+    elements) is never all-reduced -- X and sum_t dgates (rank <= B per GPU) are all-gathered and every rank
+    contracts the gathered 2b rows itself; the rest of the flat buffer is all-reduced.  Against the flat all-reduce
+    on the same two ranks: every other gradient BIT-IDENTICAL, dWx and the lstm bias equal up to the fp32 order of
+    the contraction, replicas bit-identical, and the same variables after three steps in the smooth regime
+    (reference semantics kept: air_model.py:610 mean over the global batch, :673 clip on the averaged gradient)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    D4R = HP["canvas_size"] ** 2 * 4 * HP["rnn_units"]
+    one = {ex: _dp2(prec, graph, False, ex, 1) for ex in ("flat", "factors")}
+    for ex in one:
+        assert np.array_equal(one[ex][0]["params"].view(np.int32), one[ex][1]["params"].view(np.int32))   # replicas
+        assert np.array_equal(one[ex][0]["grads"].view(np.int32), one[ex][1]["grads"].view(np.int32))
+    gf, gx = one["flat"][0]["grads"], one["factors"][0]["grads"]
+    nb = 4 * HP["rnn_units"]
+    off_bias = D4R + HP["rnn_units"] * nb                       # lstm_kernel = [Wx rows | Wh rows], then lstm_bias
+    assert np.array_equal(gf[D4R:off_bias], gx[D4R:off_bias])   # Wh
+    assert np.array_equal(gf[off_bias + nb:], gx[off_bias + nb:])   # everything after the LSTM bias, incl. loss/accuracy
+    rel = lambda a, b: np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b.astype(np.float64))  # noqa: E731
+    assert np.abs(gf[:D4R]).max() > 0
+    assert rel(gx[:D4R], gf[:D4R]) < 2e-6, rel(gx[:D4R], gf[:D4R])
+    assert rel(gx[off_bias:off_bias + nb], gf[off_bias:off_bias + nb]) < 2e-6
+    assert one["flat"][0]["out"][0][2] == pytest.approx(one["factors"][0]["out"][0][2], rel=1e-5)        # global norm
+    three = {ex: _dp2(prec, graph, True, ex, STEPS) for ex in ("flat", "factors")}
+    assert np.array_equal(three["factors"][0]["params"].view(np.int32), three["factors"][1]["params"].view(np.int32))
+    assert three["factors"][0]["step"] == STEPS
+    assert rel(three["factors"][0]["params"], three["flat"][0]["params"]) < 1e-5
 
 
 def test_bench_multi_rank_flow_on_one_device(tmp_path):

@@ -1,6 +1,7 @@
 """GPU parity tests of the individual C-ABI entry points (libair_hip.so) against
 the CPU oracle / fp64 references.  All calls go through the C ABI via ctypes."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -1120,3 +1121,58 @@ def test_wgrad_grouped_bf16_twins_bit_identical(H, shapes):
     for (M, N, K), (At, Yt, _, _), Wt in zip(shapes, ops, outs[1][0::2]):
         ref = _bf16_round(At.cpu().numpy()).T @ _bf16_round(Yt.cpu().numpy())
         assert np.abs(Wt.cpu().numpy() - ref).max() <= 1e-5 * np.sqrt(K) * 4 * np.abs(ref).max()
+
+
+_LDS_ORDER_SCRIPT = r'''
+import ctypes as C, os, sys
+import numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tf-attend-infer-repeat_amd"))
+from air import _hip as H
+from air.transformer import transformer_grad
+rng = np.random.RandomState(5)
+B, N, Cc, w = 3, 2, int(sys.argv[3]), 28
+att = np.zeros((N, B, H.ATT_STRIDE), np.float32)
+att[..., H.ATT_S] = rng.uniform(0.15, 0.5, (N, B)); att[..., H.ATT_X] = rng.uniform(-0.9, 0.9, (N, B))
+att[..., H.ATT_Y] = rng.uniform(-0.9, 0.9, (N, B)); att[..., H.ATT_Z] = rng.uniform(0.1, 1, (N, B)); att[..., H.ATT_MASK] = 1
+g = (rng.randn(B, Cc * Cc) * np.where(rng.uniform(size=(B, Cc * Cc)) < 0.08, 1e7, 1e-2)).astype(np.float32)
+vrec = rng.uniform(0.01, 0.99, (N, B, w * w)).astype(np.float32)
+t = lambda a: torch.tensor(a, device="cuda")
+att_d, g_d, v_d = t(att), t(g), t(vrec)
+dgen, dsx = torch.zeros(N, B, w * w, device="cuda"), torch.zeros(N, B, 4, device="cuda")
+p = lambda x: C.c_void_p(x.data_ptr())
+wb = H.WriteBwd(p(g_d), p(v_d), p(att_d), p(dgen), p(dsx), B, N, Cc, w, 2, None, None, None, None)
+H.check(H.lib().air_write_bwd(C.byref(wb), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+U = t(rng.uniform(0, 1, (B, 28, 28)).astype(np.float32))
+th = t((np.tile(np.array([[1.4, 0.2, 0.5], [-0.1, 1.5, -0.6]], np.float32), (B, 1, 1)) + rng.randn(B, 2, 3).astype(np.float32) * 0.1))
+d = t((rng.randn(B, 50, 50) * np.where(rng.uniform(size=(B, 50, 50)) < 0.1, 1e6, 1.0)).astype(np.float32))
+dU, dth = transformer_grad(U, th, (50, 50), d)
+torch.cuda.synchronize()
+np.savez(sys.argv[2], dgen=dgen.cpu().numpy(), dsx=dsx.cpu().numpy(), dU=dU.cpu().numpy(), dth=dth.cpu().numpy())
+'''
+
+
+@pytest.mark.parametrize("Cc", [50, 128])
+def test_lds_lane_order_probe_and_register_chain_fallback(H, tmp_path, Cc):
+    """The graph-order backward relies on ds_add_f32 applying lanes in ascending order (undocumented on gfx950).
+    The library probes that once per process; AIR_LDS_ORDER=0 forces the answer "not ordered": the register-chain
+    fallbacks of air_write_bwd(literal=2) and air_transformer_bwd must then give BIT-IDENTICAL results to the
+    LDS-pipe path (probe: ordered), so a part that orders differently stays correct instead of changing gradients."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "lds_order.py"
+    script.write_text(_LDS_ORDER_SCRIPT)
+    outs = {}
+    for mode in ("probe", "0"):
+        env = dict(os.environ)
+        env.pop("AIR_LDS_ORDER", None)
+        if mode != "probe":
+            env["AIR_LDS_ORDER"] = mode
+        out = tmp_path / ("out_%s.npz" % mode)
+        r = subprocess.run([sys.executable, str(script), root, str(out), str(Cc)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "lane order differs" not in r.stderr          # the probe finds MI355X ordered
+        outs[mode] = np.load(out)
+    for k in ("dgen", "dsx", "dU", "dth"):
+        assert np.array_equal(outs["probe"][k], outs["0"][k]), k
+    assert np.abs(outs["probe"]["dgen"]).max() > 1.0            # the residue was there

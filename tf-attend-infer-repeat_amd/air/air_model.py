@@ -102,6 +102,7 @@ class VariableStore:
         # global-norm partial sums: air_grad_sqnorm's fixed count, or one per weight-gradient workgroup
         self.partials = torch.zeros(max(H.lib().air_optim_num_partials(self.n), 16384), dtype=torch.float32, device=device)
         self.gnorm = torch.zeros(1, dtype=torch.float32, device=device)
+        self.adam_coef = torch.zeros(4, dtype=torch.float32, device=device)   # (clip scale, lr_t, global norm) of the last Adam launch
         self.synced_world = 1            # world size the replicas were last made identical for (AIRModel.sync_parameters)
         # bf16 shadow of the whole flat variable buffer (same offsets): the weight operand of every bf16 GEMM.
         # Adam rewrites it with the variables (air_adam_clip_step's bf16_shadow); any host-side change of the
@@ -225,7 +226,7 @@ class AIRModel:
                  learning_rate=1e-3, gradient_clipping_norm=100.0, cnn=True, cnn_filters=8,
                  num_summary_images=60, train=False, reuse=False, scope="air",
                  annealing_schedules=None, seed=0, gemm_precision=None, backward="reference", noise_seed=None,
-                 input_weight_gradient="stored", bf16_twins=None):
+                 input_weight_gradient="stored", bf16_twins=None, dp_exchange=None):
         if cnn:
             # reference :510-533; every caller passes cnn=False (training.py:108, demo.py:24)
             raise NotImplementedError("cnn=True front-end is outside the accelerated hot path; pass cnn=False")
@@ -333,6 +334,15 @@ class AIRModel:
         self._factor_dwx = input_weight_gradient == "factored"
         if self._factor_dwx:
             self._twins = False      # air_adam_clip_step_factored does not maintain the bf16 shadow of the variables
+        # data parallel, what crosses xGMI per step.  "flat" (default): ONE all_reduce of the whole flat gradient
+        # (16 MB at the default shapes).  "factors": the LSTM input-weight gradient dWx = X^T.(sum_t dgates) -- 64 % of
+        # the gradient elements, rank <= B per GPU -- is never reduced: its FACTORS (X and sum_t dgates, 0.9 MB per
+        # rank) are all-gathered and every rank contracts the gathered rows itself; only the other 36 % is
+        # all-reduced.  Same sum up to the fp32 order of the contraction (tests/test_gpu_dp.py).
+        self._dp_exchange = dp_exchange or os.environ.get("AIR_DP_EXCHANGE", "flat")
+        if self._dp_exchange not in ("flat", "factors"):
+            raise ValueError("dp_exchange must be 'flat' or 'factors'")
+        self._dp_factor_ops = None
         self._injected_noise = False
         self._graph = None
         self._dirty = True
@@ -526,6 +536,11 @@ class AIRModel:
 
         NB = N * B
         fwd = []
+        hosts = []          # (index in fwd, args, kwargs) of the narrow GEMMs that can carry a deferred Adam slice (see _adam_riders)
+
+        def host_gemm(*args, **kw):
+            hosts.append((len(fwd), args, kw))
+            fwd.append(self._gemm(*args, **kw))
         # hoisted x.W_x (the reference recomputes it every step, :286); split-K slabs
         job = H.StepJob(_ptr(self.sched), self._nsched, _ptr(self.dyn), _ptr(st.istate),
                         _ptr(self.normals), self.normals.numel(), _ptr(self.uniforms), self.uniforms.numel(),
@@ -555,14 +570,14 @@ class AIRModel:
         # the recurrence: the remaining LSTM steps, chained (the only sequential part of the loop -- the LSTM
         # sees the same image every step and nothing downstream feeds back into it, :286/:535)
         for t in range(1, N):
-            fwd.append(self._gemm(self.h[t], Wh, self.gates_pre, B, 4 * R, R, R, 4 * R, 4 * R,
-                                  bias=P["lstm_bias"], addend=self.xw, ldadd=4 * R, addend_slabs=self._xw_slabs,
-                                  epi=H.EPI_LSTM_FWD, p=(self.c[t],), q=(self.acts[t], self.c[t + 1], self.h[t + 1]),
-                                  extra_bytes=4 * B * R * 7, tag="lstm_fwd",
-                                  A16=o16(self.h16, t), B16=Wh16, q2_16=o16(self.h16, t + 1)))
+            host_gemm(self.h[t], Wh, self.gates_pre, B, 4 * R, R, R, 4 * R, 4 * R,
+                      bias=P["lstm_bias"], addend=self.xw, ldadd=4 * R, addend_slabs=self._xw_slabs,
+                      epi=H.EPI_LSTM_FWD, p=(self.c[t],), q=(self.acts[t], self.c[t + 1], self.h[t + 1]),
+                      extra_bytes=4 * B * R * 7, tag="lstm_fwd",
+                      A16=o16(self.h16, t), B16=Wh16, q2_16=o16(self.h16, t + 1))
         # everything else runs ONCE over all N*B (step, image) rows
-        fwd.append(self._gemm(self.h[1], P["whid"], self.hid, NB, HT, R, R, HT, HT, bias=P["bhid"],
-                              act=H.ACT_RELU, tag="heads_hid", A16=o16(self.h16, 1), B16=T("whid"), C16=self.hid16))
+        host_gemm(self.h[1], P["whid"], self.hid, NB, HT, R, R, HT, HT, bias=P["bhid"],
+                  act=H.ACT_RELU, tag="heads_hid", A16=o16(self.h16, 1), B16=T("whid"), C16=self.hid16)
         a = H.AttendFwd(_ptr(self.hid), _ptr(P["wout"]), _ptr(P["bout"]), _ptr(imgs),
                         _ptr(self.eps_scale), _ptr(self.eps_shift), _ptr(self.u), _ptr(self.dyn),
                         _ptr(self.out7), _ptr(self.att), _ptr(self.window),
@@ -571,9 +586,10 @@ class AIRModel:
         fwd.append(self._call("air_attend_fwd", C.byref(a), nbytes=NB * ((D + d + HT) * 4 + 12), tag="attend_fwd"))
         x, x16, k = self.window, self.window16, d
         for i, u in enumerate(rec_u):
-            fwd.append(self._gemm(x, P["rec%d_w" % i], self.rec_act[i], NB, u, k, k, u, u,
-                                  bias=P["rec%d_b" % i], act=H.ACT_SOFTPLUS, tag="vae_rec",
-                                  A16=x16, B16=T("rec%d_w" % i), C16=self.rec_act16[i]))
+            (host_gemm if i == 0 else (lambda *a_, **k_: fwd.append(self._gemm(*a_, **k_))))(
+                x, P["rec%d_w" % i], self.rec_act[i], NB, u, k, k, u, u,
+                bias=P["rec%d_b" % i], act=H.ACT_SOFTPLUS, tag="vae_rec",
+                A16=x16, B16=T("rec%d_w" % i), C16=self.rec_act16[i])
             x, x16, k = self.rec_act[i], self.rec_act16[i], u
         # the bottleneck (last recognition product -> reparameterised sample -> first generative layer) is
         # ONE launch where the fused kernel's limits hold (bf16 operands; vae.py:16-30); else two GEMMs
@@ -615,6 +631,8 @@ class AIRModel:
                                     _ptr(self.target_num_digits), _ptr(self.run_digits), _ptr(self._loss_item),
                                     _ptr(self.scalars), B)
         self._fwd = fwd
+        self._fwd_hosts = hosts
+        self._fwd_riders = None
         twin_job = ((_ptr(imgs), _ptr(self.images16), imgs.numel()) if self.images16 is not None else (None, None, 0))
         self._begin = self._call(
             "air_step_begin", _ptr(self.sched), self._nsched, _ptr(self.dyn), _ptr(st.istate),
@@ -787,8 +805,14 @@ class AIRModel:
     def set_dynamic(self, **kw):
         """Overrides dynamic scalars (e.g. z_pres_prior_log_odds=-2.0) -- only meaningful
         for parameters without an annealing schedule."""
+        plv = {"scale_prior_variance": H.DYN_SCALE_PLV, "shift_prior_variance": H.DYN_SHIFT_PLV,
+               "vae_prior_variance": H.DYN_VAE_PLV}
         for k, v in kw.items():
             self.dyn[_ANNEALABLE[k]] = float(v)
+            if k in plv:
+                # an override of a prior variance is a new CONSTRUCTOR value, not a schedule: the log-variance the KL
+                # uses (air_model.py:72-74, tf.log taken at construction) follows it; schedules leave that slot alone
+                self.dyn[plv[k]] = float(np.log(np.float32(v)))
         self._dirty = True
 
     def _fresh_shadow(self):
@@ -796,16 +820,18 @@ class AIRModel:
         if self._twins and self.store.shadow_stale:
             self.store.refresh_shadow(self._stream())
 
-    def _run_forward(self, s, finalize=True):
+    def _run_forward(self, s, finalize=True, riders=None):
+        """riders: {index in the launch list: the same GEMM carrying a deferred slice of the previous step's Adam}"""
         self._fresh_shadow()
+        pick = (lambda i, op: riders.get(i, op)) if riders else (lambda i, op: op)
         if self._injected_noise or os.environ.get("AIR_SEPARATE_STEP_BEGIN") == "1":
             (self._begin_sched_only if self._injected_noise else self._begin)(s)
-            for op in self._fwd:
-                op(s)
+            for i, op in enumerate(self._fwd):
+                pick(i, op)(s)
         else:
             self._xwx_with_begin(s)
-            for op in self._fwd[1:]:
-                op(s)
+            for i, op in enumerate(self._fwd[1:], 1):
+                pick(i, op)(s)
         if finalize:
             self._finalize(s)
 
@@ -860,6 +886,99 @@ class AIRModel:
             self._opt_world = world
         return self._opt
 
+    def _adam_riders(self):
+        """Deferred Adam for a train step that is followed by another one inside the same captured graph.
+        Every kernel of the forward only needs ITS OWN variables updated, so the exposed Adam launch covers the flat
+        buffer up to the first VAE variable (LSTM + heads: what the next step's first kernels read) and the VAE
+        variables -- the tail of the flat buffer -- are updated by extra workgroups of the next step's narrow GEMM
+        launches (the LSTM steps, the heads' hidden layer, the first recognition layer: 64-588 workgroups each on a
+        256-CU part), with the clip scale / lr_t the exposed launch recorded.  Same arithmetic, element for element.
+        Returns (adam_main op, {fwd index: GEMM op carrying its slice}) or None when the layout does not allow it."""
+        if self._fwd_riders is not None:
+            return self._fwd_riders or None
+        self._fwd_riders = ()
+        st = self.store
+        # OFF by default -- measured on MI355X (tools/ab_bench.sh, 400 steps, 20 per replay): 0.1838 ms/step with the slices
+        # carried, 0.1832 without.  The slice is HBM work whatever launch it sits in: the carrying GEMMs last as long as their
+        # riders and lose what the Adam launch saved.  AIR_ADAM_RIDERS=1 enables it (tests keep the path bit-identical).
+        if (not self.train or self._dwx_factors is not None or os.environ.get("AIR_ADAM_RIDERS") != "1" or not self._fwd_hosts):
+            return None
+        lo, hi = st.offsets["rec0_w"], st.n                      # the VAE variables: contiguous tail of the flat buffer
+        first_free = st.offsets.get("rec1_w", st.offsets["ml_w"])   # the first recognition GEMM reads rec0_w / rec0_b itself
+        hosts = list(self._fwd_hosts)
+        k = len(hosts)
+        cuts = [lo + ((hi - lo) * i // k) // 8 * 8 for i in range(k)] + [hi]
+        if cuts[-2] < first_free:                                # its slice would contain variables it reads: do not use it
+            hosts = hosts[:-1]
+            k = len(hosts)
+            cuts = [lo + ((hi - lo) * i // k) // 8 * 8 for i in range(k)] + [hi]
+        if k == 0:
+            return None
+        off = lambda t, i, b: C.c_void_p(t.data_ptr() + i * b)  # noqa: E731
+        riders = {}
+        for (idx, args, kw), a, b in zip(hosts, cuts[:-1], cuts[1:]):
+            job = H.StepJob(None, 0, _ptr(self.dyn), _ptr(st.istate), None, 0, None, 0, 0, None, None, 0,
+                            off(st.params, a, 4), off(st.grads, a, 4), off(st.m, a, 4), off(st.v, a, 4),
+                            off(st.params16, a, 2) if self._twins else None, b - a, _ptr(st.adam_coef), 0.9, 0.999, 1e-8)
+            kw2 = dict(kw)
+            kw2["step_job"] = job
+            kw2["extra_bytes"] = kw.get("extra_bytes", 0) + (30 if self._twins else 28) * (b - a)
+            kw2["tag"] = kw.get("tag", "gemm") + "+adam_slice"
+            riders[idx] = self._gemm(*args, **kw2)
+        npart = self._wgrad_blocks
+        main = self._call("air_adam_clip_step_blocks", _ptr(st.params), _ptr(st.grads), _ptr(st.m), _ptr(st.v),
+                          lo, _ptr(st.partials), npart, _ptr(self.dyn), _ptr(st.istate), 1.0, 0.9, 0.999, 1e-8,
+                          _ptr(st.params16) if self._twins else None, _ptr(st.gnorm), 0, _ptr(st.adam_coef),
+                          nbytes=(30 if self._twins else 28) * lo, tag="adam_clip_main")
+        main.kernel = "adam_clip_kernel"
+        self._fwd_riders = (main, riders)
+        return self._fwd_riders
+
+    def _dp_factors(self):
+        """Launch lists of the factor exchange (dp_exchange="factors", world > 1): local weight gradients WITHOUT
+        dWx (its bias gradient, the column sums of sum_t dgates, by air_colsum), and -- after the collectives -- dWx
+        from the gathered factors: ONE weight-gradient problem with K = world * B rows."""
+        world = self._world()
+        if self._dp_factor_ops is not None and self._dp_factor_ops["world"] == world:
+            return self._dp_factor_ops
+        st, G, dm = self.store, self.store.G, self.store.dims
+        B, D, R = self.batch_size, dm["D"], dm["R"]
+        dv = self.input_images.device
+        n_local = len(self._wgrad_arr) - 1                       # the input-weight problem is the last one
+        local = (H.Wgrad * n_local)(*[self._wgrad_arr[i] for i in range(n_local)])
+        x_all = torch.zeros(world * B, D, dtype=torch.float32, device=dv)
+        dg_all = torch.zeros(world * B, 4 * R, dtype=torch.float32, device=dv)
+        Gx = G["lstm_kernel"][:D]
+        fac = (H.Wgrad * 1)(H.Wgrad(_ptr(x_all), _ptr(dg_all), _ptr(Gx), None, D, 4 * R, world * B, D, 4 * R, 4 * R, 0, 0, 0, 0))
+        cs = (H.Colsum * 1)(H.Colsum(_ptr(self.dgsum), _ptr(G["lstm_bias"]), B, 4 * R, 4 * R, 0))
+        self._keep += [local, fac, cs]
+        ops = dict(world=world, x_all=x_all, dg_all=dg_all, tail=st.grads[D * 4 * R:],
+                   local=self._call("air_wgrad_grouped", local, n_local, self._prec, None, None, tag="wgrad_grouped_local"),
+                   bias=self._call("air_colsum", cs, 1, tag="lstm_bias_colsum"),
+                   dwx=self._call("air_wgrad_grouped", fac, 1, self._prec, None, None, tag="wgrad_dWx_gathered"))
+        self._dp_factor_ops = ops
+        return ops
+
+    def _dp_exchange_gradients(self):
+        """The collectives of one data-parallel step (between the two captured graphs)."""
+        dist = torch.distributed
+        if self._dp_exchange == "flat":
+            dist.all_reduce(self.store.grads)                    # ONE collective: grads + loss/accuracy tail
+            return
+        f = self._dp_factors()
+        world, B = f["world"], self.batch_size
+        for out, inp in ((f["x_all"], self.input_images), (f["dg_all"], self.dgsum)):
+            if dist.get_backend() == "nccl":
+                dist.all_gather_into_tensor(out, inp)
+            else:
+                # gloo moves device tensors only through broadcast / all_reduce: x + 0 is exact, so a zero-padded
+                # all_reduce delivers the same rows an all_gather would
+                r = dist.get_rank()
+                out.zero_()
+                out[r * B:(r + 1) * B].copy_(inp)
+                dist.all_reduce(out)
+        dist.all_reduce(f["tail"])                               # everything but dWx (+ loss / accuracy)
+
     def _run_backward(self, s, for_update=False, fused_finalize=False):
         """for_update: this backward is followed by the optimizer of a single-GPU train step -- the
         weight-gradient launch then also publishes the global-norm partials and counts the step."""
@@ -870,6 +989,11 @@ class AIRModel:
         if for_update and self._world() == 1:
             self._wgrad_fused(s)
             return
+        if for_update and self._dp_exchange == "factors":
+            f = self._dp_factors()
+            f["local"](s)
+            f["bias"](s)
+            return
         self._wgrad_plain(s)
 
     def train_step_ops(self):
@@ -877,13 +1001,19 @@ class AIRModel:
         return ([self._xwx_with_begin] + self._fwd[1:] + [self._write_bwd_fin] + self._bwd[1:] + [self._wgrad_fused]
                 + self._optimizer_ops())
 
-    def _train_phase_a(self, s):
+    def _train_phase_a(self, s, riders=None):
         """step prologue + forward + loss + backward (+ weight grads) into the flat grad buffer"""
-        self._run_forward(s, finalize=False)
+        self._run_forward(s, finalize=False, riders=riders)
         self._run_backward(s, for_update=True, fused_finalize=True)
 
-    def _train_phase_b(self, s):
-        """global-norm clip + TF-style Adam + global_step += 1 (after the all-reduce)"""
+    def _train_phase_b(self, s, main_only=None):
+        """global-norm clip + TF-style Adam + global_step += 1 (after the all-reduce).
+        main_only: the exposed part of a deferred Adam (_adam_riders) instead of the whole update"""
+        if main_only is not None:
+            main_only(s)
+            return
+        if self._world() > 1 and self._dp_exchange == "factors":
+            self._dp_factors()["dwx"](s)                         # dWx from the gathered factors, identically on every rank
         for op in self._optimizer_ops():
             op(s)
 
@@ -913,15 +1043,21 @@ class AIRModel:
             self._run_backward(s)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        # a step that is followed by another one in the same graph defers the VAE part of its Adam into the next
+        # step's narrow GEMM launches (_adam_riders); the last step of the replay updates everything itself
+        deferred = self._adam_riders() if (steps > 1 and world == 1) else None
         ga = torch.cuda.CUDAGraph()
         with torch.cuda.graph(ga):
+            carried = None
             for i in range(steps):
                 if between_steps is not None:
                     between_steps(i)
                 s = self._stream()
-                self._train_phase_a(s)
+                self._train_phase_a(s, riders=carried)
                 if world == 1:
-                    self._train_phase_b(s)
+                    defer = deferred is not None and i < steps - 1
+                    self._train_phase_b(s, main_only=deferred[0] if defer else None)
+                    carried = deferred[1] if defer else None
         gb = None
         if world > 1:
             gb = torch.cuda.CUDAGraph()
@@ -931,10 +1067,10 @@ class AIRModel:
         return self
 
     def _capture_forward_graph(self):
-        self._fresh_shadow()
         """train=False models (the demo / evaluation call, demo/model_wrapper.py:19-30): the whole
         forward -- schedules + noise, hoisted x.Wx, N x (LSTM, heads, read, VAE), compose, batch means --
         as ONE hipGraph; forward() then is a single replay."""
+        self._fresh_shadow()
         torch.cuda.synchronize()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -967,13 +1103,13 @@ class AIRModel:
             ga, gb = self._graph
             ga.replay()
             if world > 1:
-                torch.distributed.all_reduce(st.grads)
+                self._dp_exchange_gradients()
                 gb.replay()
         else:
             s = self._stream()
             self._train_phase_a(s)
             if world > 1:
-                torch.distributed.all_reduce(st.grads)            # ONE collective: grads + loss/accuracy tail
+                self._dp_exchange_gradients()
             self._train_phase_b(s)
         if world > 1:
             self.scalars[:2].mul_(1.0 / world)

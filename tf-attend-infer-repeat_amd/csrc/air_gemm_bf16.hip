@@ -28,6 +28,8 @@
 
 using namespace airg;
 
+AIR_STAMPS_READER(air_debug_stamps_gemm_tw)
+
 namespace {
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -69,10 +71,12 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16tw_kernel(Args a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int tile_m, tile_n;
     xcd_tile(tile_m, tile_n);
-    const int m0 = tile_m * BM, n0 = tile_n * BN / TN * (a.gstride == 16 ? TN : 1);
+    constexpr bool QUAD = EPI_ == EPI_LSTM_FWD_Q;         // 16 columns = 4 gates x 4 units (TN == 1, untransposed B)
+    const int m0 = tile_m * BM, n0 = QUAD ? tile_n * 4 : tile_n * BN / TN * (a.gstride == 16 ? TN : 1);
     const int kbeg = zslab * a.kslab;
     const int kend = min(a.K, kbeg + a.kslab);
 
+    AIR_STAMP(56);
     f32x4 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -89,9 +93,11 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16tw_kernel(Args a)
     constexpr int TA_N = AF32 ? (R * BM * 16 + THREADS - 1) / THREADS : (R * BM * 8 + THREADS - 1) / THREADS;
     constexpr int TBK_N = (R * BN * 8 + THREADS - 1) / THREADS;
     constexpr int TBN_N = (R * KB * (BN / 8) + THREADS - 1) / THREADS;
+    constexpr int TBQ_N = (R * KB * 4 + THREADS - 1) / THREADS;           // QUAD: (image, k, gate) -> 8 bytes = 4 units
     uint4 va[AF32 ? 1 : TA_N];
     float4 vaf[AF32 ? TA_N : 1];
-    uint4 vb[TB ? TBK_N : TBN_N];
+    uint4 vb[QUAD ? 1 : (TB ? TBK_N : TBN_N)];
+    uint2 vq[QUAD ? TBQ_N : 1];
 
     auto issue_loads = [&](int kr) __attribute__((always_inline)) {
         if (AF32) {
@@ -113,7 +119,17 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16tw_kernel(Args a)
                 va[i] = ldg16u(Ab, ((unsigned)gm * (unsigned)a.lda + (unsigned)gk) * 2u, ok);
             }
         }
-        if (TB) {
+        if (QUAD) {
+#pragma unroll
+            for (int i = 0; i < TBQ_N; ++i) {
+                const int t = tid + THREADS * i;
+                const int c = t / (KB * 4), k = (t >> 2) % KB, gate = t & 3;
+                const int gn = gate * a.gstride + n0, gk = kr + c * KB + k;
+                const bool ok = (t < R * KB * 4) && n0 < a.gwidth && gk < kend;
+                const uint2 x = *reinterpret_cast<const uint2*>(Bb + (ok ? ((unsigned)gk * (unsigned)a.ldb + (unsigned)gn) * 2u : 0u));
+                vq[i] = ok ? x : make_uint2(0u, 0u);
+            }
+        } else if (TB) {
 #pragma unroll
             for (int i = 0; i < TBK_N; ++i) {
                 const int u = tid + THREADS * i;
@@ -137,12 +153,11 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16tw_kernel(Args a)
             }
         }
     };
-
-    issue_loads(kbeg);
-    // the epilogue's operands ride behind the first round's panels (same memory round trip)
-    if (nslab == 1) epilogue_prefetch<TM, TN, EPI_>(a, pre, m0, n0, lane, wave);
-    for (int kr = kbeg; kr < kend; kr += R * KB) {
-        if (kr > kbeg) __syncthreads();                                   // images of the previous round consumed
+    // (tried: a mask-free form for interior tiles / full passes -- one per-thread base address, uniform pass offsets.
+    // In-kernel stamps: the issue phase of the K = 256 kernels 0.84 -> 0.56 us, nothing at K = 784, and the in-graph
+    // launch times did not move (the phase is bound by the CU's vector-memory path -- 64 B/clk, and a 16-column tile
+    // uses 32 bytes of every 128-byte line of a row-major weight -- not by its ~15 VALU instructions per piece))
+    auto store_images = [&](int) __attribute__((always_inline)) {
         if (AF32) {
 #pragma unroll
             for (int i = 0; i < TA_N; ++i) {
@@ -161,7 +176,13 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16tw_kernel(Args a)
                 if (u < R * BM * 8) *reinterpret_cast<uint4*>(&ImgA[(c * BM + row) * KB + ((g ^ (row & 7)) << 3)]) = va[i];
             }
         }
-        if (TB) {
+        if (QUAD) {
+#pragma unroll
+            for (int i = 0; i < TBQ_N; ++i) {
+                const int t = tid + THREADS * i;
+                if (t < R * KB * 4) *reinterpret_cast<uint2*>(&ImgB[t * 4]) = vq[i];           // [c][k][gate][4 units]: lane-linear
+            }
+        } else if (TB) {
 #pragma unroll
             for (int i = 0; i < TBK_N; ++i) {
                 const int u = tid + THREADS * i;
@@ -175,8 +196,18 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16tw_kernel(Args a)
                 if (t < R * KB * (BN / 8)) *reinterpret_cast<uint4*>(&ImgB[t * 8]) = vb[i];      // [c][k][BN]: lane-linear
             }
         }
+    };
+
+    issue_loads(kbeg);
+    // the epilogue's operands ride behind the first round's panels (same memory round trip)
+    if (nslab == 1) epilogue_prefetch<TM, TN, EPI_>(a, pre, m0, n0, lane, wave);
+    AIR_STAMP(57);
+    for (int kr = kbeg; kr < kend; kr += R * KB) {
+        if (kr > kbeg) __syncthreads();                                   // images of the previous round consumed
+        store_images(kr);
         if (kr + R * KB < kend) issue_loads(kr + R * KB);
         __syncthreads();
+        AIR_STAMP(58);
         // ---- MFMAs: wave w owns the images whose index within the slab is w (mod 4), whatever R is
         const int cfirst = (wave - ((kr - kbeg) / KB)) & 3;
 #pragma unroll
@@ -220,8 +251,10 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16tw_kernel(Args a)
             }
         }
     }
+    AIR_STAMP(59);
     __syncthreads();                                                      // Red aliases the images
     reduce_waves<TM, TN>(acc, Red, lane, wave);
+    AIR_STAMP(60);
     if (nslab > 1) {
         float* Cz = a.C + (size_t)zslab * a.slab_stride;
         for (int t = wave; t < TM * TN; t += 4) {
@@ -236,6 +269,7 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16tw_kernel(Args a)
         return;
     }
     epilogue<TM, TN, EPI_>(a, pre, Red, m0, n0, lane, wave);
+    AIR_STAMP(61);
 }
 
 // opt-in to > 48 KB of dynamic LDS once per (kernel function, device)
@@ -293,9 +327,10 @@ int twin_rounds(const Args& a, int tm, int tn, bool ta, bool tb) {
         if (e == AIR_EPI_GENERIC || ((e == AIR_EPI_LSTM_BWD || e == AIR_EPI_LSTM_BWD_TAIL) && tb)) return nimg <= 4 ? 4 : (nimg <= 8 ? 8 : 16);
         return 0;
     }
-    if (tm == 1 && tn == 4) return (!af32 && !tb && e == AIR_EPI_LSTM_FWD) ? 4 : 0;
+    if (tm == 1 && tn == 4) return (!af32 && !tb && e == AIR_EPI_LSTM_FWD) ? 4 : 0;       // (quad-unit tiles when gwidth % 4 == 0: twin_launch)
     if (tm == 2 && tn == 2) return e == AIR_EPI_GENERIC ? (af32 ? (tb ? 0 : 8) : (nimg <= 4 ? 4 : 8)) : 0;
     if (tm == 4 && tn == 2) return (e == AIR_EPI_GENERIC && !tb) ? 4 : 0;
+    if (tm == 4 && tn == 4) return (e == AIR_EPI_GENERIC && !tb) ? 4 : 0;      // 64 x 64: the deep x.Wx of large canvases
     return 0;
 }
 
@@ -312,18 +347,36 @@ int twin_launch(const Args& a, int tm, int tn, bool tb, dim3 grid, hipStream_t s
         if (e == AIR_EPI_LSTM_BWD) { if (r == 4) TW(1, 1, true, AIR_EPI_LSTM_BWD, false, 4); if (r == 8) TW(1, 1, true, AIR_EPI_LSTM_BWD, false, 8); TW(1, 1, true, AIR_EPI_LSTM_BWD, false, 16); }
         if (e == AIR_EPI_LSTM_BWD_TAIL) { if (r == 4) TW(1, 1, true, AIR_EPI_LSTM_BWD_TAIL, false, 4); if (r == 8) TW(1, 1, true, AIR_EPI_LSTM_BWD_TAIL, false, 8); TW(1, 1, true, AIR_EPI_LSTM_BWD_TAIL, false, 16); }
     }
-    if (tm == 1 && tn == 4) TW(1, 4, false, AIR_EPI_LSTM_FWD, false, 4);
+    if (tm == 1 && tn == 4) {
+        // AIR_EPI_LSTM_FWD: 16-column tiles of four units x four gates where the layout allows (8-byte pieces of 4 units)
+        if ((a.gwidth & 3) == 0 && getenv("AIR_LSTM_FWD_WIDE") == nullptr) {
+            dim3 gq((a.gwidth + 3) / 4, grid.y, grid.z);
+            Args b = a;
+            if (a.job_on) {          // the carried job's planes were sized for the wide tiles' grid: same number of workgroups
+                b.job_on = (int)((a.job_on * grid.x + gq.x - 1) / gq.x);
+                if (b.job_on < 1) b.job_on = 1;
+                gq.z = grid.z - a.job_on + b.job_on;
+            }
+            return launch_one<1, 1, false, EPI_LSTM_FWD_Q, false, 4>(b, gq, s);
+        }
+        TW(1, 4, false, AIR_EPI_LSTM_FWD, false, 4);
+    }
     if (tm == 2 && tn == 2) {
         if (af32) TW(2, 2, false, AIR_EPI_GENERIC, true, 8);
         if (tb) { if (r == 4) TW(2, 2, true, AIR_EPI_GENERIC, false, 4); TW(2, 2, true, AIR_EPI_GENERIC, false, 8); }
         if (r == 4) TW(2, 2, false, AIR_EPI_GENERIC, false, 4); TW(2, 2, false, AIR_EPI_GENERIC, false, 8);
     }
     if (tm == 4 && tn == 2) { if (af32) TW(4, 2, false, AIR_EPI_GENERIC, true, 4); TW(4, 2, false, AIR_EPI_GENERIC, false, 4); }
+    if (tm == 4 && tn == 4) { if (af32) TW(4, 4, false, AIR_EPI_GENERIC, true, 4); TW(4, 4, false, AIR_EPI_GENERIC, false, 4); }
 #undef TW
     return AIR_EINVAL;
 }
 
 void twin_kernel_name(const Args& a, int tm, int tn, bool tb, char* buf, int n) {
+    if (tm == 1 && tn == 4 && (a.gwidth & 3) == 0 && getenv("AIR_LSTM_FWD_WIDE") == nullptr) {
+        snprintf(buf, n, "gemm_bf16tw_kernel<1, 1, false, %d, false, 4>", EPI_LSTM_FWD_Q);
+        return;
+    }
     snprintf(buf, n, "gemm_bf16tw_kernel<%d, %d, %s, %d, %s, %d>", tm, tn, tb ? "true" : "false", a.epi,
              a.A16 == nullptr ? "true" : "false", twin_rounds(a, tm, tn, false, tb));
 }

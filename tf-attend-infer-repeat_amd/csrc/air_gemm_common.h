@@ -12,6 +12,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int THREADS = 256;
+// internal epilogue id (never in the ABI): AIR_EPI_LSTM_FWD on 16-column tiles of FOUR units x four gates (column
+// c = gate c >> 2 of unit n0 + (c & 3)) -- four times as many, four times lighter workgroups than the 64-column
+// grouped tiles; same accumulation per element, same epilogue arithmetic (air_gemm_bf16.hip)
+constexpr int EPI_LSTM_FWD_Q = 100;
 
 __device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
     unsigned int u = __float_as_uint(f);
@@ -109,6 +113,19 @@ __device__ __forceinline__ void epilogue_prefetch(const Args& a, Pre<TM, TN>& pr
             pre.f[32 + j] = fetch(ok && a.bias, a.bias, n);
         }
         pre.f[36] = fetch(ok, a.p0, (size_t)m * R + u);
+    } else if (E == EPI_LSTM_FWD_Q) {
+        // item of lane L of wave 0: row L >> 2, unit n0 + (L & 3) -- the operands AIR_EPI_LSTM_FWD fetches, same slots
+        const int R = a.gwidth, mm = m0 + (lane >> 2), uu = n0 + (lane & 3);
+        const bool okq = wave == 0 && mm < a.M && uu < R;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = uu + j * R;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                pre.f[j * 8 + k] = fetch(okq && k < a.add_slabs, a.addend, k * a.add_slab_stride + (size_t)mm * a.ldadd + n);
+            pre.f[32 + j] = fetch(okq && a.bias, a.bias, n);
+        }
+        pre.f[36] = fetch(okq, a.p0, (size_t)mm * R + uu);
     } else if (E == AIR_EPI_LSTM_FWD0) {
         // item of lane L (wave 0): row L >> 2, unit n0 + (L & 3); only the bias is needed (zero state, no addend)
         const int R = a.gwidth, uu = n0 + (lane & 3);
@@ -168,6 +185,34 @@ __device__ __forceinline__ void epilogue(const Args& a, const Pre<TM, TN>& pre, 
             if (a.accumulate) v += *c;
             *c = v;
             if (a.C16) a.C16[(size_t)m * a.ldc + n] = bf16_of(v);
+        }
+        return;
+    }
+    if (E == EPI_LSTM_FWD_Q) {
+        // tile columns: gate (col >> 2) of unit n0 + (col & 3); wave 0 takes the 64 (row, unit) items.  BasicLSTMCell
+        // (air_model.py:286) exactly as AIR_EPI_LSTM_FWD computes it: acc + slabs (in slab order) + bias -> i, j, f, o
+        if (wave == 0) {
+            const int R = a.gwidth, r = lane >> 2, m = m0 + r, u = n0 + (lane & 3);
+            if (m < a.M && u < R) {
+                float g[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float s = Red[(r & 3) * 64 + (r >> 2) * 16 + j * 4 + (lane & 3)];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) s += (k < a.add_slabs) ? pre.f[j * 8 + k] : 0.0f;   // fixed summation order
+                    if (a.bias) s += pre.f[32 + j];
+                    g[j] = s;
+                }
+                const float si = air_sigmoid(g[0]), tj = tanhf(g[1]);
+                const float sf = air_sigmoid(g[2] + 1.0f), so = air_sigmoid(g[3]);
+                const float cn = pre.f[36] * sf + si * tj;
+                float* ac = a.q0 + (size_t)m * 4 * R;
+                ac[u] = si; ac[R + u] = tj; ac[2 * R + u] = sf; ac[3 * R + u] = so;
+                a.q1[(size_t)m * R + u] = cn;
+                const float hn = tanhf(cn) * so;
+                a.q2[(size_t)m * R + u] = hn;
+                if (a.q2_16) a.q2_16[(size_t)m * R + u] = bf16_of(hn);
+            }
         }
         return;
     }

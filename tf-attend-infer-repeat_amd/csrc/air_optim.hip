@@ -40,11 +40,15 @@ __global__ __launch_bounds__(THREADS) void grad_sqnorm_kernel(
 __global__ __launch_bounds__(THREADS) void adam_clip_kernel(
     float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
     const float* __restrict__ partials, int npartials, const float* __restrict__ dyn, const int32_t* __restrict__ istate,
-    float prescale, float b1, float b2, float eps, uint16_t* __restrict__ shadow, float* __restrict__ gnorm_out)
+    float prescale, float b1, float b2, float eps, uint16_t* __restrict__ shadow, float* __restrict__ gnorm_out,
+    float* __restrict__ coef_out)
 {
     __shared__ float red[4];
     const AirAdamCoef cf = air_adam_coef(partials, npartials, dyn, istate, prescale, b1, b2, red);
     if (gnorm_out && blockIdx.x == 0 && threadIdx.x == 0) *gnorm_out = cf.gnorm;
+    // the record deferred slices of this step's update read (air_step_job_t.ad_coef): dyn / istate / partials may have
+    // moved on to the next step by the time they run
+    if (coef_out && blockIdx.x == 0 && threadIdx.x == 0) { coef_out[0] = cf.scale; coef_out[1] = cf.lr_t; coef_out[2] = cf.gnorm; }
     const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
 
     const long n4 = n / 4;
@@ -96,7 +100,8 @@ extern "C" int air_step_begin(const air_schedule_t* sched, int nsched, float* dy
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;
     AirStepJob job{sched, nsched, dyn, istate, normals, (long)n_normal, uniforms, (long)n_uniform,
-                   (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), twin_src, twin_dst, (long)twin_n};
+                   (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), twin_src, twin_dst, (long)twin_n,
+                   nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0.f, 0.f, 0.f};
     hipLaunchKernelGGL(step_begin_kernel, dim3((int)blocks), dim3(THREADS), 0, air_stream(stream), job);
     AIR_CHECK_LAUNCH();
     return 0;
@@ -113,19 +118,33 @@ extern "C" int air_grad_sqnorm(const float* grads, int64_t n, float* partials, i
     return 0;
 }
 
+extern "C" int air_adam_clip_step_blocks(float* params, const float* grads, float* m, float* v, int64_t n,
+                                         const float* partials, int npartials, const float* dyn, const int32_t* istate,
+                                         float grad_prescale, float beta1, float beta2, float epsilon,
+                                         uint16_t* bf16_shadow, float* gnorm_out, int max_blocks, float* coef_out, void* stream);
+
 extern "C" int air_adam_clip_step(float* params, const float* grads, float* m, float* v, int64_t n,
                                   const float* partials, int npartials, const float* dyn, const int32_t* istate,
                                   float grad_prescale, float beta1, float beta2, float epsilon,
                                   uint16_t* bf16_shadow, float* gnorm_out, void* stream) {
+    return air_adam_clip_step_blocks(params, grads, m, v, n, partials, npartials, dyn, istate, grad_prescale, beta1, beta2,
+                                     epsilon, bf16_shadow, gnorm_out, 0, nullptr, stream);
+}
+
+extern "C" int air_adam_clip_step_blocks(float* params, const float* grads, float* m, float* v, int64_t n,
+                                         const float* partials, int npartials, const float* dyn, const int32_t* istate,
+                                         float grad_prescale, float beta1, float beta2, float epsilon,
+                                         uint16_t* bf16_shadow, float* gnorm_out, int max_blocks, float* coef_out, void* stream) {
     if (!params || !grads || !m || !v || !partials || npartials <= 0 || !dyn || !istate || n <= 0) return AIR_EINVAL;
     if ((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)m | (uintptr_t)v) & 15) != 0) return AIR_EALIGN;
     if (((uintptr_t)bf16_shadow & 7) != 0) return AIR_EALIGN;
     long blocks = (n / 4 + THREADS - 1) / THREADS;
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;        // (512 .. 8192 measured: 20.3 .. 23.8 us in isolation, no difference inside the step)
+    if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
     hipLaunchKernelGGL(adam_clip_kernel, dim3((int)blocks), dim3(THREADS), 0, air_stream(stream),
                        params, grads, m, v, (long)n, partials, npartials, dyn, istate, grad_prescale, beta1, beta2,
-                       epsilon, bf16_shadow, gnorm_out);
+                       epsilon, bf16_shadow, gnorm_out, coef_out);
     AIR_CHECK_LAUNCH();
     return 0;
 }

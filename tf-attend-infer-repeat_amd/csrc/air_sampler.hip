@@ -16,6 +16,9 @@
 #include "air_common.h"
 #include <cstdio>
 #include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
 
 AIR_STAMPS_READER(air_debug_stamps)
 
@@ -181,7 +184,7 @@ __device__ __forceinline__ GenTap generic_tap(const float* th, int i, int j, int
 
 __global__ __launch_bounds__(THREADS) void transformer_bwd_kernel(
     const float* __restrict__ U, const float* __restrict__ theta, const float* __restrict__ d_out,
-    float* __restrict__ d_U, float* __restrict__ d_theta, int Hi, int Wi, int Ho, int Wo)
+    float* __restrict__ d_U, float* __restrict__ d_theta, int Hi, int Wi, int Ho, int Wo, int lds_ordered)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -218,7 +221,18 @@ __global__ __launch_bounds__(THREADS) void transformer_bwd_kernel(
     }
     if (d_U) {
         __syncthreads();
-        if (wave == 0) {
+        if (!lds_ordered) {
+            // fallback for a part whose LDS atomics do not apply lanes in ascending order (lds_order_probe): ONE lane
+            // walks the terms -- slow, but the reference's scatter order by construction
+            if (tid == 0)
+                for (int ph = 0; ph < 4; ++ph)
+                    for (int p = 0; p < NO; ++p) {
+                        const GenTap t = generic_tap(sh_th, p / Wo, p % Wo, Hi, Wi, Ho, Wo);
+                        const float wgt = ((ph & 2) ? t.wx1 : t.wx0) * ((ph & 1) ? t.wy1 : t.wy0);
+                        const int idx = ((ph & 1) ? t.y1 : t.y0) * Wi + ((ph & 2) ? t.x1 : t.x0);
+                        sh_dU[idx] = sh_dU[idx] + wgt * g[p];
+                    }
+        } else if (wave == 0) {
             for (int ph = 0; ph < 4; ++ph)
                 for (int p0 = 0; p0 < NO; p0 += 64) {
                     const int p = p0 + lane;
@@ -981,8 +995,8 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_kernel(air_write_bwd_t a
 //            (a lone wave issues a dependent v_add_f32 every ~8 cycles -- fine for the short
 //            in-range and edge runs).  The FOUR CORNER slots own every pixel that is outside the
 //            glimpse in both axes -- (C - s*C)^2 terms per tap, most of the canvas -- and go through
-//            the LDS instead: the last wave feeds their streams, 64 terms per instruction, to
-//            ds_add_f32 on one LDS word per corner.  gfx950's LDS applies the lanes of one
+//            the LDS instead: after everything else is published, waves 0..3 feed one corner each, 64 terms per
+//            instruction, to ds_add_f32 on one LDS word per corner.  gfx950's LDS applies the lanes of one
 //            instruction in ascending lane order and a wave's instructions in program order
 //            (measured: tools/exp/lds_atomic_order.hip; pinned by the bit-for-bit test), i.e. it IS
 //            a sequential fp32 accumulator, at ~4 cycles per term and without occupying the VALU:
@@ -1013,11 +1027,11 @@ __device__ __forceinline__ float stream_add(float acc, const float* T, int start
 // ALLPH: the terms of all four taps are resident (4*C*C floats of LDS, no barrier between taps);
 // otherwise one tap at a time through one buffer (large canvases)
 template <bool ALLPH>
-__global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_bwd_t a)
+__global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_bwd_t a, int lds_ordered)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x, t = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int NW = WB_THREADS / 64, FEED = NW - 1;     // the last wave feeds the corner accumulators
+    constexpr int NW = WB_THREADS / 64;
     const int C = a.C, w = a.w, CC = C * C, CCp = (CC + 3) & ~3;
     const size_t row = (size_t)t * a.B + b;
     float* sh_red = smem;                                  // [128]: fin sums / per-wave partials [NW][8]
@@ -1118,17 +1132,15 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
     };
     const int sp = tid / w, sq = tid % w;
     const bool is_slot = tid < w * w;
-    const bool corner = is_slot && (sp == 0 || sp == w - 1) && (sq == 0 || sq == w - 1);
+    // (a part whose LDS atomics are not lane-ordered -- lds_order_probe -- has no "corner" slots: their four long runs go
+    // through the register chains like every other slot's; slow, but the same sequential order by construction)
+    const bool corner = lds_ordered && is_slot && (sp == 0 || sp == w - 1) && (sq == 0 || sq == w - 1);
     float acc = 0.0f;
     float d00 = 0.f, d02 = 0.f, d11 = 0.f, d12 = 0.f, dz = 0.f;
     // The corner slots' streams -> ds_add_f32 on one LDS word per corner: wave c feeds corner c, 64
     // consecutive terms per instruction, tap after tap (an instruction costs ~140 + 1.8 cycles per active
-    // lane, tools/exp/lds_atomic_cost.hip: full instructions, and the four corners' fixed parts
-    // overlap across the four waves).  16 instructions per batch: a wave's LDS operations execute in
-    // order, so a read queued behind an add waits for it -- the reads of batch i+1 are issued right
-    // behind the adds of batch i and have landed when those finish.  Reads, adds and waits are inline
-    // asm (the compiler's own s_waitcnt bookkeeping would put an lgkmcnt(0) in front of every add);
-    // the register dependence is carried through the wait.
+    // lane, tools/exp/lds_atomic_cost.hip).  16 instructions per batch; reads, adds and waits are inline asm
+    // (the compiler's own s_waitcnt bookkeeping would put an lgkmcnt(0) in front of every add).
     auto feed_corner = [&](int c, int ph0, int ph1) {
         constexpr int NB = 16;
         // stream descriptors of this corner: lane ph computes tap ph's run, broadcast to scalars
@@ -1159,40 +1171,41 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
                 ent_n[h] = i < ninstr ? min(64, (ph == 0 ? ln[0] : ph == 1 ? ln[1] : ph == 2 ? ln[2] : ln[3]) - k0) : 0;
             }
             const int m = min(128, ninstr - base);
-            auto reads = [&](float (&r)[NB], int (&d)[NB], int j0) {
+            // One batch: 16 reads in two asm statements of 8, each statement ENDING with its own s_waitcnt -- when the
+            // statement is over its outputs are architecturally valid, so the compiler may move, copy or spill them freely
+            // (it cannot see LDS returns in flight across asm statements).  The reads queue behind the previous
+            // batch's adds (a wave's LDS operations execute in order), i.e. the wait also drains those: the atomic pipe
+            // idles only for the ~2 x 100 cycles of the two read round trips per 16 x 255-cycle batch.
+            auto batch = [&](int j0) {
+                float r[NB];
+                int d[NB];
+                unsigned ad[NB];
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
                     const int j = j0 + u;                          // uniform
-                    d[u] = 0;
+                    d[u] = 0; ad[u] = (unsigned)(size_t)(air_lds_float*)sh_T;
                     if (j < m) {
                         const int a0 = __builtin_amdgcn_readlane(j < 64 ? ent_a[0] : ent_a[1], j & 63);
                         d[u] = __builtin_amdgcn_readlane(j < 64 ? ent_n[0] : ent_n[1], j & 63);
-                        const unsigned addr = (unsigned)(size_t)(air_lds_float*)(sh_T + a0 + min(lane, d[u] - 1));
-                        asm volatile("ds_read_b32 %0, %1" : "=v"(r[u]) : "v"(addr) : "memory");
+                        ad[u] = (unsigned)(size_t)(air_lds_float*)(sh_T + a0 + min(lane, max(d[u] - 1, 0)));
                     }
                 }
-            };
-            auto adds = [&](float (&r)[NB], const int (&d)[NB]) {
-                asm volatile("s_waitcnt lgkmcnt(0)"
-                             : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]),
-                               "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15]) :: "memory");
+#pragma unroll
+                for (int h = 0; h < NB; h += 8)
+                    asm volatile("ds_read_b32 %0, %8\n ds_read_b32 %1, %9\n ds_read_b32 %2, %10\n ds_read_b32 %3, %11\n"
+                                 "ds_read_b32 %4, %12\n ds_read_b32 %5, %13\n ds_read_b32 %6, %14\n ds_read_b32 %7, %15\n"
+                                 "s_waitcnt lgkmcnt(0)"
+                                 : "=&v"(r[h]), "=&v"(r[h + 1]), "=&v"(r[h + 2]), "=&v"(r[h + 3]),
+                                   "=&v"(r[h + 4]), "=&v"(r[h + 5]), "=&v"(r[h + 6]), "=&v"(r[h + 7])
+                                 : "v"(ad[h]), "v"(ad[h + 1]), "v"(ad[h + 2]), "v"(ad[h + 3]),
+                                   "v"(ad[h + 4]), "v"(ad[h + 5]), "v"(ad[h + 6]), "v"(ad[h + 7])
+                                 : "memory");
 #pragma unroll
                 for (int u = 0; u < NB; ++u)
                     if (lane < d[u]) asm volatile("ds_add_f32 %0, %1" :: "v"(acc_addr), "v"(r[u]) : "memory");   // valid lanes only (EXEC)
             };
-            float ra[NB], rb[NB];
-            int da[NB], db[NB];
-#pragma unroll
-            for (int u = 0; u < NB; ++u) { ra[u] = 0.f; rb[u] = 0.f; }
-            reads(ra, da, 0);
 #pragma unroll 1
-            for (int j0 = 0; j0 < m; j0 += 2 * NB) {
-                if (j0 + NB < m) reads(rb, db, j0 + NB);
-                adds(ra, da);
-                if (j0 + NB >= m) break;
-                if (j0 + 2 * NB < m) reads(ra, da, j0 + 2 * NB);
-                adds(rb, db);
-            }
+            for (int j0 = 0; j0 < m; j0 += NB) batch(j0);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
@@ -1257,7 +1270,7 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
         AIR_STAMP(39);
         __syncthreads();
         AIR_STAMP(44);
-        if (wave < 4) feed_corner(wave, 0, 4);
+        if (wave < 4 && lds_ordered) feed_corner(wave, 0, 4);
         __syncthreads();
     } else {
         for (int ph = 0; ph < 4; ++ph) {
@@ -1266,7 +1279,7 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
             if (ph == 0) theta_loop(WB_THREADS);
             chains(ph, ph + 1);
             __syncthreads();
-            if (wave < 4) feed_corner(wave, ph, ph + 1);
+            if (wave < 4 && lds_ordered) feed_corner(wave, ph, ph + 1);
             __syncthreads();
         }
     }
@@ -1311,6 +1324,61 @@ size_t write_bwd_graph_smem(int C, int w, bool allph) {
 }
 size_t write_bwd_smem(int C, int w) { return (64 + 8 * C + C + 8 * w + 8 * (w + 2) + (size_t)w * w + 4 * (size_t)(w + 2) * w + 2 * (size_t)C * (w + 2) + (size_t)C * C) * sizeof(float); }
 
+// ---------------------------------------------------------------------------
+// The bit-for-bit reproduction of the reference's UnsortedSegmentSum rests on a property of gfx950 that no manual
+// states: a same-address ds_add_f32 applies the 64 lanes of an instruction in ascending lane order, and a wave's
+// instructions in program order.  It is probed ONCE per process on the first eager call that needs it (a known-order
+// sum whose value depends on the order; the probe needs a stream synchronise and is therefore skipped -- property
+// assumed -- while the stream is being captured: capture_graph() warms up eagerly first).  A part that orders
+// differently takes the register-chain fallbacks (same results, slower) instead of silently changing gradients.
+// AIR_LDS_ORDER=0 / 1 forces the answer (tests run both paths against each other).
+// ---------------------------------------------------------------------------
+constexpr int PROBE_N = 8 * 64;
+__device__ float air_probe_vals[PROBE_N];
+__device__ float air_probe_out[4];
+__global__ void lds_order_probe_kernel() {
+    __shared__ float slot[2];
+    if (threadIdx.x < 2) slot[threadIdx.x] = 0.0f;
+    __syncthreads();
+    for (int k = 0; k < PROBE_N / 64; ++k) lds_fadd(&slot[0], air_probe_vals[k * 64 + threadIdx.x]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) air_probe_out[0] = slot[0];
+}
+
+int lds_ordered(hipStream_t s) {
+    static std::atomic<int> state{0};                    // 0 unknown, 1 ordered, 2 not ordered
+    int st = state.load(std::memory_order_acquire);
+    if (st) return st == 1;
+    if (const char* e = getenv("AIR_LDS_ORDER")) { st = (e[0] == '0') ? 2 : 1; state.store(st, std::memory_order_release); return st == 1; }
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return 1;   // cannot synchronise here
+    float vals[PROBE_N];
+    unsigned x = 12345u;
+    float want = 0.0f;
+    for (int i = 0; i < PROBE_N; ++i) {
+        x = x * 1664525u + 1013904223u;
+        // magnitudes over 2^-8 .. 2^23 with mixed signs: every partial sum rounds, so the value pins the order
+        const float mant = 1.0f + (float)((x >> 9) & 0x3fffu) / 16384.0f;
+        const int ex = (int)((x >> 24) & 31u) - 8;
+        vals[i] = ((x >> 31) ? -1.0f : 1.0f) * ldexpf(mant, ex);
+        want = want + vals[i];                           // ascending lane, program order
+    }
+    float got = 0.0f;
+    bool ok = hipMemcpyToSymbolAsync(HIP_SYMBOL(air_probe_vals), vals, sizeof(vals), 0, hipMemcpyHostToDevice, s) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(lds_order_probe_kernel, dim3(1), dim3(64), 0, s);
+        ok = hipGetLastError() == hipSuccess &&
+             hipMemcpyFromSymbolAsync(&got, HIP_SYMBOL(air_probe_out), sizeof(float), 0, hipMemcpyDeviceToHost, s) == hipSuccess &&
+             hipStreamSynchronize(s) == hipSuccess;
+    }
+    st = (ok && memcmp(&got, &want, sizeof(float)) == 0) ? 1 : 2;
+    if (st == 2) fprintf(stderr, "libair_hip: ds_add_f32 lane order differs on this part (probe %.9g, expected %.9g): "
+                                 "the sampler backward takes its register-chain fallback\n", (double)got, (double)want);
+    state.store(st, std::memory_order_release);
+    return st == 1;
+}
+
 // Opt-in to > 48 KB of dynamic LDS, ONCE per kernel function (the full 160 KB is granted the first
 // time a kernel asks for more than the default): hipFuncSetAttribute is a host-side driver call
 // and must not sit on every launch -- in particular not inside stream capture.
@@ -1352,7 +1420,7 @@ extern "C" int air_transformer_bwd(const float* U, const float* theta, const flo
     int rc = ensure_lds(transformer_bwd_kernel, lds);
     if (rc) return rc;
     hipLaunchKernelGGL(transformer_bwd_kernel, dim3(B), dim3(THREADS), lds, air_stream(stream),
-                       U, theta, d_out, d_U, d_theta, Hi, Wi, Ho, Wo);
+                       U, theta, d_out, d_U, d_theta, Hi, Wi, Ho, Wo, d_U ? lds_ordered(air_stream(stream)) : 1);
     AIR_CHECK_LAUNCH();
     return 0;
 }
@@ -1419,8 +1487,9 @@ extern "C" int air_write_bwd(const air_write_bwd_t* a, void* stream) {
         const size_t lds = write_bwd_graph_smem(a->C, a->w, allph);
         int rc = allph ? ensure_lds(write_bwd_graph_kernel<true>, lds) : ensure_lds(write_bwd_graph_kernel<false>, lds);
         if (rc) return rc;
-        if (allph) hipLaunchKernelGGL(write_bwd_graph_kernel<true>, dim3(a->B, a->N), dim3(WB_THREADS), lds, air_stream(stream), *a);
-        else hipLaunchKernelGGL(write_bwd_graph_kernel<false>, dim3(a->B, a->N), dim3(WB_THREADS), lds, air_stream(stream), *a);
+        const int ordered = lds_ordered(air_stream(stream));
+        if (allph) hipLaunchKernelGGL(write_bwd_graph_kernel<true>, dim3(a->B, a->N), dim3(WB_THREADS), lds, air_stream(stream), *a, ordered);
+        else hipLaunchKernelGGL(write_bwd_graph_kernel<false>, dim3(a->B, a->N), dim3(WB_THREADS), lds, air_stream(stream), *a, ordered);
         AIR_CHECK_LAUNCH();
         return 0;
     }

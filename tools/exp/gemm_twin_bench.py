@@ -55,4 +55,7 @@ for shape in [(192, 320, 256, 0), (192, 512, 784, 0), (192, 256, 512, 0), (192, 
     bench(*shape)
 bench(64, 1024, 2500, 0, tile=(2, 2), ksplit=4)
 bench(256, 1024, 16384, 0, tile=(4, 2), ksplit=4)
+bench(256, 1024, 16384, 0, tile=(4, 4), ksplit=4)
+bench(256, 1024, 16384, 0, tile=(4, 4), ksplit=8)
+bench(64, 1024, 256, 0, epi=1)
 bench(1280, 512, 784, 0); bench(1280, 784, 512, 1); bench(1280, 784, 512, 0)

@@ -7,13 +7,17 @@ PKG = os.path.join(ROOT, "tf-attend-infer-repeat_amd")
 sys.path.insert(0, ROOT); sys.path.insert(0, PKG)
 out = "/tmp/libair_hip_stamps.so"
 src = sorted(glob.glob(os.path.join(PKG, "csrc", "*.hip")))
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
-                       "-shared", "-DAIR_STAMPS", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "csrc")]
-                      + src + ["-o", out])
+from concurrent.futures import ThreadPoolExecutor
+flags = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-DAIR_STAMPS",
+         "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "csrc")]
+objs = ["/tmp/stamps_%s.o" % os.path.basename(f) for f in src]
+with ThreadPoolExecutor(8) as ex:
+    list(ex.map(lambda fo: subprocess.check_call(flags + ["-c", fo[0], "-o", fo[1]]), zip(src, objs)))
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out])
 import torch
 from air import _hip as H
 H._LIB = H.load(out)
-for fn in ("air_debug_stamps", "air_debug_stamps_gemm", "air_debug_stamps_wgrad"):
+for fn in ("air_debug_stamps", "air_debug_stamps_gemm", "air_debug_stamps_gemm_tw", "air_debug_stamps_wgrad"):
     getattr(H._LIB, fn).restype = C.c_int
     getattr(H._LIB, fn).argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 from bench import HP, ANNEAL, synthetic_canvases
@@ -35,7 +39,8 @@ for want in names:
                 op(s)
             torch.cuda.synchronize()
             base = {"write_bwd": 40, "attend_fwd": 10, "attend_bwd": 20, "compose": 30, "wgrad": 0}.get(want, 56)
-            {56: H._LIB.air_debug_stamps_gemm, 0: H._LIB.air_debug_stamps_wgrad}.get(base, H._LIB.air_debug_stamps)(buf, 64)
+            {56: (H._LIB.air_debug_stamps_gemm_tw if "tw_kernel" in op.kernel else H._LIB.air_debug_stamps_gemm),
+             0: H._LIB.air_debug_stamps_wgrad}.get(base, H._LIB.air_debug_stamps)(buf, 64)
             v = [int(x) for x in buf]
             idx = [i for i in range(base - (1 if base == 40 else 0), base + (8 if base == 56 else 10)) if v[i]]
             idx.sort(key=lambda i: v[i])

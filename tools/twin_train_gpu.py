@@ -2,7 +2,7 @@
 (oracle/air_oracle_torch.py: un-fused fp32 ops, autograd's own residue-carrying gradients) with
 torch-ROCm kernels on the same data, annealing and optimizer as training.py -- an independent
 implementation of "the reference's fp32 autodiff" to compare success rates with.
-  python tools/twin_train_gpu.py <seed> <iterations>"""
+  python tools/twin_train_gpu.py <seed> <iterations> [<backgrounds.npz>:<key>]   (clutter: BASELINE configs[4])"""
 import json, math, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tf-attend-infer-repeat_amd"))
@@ -13,7 +13,11 @@ from multi_mnist import generate_dataset, shift_zero_digits_images
 seed, iters = int(sys.argv[1]), int(sys.argv[2])
 torch.set_default_device("cuda")
 hp = dict(ao.TRAINING_HP)
-ds = generate_dataset()
+bg = None
+if len(sys.argv) > 3:                                      # clutter background, already scaled (tests/golden/backgrounds.npz)
+    f_, key_ = sys.argv[3].rsplit(":", 1)
+    bg = np.load(f_)[key_].astype(np.float32)
+ds = generate_dataset(bg=bg)
 te_im, te_dg = shift_zero_digits_images(ds["test_images"], ds["test_digits"])
 tr_im, tr_dg = torch.tensor(ds["train_images"]), torch.tensor(ds["train_digits"].astype(np.int32))
 te_im, te_dg = torch.tensor(np.ascontiguousarray(te_im)), torch.tensor(np.ascontiguousarray(te_dg).astype(np.int32))
