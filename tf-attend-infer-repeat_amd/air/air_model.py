@@ -409,7 +409,9 @@ class AIRModel:
 
         # the hoisted x.Wx: 4 split-K slabs (the LSTM epilogues sum them); 32x32 tiles at D = 2500 (0.1977 ->
         # 0.1968 ms per step against 8 slabs), 64x32 for the 128x128 canvases (0.923 -> 0.898 ms) -- measured sweeps
-        self._xw_ksplit, self._xw_tile = 4, ((2, 2) if D <= 4096 else (4, 2))
+        # (bf16 twins, large canvases: 64x64 tiles -- the image batch is re-read by 16 instead of 32 column tiles and the
+        # row-major Wx shadow is fetched in whole 128-byte lines: [256x1024x16384] 59.6 -> 42.2 us, tools/exp/gemm_twin_bench.py)
+        self._xw_ksplit, self._xw_tile = 4, ((2, 2) if D <= 4096 else ((4, 4) if self._twins else (4, 2)))
         if os.environ.get("AIR_XW_TILE"):                    # tuning hook: "tm,tn,ksplit" (ksplit <= 8 slabs)
             tm_, tn_, ks_ = (int(v) for v in os.environ["AIR_XW_TILE"].split(","))
             self._xw_ksplit, self._xw_tile = ks_, (tm_, tn_)

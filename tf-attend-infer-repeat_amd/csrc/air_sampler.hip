@@ -16,6 +16,7 @@
 #include "air_common.h"
 #include <cstdio>
 #include <atomic>
+#include <type_traits>
 #include <cstdlib>
 #include <cstring>
 #include <cmath>
@@ -429,31 +430,27 @@ __global__ __launch_bounds__(THREADS) void attend_fwd_kernel(air_attend_fwd_t a)
     if (tid < w) sh_tx[tid] = axis_tap(tid, w, C, s, sx);
     else if (tid >= 64 && tid < 64 + w) sh_ty[tid - 64] = axis_tap(tid - 64, w, C, s, sy);
     __syncthreads();
-    int xlo = 0, ylo = 0, bw = C;
-    if (!whole) {
-        if (tid == 0) {
-            // taps are monotone in the output index (s > 0): the bounding box is set by the ends
-            sh_box[0] = min(sh_tx[0].i0, sh_tx[w - 1].i0); sh_box[1] = max(sh_tx[0].i1, sh_tx[w - 1].i1);
-            sh_box[2] = min(sh_ty[0].i0, sh_ty[w - 1].i0); sh_box[3] = max(sh_ty[0].i1, sh_ty[w - 1].i1);
-        }
-        __syncthreads();
-        xlo = sh_box[0]; bw = sh_box[1] - sh_box[0] + 1;
-        ylo = sh_box[2];
-        const int bh = sh_box[3] - sh_box[2] + 1;
-        for (int p = tid; p < bw * bh; p += THREADS) sh_img[p] = img[(ylo + p / bw) * C + xlo + p % bw];   // coalesced row segments
-        __syncthreads();
-    }
+    // a canvas beyond one prefetch pass (128x128 = 64 KB) is NOT staged in LDS: the glimpse's 4 x w*w taps are
+    // gathered straight from memory -- they fall into a box of ~(s*C)^2 pixels that stays in the CU's L1, and without the
+    // C*C floats of LDS five workgroups share a CU instead of one (stress configuration: 48 -> 12 us for 1280 of them)
     AIR_STAMP(14);
     float* win = a.window + row * w * w;
     unsigned short* win16 = a.window16 ? a.window16 + row * w * w : nullptr;      // bf16 twin: A operand of the first recognition GEMM
-    for (int p = tid; p < w * w; p += THREADS) {
-        const int i = p / w, j = p % w;
-        const Tap tx = sh_tx[j], ty = sh_ty[i];
-        const int r0 = (ty.i0 - ylo) * bw - xlo, r1 = (ty.i1 - ylo) * bw - xlo;
-        const float v = bilinear4(tx, ty, sh_img[r0 + tx.i0], sh_img[r1 + tx.i0], sh_img[r0 + tx.i1], sh_img[r1 + tx.i1]);
-        win[p] = v;
-        if (win16) win16[p] = air_bf16_of(v);
-    }
+    // (the loop is instantiated per address space behind ONE uniform branch: an LDS and a global pointer must not meet
+    // in a flat pointer)
+    auto read_loop = [&](auto staged_t) __attribute__((always_inline)) {
+        constexpr bool STAGED = decltype(staged_t)::value;
+        for (int p = tid; p < w * w; p += THREADS) {
+            const int i = p / w, j = p % w;
+            const Tap tx = sh_tx[j], ty = sh_ty[i];
+            const int r0 = ty.i0 * C, r1 = ty.i1 * C;
+            const float v = STAGED ? bilinear4(tx, ty, sh_img[r0 + tx.i0], sh_img[r1 + tx.i0], sh_img[r0 + tx.i1], sh_img[r1 + tx.i1])
+                                   : bilinear4(tx, ty, img[r0 + tx.i0], img[r1 + tx.i0], img[r0 + tx.i1], img[r1 + tx.i1]);
+            win[p] = v;
+            if (win16) win16[p] = air_bf16_of(v);
+        }
+    };
+    if (whole) read_loop(std::true_type{}); else read_loop(std::false_type{});
     AIR_STAMP(15);
 }
 
@@ -510,40 +507,34 @@ __global__ __launch_bounds__(THREADS) void attend_bwd_kernel(air_attend_bwd_t a)
         for (int k = 0; k < PF; ++k) { const int p = tid + k * THREADS; if (p < C * C) sh_img[p] = pf[k]; }
     }
     __syncthreads();
-    int xlo = 0, ylo = 0, bw = C;
-    if (!whole) {
-        if (tid == 0) {
-            sh_box[0] = min(sh_tx[0].i0, sh_tx[w - 1].i0); sh_box[1] = max(sh_tx[0].i1, sh_tx[w - 1].i1);
-            sh_box[2] = min(sh_ty[0].i0, sh_ty[w - 1].i0); sh_box[3] = max(sh_ty[0].i1, sh_ty[w - 1].i1);
-        }
-        __syncthreads();
-        xlo = sh_box[0]; bw = sh_box[1] - sh_box[0] + 1;
-        ylo = sh_box[2];
-        const int bh = sh_box[3] - sh_box[2] + 1;
-        for (int p = tid; p < bw * bh; p += THREADS) sh_img[p] = img[(ylo + p / bw) * C + xlo + p % bw];
-        __syncthreads();
-    }
-
     // d out / dX = (Ic-Ia)(y1-Y) + (Id-Ib)(Y-y0);  d out / dY = (Ib-Ia)(x1-X) + (Id-Ic)(X-x0)
     const float half_c = ((float)C - 1.001f) / 2.0f;     // dX/dx_s
     float ds = 0.f, dx = 0.f, dy = 0.f;
-    for (int p = tid, k = 0; p < w * w; p += THREADS, ++k) {
-        const int i = p / w, j = p % w;
-        const Tap tx = sh_tx[j], ty = sh_ty[i];
-        const int r0 = (ty.i0 - ylo) * bw - xlo, r1 = (ty.i1 - ylo) * bw - xlo;
-        const float Ia = sh_img[r0 + tx.i0], Ib = sh_img[r1 + tx.i0], Ic = sh_img[r0 + tx.i1], Id = sh_img[r1 + tx.i1];
-        const float gv = k < GF ? gf[k < GF ? k : 0] : g[p];
-        float gX, gY;
-        if (a.literal == 2) graph_dxy(gv, Ia, Ib, Ic, Id, tx, ty, (float)C - 1.001f, gX, gY);
-        else if (a.literal) literal_dxy(gv, Ia, Ib, Ic, Id, tx, ty, (float)C - 1.001f, gX, gY);
-        else {
-            gX = gv * ((Ic - Ia) * ty.w0 + (Id - Ib) * ty.w1) * half_c;
-            gY = gv * ((Ib - Ia) * tx.w0 + (Id - Ic) * tx.w1) * half_c;
+    // large canvases: the taps are gathered from memory (see attend_fwd).  The loop is instantiated per address space
+    // behind ONE uniform branch: an LDS and a global pointer must not meet in a flat pointer
+    auto pixel_loop = [&](auto staged_t) __attribute__((always_inline)) {
+        constexpr bool STAGED = decltype(staged_t)::value;
+        for (int p = tid, k = 0; p < w * w; p += THREADS, ++k) {
+            const int i = p / w, j = p % w;
+            const Tap tx = sh_tx[j], ty = sh_ty[i];
+            const int r0 = ty.i0 * C, r1 = ty.i1 * C;
+            float Ia, Ib, Ic, Id;
+            if (STAGED) { Ia = sh_img[r0 + tx.i0]; Ib = sh_img[r1 + tx.i0]; Ic = sh_img[r0 + tx.i1]; Id = sh_img[r1 + tx.i1]; }
+            else { Ia = img[r0 + tx.i0]; Ib = img[r1 + tx.i0]; Ic = img[r0 + tx.i1]; Id = img[r1 + tx.i1]; }
+            const float gv = k < GF ? gf[k < GF ? k : 0] : g[p];
+            float gX, gY;
+            if (a.literal == 2) graph_dxy(gv, Ia, Ib, Ic, Id, tx, ty, (float)C - 1.001f, gX, gY);
+            else if (a.literal) literal_dxy(gv, Ia, Ib, Ic, Id, tx, ty, (float)C - 1.001f, gX, gY);
+            else {
+                gX = gv * ((Ic - Ia) * ty.w0 + (Id - Ib) * ty.w1) * half_c;
+                gY = gv * ((Ib - Ia) * tx.w0 + (Id - Ic) * tx.w1) * half_c;
+            }
+            ds += gX * sh_t[j] + gY * sh_t[i];
+            dx += gX;
+            dy += gY;
         }
-        ds += gX * sh_t[j] + gY * sh_t[i];
-        dx += gX;
-        dy += gY;
-    }
+    };
+    if (whole) pixel_loop(std::true_type{}); else pixel_loop(std::false_type{});
     {
         float r4[4] = {ds, dx, dy, 0.0f};
         air_block_sum4<THREADS / 64>(r4, sh_red);
@@ -1041,8 +1032,13 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
     float* sh_t = reinterpret_cast<float*>(sh_ty + C);     // [C] linspace
     int* sh_run = reinterpret_cast<int*>(sh_t + ((C + 3) & ~3));   // [4][w][2]: run [lo,hi] of every key of x0 / x1 / y0 / y1
     float* sh_win = reinterpret_cast<float*>(sh_run + ((8 * w + 3) & ~3));   // [w*w]
-    float* sh_g = sh_win + ((w * w + 3) & ~3);             // [C*C] d loss / d (masked z * window_recon)
-    float* sh_T = sh_g + CCp;                              // [4 or 1][C*C] terms, rectangle-blocked per tap (16-byte aligned)
+    // d loss / d (masked z * window_recon): staged in LDS when all taps are resident (small canvases); a large canvas
+    // reads it from memory where needed (its 5 uses per pixel hit L2: every step of an image reads the same row) --
+    // 76 KB instead of 140 KB of LDS at 128x128, i.e. two workgroups per CU: one's LDS-atomic corner phase runs under
+    // the other's term / pixel-loop phases
+    float* sh_g = sh_win + ((w * w + 3) & ~3);             // [C*C] (ALLPH only)
+    float* sh_T = ALLPH ? sh_g + CCp : sh_g;               // [4 or 1][C*C] terms, rectangle-blocked per tap (16-byte aligned)
+    const float* gsrc = a.d_recon + (size_t)b * CC;
 
     if (a.fin_scalars && b == 0 && t == 0) {
         float r4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1076,8 +1072,7 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
     if (tid < 8) sh_acc[tid] = 0.0f;
     const float* v = a.vrec + row * w * w;
     for (int p = tid; p < w * w; p += WB_THREADS) sh_win[p] = v[p];
-    {
-        const float* gsrc = a.d_recon + (size_t)b * CC;
+    if (ALLPH) {
         for (int p0 = 0; p0 < CC; p0 += 8 * WB_THREADS) {
             float r[8];
 #pragma unroll
@@ -1107,7 +1102,7 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
         int i = tid / C, j = tid % C;
         for (int p = tid; p < CC; p += WB_THREADS) {
             const Tap tx = sh_tx[j], ty = sh_ty[i];
-            const float gp = z * sh_g[p];                                           // canvas/mul_grad: z * Select_grad
+            const float gp = z * (ALLPH ? sh_g[p] : gsrc[p]);                       // canvas/mul_grad: z * Select_grad
             const int cl0 = sh_run[tx.i0 * 2], cn0 = sh_run[tx.i0 * 2 + 1] - cl0 + 1;               // x0 run
             const int cl1 = sh_run[(w + tx.i1) * 2], cn1 = sh_run[(w + tx.i1) * 2 + 1] - cl1 + 1;   // x1 run
             const int rl0 = sh_run[(2 * w + ty.i0) * 2], rn0 = sh_run[(2 * w + ty.i0) * 2 + 1] - rl0 + 1;
@@ -1219,7 +1214,7 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
             for (int k = 0; k < 3; ++k) {
                 const int p = min(p0 + k * NT, CC - 1), i = p / C, j = p - i * C;
                 tx[k] = sh_tx[j]; ty[k] = sh_ty[i]; tj[k] = sh_t[j]; ti[k] = sh_t[i];
-                gv[k] = (p0 + k * NT < CC) ? sh_g[p] : 0.0f;     // a pixel past the end contributes exact zeros
+                gv[k] = (p0 + k * NT < CC) ? (ALLPH ? sh_g[p] : gsrc[p]) : 0.0f;     // a pixel past the end contributes exact zeros
             }
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -1311,16 +1306,18 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
     AIR_STAMP(47);
 }
 
+// the canvas is staged in LDS only when one prefetch pass covers it (PF * THREADS floats, see the kernels)
+size_t attend_canvas_floats(int C) { return (size_t)C * C <= 10 * (size_t)THREADS ? (size_t)C * C : 0; }
 size_t attend_smem(int C, int w, int HT) {
-    return (16 + MAX_STEPS + 8 * w + 4 + ((HT + 3) & ~3) + 7 * (size_t)HT + MAX_STEPS * (size_t)HT + (size_t)C * C) * sizeof(float);
+    return (16 + MAX_STEPS + 8 * w + 4 + ((HT + 3) & ~3) + 7 * (size_t)HT + MAX_STEPS * (size_t)HT + attend_canvas_floats(C)) * sizeof(float);
 }
 size_t attend_bwd_smem(int C, int w) {
-    return (24 + 8 * w + w + 4 + (size_t)C * C) * sizeof(float);
+    return (24 + 8 * w + w + 4 + attend_canvas_floats(C)) * sizeof(float);
 }
 size_t write_smem(int N, int C, int w) { return (16 + 3 * MAX_STEPS + (size_t)N * (8 * C + (size_t)w * w)) * sizeof(float); }
 size_t write_bwd_graph_smem(int C, int w, bool allph) {
     return (136 + 8 * C + ((C + 3) & ~3) + ((8 * w + 3) & ~3) + (((size_t)w * w + 3) & ~3) +
-            (allph ? 5 : 2) * (((size_t)C * C + 3) & ~3)) * sizeof(float);
+            (allph ? 5 : 1) * (((size_t)C * C + 3) & ~3)) * sizeof(float);
 }
 size_t write_bwd_smem(int C, int w) { return (64 + 8 * C + C + 8 * w + 8 * (w + 2) + (size_t)w * w + 4 * (size_t)(w + 2) * w + 2 * (size_t)C * (w + 2) + (size_t)C * C) * sizeof(float); }
 
