@@ -38,6 +38,10 @@ __device__ __forceinline__ uint4 ldg16u(const char* base, unsigned off, bool ok)
     const uint4 t = *reinterpret_cast<const uint4*>(base + (ok ? off : 0u));
     return ok ? t : make_uint4(0u, 0u, 0u, 0u);
 }
+__device__ __forceinline__ uint2 ldg8u(const char* base, unsigned off, bool ok) {
+    const uint2 t = *reinterpret_cast<const uint2*>(base + (ok ? off : 0u));
+    return ok ? t : make_uint2(0u, 0u);
+}
 __device__ __forceinline__ float4 ldg16f(const char* base, unsigned off, bool ok) {
     const float4 t = *reinterpret_cast<const float4*>(base + (ok ? off : 0u));
     return ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -126,8 +130,7 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16tw_kernel(Args a)
                 const int c = t / (KB * 4), k = (t >> 2) % KB, gate = t & 3;
                 const int gn = gate * a.gstride + n0, gk = kr + c * KB + k;
                 const bool ok = (t < R * KB * 4) && n0 < a.gwidth && gk < kend;
-                const uint2 x = *reinterpret_cast<const uint2*>(Bb + (ok ? ((unsigned)gk * (unsigned)a.ldb + (unsigned)gn) * 2u : 0u));
-                vq[i] = ok ? x : make_uint2(0u, 0u);
+                vq[i] = ldg8u(Bb, ((unsigned)gk * (unsigned)a.ldb + (unsigned)gn) * 2u, ok);
             }
         } else if (TB) {
 #pragma unroll

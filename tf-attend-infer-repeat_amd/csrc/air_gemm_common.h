@@ -115,17 +115,33 @@ __device__ __forceinline__ void epilogue_prefetch(const Args& a, Pre<TM, TN>& pr
         pre.f[36] = fetch(ok, a.p0, (size_t)m * R + u);
     } else if (E == EPI_LSTM_FWD_Q) {
         // item of lane L of wave 0: row L >> 2, unit n0 + (L & 3) -- the operands AIR_EPI_LSTM_FWD fetches, same slots
+        // only wave 0 owns items, and only the slabs that exist are fetched: both conditions are wave-uniform, so they
+        // are real branches around the loads (no dummy loads, no address arithmetic on the other three waves -- the
+        // in-kernel stamps showed 1.5 us of this 3 us kernel going into issuing 37 selected loads per lane on all waves)
         const int R = a.gwidth, mm = m0 + (lane >> 2), uu = n0 + (lane & 3);
-        const bool okq = wave == 0 && mm < a.M && uu < R;
+        const bool okq = mm < a.M && uu < R;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = uu + j * R;
+        for (int i = 0; i < 37; ++i) pre.f[i] = 0.0f;
+        if (wave == 0) {
+            const size_t base = (size_t)(okq ? mm : 0) * a.ldadd + (okq ? uu : 0);
+            if (a.add_slabs == 4) {                        // the train step's slab count: 16 loads back to back, no join between them
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
-                pre.f[j * 8 + k] = fetch(okq && k < a.add_slabs, a.addend, k * a.add_slab_stride + (size_t)mm * a.ldadd + n);
-            pre.f[32 + j] = fetch(okq && a.bias, a.bias, n);
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pre.f[j * 8 + k] = a.addend[k * a.add_slab_stride + base + (size_t)j * R];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        pre.f[j * 8 + k] = fetch(k < a.add_slabs, a.addend, k * a.add_slab_stride + base + (size_t)j * R);
+            }
+            if (a.bias) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pre.f[32 + j] = a.bias[(okq ? uu : 0) + j * R];
+            }
+            pre.f[36] = a.p0[(size_t)(okq ? mm : 0) * R + (okq ? uu : 0)];
         }
-        pre.f[36] = fetch(okq, a.p0, (size_t)mm * R + uu);
     } else if (E == AIR_EPI_LSTM_FWD0) {
         // item of lane L (wave 0): row L >> 2, unit n0 + (L & 3); only the bias is needed (zero state, no addend)
         const int R = a.gwidth, uu = n0 + (lane & 3);

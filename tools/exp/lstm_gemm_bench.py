@@ -52,6 +52,15 @@ for label, env in (("quad", None), ("wide", "1")):
           p0=c_prev, q0=acts, q1=c1, q2=h1, q2_16=h16, A16=hA, B16=WB)
     print("LSTM_FWD %-5s %.2f us  %s" % (label, *timeit(g)))
 os.environ.pop("AIR_LSTM_FWD_WIDE", None)
+for ns in (1, 2, 8):
+    sl = f(ns, Bn, 4 * R)
+    keep.append(sl)
+    g = G(h, Wh, dummy, Bn, 4 * R, R, R, 4 * R, 4 * R, bias=bias, addend=sl, ldadd=4 * R, addend_slabs=ns, epi=H.EPI_LSTM_FWD,
+          p0=c_prev, q0=acts, q1=c1, q2=h1, q2_16=h16, A16=hA, B16=WB)
+    print("LSTM_FWD quad, %d slab(s) %.2f us" % (ns, timeit(g)[0]))
+g = G(h, Wh, dummy, Bn, 4 * R, R, R, 4 * R, 4 * R, addend=slabs, ldadd=4 * R, addend_slabs=4, epi=H.EPI_LSTM_FWD,
+      p0=c_prev, q0=acts, q1=c1, q2=h1, A16=hA, B16=WB)
+print("LSTM_FWD quad, no bias, no h16 %.2f us" % timeit(g)[0])
 g = G(h, Wh, dummy, Bn, 4 * R, R, R, 4 * R, 4 * R, bias=bias, A16=hA, B16=WB)
 print("plain 64x1024x256 nn      %.2f us  %s" % timeit(g))
 g = G(h, Wh, dummy, Bn, 4 * R, R, R, 4 * R, 4 * R, bias=bias, addend=slabs, ldadd=4 * R, A16=hA, B16=WB)
