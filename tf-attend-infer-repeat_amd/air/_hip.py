@@ -9,6 +9,9 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- FIRST: torch brings its own libamdhip64; loading libair_hip.so before it binds the library to a
+#                              second HIP runtime that sees no device ("no ROCm-capable device is detected" at the first launch)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AIR_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "libair_hip.so")   # override: A/B builds in tools/
 
