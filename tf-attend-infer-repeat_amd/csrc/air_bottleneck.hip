@@ -324,27 +324,8 @@ __global__ __launch_bounds__(THREADS) void bottleneck_bwd_kernel(BwdArgs a)
     }
 }
 
-// opt-in to > 48 KB of dynamic LDS once per (kernel function, device); hipFuncSetAttribute is a host-side driver
-// call and must not sit on every launch (in particular not inside stream capture)
 template <typename K>
-int grant_lds(K kernel, size_t bytes) {
-    struct Slot { std::atomic<const void*> fn; std::atomic<int> dev; };
-    static Slot granted[16];
-    if (bytes > 160 * 1024) return AIR_ELIMIT;
-    const void* fn = reinterpret_cast<const void*>(kernel);
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-    int free_slot = -1;
-    for (int i = 0; i < 16; ++i) {
-        const void* g = granted[i].fn.load(std::memory_order_acquire);
-        if (g == fn && granted[i].dev.load(std::memory_order_relaxed) == dev) return 0;
-        if (!g && free_slot < 0) free_slot = i;
-    }
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    if (free_slot >= 0) { granted[free_slot].dev.store(dev, std::memory_order_relaxed); granted[free_slot].fn.store(fn, std::memory_order_release); }
-    return 0;
-}
+int grant_lds(K kernel, size_t bytes) { return air_grant_lds(reinterpret_cast<const void*>(kernel), bytes); }
 
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 

@@ -6,6 +6,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "air_hip.h"
 
 #define AIR_EPS 1e-9f   // the sources' 10e-10 (air_model.py:95,587; concrete.py:20,33)
@@ -17,6 +18,31 @@
     } while (0)
 
 static inline hipStream_t air_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Opt-in to more than 48 KB of dynamic LDS, ONCE per (kernel function, device): hipFuncSetAttribute is a host-side
+// driver call and must not sit on every launch -- in particular not inside stream capture (callers warm up eagerly).
+// The attribute is per device, so the cache is keyed on the current device as well (one table per translation unit).
+static inline int air_grant_lds(const void* fn, size_t bytes) {
+    struct Slot { std::atomic<const void*> fn; std::atomic<int> dev; };
+    static Slot granted[128];
+    if (bytes > 160 * 1024) return AIR_ELIMIT;
+    if (bytes <= 48 * 1024) return 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    int free_slot = -1;
+    for (int i = 0; i < 128; ++i) {
+        const void* g = granted[i].fn.load(std::memory_order_acquire);
+        if (g == fn && granted[i].dev.load(std::memory_order_relaxed) == dev) return 0;
+        if (!g && free_slot < 0) free_slot = i;
+    }
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    if (free_slot >= 0) {
+        granted[free_slot].dev.store(dev, std::memory_order_relaxed);
+        granted[free_slot].fn.store(fn, std::memory_order_release);
+    }
+    return 0;
+}
 
 __device__ __forceinline__ float air_sigmoid(float x) {
     // tf.nn.sigmoid: 1 / (1 + exp(-x))

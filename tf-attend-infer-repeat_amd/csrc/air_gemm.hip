@@ -899,24 +899,20 @@ int launch(const air_gemm_t* g, const Args& a0, hipStream_t s) {
     else if (use_bf16_v2(a, TA, TB) && getenv("AIR_GEMM_F32_V1") == nullptr) {   // same operand requirements
         using Cfg = F32V2Cfg<TM, TN>;
         if (Cfg::BYTES > 48 * 1024) {
-            // opt-in to the large dynamic LDS once per kernel function (all epilogue variants of this tile)
-            static bool attr_set = false;
-            if (!attr_set) {
-                const void* fns[] = {
-                    reinterpret_cast<const void*>(&gemm_f32v2_kernel<TM, TN, TB, AIR_EPI_GENERIC>),
-                    T14 && !TB ? reinterpret_cast<const void*>(&gemm_f32v2_kernel<1, 4, false, AIR_EPI_LSTM_FWD>) : nullptr,
-                    T12 && !TB ? reinterpret_cast<const void*>(&gemm_f32v2_kernel<1, 2, false, AIR_EPI_REPARAM_FWD>) : nullptr,
-                    T11 ? reinterpret_cast<const void*>(&gemm_f32v2_kernel<1, 1, TB, AIR_EPI_LSTM_BWD>) : nullptr,
-                    T11 ? reinterpret_cast<const void*>(&gemm_f32v2_kernel<1, 1, TB, AIR_EPI_LSTM_BWD_TAIL>) : nullptr,
-                    T11 ? reinterpret_cast<const void*>(&gemm_f32v2_kernel<1, 1, TB, AIR_EPI_REPARAM_BWD>) : nullptr,
-                    T11 && !TB ? reinterpret_cast<const void*>(&gemm_f32v2_kernel<1, 1, false, AIR_EPI_LSTM_FWD0>) : nullptr};
-                for (const void* fn : fns)
-                    if (fn) {
-                        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::BYTES);
-                        if (e != hipSuccess) return (int)e;
-                    }
-                attr_set = true;
-            }
+            // opt-in to the large dynamic LDS once per (kernel function, device): all epilogue variants of this tile
+            const void* fns[] = {
+                reinterpret_cast<const void*>(&gemm_f32v2_kernel<TM, TN, TB, AIR_EPI_GENERIC>),
+                T14 && !TB ? reinterpret_cast<const void*>(&gemm_f32v2_kernel<1, 4, false, AIR_EPI_LSTM_FWD>) : nullptr,
+                T12 && !TB ? reinterpret_cast<const void*>(&gemm_f32v2_kernel<1, 2, false, AIR_EPI_REPARAM_FWD>) : nullptr,
+                T11 ? reinterpret_cast<const void*>(&gemm_f32v2_kernel<1, 1, TB, AIR_EPI_LSTM_BWD>) : nullptr,
+                T11 ? reinterpret_cast<const void*>(&gemm_f32v2_kernel<1, 1, TB, AIR_EPI_LSTM_BWD_TAIL>) : nullptr,
+                T11 ? reinterpret_cast<const void*>(&gemm_f32v2_kernel<1, 1, TB, AIR_EPI_REPARAM_BWD>) : nullptr,
+                T11 && !TB ? reinterpret_cast<const void*>(&gemm_f32v2_kernel<1, 1, false, AIR_EPI_LSTM_FWD0>) : nullptr};
+            for (const void* fn : fns)
+                if (fn) {
+                    const int rc = air_grant_lds(fn, Cfg::BYTES);
+                    if (rc) return rc;
+                }
         }
         AIR_V2_LAUNCH(gemm_f32v2_kernel, Cfg::BYTES);
     } else

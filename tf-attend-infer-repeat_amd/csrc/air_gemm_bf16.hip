@@ -275,30 +275,11 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16tw_kernel(Args a)
     AIR_STAMP(61);
 }
 
-// opt-in to > 48 KB of dynamic LDS once per (kernel function, device)
-int grant_lds(const void* fn, int bytes) {
-    if (bytes <= 48 * 1024) return 0;
-    struct Slot { std::atomic<const void*> fn; std::atomic<int> dev; };
-    static Slot granted[128];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-    int free_slot = -1;
-    for (int i = 0; i < 128; ++i) {
-        const void* g = granted[i].fn.load(std::memory_order_acquire);
-        if (g == fn && granted[i].dev.load(std::memory_order_relaxed) == dev) return 0;
-        if (!g && free_slot < 0) free_slot = i;
-    }
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e != hipSuccess) return (int)e;
-    if (free_slot >= 0) { granted[free_slot].dev.store(dev, std::memory_order_relaxed); granted[free_slot].fn.store(fn, std::memory_order_release); }
-    return 0;
-}
-
 template <int TM, int TN, bool TB, int EPI_, bool AF32, int R>
 int launch_one(const Args& a, dim3 grid, hipStream_t s) {
     using Cfg = TwCfg<TM, TN, R>;
     auto kern = gemm_bf16tw_kernel<TM, TN, TB, EPI_, AF32, R>;
-    const int rc = grant_lds(reinterpret_cast<const void*>(kern), Cfg::BYTES);
+    const int rc = air_grant_lds(reinterpret_cast<const void*>(kern), Cfg::BYTES);
     if (rc) return rc;
     hipLaunchKernelGGL(kern, grid, dim3(THREADS), Cfg::BYTES, s, a);
     AIR_CHECK_LAUNCH();

@@ -1376,26 +1376,8 @@ int lds_ordered(hipStream_t s) {
     return st == 1;
 }
 
-// Opt-in to > 48 KB of dynamic LDS, ONCE per kernel function (the full 160 KB is granted the first
-// time a kernel asks for more than the default): hipFuncSetAttribute is a host-side driver call
-// and must not sit on every launch -- in particular not inside stream capture.
 template <typename K>
-int ensure_lds(K kernel, size_t bytes) {
-    static std::atomic<const void*> granted[16];           // kernels that already hold the large-LDS attribute
-    if (bytes > 160 * 1024) return AIR_ELIMIT;
-    if (bytes <= 48 * 1024) return 0;
-    const void* fn = reinterpret_cast<const void*>(kernel);
-    int free_slot = -1;
-    for (int i = 0; i < 16; ++i) {
-        const void* g = granted[i].load(std::memory_order_acquire);
-        if (g == fn) return 0;
-        if (!g && free_slot < 0) free_slot = i;
-    }
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    if (free_slot >= 0) granted[free_slot].store(fn, std::memory_order_release);
-    return 0;
-}
+int ensure_lds(K kernel, size_t bytes) { return air_grant_lds(reinterpret_cast<const void*>(kernel), bytes); }
 
 }  // namespace
 
