@@ -157,7 +157,9 @@ typedef struct {
     int32_t accumulate;            /* C += result                        */
     int32_t precision;             /* 0 fp32, 1 bf16                     */
     int32_t epi;                   /* AIR_EPI_*                          */
-    int32_t tile_m, tile_n;        /* output tile in units of 16 (0 = auto): (1,1)(1,2)(1,4)(2,2)(2,4)(4,1)(4,2)(4,4) */
+    int32_t tile_m, tile_n;        /* output tile in units of 16 (0 = auto): (1,1)(1,2)(1,4)(2,2)(2,4)(4,1)(4,2)(4,4); (8,4) = the
+                                      throughput tiling for a deep split-K product of an fp32 A with a bf16 B16 (M % 128, N % 64, K-slab % 64 == 0,
+                                      ksplit > 1, generic epilogue; AIR_EINVAL / AIR_EALIGN otherwise -- callers fall back to (4,4)) */
     int32_t ksplit;                /* > 1: split K over grid.z; C receives `air_gemm_slabs()` slabs of
                                       [M,ldc] (plain stores, generic epilogue skipped)            */
     int32_t addend_slabs;          /* addend is that many [M,ldadd] slabs (0/1 = one)            */

@@ -256,6 +256,12 @@ def test_step_begin_schedule_and_noise(H):
     x, u = normals.double(), unif.double()
     assert abs(float(x.mean())) < 0.01 and abs(float(x.std()) - 1.0) < 0.01
     assert abs(float((x ** 4).mean()) - 3.0) < 0.1
+    # Box-Muller runs on the hardware log / sin / cos: tails, symmetry and the independence of the (cos, sin) pair
+    assert bool(torch.isfinite(x).all()) and float(x.abs().max()) < 6.5
+    assert abs(float((x.abs() > 3.0).double().mean()) - 0.0027) < 0.0008 and abs(float((x ** 3).mean())) < 0.05
+    pairs = x[: (nn // 2) * 2].reshape(-1, 2)
+    assert abs(float((pairs[:, 0] * pairs[:, 1]).mean())) < 0.01
+    assert abs(float(((pairs ** 2).sum(1) < 2 * 0.6931).double().mean()) - 0.5) < 0.01      # r^2 = -2 ln u: median 2 ln 2
     assert float(u.min()) >= 0.0 and float(u.max()) < 1.0 and abs(float(u.mean()) - 0.5) < 0.01
     assert not torch.equal(outs[0], outs[1])         # stream advances with global_step
     ist = torch.tensor([39000, 0, 0, 0], dtype=torch.int32, device=dev)
@@ -1176,3 +1182,36 @@ def test_lds_lane_order_probe_and_register_chain_fallback(H, tmp_path, Cc):
     for k in ("dgen", "dsx", "dU", "dth"):
         assert np.array_equal(outs["probe"][k], outs["0"][k]), k
     assert np.abs(outs["probe"]["dgen"]).max() > 1.0            # the residue was there
+
+
+def test_gemm_throughput_tiling_for_the_deep_input_product(H):
+    """tile (8, 4): the 128 x 64 throughput kernel for the hoisted x.Wx of a large canvas (fp32 image batch x bf16
+    shadow of Wx, split-K slabs; air_model.py:286 recomputed once per step).  Sum of its slabs vs the bf16-rounded fp64
+    product; ineligible shapes are refused (the caller falls back to the latency tiles)."""
+    rng = np.random.RandomState(31)
+    for M, N, K, ks in ((256, 1024, 16384, 8), (128, 128, 1024, 4), (256, 64, 4096, 8)):
+        A = torch.tensor(rng.uniform(0, 1, (M, K)).astype(np.float32), device="cuda")
+        B = torch.tensor(rng.uniform(-0.05, 0.05, (K, N)).astype(np.float32), device="cuda")
+        B16 = _bf16_twin(H, B)
+        S = H.lib().air_gemm_slabs(K, ks)
+        Ct = torch.full((S, M, N), float("nan"), device="cuda")
+        g = _gemm_struct(H, A, B, Ct, M, N, K, K, N, N, 1, ksplit=ks, tile_m=8, tile_n=4, B16=B16)
+        assert _kernel_name(H, g) == "gemm_xw_tp_kernel"
+        H.check(H.lib().air_gemm(C.byref(g), _stream()))
+        torch.cuda.synchronize()
+        got = Ct.double().sum(0).cpu().numpy()
+        ref = _ref_gemm(A.cpu().numpy(), B.cpu().numpy(), 0, 0, 1)
+        assert np.abs(got - ref).max() / np.sqrt(K) < 2e-5, (M, N, K)
+        # and it agrees with the latency tiles on the same twins up to the fp32 summation order
+        C2 = torch.zeros((S, M, N), device="cuda")
+        g2 = _gemm_struct(H, A, B, C2, M, N, K, K, N, N, 1, ksplit=ks, tile_m=4, tile_n=4, B16=B16)
+        H.check(H.lib().air_gemm(C.byref(g2), _stream()))
+        torch.cuda.synchronize()
+        assert np.abs(got - C2.double().sum(0).cpu().numpy()).max() < 1e-3 * np.abs(ref).max()
+    # refused: ragged M, no shadow, no split
+    A = torch.zeros(100, 1024, device="cuda"); B = torch.zeros(1024, 64, device="cuda"); Ct = torch.zeros(4, 100, 64, device="cuda")
+    g = _gemm_struct(H, A, B, Ct, 100, 64, 1024, 1024, 64, 64, 1, ksplit=4, tile_m=8, tile_n=4, B16=_bf16_twin(H, B))
+    assert H.lib().air_gemm(C.byref(g), _stream()) == -3
+    A = torch.zeros(128, 1024, device="cuda"); Ct = torch.zeros(4, 128, 64, device="cuda")
+    g = _gemm_struct(H, A, B, Ct, 128, 64, 1024, 1024, 64, 64, 1, ksplit=4, tile_m=8, tile_n=4)
+    assert H.lib().air_gemm(C.byref(g), _stream()) == -1

@@ -412,6 +412,9 @@ class AIRModel:
         # (bf16 twins, large canvases: 64x64 tiles -- the image batch is re-read by 16 instead of 32 column tiles and the
         # row-major Wx shadow is fetched in whole 128-byte lines: [256x1024x16384] 59.6 -> 42.2 us, tools/exp/gemm_twin_bench.py)
         self._xw_ksplit, self._xw_tile = 4, ((2, 2) if D <= 4096 else ((4, 4) if self._twins else (4, 2)))
+        if self._twins and D > 4096 and B % 64 == 0 and R % 16 == 0 and D % 512 == 0:
+            # full batches of a large canvas: the throughput tiling (64 x 64 per workgroup, 8 K-slabs), gemm_xw_tp_kernel
+            self._xw_ksplit, self._xw_tile = 8, (8, 4)
         if os.environ.get("AIR_XW_TILE"):                    # tuning hook: "tm,tn,ksplit" (ksplit <= 8 slabs)
             tm_, tn_, ks_ = (int(v) for v in os.environ["AIR_XW_TILE"].split(","))
             self._xw_ksplit, self._xw_tile = ks_, (tm_, tn_)

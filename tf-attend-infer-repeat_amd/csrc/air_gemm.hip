@@ -36,6 +36,8 @@ namespace airg {
 int twin_rounds(const Args& a, int tm, int tn, bool ta, bool tb);
 int twin_launch(const Args& a, int tm, int tn, bool tb, dim3 grid, hipStream_t s);
 void twin_kernel_name(const Args& a, int tm, int tn, bool tb, char* buf, int n);
+int xw_tp_ok(const Args& a, int precision, bool ta, bool tb, int ksplit);
+int xw_tp_launch(const Args& a, int job_planes_hint, hipStream_t s);
 }
 
 namespace {
@@ -973,6 +975,13 @@ extern "C" int air_gemm(const air_gemm_t* g, void* stream) {
     const int rc = fill_args(g, a);
     if (rc) return rc;
     hipStream_t s = air_stream(stream);
+    if (g->tile_m == 8 && g->tile_n == 4) {
+        // the throughput tiling (fp32 A x bf16 shadow, split-K slabs): air_gemm_bf16.hip::gemm_xw_tp_kernel
+        const int ks = g->ksplit > 1 ? g->ksplit : 1;
+        a.kslab = ((a.K + ks - 1) / ks + 3) & ~3;
+        const int ok = xw_tp_ok(a, g->precision, g->transA != 0, g->transB != 0, g->ksplit);
+        return ok ? ok : xw_tp_launch(a, 0, s);
+    }
     if (g->transA) return pick_tile<true, false>(g, a, s);
     if (g->transB) return pick_tile<false, true>(g, a, s);
     return pick_tile<false, false>(g, a, s);
@@ -991,6 +1000,12 @@ extern "C" int air_gemm_kernel_name(const air_gemm_t* g, char* buf, int n) {
     {
         const int ks = g->ksplit > 1 ? g->ksplit : 1;
         a.kslab = ((a.K + ks - 1) / ks + 3) & ~3;
+    }
+    if (g->tile_m == 8 && g->tile_n == 4) {
+        const int ok = xw_tp_ok(a, g->precision, ta, tb, g->ksplit);
+        if (ok) return ok;
+        snprintf(buf, n, "gemm_xw_tp_kernel");
+        return 0;
     }
     if (g->precision == 1 && !ta && twin_rounds(a, tm, tn, false, tb) > 0) { twin_kernel_name(a, tm, tn, tb, buf, n); return 0; }
     if (g->precision == 1 && use_bf16_v2(a, ta, tb))

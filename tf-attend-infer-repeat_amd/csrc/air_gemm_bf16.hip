@@ -275,6 +275,128 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16tw_kernel(Args a)
     AIR_STAMP(61);
 }
 
+
+// ---------------------------------------------------------------------------
+// Throughput tiling for the ONE deep contraction of a large canvas: the hoisted x.Wx of the 128x128 configuration,
+// [256 x 1024 x 16384] -- fp32 image batch (the caller's tensor) x the bf16 shadow of Wx, split-K slabs out.
+// The latency kernel above splits K over its four waves and re-reads the image batch once per 32/64-column tile
+// (512 / 256 MB through the L1s).  Here a workgroup owns a 64 x 64 output tile, each wave a 32 x 32 quadrant of it
+// over the WHOLE K slab (no cross-wave reduction), operands stream through double-buffered 64-deep LDS stages with the
+// loads of FOUR stages in flight per thread and two workgroups per CU; the row panel of a (row tile, slab) pair is kept in
+// one XCD's L2 for its 16 column tiles.  Interior tiles only (M % 64, N % 64, K slab % 64 == 0: the dispatcher checks).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(THREADS) void gemm_xw_tp_kernel(Args a)
+{
+    constexpr int BM = 64, BN = 64, KB = 64, D = 4;      // D: stages of global loads in flight per thread (a memory round
+                                                         // trip is ~1 us, a stage's MFMAs ~0.15 us: one stage ahead is not enough)
+    __shared__ __attribute__((aligned(16))) unsigned short ImgA[2][BM * KB];   // [row][64 k], 16-byte slots swizzled by row
+    __shared__ __attribute__((aligned(16))) unsigned short ImgB[2][KB * BN];   // [k][64 n] as it lies (transpose read)
+    if ((int)blockIdx.z < a.job_on) {                    // the step prologue's planes of workgroups (dispatched first)
+        const long plane = (long)gridDim.x * gridDim.y;
+        air_step_job_run(a.job, blockIdx.z * plane + (long)blockIdx.y * gridDim.x + blockIdx.x, plane * a.job_on);
+        return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // XCD-aware map for the BIG operand: the image batch (16.8 MB fp32) does not fit an L2 (4 MB per XCD), but the
+    // [64 rows x K-slab] panel one (row tile, slab) pair needs does (0.5 MB) -- so all column tiles of a pair run on ONE
+    // XCD (workgroup b runs on XCD b % 8): the panel is fetched from memory once and its 16 users hit in that L2
+    int tile_m = blockIdx.y, tile_n = blockIdx.x, zslab = (int)blockIdx.z - a.job_on;
+    {
+        const int nx = gridDim.x, ny = gridDim.y, nz = (int)gridDim.z - a.job_on, pairs = ny * nz;
+        if ((pairs & 7) == 0) {
+            const int lin = (zslab * ny + (int)blockIdx.y) * nx + (int)blockIdx.x;
+            const int xcd = lin & 7, slot = lin >> 3;
+            const int pair = xcd + 8 * (slot / nx);
+            tile_n = slot % nx; tile_m = pair % ny; zslab = pair / ny;
+        }
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int kbeg = zslab * a.kslab, kend = min(a.K, kbeg + a.kslab);
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;      // this wave's 32 x 32 quadrant, over the whole K slab
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // staging maps: A piece = float4 (4 k) of row (tid >> 4) + 16 i; B piece = 16 bytes (8 columns) of k row (tid >> 3) + 32 i
+    const int ar = tid >> 4, ah = tid & 15, bk = tid >> 3, bh = tid & 7;
+    const float* pa = a.A + (size_t)(m0 + ar) * a.lda + ah * 4;
+    const unsigned short* pb = a.B16 + (size_t)bk * a.ldb + n0 + bh * 8;
+    const unsigned la = ar * KB + (((ah >> 1) ^ (ar & 7)) << 3) + (ah & 1) * 4;      // (row + 16 i) & 7 == ar & 7
+    typedef float f32v4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32v4 __attribute__((ext_vector_type(4)));
+    f32v4 va[D][4];                                       // (native vector types: the HIP structs kept this ring in scratch)
+    u32v4 vb[D][2];
+    // (the ring slot is a compile-time constant everywhere -- std::integral_constant -- so that the ring lives in
+    // registers: with a run-time slot index the arrays went to scratch memory, 39.8 -> 54.6 us)
+    auto load_stage = [&](auto dc, int k0) __attribute__((always_inline)) {
+        constexpr int d = decltype(dc)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) va[d][i] = *reinterpret_cast<const f32v4*>(pa + (size_t)(16 * i) * a.lda + k0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) vb[d][i] = *reinterpret_cast<const u32v4*>(pb + (size_t)(k0 + 32 * i) * a.ldb);
+    };
+    int buf = 0;
+    auto stage = [&](auto dc, int k0) __attribute__((always_inline)) {
+        constexpr int d = decltype(dc)::value;
+        if (k0 >= kend) return;                            // (uniform)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint2 w;
+            w.x = pack_bf16(va[d][i].x, va[d][i].y); w.y = pack_bf16(va[d][i].z, va[d][i].w);
+            *reinterpret_cast<uint2*>(&ImgA[buf][la + 16 * i * KB]) = w;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<u32v4*>(&ImgB[buf][(bk + 32 * i) * BN + bh * 8]) = vb[d][i];
+        if (k0 + D * KB < kend) load_stage(dc, k0 + D * KB);        // refill this ring slot: D stages ahead
+        __syncthreads();                                  // (also: everyone is past the MFMAs of the stage that used the other buffer)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int slot = ks * 4 + (lane >> 4), il = lane & 15;
+            bf16x8 av[2], bv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = wm + i * 16 + il;
+                av[i] = *reinterpret_cast<const bf16x8*>(&ImgA[buf][row * KB + ((slot ^ (row & 7)) << 3)]);
+            }
+            const unsigned short* blk = &ImgB[buf][(ks * 32 + (lane >> 4) * 8 + (il >> 2)) * BN + wn + (il & 3) * 4];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(blk + j * 16));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(blk + j * 16 + 4 * BN));
+                bv[j] = bf16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        buf ^= 1;
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    static_assert(D == 4, "ring depth");
+    if (kbeg < kend) load_stage(I0{}, kbeg);
+    if (kbeg + KB < kend) load_stage(I1{}, kbeg + KB);
+    if (kbeg + 2 * KB < kend) load_stage(I2{}, kbeg + 2 * KB);
+    if (kbeg + 3 * KB < kend) load_stage(I3{}, kbeg + 3 * KB);
+    for (int kb = kbeg; kb < kend; kb += D * KB) {
+        stage(I0{}, kb); stage(I1{}, kb + KB); stage(I2{}, kb + 2 * KB); stage(I3{}, kb + 3 * KB);
+    }
+    float* Cz = a.C + (size_t)zslab * a.slab_stride;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                Cz[(size_t)(m0 + wm + i * 16 + (lane >> 4) * 4 + q) * a.ldc + n0 + wn + j * 16 + (lane & 15)] = acc[i][j][q];
+}
+
 template <int TM, int TN, bool TB, int EPI_, bool AF32, int R>
 int launch_one(const Args& a, dim3 grid, hipStream_t s) {
     using Cfg = TwCfg<TM, TN, R>;
@@ -354,6 +476,32 @@ int twin_launch(const Args& a, int tm, int tn, bool tb, dim3 grid, hipStream_t s
     if (tm == 4 && tn == 4) { if (af32) TW(4, 4, false, AIR_EPI_GENERIC, true, 4); TW(4, 4, false, AIR_EPI_GENERIC, false, 4); }
 #undef TW
     return AIR_EINVAL;
+}
+
+// tile (8, 4) of the ABI = the throughput kernel (128 x 64 per workgroup, quadrant per wave): eligibility and launch
+int xw_tp_ok(const Args& a, int precision, bool ta, bool tb, int ksplit) {
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (precision != 1 || ta || tb || !a.B16 || a.epi != AIR_EPI_GENERIC || ksplit <= 1) return AIR_EINVAL;
+    if ((a.M % 64) || (a.N % 64) || (a.kslab % 64) || (a.K % 64)) return AIR_EALIGN;
+    if (!al16(a.A) || !al16(a.B16) || (a.lda & 3) || (a.ldb & 7)) return AIR_EALIGN;
+    return 0;
+}
+
+int xw_tp_launch(const Args& a0, int job_planes_hint, hipStream_t s) {
+    Args a = a0;
+    dim3 grid(a.N / 64, a.M / 64, 1);
+    if (a.job_on) {
+        const long quads = (a.job.n_normal + 3) / 4 + (a.job.n_uniform + 3) / 4 + (a.job.twin_n + 3) / 4 + a.job.ad_n / 4;
+        const long plane = (long)grid.x * grid.y * THREADS;
+        long planes = (quads + plane - 1) / plane;
+        a.job_on = (int)(planes < 1 ? 1 : (planes > 64 ? 64 : planes));
+    }
+    (void)job_planes_hint;
+    grid.z = (a.K + a.kslab - 1) / a.kslab + a.job_on;
+    a.slab_stride = (long)a.M * a.ldc;
+    hipLaunchKernelGGL(gemm_xw_tp_kernel, grid, dim3(THREADS), 0, s, a);
+    AIR_CHECK_LAUNCH();
+    return 0;
 }
 
 void twin_kernel_name(const Args& a, int tm, int tn, bool tb, char* buf, int n) {

@@ -86,10 +86,15 @@ __device__ __forceinline__ void air_step_job_run(const AirStepJob& j, long wg, l
         air_philox4x32_10(c, j.seed_lo, j.seed_hi);
         float v[4];
         if (q < quads_n) {
-            // Box-Muller on two pairs
-            const float r0 = sqrtf(-2.0f * logf(air_u01_open_low(c[0]))), a0 = 6.283185307179586f * air_u01_half_open(c[1]);
-            const float r1 = sqrtf(-2.0f * logf(air_u01_open_low(c[2]))), a1 = 6.283185307179586f * air_u01_half_open(c[3]);
-            v[0] = r0 * cosf(a0); v[1] = r0 * sinf(a0); v[2] = r1 * cosf(a1); v[3] = r1 * sinf(a1);
+            // Box-Muller on two pairs, on the hardware transcendentals: v_log_f32 (2^-23-level relative error away from 1),
+            // v_sin_f32 / v_cos_f32 take their argument in REVOLUTIONS, i.e. the uniform itself -- no 2*pi range reduction.
+            // (The library sinf / cosf / logf cost ~400 instructions per quad: at the 128x128 configuration the noise planes
+            // -- 1.07 M normals per step -- were ~20 us of the x.Wx launch that carries them.  The reference's RNG ops are
+            // unseeded; only the distribution matters, tests/test_gpu_kernels.py::test_step_begin_schedule_and_noise.)
+            const float r0 = sqrtf(-2.0f * __logf(air_u01_open_low(c[0]))), a0 = air_u01_half_open(c[1]);
+            const float r1 = sqrtf(-2.0f * __logf(air_u01_open_low(c[2]))), a1 = air_u01_half_open(c[3]);
+            v[0] = r0 * __builtin_amdgcn_cosf(a0); v[1] = r0 * __builtin_amdgcn_sinf(a0);
+            v[2] = r1 * __builtin_amdgcn_cosf(a1); v[3] = r1 * __builtin_amdgcn_sinf(a1);
             const long base = q * 4;
             for (int k = 0; k < 4; ++k) if (base + k < j.n_normal) j.normals[base + k] = v[k];
         } else {
