@@ -500,10 +500,11 @@ __device__ __forceinline__ float tile_bf16_tw(const Prob& pr, int m0, int n0, un
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     constexpr int T8 = NIMG * KB * 16 / THREADS;             // 8-byte pieces per thread per operand (two of them = one 16-byte piece)
-    for (int kr = 0; kr < K; kr += NIMG * KB) {
-        if (kr > 0) __syncthreads();
-        uint2 ra[T8], rb[T8];
-        // ---- all operand loads of the round, one wave-uniform branch per operand
+    uint2 ra[T8], rb[T8];
+    // all operand loads of one round, one wave-uniform branch per operand.  Rounds are software-pipelined: the loads of
+    // round r+1 are issued as soon as round r's registers are in LDS, i.e. under its barrier and MFMAs (K > 192: the
+    // 128x128 configuration contracts over 256 rows)
+    auto issue_round = [&](int kr) __attribute__((always_inline)) {
         if (a16) {
 #pragma unroll
             for (int i = 0; i < T8 / 2; ++i) {
@@ -540,6 +541,10 @@ __device__ __forceinline__ float tile_bf16_tw(const Prob& pr, int m0, int n0, un
                 rb[i] = ok ? x : make_uint2(0u, 0u);
             }
         }
+    };
+    issue_round(0);
+    for (int kr = 0; kr < K; kr += NIMG * KB) {
+        if (kr > 0) __syncthreads();
         // ---- straight into the [k][64] images (lane-linear rows)
         if (a16) {
 #pragma unroll
@@ -557,6 +562,7 @@ __device__ __forceinline__ float tile_bf16_tw(const Prob& pr, int m0, int n0, un
 #pragma unroll
             for (int i = 0; i < T8; ++i) *reinterpret_cast<uint2*>(&ImgB[(tid + THREADS * i) * 4]) = rb[i];
         }
+        if (kr + NIMG * KB < K) issue_round(kr + NIMG * KB);
         __syncthreads();
         // ---- MFMAs: fragments through the transpose read (lane i of a 16-lane group hands in row 8g + i/4 (+4), column quad i%4)
         const int il = lane & 15;
@@ -588,25 +594,31 @@ __device__ __forceinline__ float tile_bf16_tw(const Prob& pr, int m0, int n0, un
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
                 }
             }
-        if (bias_thread) {
-            // fp32 column sums of dY (m0 == 0 tiles only) in tile_bf16's order: per k-run g the rows g*8 + r of image c
-            // (c-major); the xor-tree over g follows the last round.  One image at a time: 8 loads in flight, few registers
-            // (these tiles are the first of their problem, not the tail of the launch).
-            const bool vec = ((ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(pr.dY) & 15) == 0);
-#pragma unroll 1
-            for (int c = 0; c < NIMG; ++c)
-                if (kr + c * KB < K) {
-                    float4 v[8];
+    }
+    if (bias_thread) {
+        // fp32 column sums of dY (m0 == 0 tiles only) in tile_bf16's order: per k-run g the rows g*8 + r of image c, images
+        // in order; the xor-tree over g follows.  After the MFMAs (the operand registers are free), the next image's 8 loads
+        // in flight while this one is summed: ONE exposed round trip per tile (three sequential ones per round made the
+        // bias tiles the long pole of the launch: 41 us at K = 1280).
+        const bool vec = ((ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(pr.dY) & 15) == 0);
+        const int nimg = (K + KB - 1) / KB;
+        float4 cur[8], nxt[8];
+        auto fetch_img = [&](float4 (&v)[8], int c) __attribute__((always_inline)) {
 #pragma unroll
-                    for (int r = 0; r < 8; ++r)
-                        v[r] = vec ? fetch4<true>(pr.dY, ldb, kr + c * KB + bg * 8 + r, n0 + 4 * bq, K, N)
-                                   : fetch4<false>(pr.dY, ldb, kr + c * KB + bg * 8 + r, n0 + 4 * bq, K, N);
+            for (int r = 0; r < 8; ++r)
+                v[r] = vec ? fetch4<true>(pr.dY, ldb, c * KB + bg * 8 + r, n0 + 4 * bq, K, N)
+                           : fetch4<false>(pr.dY, ldb, c * KB + bg * 8 + r, n0 + 4 * bq, K, N);
+        };
+        fetch_img(cur, 0);
+        for (int c = 0; c < nimg; ++c) {
+            if (c + 1 < nimg) fetch_img(nxt, c + 1);
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        const float4 t = mask4(v[r], kr + c * KB + bg * 8 + r, n0 + 4 * bq, K, N);
-                        csum[0] += t.x; csum[1] += t.y; csum[2] += t.z; csum[3] += t.w;
-                    }
-                }
+            for (int r = 0; r < 8; ++r) {
+                const float4 t = mask4(cur[r], c * KB + bg * 8 + r, n0 + 4 * bq, K, N);
+                csum[0] += t.x; csum[1] += t.y; csum[2] += t.z; csum[3] += t.w;
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) cur[r] = nxt[r];
         }
     }
 
