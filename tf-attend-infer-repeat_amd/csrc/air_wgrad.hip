@@ -542,7 +542,9 @@ __device__ __forceinline__ float tile_bf16_tw(const Prob& pr, int m0, int n0, un
             }
         }
     };
+    AIR_STAMP(1);
     issue_round(0);
+    AIR_STAMP(2);
     for (int kr = 0; kr < K; kr += NIMG * KB) {
         if (kr > 0) __syncthreads();
         // ---- straight into the [k][64] images (lane-linear rows)
@@ -562,8 +564,10 @@ __device__ __forceinline__ float tile_bf16_tw(const Prob& pr, int m0, int n0, un
 #pragma unroll
             for (int i = 0; i < T8; ++i) *reinterpret_cast<uint2*>(&ImgB[(tid + THREADS * i) * 4]) = rb[i];
         }
+        AIR_STAMP(3);
         if (kr + NIMG * KB < K) issue_round(kr + NIMG * KB);
         __syncthreads();
+        AIR_STAMP(4);
         // ---- MFMAs: fragments through the transpose read (lane i of a 16-lane group hands in row 8g + i/4 (+4), column quad i%4)
         const int il = lane & 15;
 #pragma unroll
@@ -595,6 +599,7 @@ __device__ __forceinline__ float tile_bf16_tw(const Prob& pr, int m0, int n0, un
                 }
             }
     }
+    AIR_STAMP(5);
     if (bias_thread) {
         // fp32 column sums of dY (m0 == 0 tiles only) in tile_bf16's order: per k-run g the rows g*8 + r of image c, images
         // in order; the xor-tree over g follows.  After the MFMAs (the operand registers are free), the next image's 8 loads
