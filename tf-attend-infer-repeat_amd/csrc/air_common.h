@@ -137,11 +137,15 @@ __device__ __forceinline__ float air_block_sum_256(float v, float* red) {
 // clip_by_global_norm + ApplyAdam coefficients, identical in every workgroup: the partial sums are
 // re-reduced in one fixed order (air_model.py:673, TF 1.3 training_ops ApplyAdam).
 struct AirAdamCoef { float scale, lr_t, gnorm; };
-__device__ __forceinline__ AirAdamCoef air_adam_coef(const float* __restrict__ partials, int npartials,
-                                                     const float* __restrict__ dyn, const int32_t* __restrict__ istate,
-                                                     float prescale, float b1, float b2, float* red /* >= 4 floats of LDS */) {
+// in two halves so a streaming kernel can put its first operand loads between them: this thread's share of the partial
+// sums (loads only), then the block reduction and the scalar arithmetic
+__device__ __forceinline__ float air_adam_partial_share(const float* __restrict__ partials, int npartials) {
     float s = 0.0f;
     for (int i = threadIdx.x; i < npartials; i += 256) s += partials[i];
+    return s;
+}
+__device__ __forceinline__ AirAdamCoef air_adam_coef_from_share(float s, const float* __restrict__ dyn, const int32_t* __restrict__ istate,
+                                                                float prescale, float b1, float b2, float* red /* >= 4 floats of LDS */) {
     s = air_block_sum_256(s, red);
     AirAdamCoef c;
     c.gnorm = sqrtf(s) * prescale;                     // norm of the (pre-scaled, e.g. averaged) gradient
@@ -151,6 +155,11 @@ __device__ __forceinline__ AirAdamCoef air_adam_coef(const float* __restrict__ p
     const float t = (float)istate[AIR_IST_GLOBAL_STEP];     // already incremented (grad_sqnorm / fused wgrad)
     c.lr_t = dyn[AIR_DYN_LEARNING_RATE] * sqrtf(1.0f - powf(b2, t)) / (1.0f - powf(b1, t));
     return c;
+}
+__device__ __forceinline__ AirAdamCoef air_adam_coef(const float* __restrict__ partials, int npartials,
+                                                     const float* __restrict__ dyn, const int32_t* __restrict__ istate,
+                                                     float prescale, float b1, float b2, float* red /* >= 4 floats of LDS */) {
+    return air_adam_coef_from_share(air_adam_partial_share(partials, npartials), dyn, istate, prescale, b1, b2, red);
 }
 // m += (g-m)(1-b1); v += (g^2-v)(1-b2); var -= lr_t*m/(sqrt(v)+eps)
 __device__ __forceinline__ void air_adam_update(float& p, float& m, float& v, float g, const AirAdamCoef& c,

@@ -44,26 +44,36 @@ __global__ __launch_bounds__(THREADS) void adam_clip_kernel(
     float* __restrict__ coef_out)
 {
     __shared__ float red[4];
-    const AirAdamCoef cf = air_adam_coef(partials, npartials, dyn, istate, prescale, b1, b2, red);
+    // The first quad's loads go out BETWEEN the partial-sum loads and their reduction (vmcnt retires in order, so the
+    // partials have to be the older loads), and every later quad's loads before the previous quad's arithmetic: the
+    // coefficient prologue (one round trip, two barriers, sqrt / pow: ~2 us) no longer delays the stream.
+    const float share = air_adam_partial_share(partials, npartials);
+    const long n4 = n / 4;
+    float4* p4 = reinterpret_cast<float4*>(p);
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    float4* m4 = reinterpret_cast<float4*>(m);
+    float4* v4 = reinterpret_cast<float4*>(v);
+    const long stride = (long)gridDim.x * THREADS;
+    long i = (long)blockIdx.x * THREADS + threadIdx.x;
+    float4 pp, mm, vv, gg;
+    if (i < n4) { pp = p4[i]; mm = m4[i]; vv = v4[i]; gg = g4[i]; }
+    const AirAdamCoef cf = air_adam_coef_from_share(share, dyn, istate, prescale, b1, b2, red);
     if (gnorm_out && blockIdx.x == 0 && threadIdx.x == 0) *gnorm_out = cf.gnorm;
     // the record deferred slices of this step's update read (air_step_job_t.ad_coef): dyn / istate / partials may have
     // moved on to the next step by the time they run
     if (coef_out && blockIdx.x == 0 && threadIdx.x == 0) { coef_out[0] = cf.scale; coef_out[1] = cf.lr_t; coef_out[2] = cf.gnorm; }
     const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
 
-    const long n4 = n / 4;
-    float4* p4 = reinterpret_cast<float4*>(p);
-    const float4* g4 = reinterpret_cast<const float4*>(g);
-    float4* m4 = reinterpret_cast<float4*>(m);
-    float4* v4 = reinterpret_cast<float4*>(v);
-    for (long i = (long)blockIdx.x * THREADS + threadIdx.x; i < n4; i += (long)gridDim.x * THREADS) {
-        float4 pp = p4[i], mm = m4[i], vv = v4[i];
-        const float4 gg = g4[i];
+    for (; i < n4; i += stride) {
+        float4 pn, mn, vn, gn;
+        const bool more = i + stride < n4;
+        if (more) { pn = p4[i + stride]; mn = m4[i + stride]; vn = v4[i + stride]; gn = g4[i + stride]; }
         float* pa = &pp.x; float* ma = &mm.x; float* va = &vv.x; const float* ga = &gg.x;
 #pragma unroll
         for (int k = 0; k < 4; ++k) air_adam_update(pa[k], ma[k], va[k], ga[k], cf, omb1, omb2, eps);
         p4[i] = pp; m4[i] = mm; v4[i] = vv;
         if (shadow) reinterpret_cast<uint2*>(shadow)[i] = make_uint2(air_pack_bf16(pp.x, pp.y), air_pack_bf16(pp.z, pp.w));
+        if (more) { pp = pn; mm = mn; vv = vn; gg = gn; }
     }
     if (blockIdx.x == 0 && threadIdx.x < (int)(n - n4 * 4)) {
         const long i = n4 * 4 + threadIdx.x;

@@ -22,6 +22,16 @@
 #include <cmath>
 
 AIR_STAMPS_READER(air_debug_stamps)
+// per-workgroup phase stamps of the graph-order write backward (debug builds only): [workgroup][8]
+#ifdef AIR_STAMPS
+static __device__ unsigned long long air_stamps_wg[4096 * 8];
+extern "C" int air_debug_stamps_wg(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(air_stamps_wg), sizeof(unsigned long long) * (n < 4096 * 8 ? n : 4096 * 8));
+}
+#define AIR_STAMP_WG(i) do { if (threadIdx.x == 0) air_stamps_wg[((blockIdx.y * gridDim.x + blockIdx.x) & 4095) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define AIR_STAMP_WG(i) do { } while (0)
+#endif
 
 namespace {
 
@@ -990,9 +1000,9 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_kernel(air_write_bwd_t a
 //            instruction, to ds_add_f32 on one LDS word per corner.  gfx950's LDS applies the lanes of one
 //            instruction in ascending lane order and a wave's instructions in program order
 //            (measured: tools/exp/lds_atomic_order.hip; pinned by the bit-for-bit test), i.e. it IS
-//            a sequential fp32 accumulator, at ~4 cycles per term and without occupying the VALU:
-//            the other 15 waves run the coordinate-gradient pixel loop and the short chains
-//            underneath it.
+//            a sequential fp32 accumulator, at ~4 cycles per term and without occupying the VALU.  While it runs,
+//            every other LDS request of the CU starves, so the short chains go first and the coordinate-gradient
+//            pixel loop -- rewritten to touch no LDS at all -- runs on the other twelve waves underneath it.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float stream_add(float acc, const float* T, int start, int n) {
     int k = start;
@@ -1051,6 +1061,7 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
         __syncthreads();
     }
     AIR_STAMP(40);
+    AIR_STAMP_WG(0);
     const float* at = a.att + row * AIR_ATT_STRIDE;
     float* dgen = a.d_gen_pre + row * w * w;
     unsigned short* dgen16 = a.d_gen_pre16 ? a.d_gen_pre16 + row * w * w : nullptr;
@@ -1070,6 +1081,7 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
     }
     for (int it = tid; it < 4 * w; it += WB_THREADS) { sh_run[2 * it] = 0; sh_run[2 * it + 1] = -1; }
     if (tid < 8) sh_acc[tid] = 0.0f;
+    if (tid >= 64 && tid < 64 + NW * 8) sh_red[tid - 64] = 0.0f;          // the feeding waves publish no pixel-loop partials
     const float* v = a.vrec + row * w * w;
     for (int p = tid; p < w * w; p += WB_THREADS) sh_win[p] = v[p];
     if (ALLPH) {
@@ -1204,22 +1216,27 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
-    // theta / z gradients, per canvas pixel: NT threads share the canvas, three pixels in flight per thread
-    auto theta_loop = [&](int NT) {
-        if (tid >= NT) return;
-        for (int p0 = tid; p0 < CC; p0 += 3 * NT) {
+    // theta / z gradients, per canvas pixel: the NT threads tid0 .. tid0 + NT - 1 share the canvas, three pixels in flight
+    // per thread.  NO LDS access: the loop runs on waves 4..15 WHILE waves 0..3 push the corner terms through the LDS
+    // atomic pipe (whose traffic starves every other LDS request of the CU), so the taps are recomputed per pixel
+    // (axis_tap: the same function of the same inputs as the tables) and d_recon / the window come from memory (L1 / L2:
+    // 10 KB + 3 KB per workgroup at 50 x 50).
+    auto theta_loop = [&](int tid0, int NT) {
+        const int tt = tid - tid0;
+        if (tt < 0 || tt >= NT) return;
+        for (int p0 = tt; p0 < CC; p0 += 3 * NT) {
             Tap tx[3], ty[3];
             float Iv[3][4], gv[3], tj[3], ti[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const int p = min(p0 + k * NT, CC - 1), i = p / C, j = p - i * C;
-                tx[k] = sh_tx[j]; ty[k] = sh_ty[i]; tj[k] = sh_t[j]; ti[k] = sh_t[i];
-                gv[k] = (p0 + k * NT < CC) ? (ALLPH ? sh_g[p] : gsrc[p]) : 0.0f;     // a pixel past the end contributes exact zeros
+                gv[k] = (p0 + k * NT < CC) ? gsrc[p] : 0.0f;     // a pixel past the end contributes exact zeros
+                tx[k] = axis_tap(j, C, w, ia, bx, &tj[k]); ty[k] = axis_tap(i, C, w, ia, by, &ti[k]);
             }
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                Iv[k][0] = sh_win[ty[k].i0 * w + tx[k].i0]; Iv[k][1] = sh_win[ty[k].i1 * w + tx[k].i0];
-                Iv[k][2] = sh_win[ty[k].i0 * w + tx[k].i1]; Iv[k][3] = sh_win[ty[k].i1 * w + tx[k].i1];
+                Iv[k][0] = v[ty[k].i0 * w + tx[k].i0]; Iv[k][1] = v[ty[k].i1 * w + tx[k].i0];
+                Iv[k][2] = v[ty[k].i0 * w + tx[k].i1]; Iv[k][3] = v[ty[k].i1 * w + tx[k].i1];
             }
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -1230,6 +1247,9 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
                 d11 += gY * ti[k]; d12 += gY;
             }
         }
+        // this wave's coordinate / z gradient partials (combined over the waves in a fixed order at the end)
+        d00 = air_wave_sum(d00); d02 = air_wave_sum(d02); d11 = air_wave_sum(d11); d12 = air_wave_sum(d12); dz = air_wave_sum(dz);
+        if (lane == 0) { float* r = sh_red + wave * 8; r[0] = d00; r[1] = d02; r[2] = d11; r[3] = d12; r[4] = dz; }
     };
     auto chains = [&](int ph0, int ph1) {
         if (is_slot && !corner)
@@ -1239,11 +1259,8 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
                 acc = stream_add(acc, sh_T, start, n);
             }
     };
-    // everything a wave owes besides the corner slots: its coordinate / z gradient partials (combined
-    // over the waves in a fixed order at the end) and the non-corner slots' outputs
+    // the non-corner slots' outputs
     auto publish = [&]() {
-        d00 = air_wave_sum(d00); d02 = air_wave_sum(d02); d11 = air_wave_sum(d11); d12 = air_wave_sum(d12); dz = air_wave_sum(dz);
-        if (lane == 0) { float* r = sh_red + wave * 8; r[0] = d00; r[1] = d02; r[2] = d11; r[3] = d12; r[4] = dz; }
         if (is_slot && !corner) {
             const float r = sh_win[tid];
             const float dgv = (acc * r) * (1.0f - r);        // SigmoidGrad of vae.py:39-41: dy * y * (1 - y)
@@ -1251,31 +1268,41 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
             if (dgen16) dgen16[tid] = air_bf16_of(dgv);
         }
     };
+    // waves 0..3 feed one corner each to the atomic pipe; the pixel loop runs beside them on the other twelve
+    constexpr int TH0 = 4 * 64, THN = WB_THREADS - TH0;
     if (ALLPH) {
-        // [terms of all taps] | [pixel loop + short chains + outputs on all waves: no LDS atomics in flight,
-        // every dependent LDS read returns at full speed] | [corner accumulation, the LDS to itself]
+        // [terms of all taps] | [short chains + slot outputs on all waves: no LDS atomics in flight, every dependent LDS
+        // read returns at full speed] | [corner accumulation on the LDS || pixel loop on VALU / memory]
+        AIR_STAMP_WG(1);
         stage_T(0, 4);
         __syncthreads();
         AIR_STAMP(43);
-        theta_loop(WB_THREADS);
-        AIR_STAMP(48);
+        AIR_STAMP_WG(2);
         chains(0, 4);
         AIR_STAMP(49);
         publish();
         AIR_STAMP(39);
         __syncthreads();
         AIR_STAMP(44);
-        if (wave < 4 && lds_ordered) feed_corner(wave, 0, 4);
+        AIR_STAMP_WG(3);
+        if (wave < 4) { if (lds_ordered) feed_corner(wave, 0, 4); }
+        else theta_loop(TH0, THN);
+        AIR_STAMP(48);
+        AIR_STAMP_WG(4);                       // wave 0's own feed is over
         __syncthreads();
+        AIR_STAMP_WG(5);
     } else {
         for (int ph = 0; ph < 4; ++ph) {
             stage_T(ph, ph + 1);
             __syncthreads();
-            if (ph == 0) theta_loop(WB_THREADS);
+            AIR_STAMP(50 + 3 * ph);
             chains(ph, ph + 1);
             __syncthreads();
-            if (wave < 4 && lds_ordered) feed_corner(wave, ph, ph + 1);
+            AIR_STAMP(51 + 3 * ph);
+            if (wave < 4) { if (lds_ordered) feed_corner(wave, ph, ph + 1); }
+            else if (ph == 0) theta_loop(TH0, THN);
             __syncthreads();
+            AIR_STAMP(52 + 3 * ph);
         }
     }
     if (!ALLPH) { publish(); __syncthreads(); }
@@ -1304,6 +1331,7 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
         }
     }
     AIR_STAMP(47);
+    AIR_STAMP_WG(6);
 }
 
 // the canvas is staged in LDS only when one prefetch pass covers it (PF * THREADS floats, see the kernels)

@@ -22,9 +22,14 @@ for fn in ("air_debug_stamps", "air_debug_stamps_gemm", "air_debug_stamps_gemm_t
     getattr(H._LIB, fn).argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 from bench import HP, ANNEAL, synthetic_canvases
 from air import air_model as am
-images, targets = synthetic_canvases(64, 50, 2, 1)
+hp = dict(HP)
+STRESS = "--stress" in sys.argv                      # configs[3]: 128x128 canvas, 5 steps, batch 256
+if STRESS:
+    sys.argv.remove("--stress")
+    hp.update(canvas_size=128, max_steps=5, max_digits=4)
+images, targets = synthetic_canvases(256 if STRESS else 64, hp["canvas_size"], hp["max_digits"], 1)
 m = am.AIRModel(torch.tensor(images, device="cuda"), torch.tensor(targets, device="cuda"), cnn=False, train=True,
-                annealing_schedules=ANNEAL, gemm_precision="bf16", **HP)
+                annealing_schedules=ANNEAL, gemm_precision="bf16", **hp)
 for _ in range(3):
     m.training()
 torch.cuda.synchronize()
@@ -42,7 +47,7 @@ for want in names:
             {56: (H._LIB.air_debug_stamps_gemm_tw if "tw_kernel" in op.kernel else H._LIB.air_debug_stamps_gemm),
              0: H._LIB.air_debug_stamps_wgrad}.get(base, H._LIB.air_debug_stamps)(buf, 64)
             v = [int(x) for x in buf]
-            idx = [i for i in range(base - (1 if base == 40 else 0), base + (8 if base == 56 else 10)) if v[i]]
+            idx = [i for i in range(base - (1 if base == 40 else 0), base + (8 if base == 56 else 22 if base == 40 else 10)) if v[i]]
             idx.sort(key=lambda i: v[i])
             d = ["%d:%.2f" % (i, (v[i] - v[j]) / 100.0) for j, i in zip(idx, idx[1:])]
             print("%-14s total %.2f us | deltas(us) %s" % (op.name, (v[idx[-1]] - v[idx[0]]) / 100.0 if idx else 0, " ".join(d)))
