@@ -391,14 +391,19 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16_kernel(Args a)
 // ---------------------------------------------------------------------------
 // (tried: raw buffer loads with the hardware range check standing in for the EXEC-masked branches --
 // same results, no gain on the 16x16-tile kernels and 8.5 -> 11.7 us on the K = 2500 one)
+// (the zeroing is a bit mask, not a select: where the loaded registers are shuffled before their first use -- the NN-B
+// transposition of the fp32 kernel -- the compiler turned `ok ? t : 0` into an EXEC-masked branch around the load AND the
+// shuffle, with an s_waitcnt vmcnt(0) inside: eight loads of a task completed one after the other, ~4 us of an 8.5 us launch)
 __device__ __forceinline__ float4 ldg16(const char* base, unsigned off, bool ok) {
-    const float4 t = *reinterpret_cast<const float4*>(base + (ok ? off : 0u));
-    return ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint4 t = *reinterpret_cast<const uint4*>(base + (ok ? off : 0u));
+    const unsigned m = ok ? 0xffffffffu : 0u;
+    return make_float4(__uint_as_float(t.x & m), __uint_as_float(t.y & m), __uint_as_float(t.z & m), __uint_as_float(t.w & m));
 }
 
 __device__ __forceinline__ float2 ldg8(const char* base, unsigned off, bool ok) {
-    const float2 t = *reinterpret_cast<const float2*>(base + (ok ? off : 0u));
-    return ok ? t : make_float2(0.f, 0.f);
+    const uint2 t = *reinterpret_cast<const uint2*>(base + (ok ? off : 0u));
+    const unsigned m = ok ? 0xffffffffu : 0u;
+    return make_float2(__uint_as_float(t.x & m), __uint_as_float(t.y & m));
 }
 // 16 bytes as one load, or as two 8-byte loads when the operand is only 8-byte aligned
 // (row strides / column-group strides that are even but not multiples of 4: Z = 50)
