@@ -291,18 +291,22 @@ __global__ __launch_bounds__(THREADS) void gemm_xw_tp_kernel(Args a)
                                                          // trip is ~1 us, a stage's MFMAs ~0.15 us: one stage ahead is not enough)
     __shared__ __attribute__((aligned(16))) unsigned short ImgA[2][BM * KB];   // [row][64 k], 16-byte slots swizzled by row
     __shared__ __attribute__((aligned(16))) unsigned short ImgB[2][KB * BN];   // [k][64 n] as it lies (transpose read)
-    if ((int)blockIdx.z < a.job_on) {                    // the step prologue's planes of workgroups (dispatched first)
+    // the step prologue's planes of workgroups come LAST in dispatch order here: the product's 512 workgroups take their
+    // CUs first and the prologue (at 128 x 128: 1.3 M quads of noise and image-twin work, 4 096 workgroups) fills in beside
+    // them -- in front, it delayed the product by its whole duration (54.5 us per launch against 34 + 6 as two launches)
+    const int nz = (int)gridDim.z - a.job_on;
+    if ((int)blockIdx.z >= nz) {
         const long plane = (long)gridDim.x * gridDim.y;
-        air_step_job_run(a.job, blockIdx.z * plane + (long)blockIdx.y * gridDim.x + blockIdx.x, plane * a.job_on);
+        air_step_job_run(a.job, ((int)blockIdx.z - nz) * plane + (long)blockIdx.y * gridDim.x + blockIdx.x, plane * a.job_on);
         return;
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // XCD-aware map for the BIG operand: the image batch (16.8 MB fp32) does not fit an L2 (4 MB per XCD), but the
     // [64 rows x K-slab] panel one (row tile, slab) pair needs does (0.5 MB) -- so all column tiles of a pair run on ONE
     // XCD (workgroup b runs on XCD b % 8): the panel is fetched from memory once and its 16 users hit in that L2
-    int tile_m = blockIdx.y, tile_n = blockIdx.x, zslab = (int)blockIdx.z - a.job_on;
+    int tile_m = blockIdx.y, tile_n = blockIdx.x, zslab = (int)blockIdx.z;
     {
-        const int nx = gridDim.x, ny = gridDim.y, nz = (int)gridDim.z - a.job_on, pairs = ny * nz;
+        const int nx = gridDim.x, ny = gridDim.y, pairs = ny * nz;
         if ((pairs & 7) == 0) {
             const int lin = (zslab * ny + (int)blockIdx.y) * nx + (int)blockIdx.x;
             const int xcd = lin & 7, slot = lin >> 3;
