@@ -1028,8 +1028,11 @@ __device__ __forceinline__ float stream_add(float acc, const float* T, int start
 // ALLPH: the terms of all four taps are resident (4*C*C floats of LDS, no barrier between taps);
 // otherwise one tap at a time through one buffer (large canvases)
 template <bool ALLPH>
-__global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_bwd_t a, int lds_ordered)
+__global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_bwd_t a, int seq_flags)
 {
+    // seq_flags (accumulators(), below): bit 0 the LDS atomic pipe applies lanes in order, bit 1 the lane-ring accumulator
+    // is exact on this part (used when the pipe is not)
+    const bool lds_ordered = seq_flags & 1, ring_ok = seq_flags & 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x, t = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NW = WB_THREADS / 64;
@@ -1141,7 +1144,7 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
     const bool is_slot = tid < w * w;
     // (a part whose LDS atomics are not lane-ordered -- lds_order_probe -- has no "corner" slots: their four long runs go
     // through the register chains like every other slot's; slow, but the same sequential order by construction)
-    const bool corner = lds_ordered && is_slot && (sp == 0 || sp == w - 1) && (sq == 0 || sq == w - 1);
+    const bool corner = (lds_ordered || ring_ok) && is_slot && (sp == 0 || sp == w - 1) && (sq == 0 || sq == w - 1);
     float acc = 0.0f;
     float d00 = 0.f, d02 = 0.f, d11 = 0.f, d12 = 0.f, dz = 0.f;
     // The corner slots' streams -> ds_add_f32 on one LDS word per corner: wave c feeds corner c, 64
@@ -1216,6 +1219,43 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
+    // The SECOND sequential accumulator: a ring over the lanes of one wave.  Lane k holds term k of a batch of 64 (one
+    // coalesced ds_read_b32), the running sum travels S[k] = S[k-1] + r[k] with one v_add_f32 ... wave_ror:1 per term, lane
+    // 63 carries it into the next batch (lane 0 reads lane 63); padding lanes hold -0.0f (x + -0 == x).  12 cycles per
+    // term against the pipe's 4 and a register chain's 8.4 -- but it needs ONE LDS request per 64 terms and no per-lane
+    // control flow, and the four corners run on the four SIMDs at once: tools/exp/dpp_chain.hip.
+    // A DPP operand reading the previous instruction's result formally wants two wait states; gfx950 interlocks it
+    // (bit-exact over 10^4-term streams without them, 16.4 cycles with s_nop 0, 18.2 with s_nop 1) -- probed at load time
+    // like the pipe's lane order (accumulators()).
+    auto ring_corner = [&](int c, int ph0, int ph1) {
+        float S = sh_acc[c];                                  // (lane 63's copy is the accumulator)
+        // a ring issues one dependent instruction every 12 cycles and idles in between: at the top issue priority it keeps
+        // that cadence beside the other waves of its SIMD (the pixel loop, the other workgroup's term phase)
+        __builtin_amdgcn_s_setprio(3);
+        for (int ph = ph0; ph < ph1; ++ph) {
+            int start, n;
+            slot_run(ph, (c & 2) ? w - 1 : 0, (c & 1) ? w - 1 : 0, start, n);
+            start = __builtin_amdgcn_readfirstlane(start); n = __builtin_amdgcn_readfirstlane(n);
+            if (n <= 0) continue;
+            float r = lane < n ? sh_T[start + lane] : -0.0f;
+            for (int b = 0; b < n; b += 64) {
+                const int nx = b + 64 + lane;
+                const float rn = nx < n ? sh_T[start + nx] : -0.0f;      // the next batch's read under this batch's adds
+#pragma unroll
+                for (int k = 0; k < 64; ++k)
+                    asm volatile("v_add_f32_dpp %0, %0, %1 wave_ror:1 row_mask:0xf bank_mask:0xf" : "+v"(S) : "v"(r));
+                r = rn;
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (lane == 63) sh_acc[c] = S;
+    };
+    // (A per-workgroup split -- the longest corner streams on the pipe, the others as rings beside it, the count chosen
+    // to balance 4 against 12 cycles per term -- was built and measured: bit-identical, and no faster at either
+    // configuration (0.1806 / 0.716 ms with the pipe alone, 0.1807 / 0.715-0.726 split): the pipe runs at its uncontended
+    // 4.0 cycles per term even with two workgroups per CU, and the launch waits for the workgroup whose ONE corner owns
+    // everything.  The rings are the fallback of a part whose pipe is not ordered: 0.195 / 0.840 ms, against
+    // 0.207 / 1.214 ms for the register chains.)
     // theta / z gradients, per canvas pixel: the NT threads tid0 .. tid0 + NT - 1 share the canvas, three pixels in flight
     // per thread.  NO LDS access: the loop runs on waves 4..15 WHILE waves 0..3 push the corner terms through the LDS
     // atomic pipe (whose traffic starves every other LDS request of the CU), so the taps are recomputed per pixel
@@ -1285,8 +1325,10 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
         __syncthreads();
         AIR_STAMP(44);
         AIR_STAMP_WG(3);
-        if (wave < 4) { if (lds_ordered) feed_corner(wave, 0, 4); }
-        else theta_loop(TH0, THN);
+        if (wave < 4) {
+            if (lds_ordered) feed_corner(wave, 0, 4);
+            else if (ring_ok) ring_corner(wave, 0, 4);
+        } else theta_loop(TH0, THN);
         AIR_STAMP(48);
         AIR_STAMP_WG(4);                       // wave 0's own feed is over
         __syncthreads();
@@ -1299,8 +1341,10 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
             chains(ph, ph + 1);
             __syncthreads();
             AIR_STAMP(51 + 3 * ph);
-            if (wave < 4) { if (lds_ordered) feed_corner(wave, ph, ph + 1); }
-            else if (ph == 0) theta_loop(TH0, THN);
+            if (wave < 4) {
+                if (lds_ordered) feed_corner(wave, ph, ph + 1);
+                else if (ring_ok) ring_corner(wave, ph, ph + 1);
+            } else if (ph == 0) theta_loop(TH0, THN);
             __syncthreads();
             AIR_STAMP(52 + 3 * ph);
         }
@@ -1369,40 +1413,64 @@ __global__ void lds_order_probe_kernel() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) air_probe_out[0] = slot[0];
+    // the lane ring of write_bwd_graph_kernel (ring_corner) on the same stream: the same value if the DPP read of the
+    // previous instruction's result is interlocked and wave_ror:1 hands lane k-1 (63 for lane 0) to lane k
+    float S = 0.0f;
+    for (int k = 0; k < PROBE_N / 64; ++k) {
+        const float r = air_probe_vals[k * 64 + threadIdx.x];
+#pragma unroll
+        for (int i = 0; i < 64; ++i)
+            asm volatile("v_add_f32_dpp %0, %0, %1 wave_ror:1 row_mask:0xf bank_mask:0xf" : "+v"(S) : "v"(r));
+    }
+    if (threadIdx.x == 63) air_probe_out[1] = S;
 }
 
-int lds_ordered(hipStream_t s) {
-    static std::atomic<int> state{0};                    // 0 unknown, 1 ordered, 2 not ordered
+// bit 0: the LDS atomic pipe is a sequential accumulator on this part; bit 1: so is the lane ring
+int accumulators(hipStream_t s) {
+    static std::atomic<int> state{0};                    // 0 unknown, else 4 | flags
     int st = state.load(std::memory_order_acquire);
-    if (st) return st == 1;
-    if (const char* e = getenv("AIR_LDS_ORDER")) { st = (e[0] == '0') ? 2 : 1; state.store(st, std::memory_order_release); return st == 1; }
+    if (st) return st & 3;
+    const char* e0 = getenv("AIR_LDS_ORDER");
+    const char* e1 = getenv("AIR_WB_RING");
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return 1;   // cannot synchronise here
-    float vals[PROBE_N];
-    unsigned x = 12345u;
-    float want = 0.0f;
-    for (int i = 0; i < PROBE_N; ++i) {
-        x = x * 1664525u + 1013904223u;
-        // magnitudes over 2^-8 .. 2^23 with mixed signs: every partial sum rounds, so the value pins the order
-        const float mant = 1.0f + (float)((x >> 9) & 0x3fffu) / 16384.0f;
-        const int ex = (int)((x >> 24) & 31u) - 8;
-        vals[i] = ((x >> 31) ? -1.0f : 1.0f) * ldexpf(mant, ex);
-        want = want + vals[i];                           // ascending lane, program order
+    const bool capturing = hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
+    int probed = 3;
+    if (!(e0 && e1)) {
+        if (capturing) return (e0 ? (e0[0] != '0') : 1) | (e1 ? (e1[0] != '0') << 1 : 2);   // cannot synchronise here: assumed, not remembered
+        float vals[PROBE_N];
+        unsigned x = 12345u;
+        float want = 0.0f;
+        for (int i = 0; i < PROBE_N; ++i) {
+            x = x * 1664525u + 1013904223u;
+            // magnitudes over 2^-8 .. 2^23 with mixed signs: every partial sum rounds, so the value pins the order
+            const float mant = 1.0f + (float)((x >> 9) & 0x3fffu) / 16384.0f;
+            const int ex = (int)((x >> 24) & 31u) - 8;
+            vals[i] = ((x >> 31) ? -1.0f : 1.0f) * ldexpf(mant, ex);
+            want = want + vals[i];                           // ascending lane, program order
+        }
+        float got[2] = {0.0f, 0.0f};
+        bool ok = hipMemcpyToSymbolAsync(HIP_SYMBOL(air_probe_vals), vals, sizeof(vals), 0, hipMemcpyHostToDevice, s) == hipSuccess;
+        if (ok) {
+            hipLaunchKernelGGL(lds_order_probe_kernel, dim3(1), dim3(64), 0, s);
+            ok = hipGetLastError() == hipSuccess &&
+                 hipMemcpyFromSymbolAsync(got, HIP_SYMBOL(air_probe_out), sizeof(got), 0, hipMemcpyDeviceToHost, s) == hipSuccess &&
+                 hipStreamSynchronize(s) == hipSuccess;
+        }
+        probed = ((ok && memcmp(&got[0], &want, sizeof(float)) == 0) ? 1 : 0) | ((ok && memcmp(&got[1], &want, sizeof(float)) == 0) ? 2 : 0);
+        if (!(probed & 1) && !e0)
+            fprintf(stderr, "libair_hip: ds_add_f32 lane order differs on this part (probe %.9g, expected %.9g): "
+                            "the sampler backward takes its ring / register-chain fallbacks\n", (double)got[0], (double)want);
+        if (!(probed & 2) && !e1)
+            fprintf(stderr, "libair_hip: the DPP lane ring is not an in-order accumulator on this part (probe %.9g, expected %.9g): "
+                            "the sampler backward keeps every corner stream on the LDS atomic pipe\n", (double)got[1], (double)want);
     }
-    float got = 0.0f;
-    bool ok = hipMemcpyToSymbolAsync(HIP_SYMBOL(air_probe_vals), vals, sizeof(vals), 0, hipMemcpyHostToDevice, s) == hipSuccess;
-    if (ok) {
-        hipLaunchKernelGGL(lds_order_probe_kernel, dim3(1), dim3(64), 0, s);
-        ok = hipGetLastError() == hipSuccess &&
-             hipMemcpyFromSymbolAsync(&got, HIP_SYMBOL(air_probe_out), sizeof(float), 0, hipMemcpyDeviceToHost, s) == hipSuccess &&
-             hipStreamSynchronize(s) == hipSuccess;
-    }
-    st = (ok && memcmp(&got, &want, sizeof(float)) == 0) ? 1 : 2;
-    if (st == 2) fprintf(stderr, "libair_hip: ds_add_f32 lane order differs on this part (probe %.9g, expected %.9g): "
-                                 "the sampler backward takes its register-chain fallback\n", (double)got, (double)want);
-    state.store(st, std::memory_order_release);
-    return st == 1;
+    int flags = probed;
+    if (e0) flags = (flags & 2) | (e0[0] != '0' ? 1 : 0);
+    if (e1) flags = (flags & 1) | (e1[0] != '0' ? 2 : 0);
+    state.store(4 | flags, std::memory_order_release);
+    return flags;
 }
+int lds_ordered(hipStream_t s) { return accumulators(s) & 1; }
 
 template <typename K>
 int ensure_lds(K kernel, size_t bytes) { return air_grant_lds(reinterpret_cast<const void*>(kernel), bytes); }
@@ -1494,9 +1562,9 @@ extern "C" int air_write_bwd(const air_write_bwd_t* a, void* stream) {
         const size_t lds = write_bwd_graph_smem(a->C, a->w, allph);
         int rc = allph ? ensure_lds(write_bwd_graph_kernel<true>, lds) : ensure_lds(write_bwd_graph_kernel<false>, lds);
         if (rc) return rc;
-        const int ordered = lds_ordered(air_stream(stream));
-        if (allph) hipLaunchKernelGGL(write_bwd_graph_kernel<true>, dim3(a->B, a->N), dim3(WB_THREADS), lds, air_stream(stream), *a, ordered);
-        else hipLaunchKernelGGL(write_bwd_graph_kernel<false>, dim3(a->B, a->N), dim3(WB_THREADS), lds, air_stream(stream), *a, ordered);
+        const int flags = accumulators(air_stream(stream));
+        if (allph) hipLaunchKernelGGL(write_bwd_graph_kernel<true>, dim3(a->B, a->N), dim3(WB_THREADS), lds, air_stream(stream), *a, flags);
+        else hipLaunchKernelGGL(write_bwd_graph_kernel<false>, dim3(a->B, a->N), dim3(WB_THREADS), lds, air_stream(stream), *a, flags);
         AIR_CHECK_LAUNCH();
         return 0;
     }
