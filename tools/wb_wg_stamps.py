@@ -29,7 +29,8 @@ for _ in range(5):
     m.training()
 torch.cuda.synchronize()
 s = m._stream()
-op = [o for o in m._bwd if "write_bwd" in o.name][0]
+which = sys.argv[1] if len(sys.argv) > 1 else "write_bwd"
+op = [o for o in m._fwd + m._bwd if which in o.name][0]
 names = ["setup", "stage_T", "chains+outputs", "feed(wave 0)", "wait for the others", "final"]
 for rep in range(3):
     op(s)
@@ -38,6 +39,10 @@ for rep in range(3):
     buf = (C.c_ulonglong * (n * 8))()
     H._LIB.air_debug_stamps_wg(buf, n * 8)
     v = np.array(list(buf), dtype=np.int64).reshape(n, 8)[:, :7] / 100.0
+    if which != "write_bwd":
+        print("launch %d (%s): start skew %.2f us, first start -> last end %.2f us, workgroup total mean %.2f max %.2f" % (
+            rep, which, v[:, 0].max() - v[:, 0].min(), v[:, 6].max() - v[:, 0].min(), (v[:, 6] - v[:, 0]).mean(), (v[:, 6] - v[:, 0]).max()))
+        continue
     live = v[:, 1] > 0
     v = v[live]
     t0 = v[:, 0].min()
