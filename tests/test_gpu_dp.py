@@ -215,3 +215,59 @@ def test_bench_multi_rank_flow_on_one_device(tmp_path):
         q = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "0"], cwd=root,
                            capture_output=True, text=True, timeout=300)
         assert q.returncode != 0 and "refusing" in q.stderr and not any(l.startswith("{") for l in q.stdout.splitlines())
+
+
+_RCCL_ONE_RANK = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tf-attend-infer-repeat_amd"))
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[2], RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+from oracle import air_oracle as ao
+from oracle.synth import blob_canvases
+from air import air_model as am
+HP = dict(ao.TRAINING_HP)
+images, targets = blob_canvases(8, HP["canvas_size"], HP["max_digits"], seed=23)
+for exchange in ("flat", "factors"):
+    am.reset_default_graph()
+    m = am.AIRModel(torch.tensor(images, device="cuda"), torch.tensor(targets, device="cuda"), cnn=False, train=True,
+                    scope="air", gemm_precision="bf16", seed=0, dp_exchange=exchange, **HP)
+    m.sync_parameters()                                    # broadcast over RCCL
+    s = m._stream()
+    m._run_forward(s, finalize=False)
+    m._run_backward(s, for_update=False, fused_finalize=True)
+    torch.cuda.synchronize()
+    before = m.store.grads.clone()
+    m._dp_exchange_gradients()                             # all_reduce (+ all_gather_into_tensor) over RCCL
+    torch.cuda.synchronize()
+    assert torch.equal(before, m.store.grads), exchange    # one rank: the sum over ranks is the identity
+    if exchange == "factors":
+        f = m._dp_factors()
+        assert torch.equal(f["x_all"], m.input_images) and torch.equal(f["dg_all"], m.dgsum)
+    assert float(before.abs().max()) > 0
+    # and a whole train step on the single-rank process group (world == 1: the fused single-GPU branch)
+    m.training()
+    torch.cuda.synchronize()
+print("RCCL", ".".join(str(v) for v in torch.cuda.nccl.version()))
+dist.destroy_process_group()
+'''
+
+
+def test_rccl_collectives_execute_on_the_product_buffers(tmp_path):
+    """The `nccl` (= RCCL) calls of the data-parallel branch -- broadcast of the variables, ONE all_reduce of the flat
+    gradient buffer, all_gather_into_tensor of the dWx factors + the all_reduce of the tail -- executed on this box's one
+    GPU with a single-rank process group (RCCL refuses two ranks per device, and one rank is all a 1-GPU lease allows):
+    not a scaling test, but the calls, dtypes, sizes and alignments of the buffers the product hands to RCCL are
+    exercised on hardware, and a one-rank sum must leave them unchanged."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rccl_one_rank.py"
+    script.write_text(_RCCL_ONE_RANK)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script), root, str(_free_port())], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "RCCL" in r.stdout
