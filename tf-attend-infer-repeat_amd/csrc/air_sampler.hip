@@ -1043,7 +1043,9 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
     Tap* sh_tx = reinterpret_cast<Tap*>(smem + 136);       // [C]
     Tap* sh_ty = sh_tx + C;                                // [C]
     float* sh_t = reinterpret_cast<float*>(sh_ty + C);     // [C] linspace
-    int* sh_run = reinterpret_cast<int*>(sh_t + ((C + 3) & ~3));   // [4][w][2]: run [lo,hi] of every key of x0 / x1 / y0 / y1
+    int4* sh_ci = reinterpret_cast<int4*>(sh_t + ((C + 3) & ~3));  // [C] per canvas column: {first, count} of the run of its x0 key, of its x1 key
+    int4* sh_ri = sh_ci + C;                                       // [C] per canvas row: the same for y0 / y1
+    int* sh_run = reinterpret_cast<int*>(sh_ri + C);               // [4][w][2]: run [lo,hi] of every key of x0 / x1 / y0 / y1
     float* sh_win = reinterpret_cast<float*>(sh_run + ((8 * w + 3) & ~3));   // [w*w]
     // d loss / d (masked z * window_recon): staged in LDS when all taps are resident (small canvases); a large canvas
     // reads it from memory where needed (its 5 uses per pixel hit L2: every step of an image reads the same row) --
@@ -1109,6 +1111,16 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
         if (kn != k) sh_run[(arr * w + k) * 2 + 1] = J;
     }
     __syncthreads();
+    // ... and every canvas column / row the runs of its two keys: the term phase then needs ONE LDS round trip per
+    // pixel (two taps + two run records, all independent) instead of eight run lookups that wait for the taps
+    for (int it = tid; it < 2 * C; it += WB_THREADS) {
+        const int ax = it / C, J = it - ax * C;
+        const Tap tp = ax ? sh_ty[J] : sh_tx[J];
+        const int* r0 = sh_run + ((2 * ax) * w + tp.i0) * 2;
+        const int* r1 = sh_run + ((2 * ax + 1) * w + tp.i1) * 2;
+        (ax ? sh_ri : sh_ci)[J] = make_int4(r0[0], r0[1] - r0[0] + 1, r1[0], r1[1] - r1[0] + 1);
+    }
+    __syncthreads();
     AIR_STAMP(42);
 
     // tap ph = a, b, c, d <-> (y0,x0), (y1,x0), (y0,x1), (y1,x1)
@@ -1118,10 +1130,9 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
         for (int p = tid; p < CC; p += WB_THREADS) {
             const Tap tx = sh_tx[j], ty = sh_ty[i];
             const float gp = z * (ALLPH ? sh_g[p] : gsrc[p]);                       // canvas/mul_grad: z * Select_grad
-            const int cl0 = sh_run[tx.i0 * 2], cn0 = sh_run[tx.i0 * 2 + 1] - cl0 + 1;               // x0 run
-            const int cl1 = sh_run[(w + tx.i1) * 2], cn1 = sh_run[(w + tx.i1) * 2 + 1] - cl1 + 1;   // x1 run
-            const int rl0 = sh_run[(2 * w + ty.i0) * 2], rn0 = sh_run[(2 * w + ty.i0) * 2 + 1] - rl0 + 1;
-            const int rl1 = sh_run[(3 * w + ty.i1) * 2], rn1 = sh_run[(3 * w + ty.i1) * 2 + 1] - rl1 + 1;
+            const int4 ci = sh_ci[j], ri = sh_ri[i];
+            const int cl0 = ci.x, cn0 = ci.y, cl1 = ci.z, cn1 = ci.w;               // runs of this column's x0 / x1 key
+            const int rl0 = ri.x, rn0 = ri.y, rl1 = ri.z, rn1 = ri.w;               // runs of this row's y0 / y1 key
             for (int ph = ph0; ph < ph1; ++ph) {
                 const bool x1 = ph >> 1, y1 = ph & 1;
                 const float wgt = (x1 ? tx.w1 : tx.w0) * (y1 ? ty.w1 : ty.w0);      // wa..wd (transformer.py:108-115)
@@ -1388,7 +1399,7 @@ size_t attend_bwd_smem(int C, int w) {
 }
 size_t write_smem(int N, int C, int w) { return (16 + 3 * MAX_STEPS + (size_t)N * (8 * C + (size_t)w * w)) * sizeof(float); }
 size_t write_bwd_graph_smem(int C, int w, bool allph) {
-    return (136 + 8 * C + ((C + 3) & ~3) + ((8 * w + 3) & ~3) + (((size_t)w * w + 3) & ~3) +
+    return (136 + 8 * C + ((C + 3) & ~3) + 8 * C + ((8 * w + 3) & ~3) + (((size_t)w * w + 3) & ~3) +
             (allph ? 5 : 1) * (((size_t)C * C + 3) & ~3)) * sizeof(float);
 }
 size_t write_bwd_smem(int C, int w) { return (64 + 8 * C + C + 8 * w + 8 * (w + 2) + (size_t)w * w + 4 * (size_t)(w + 2) * w + 2 * (size_t)C * (w + 2) + (size_t)C * C) * sizeof(float); }
