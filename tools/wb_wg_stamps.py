@@ -52,5 +52,8 @@ for rep in range(3):
     print("  workgroup total: mean %.2f  max %.2f" % (tot.mean(), tot.max()))
     for k, nm in enumerate(names):
         print("  %-22s mean %6.2f  max %6.2f" % (nm, d[:, k].mean(), d[:, k].max()))
+    order = np.argsort(-tot)
+    print("  slowest workgroups, total (chains+outputs, feed phase): " + "  ".join("%.1f (%.1f, %.1f)" % (tot[i], d[i, 2], d[i, 3] + d[i, 4]) for i in order[:10]))
+    print("  longest total without the chain phase: %.2f us" % (tot - d[:, 2]).max())
     w = int(np.argmax(v[:, 6]))
     print("  last workgroup to end: started +%.2f, phases %s" % (v[w, 0] - t0, " ".join("%.2f" % x for x in d[w])))
