@@ -514,6 +514,8 @@ class AIRModel:
     def _call(self, name, *args, nbytes=0, flops=0, tag=None):
         fn = getattr(self.lib, name)
         kernel = self._KERNEL_OF.get(name)
+        if name == "air_lstm_first_step":                    # instantiated per slab count: <4> in the train step, <0> = run-time count
+            kernel = "lstm_first_step_kernel<%d>" % (4 if args[1] == 4 else 0)
         if name == "air_wgrad_grouped":
             kernel = "wgrad_grouped_bf16_kernel" if self._prec else "wgrad_grouped_kernel"
         if name == "air_adam_clip_step_factored":

@@ -32,6 +32,8 @@ __global__ __launch_bounds__(THREADS) void lstm_gates_fwd_kernel(
 // The FIRST step of the recurrence: h_0 = c_0 = 0 (zero_state, air_model.py:540), so [x, h].K reduces to
 // the hoisted x.Wx and no MatMul is needed.  Pre-activation = ((0 + slab_0) + slab_1 ...) + bias -- the
 // summation order of the fused GEMM epilogue (AIR_EPI_LSTM_FWD) with a zero accumulator, bit for bit.
+// NS > 0: the slab count is a compile-time constant (4 in the train step); NS == 0: run-time count up to 8
+template <int NS>
 __global__ __launch_bounds__(THREADS) void lstm_first_step_kernel(
     const float* __restrict__ slabs, int nslabs, long slab_stride, const float* __restrict__ bias,
     float* __restrict__ acts, float* __restrict__ c, float* __restrict__ h, unsigned short* __restrict__ h16, int B, int R)
@@ -39,14 +41,25 @@ __global__ __launch_bounds__(THREADS) void lstm_first_step_kernel(
     const int idx = blockIdx.x * THREADS + threadIdx.x;
     if (idx >= B * R) return;
     const int b = idx / R, u = idx % R;
-    // all 4 x 8 loads in flight before the first add (one memory round trip, not thirty-two)
+    // all 4 x nslabs loads in flight before the first add (one memory round trip).  No control flow between them: with
+    // `k < nslabs ? load : 0` and `bias ? load : 0` the compiler laid a branch around every load and an s_waitcnt
+    // vmcnt(0) at several of the joins -- six round trips in a row in a kernel that has nothing else to do.  An absent slab /
+    // bias is read from a valid stand-in address and masked to +0.0f by bit operations.
     float v[4][8], bj[4], g[4];
+    const unsigned bmask = bias ? 0xffffffffu : 0u;
+    const float* bsrc = bias ? bias : slabs;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const size_t o = (size_t)b * 4 * R + j * R + u;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[j][k] = k < nslabs ? slabs[k * slab_stride + o] : 0.0f;
-        bj[j] = bias ? bias[j * R + u] : 0.0f;
+        for (int k = 0; k < 8; ++k) {
+            if (NS > 0) v[j][k] = k < NS ? slabs[k * slab_stride + o] : 0.0f;
+            else {
+                const unsigned m = k < nslabs ? 0xffffffffu : 0u;
+                v[j][k] = __uint_as_float(__float_as_uint(slabs[(k < nslabs ? k : 0) * slab_stride + o]) & m);
+            }
+        }
+        bj[j] = __uint_as_float(__float_as_uint(bsrc[bias ? j * R + u : 0]) & bmask);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -259,8 +272,12 @@ extern "C" int air_lstm_first_step(const float* xw_slabs, int nslabs, const floa
                                    float* c, float* h, uint16_t* h16, int B, int R, void* stream) {
     if (!xw_slabs || !acts || !c || !h || B <= 0 || R <= 0 || nslabs <= 0) return AIR_EINVAL;
     if (nslabs > 8) return AIR_ELIMIT;
-    hipLaunchKernelGGL(lstm_first_step_kernel, dim3((B * R + THREADS - 1) / THREADS), dim3(THREADS), 0,
-                       air_stream(stream), xw_slabs, nslabs, (long)B * 4 * R, bias, acts, c, h, h16, B, R);
+    if (nslabs == 4)
+        hipLaunchKernelGGL(lstm_first_step_kernel<4>, dim3((B * R + THREADS - 1) / THREADS), dim3(THREADS), 0,
+                           air_stream(stream), xw_slabs, nslabs, (long)B * 4 * R, bias, acts, c, h, h16, B, R);
+    else
+        hipLaunchKernelGGL(lstm_first_step_kernel<0>, dim3((B * R + THREADS - 1) / THREADS), dim3(THREADS), 0,
+                           air_stream(stream), xw_slabs, nslabs, (long)B * 4 * R, bias, acts, c, h, h16, B, R);
     AIR_CHECK_LAUNCH();
     return 0;
 }

@@ -328,12 +328,17 @@ __global__ __launch_bounds__(THREADS) void attend_fwd_kernel(air_attend_fwd_t a)
     // the sampling / KL section below is spread over the lanes of wave 0: lanes 0..2 take the three Gaussian
     // heads (scale, shift x, shift y), lane 3 the Concrete z_pres of this step, lanes 8.. the z_pres of the
     // earlier steps (for the stopping sum); each lane fetches its own noise
+    // (ONE load through a selected address: an if / else-if chain made wave 0 walk five branches, each with its own load
+    // and s_waitcnt -- five memory round trips in front of the workgroup's first barrier)
     float in_eps = 0.0f, in_u = 0.5f;
-    if (tid == 0) in_eps = a.eps_scale[row];
-    else if (tid == 1) in_eps = a.eps_shift[2 * row];
-    else if (tid == 2) in_eps = a.eps_shift[2 * row + 1];
-    else if (tid == 3) in_u = a.u[row];
-    else if (tid >= 8 && tid < 8 + t) in_u = a.u[(size_t)(tid - 8) * B + b];
+    {
+        const bool prev = tid >= 8 && tid < 8 + t;
+        const float* nsrc = tid == 0 ? a.eps_scale + row : tid == 1 ? a.eps_shift + 2 * row : tid == 2 ? a.eps_shift + 2 * row + 1
+                          : prev ? a.u + (size_t)(tid - 8) * B + b : a.u + row;
+        const float nv = *nsrc;
+        in_eps = tid < 3 ? nv : 0.0f;
+        in_u = (tid == 3 || prev) ? nv : 0.5f;
+    }
     for (int j = tid; j < HT; j += THREADS) sh_hid[j] = a.hid[row * HT + j];
     for (int j = tid; j < 7 * a.wout_ld; j += THREADS) sh_wout[j] = a.wout[j];
     for (int j = tid; j < t * hs.wid[4]; j += THREADS) {
@@ -594,10 +599,19 @@ __global__ __launch_bounds__(THREADS) void attend_bwd_kernel(air_attend_bwd_t a)
         int h = 0;
         while (h < 4 && j >= hs.off[h + 1]) ++h;
         const int jj = j - hs.off[h];
+        // all seven weights and the activation fetched unconditionally (jj < wout_ld for every unit), the units of other
+        // heads masked to an exact +0 term: the conditional form was one load + s_waitcnt per unit, one after the other
+        float wv[7];
+#pragma unroll
+        for (int o = 0; o < 7; ++o) wv[o] = a.wout[o * a.wout_ld + jj];
+        const float hv = a.hid[row * HT + j];
         float v = 0.0f;
-        for (int o = 0; o < 7; ++o)
-            if (kOutHead[o] == h) v += sh_d[o] * a.wout[o * a.wout_ld + jj];
-        const float dv = (a.hid[row * HT + j] > 0.0f) ? v : 0.0f;
+#pragma unroll
+        for (int o = 0; o < 7; ++o) {
+            const float term = sh_d[o] * wv[o];
+            v += (kOutHead[o] == h) ? term : 0.0f;
+        }
+        const float dv = (hv > 0.0f) ? v : 0.0f;
         a.d_hid[row * HT + j] = dv;
         if (a.d_hid16) a.d_hid16[row * HT + j] = air_bf16_of(dv);
     }
@@ -623,7 +637,8 @@ __global__ __launch_bounds__(CF_THREADS) void write_fwd_kernel(air_write_fwd_t a
     float* sh_z = smem + 16;                                 // [MAX_STEPS] z_pres
     int* sh_act = reinterpret_cast<int*>(smem + 16 + MAX_STEPS);         // [MAX_STEPS]
     float* sh_kl = smem + 16 + 2 * MAX_STEPS;                            // [MAX_STEPS] VAE KL per step
-    Tap* sh_tx = reinterpret_cast<Tap*>(smem + 16 + 3 * MAX_STEPS);      // [N][C]
+    float* sh_rec = smem + 16 + 3 * MAX_STEPS;                           // [MAX_STEPS][4]: mask_prev, KL z, KL scale, KL shift
+    Tap* sh_tx = reinterpret_cast<Tap*>(smem + 16 + 7 * MAX_STEPS);      // [N][C]
     Tap* sh_ty = sh_tx + (size_t)N * C;                                    // [N][C]
     float* sh_win = reinterpret_cast<float*>(sh_ty + (size_t)N * C);      // [N][w*w]
     const float* dyn = a.dyn;
@@ -656,11 +671,17 @@ __global__ __launch_bounds__(CF_THREADS) void write_fwd_kernel(air_write_fwd_t a
         sh_win[it] = a.vrec[((size_t)t * B + b) * w * w + (it - t * w * w)];
     }
     if (tid < N) {
+        // one thread per step fetches its record (six independent loads); thread 0 below then sums from LDS -- as a loop
+        // of conditional loads on one thread it was a dozen memory round trips in a row
         const float* at = a.att + ((size_t)tid * B + b) * AIR_ATT_STRIDE;
-        sh_z[tid] = at[AIR_ATT_Z];
-        sh_act[tid] = at[AIR_ATT_MASK] != 0.0f ? 1 : 0;
+        const float zv = at[AIR_ATT_Z], mk = at[AIR_ATT_MASK], mp = at[AIR_ATT_MASK_PREV];
+        const float kz = at[AIR_ATT_KL_Z], ks = at[AIR_ATT_KL_SCALE], kh = at[AIR_ATT_KL_SHIFT];
+        sh_z[tid] = zv;
+        sh_act[tid] = mk != 0.0f ? 1 : 0;
+        sh_rec[4 * tid] = mp; sh_rec[4 * tid + 1] = kz; sh_rec[4 * tid + 2] = ks; sh_rec[4 * tid + 3] = kh;
     }
     __syncthreads();
+    float Lkeep = 0.0f;
     if (tid == 0) {
         // running loss in the reference order: z KL (old mask), scale, shift, VAE KL (new mask) :411-493
         float L = 0.0f;
@@ -668,18 +689,17 @@ __global__ __launch_bounds__(CF_THREADS) void write_fwd_kernel(air_write_fwd_t a
         for (int t = 0; t < N; ++t) {
             float* at = a.att + ((size_t)t * B + b) * AIR_ATT_STRIDE;
             const bool mask = sh_act[t] != 0;
-            L = L + (at[AIR_ATT_MASK_PREV] != 0.0f ? at[AIR_ATT_KL_Z] : 0.0f);
-            L = L + (mask ? at[AIR_ATT_KL_SCALE] : 0.0f);
-            L = L + (mask ? at[AIR_ATT_KL_SHIFT] : 0.0f);
+            L = L + (sh_rec[4 * t] != 0.0f ? sh_rec[4 * t + 1] : 0.0f);
+            L = L + (mask ? sh_rec[4 * t + 2] : 0.0f);
+            L = L + (mask ? sh_rec[4 * t + 3] : 0.0f);
             L = L + (mask ? sh_kl[t] : 0.0f);
             digits += mask ? 1 : 0;
             at[AIR_ATT_KL_VAE] = sh_kl[t];
         }
         a.run_loss[b] = L;
         a.run_digits[b] = digits;
+        Lkeep = L;
     }
-    float Lkeep = 0.0f;
-    if (tid == 0) Lkeep = a.run_loss[b];          // thread 0 re-reads its own store
 
     // phase B -- canvas + Bernoulli cross-entropy, pixel by pixel
     const float gsc = dyn[AIR_DYN_GRAD_SCALE];
@@ -1397,7 +1417,7 @@ size_t attend_smem(int C, int w, int HT) {
 size_t attend_bwd_smem(int C, int w) {
     return (24 + 8 * w + w + 4 + attend_canvas_floats(C)) * sizeof(float);
 }
-size_t write_smem(int N, int C, int w) { return (16 + 3 * MAX_STEPS + (size_t)N * (8 * C + (size_t)w * w)) * sizeof(float); }
+size_t write_smem(int N, int C, int w) { return (16 + 7 * MAX_STEPS + (size_t)N * (8 * C + (size_t)w * w)) * sizeof(float); }
 size_t write_bwd_graph_smem(int C, int w, bool allph) {
     return (136 + 8 * C + ((C + 3) & ~3) + 8 * C + ((8 * w + 3) & ~3) + (((size_t)w * w + 3) & ~3) +
             (allph ? 5 : 1) * (((size_t)C * C + 3) & ~3)) * sizeof(float);
