@@ -1091,6 +1091,15 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
     float* dgen = a.d_gen_pre + row * w * w;
     unsigned short* dgen16 = a.d_gen_pre16 ? a.d_gen_pre16 + row * w * w : nullptr;
     float* dsx = a.d_sxy_write + row * 4;
+    // the window and (small canvases) the first pass over d_recon do not depend on the record: their loads go out
+    // BEFORE the mask test waits for it -- one memory round trip for the set-up instead of two
+    const float* v = a.vrec + row * w * w;
+    const float win_pre = tid < w * w ? v[tid] : 0.0f;      // (w * w <= WB_THREADS: checked by the launcher)
+    float g_pre[8];
+    if (ALLPH) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const int p = k * WB_THREADS + tid; g_pre[k] = p < CC ? gsrc[p] : 0.0f; }
+    }
     if (at[AIR_ATT_MASK] == 0.0f) {                        // Select(active, ., 0): no gradient
         for (int p = tid; p < w * w; p += WB_THREADS) { dgen[p] = 0.0f; if (dgen16) dgen16[p] = 0; }
         if (tid < 4) dsx[tid] = 0.0f;
@@ -1107,10 +1116,11 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
     for (int it = tid; it < 4 * w; it += WB_THREADS) { sh_run[2 * it] = 0; sh_run[2 * it + 1] = -1; }
     if (tid < 8) sh_acc[tid] = 0.0f;
     if (tid >= 64 && tid < 64 + NW * 8) sh_red[tid - 64] = 0.0f;          // the feeding waves publish no pixel-loop partials
-    const float* v = a.vrec + row * w * w;
-    for (int p = tid; p < w * w; p += WB_THREADS) sh_win[p] = v[p];
+    if (tid < w * w) sh_win[tid] = win_pre;
     if (ALLPH) {
-        for (int p0 = 0; p0 < CC; p0 += 8 * WB_THREADS) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const int p = k * WB_THREADS + tid; if (p < CC) sh_g[p] = g_pre[k]; }
+        for (int p0 = 8 * WB_THREADS; p0 < CC; p0 += 8 * WB_THREADS) {
             float r[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) { const int p = p0 + k * WB_THREADS + tid; r[k] = p < CC ? gsrc[p] : 0.0f; }
