@@ -392,6 +392,12 @@ def main():
                                  "busy_cycles_per_launch": prof.get("mfma_busy_cycles")}
                 if prof.get("stale"):
                     r["profile_stale"] = True        # profiles/kernel_profile.json was taken from other sources
+                if name.startswith("write_bwd_graph_kernel"):
+                    # neither of the schema's two bounds is what holds this kernel: say so next to the HBM fraction
+                    r["note"] = ("bound by the CU's LDS atomic pipe, not HBM: the reference's UnsortedSegmentSum order needs ONE "
+                                 "sequential fp32 accumulator per corner slot, ds_add_f32 delivers 4.0 cycles per term and the slowest "
+                                 "workgroup owns up to 4*C*C terms (16.9 of its 24 us at 50x50) -- DESIGN.md section 8; the step's "
+                                 "HBM-bound kernel is adam_clip_kernel (roofline_all)")
                 return r
             # dominant kernel = the kernel function with the largest share of the step (what the
             # rocprofv3 stats table lists first); the other functions follow in `roofline_all`
