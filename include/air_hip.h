@@ -365,6 +365,9 @@ typedef struct {
     float* ml; float* z; float* g;
     int32_t M, K1, Z, H, ldx;
     uint16_t* z16; uint16_t* g16;        /* bf16 twins of z / g written next to them (nullable) */
+    const uint16_t* X16; const uint16_t* Wml16; const uint16_t* Wg16;   /* bf16 twins of the three operands (all or none;
+                                          * X16 16-byte aligned with ldx % 8 == 0, the weights 8-byte aligned): read instead of
+                                          * the fp32 arrays, same results */
 } air_bottleneck_fwd_t;
 typedef struct {
     const float* dG; const float* Wg; const float* ml; const float* eps;
@@ -373,6 +376,7 @@ typedef struct {
     float* d_ml; float* d_x;
     int32_t M, K1, Z, H;
     uint16_t* d_ml16; uint16_t* d_x16;   /* bf16 twins of d_ml / d_x written next to them (nullable) */
+    const uint16_t* dG16; const uint16_t* Wg16; const uint16_t* Wml16;  /* bf16 twins of the three operands (all or none) */
 } air_bottleneck_bwd_t;
 int air_vae_bottleneck_fwd(const air_bottleneck_fwd_t* a, void* stream);
 int air_vae_bottleneck_bwd(const air_bottleneck_bwd_t* a, void* stream);

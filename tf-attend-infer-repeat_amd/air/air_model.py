@@ -516,6 +516,8 @@ class AIRModel:
         kernel = self._KERNEL_OF.get(name)
         if name == "air_lstm_first_step":                    # instantiated per slab count: <4> in the train step, <0> = run-time count
             kernel = "lstm_first_step_kernel<%d>" % (4 if args[1] == 4 else 0)
+        if name in ("air_vae_bottleneck_fwd", "air_vae_bottleneck_bwd"):   # instantiated per operand form (bf16 twins or fp32)
+            kernel = "bottleneck_%s_kernel<256, %s>" % (name[-3:], "true" if self._twins else "false")
         if name == "air_wgrad_grouped":
             kernel = "wgrad_grouped_bf16_kernel" if self._prec else "wgrad_grouped_kernel"
         if name == "air_adam_clip_step_factored":
@@ -607,7 +609,7 @@ class AIRModel:
         if fuse_f:
             bf = H.BottleneckFwd(_ptr(x), _ptr(P["ml_w"]), _ptr(P["ml_b"]), _ptr(self.eps_z), _ptr(P["gen0_w"]),
                                  _ptr(P["gen0_b"]), _ptr(self.ml), _ptr(self.zs), _ptr(self.gen_act[0]), NB, k, Z, gen_u[0], k,
-                                 _ptr(self.zs16), _ptr(self.gen_act16[0]))
+                                 _ptr(self.zs16), _ptr(self.gen_act16[0]), _ptr(x16), _ptr(T("ml_w")), _ptr(T("gen0_w")))
             keep.append(bf)
             fwd.append(self._call("air_vae_bottleneck_fwd", C.byref(bf),
                                   nbytes=4 * (NB * (k + 4 * Z + gen_u[0]) + k * 2 * Z + Z * gen_u[0]),
@@ -680,7 +682,8 @@ class AIRModel:
             # d_gen[0] -> d_z -> (d_mean | d_lv) -> d_rec[last] in ONE launch (vae.py:22-24 and the KL, backwards)
             bb = H.BottleneckBwd(_ptr(dy), _ptr(P["gen0_w"]), _ptr(self.ml), _ptr(self.eps_z), _ptr(self.att), _ptr(self.dyn),
                                  _ptr(P["ml_w"]), _ptr(self.rec_act[-1]), _ptr(self.d_ml), _ptr(self.d_rec[-1]),
-                                 NB, rec_u[-1], Z, gen_u[0], _ptr(self.d_ml16), _ptr(self.d_rec16[-1]))
+                                 NB, rec_u[-1], Z, gen_u[0], _ptr(self.d_ml16), _ptr(self.d_rec16[-1]),
+                                 _ptr(dy16), _ptr(T("gen0_w")), _ptr(T("ml_w")))
             keep.append(bb)
             bwd.append(self._call("air_vae_bottleneck_bwd", C.byref(bb),
                                   nbytes=4 * (NB * (gen_u[0] + 5 * Z + 2 * rec_u[-1]) + Z * gen_u[0] + rec_u[-1] * 2 * Z),

@@ -40,6 +40,23 @@ __device__ __forceinline__ float4 zero_unless(bool ok, float4 v) {
 }
 __device__ __forceinline__ float comp(const float4& t, int j) { return j == 0 ? t.x : j == 1 ? t.y : j == 2 ? t.z : t.w; }
 
+// twin operands: 8 / 16 bytes of bf16 with the out-of-range case redirected to element 0 and zeroed by a bit mask
+__device__ __forceinline__ uint2 fetch8h(const unsigned short* __restrict__ base, bool ok, size_t at) {
+    const uint2 t = *reinterpret_cast<const uint2*>(base + (ok ? at : 0));
+    const unsigned m = ok ? 0xffffffffu : 0u;
+    return make_uint2(t.x & m, t.y & m);
+}
+__device__ __forceinline__ uint4 fetch16h(const unsigned short* __restrict__ base, bool ok, size_t at) {
+    const uint4 t = *reinterpret_cast<const uint4*>(base + (ok ? at : 0));
+    const unsigned m = ok ? 0xffffffffu : 0u;
+    return make_uint4(t.x & m, t.y & m, t.z & m, t.w & m);
+}
+// element j (0..3) of the four bf16 a row piece holds, from two rows -> one dword of a [column][k] image
+__device__ __forceinline__ unsigned pair16(const uint2& r0, const uint2& r1, int j) {
+    const unsigned a = j < 2 ? r0.x : r0.y, b = j < 2 ? r1.x : r1.y;
+    return (j & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
+}
+
 // fragment of a [row][k] image: lane l -> row (l & 15), the 8 k of slot ks*4 + (l >> 4)
 __device__ __forceinline__ bf16x8 frag(const unsigned short* img, int ld, int row0, int ks, int lane) {
     return *reinterpret_cast<const bf16x8*>(&img[(row0 + (lane & 15)) * ld + ks * 32 + (lane >> 4) * 8]);
@@ -50,10 +67,14 @@ struct FwdArgs {
     float* ml; float* z; float* g;
     int M, Z, H, ldx;
     unsigned short* z16; unsigned short* g16;      // bf16 twins of z / g (nullable)
+    const unsigned short* X16; const unsigned short* Wml16; const unsigned short* Wg16;   // bf16 twins of the operands (TW)
 };
 
 // K1 = width of X (the last recognition layer), compile-time
-template <int K1>
+// TW: X, Wml and Wg are read from their bf16 twins (the producing GEMM's C16 / Adam's shadow): half the bytes through the
+// CU's vector-memory path (65 instead of 129 KB per workgroup), no conversion; the RNE twins are what pack_bf16 makes of
+// the fp32 arrays, so both forms give the same bits.
+template <int K1, bool TW>
 __global__ __launch_bounds__(THREADS) void bottleneck_fwd_kernel(FwdArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
@@ -70,17 +91,28 @@ __global__ __launch_bounds__(THREADS) void bottleneck_fwd_kernel(FwdArgs a)
     // ---- every load of the workgroup, back to back ------------------------------------------------
     // X tile: 16 x K1 floats, consecutive lanes along the row
     constexpr int NX = 16 * K1 / 4 / THREADS;
-    float4 vx[NX];
+    float4 vx[TW ? 1 : NX];
+    constexpr int NXH = 16 * K1 / 8 / THREADS;     // twin: 16-byte pieces of 8 k
+    uint4 vxh[TW ? NXH : 1];
+    if (TW) {
 #pragma unroll
-    for (int i = 0; i < NX; ++i) {
-        const int t = tid + THREADS * i, row = t / (K1 / 4), c4 = t % (K1 / 4);
-        vx[i] = fetch16(a.X, m0 + row < M, (size_t)(m0 + row) * a.ldx + c4 * 4);
+        for (int i = 0; i < NXH; ++i) {
+            const int t = tid + THREADS * i, row = t / (K1 / 8), c8 = t % (K1 / 8);
+            vxh[i] = fetch16h(a.X16, m0 + row < M, (size_t)(m0 + row) * a.ldx + c8 * 8);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int t = tid + THREADS * i, row = t / (K1 / 4), c4 = t % (K1 / 4);
+            vx[i] = fetch16(a.X, m0 + row < M, (size_t)(m0 + row) * a.ldx + c4 * 4);
+        }
     }
     // Wml [K1, 2Z] (columns contiguous): task = (k-run g of 8 rows, column quad) -> 8 float4, transposed in registers
     const int NQ = (Z2 + 3) >> 2;
     const int ntask = NQ * (K1 / 8);
     constexpr int NW = 4;                          // tasks per thread: 2Z <= 128 -> <= 32 quads x K1/8 runs <= 1024 (K1 = 256)
-    float4 vw[NW][8];
+    float4 vw[TW ? 1 : NW][8];
+    uint2 vwh[TW ? NW : 1][8];
     int wg_[NW], wq_[NW];
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
@@ -89,14 +121,21 @@ __global__ __launch_bounds__(THREADS) void bottleneck_fwd_kernel(FwdArgs a)
         const int g = ok ? t / NQ : 0, cq = ok ? t - g * NQ : 0;
         wg_[i] = ok ? g : -1; wq_[i] = cq;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) vw[i][r] = fetch16(a.Wml, ok, (size_t)(g * 8 + r) * Z2 + cq * 4);
+        for (int r = 0; r < 8; ++r) {
+            if (TW) vwh[i][r] = fetch8h(a.Wml16, ok, (size_t)(g * 8 + r) * Z2 + cq * 4);
+            else vw[i][r] = fetch16(a.Wml, ok, (size_t)(g * 8 + r) * Z2 + cq * 4);
+        }
     }
     // Wg [Z, H] slice (columns n0 .. n0+63 contiguous): threads 0..127, task = (k-run g, column quad)
-    float4 vg[8];
+    float4 vg[TW ? 1 : 8];
+    uint2 vgh[TW ? 8 : 1];
     const int gg = (tid >> 4) & 7, gq = tid & 15;
     const bool gcol = tid < 128 && n0 + gq * 4 < H;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) vg[r] = fetch16(a.Wg, gcol && gg * 8 + r < Z, (size_t)(gg * 8 + r) * H + n0 + gq * 4);
+    for (int r = 0; r < 8; ++r) {
+        if (TW) vgh[r] = fetch8h(a.Wg16, gcol && gg * 8 + r < Z, (size_t)(gg * 8 + r) * H + n0 + gq * 4);
+        else vg[r] = fetch16(a.Wg, gcol && gg * 8 + r < Z, (size_t)(gg * 8 + r) * H + n0 + gq * 4);
+    }
     // epilogue operands in the accumulator layout: row = (lane>>4)*4 + q, unit / column = 16*wave + (lane&15)
     const int u = wave * 16 + (lane & 15);
     const bool uok = u < Z;
@@ -110,7 +149,35 @@ __global__ __launch_bounds__(THREADS) void bottleneck_fwd_kernel(FwdArgs a)
     const int n = n0 + u;
     const float b_g = a.bg[n < H ? n : 0];
 
-    // ---- round to bf16 into the images --------------------------------------------------------------
+    // ---- into the images (fp32 operands: rounded to bf16 here) -----------------------------------------
+    if (TW) {
+#pragma unroll
+        for (int i = 0; i < NXH; ++i) {
+            const int t = tid + THREADS * i, row = t / (K1 / 8), c8 = t % (K1 / 8);
+            *reinterpret_cast<uint4*>(&A1[row * L1 + c8 * 8]) = vxh[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            if (wg_[i] < 0) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = wq_[i] * 4 + j;
+                if (c >= Z2) continue;
+                const int col = c < Z ? c : 64 + (c - Z);
+                const uint4 w = make_uint4(pair16(vwh[i][0], vwh[i][1], j), pair16(vwh[i][2], vwh[i][3], j),
+                                           pair16(vwh[i][4], vwh[i][5], j), pair16(vwh[i][6], vwh[i][7], j));
+                *reinterpret_cast<uint4*>(&B1[col * L1 + wg_[i] * 8]) = w;
+            }
+        }
+        if (tid < 128) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint4 w = make_uint4(pair16(vgh[0], vgh[1], j), pair16(vgh[2], vgh[3], j),
+                                           pair16(vgh[4], vgh[5], j), pair16(vgh[6], vgh[7], j));
+                *reinterpret_cast<uint4*>(&B2[(gq * 4 + j) * L2 + gg * 8]) = w;
+            }
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
         const int t = tid + THREADS * i, row = t / (K1 / 4), c4 = t % (K1 / 4);
@@ -143,6 +210,7 @@ __global__ __launch_bounds__(THREADS) void bottleneck_fwd_kernel(FwdArgs a)
             w.z = pack_bf16(comp(t8[4], j), comp(t8[5], j)); w.w = pack_bf16(comp(t8[6], j), comp(t8[7], j));
             *reinterpret_cast<uint4*>(&B2[(gq * 4 + j) * L2 + gg * 8]) = w;
         }
+    }
     }
     __syncthreads();
 
@@ -192,10 +260,13 @@ struct BwdArgs {
     float* d_ml; float* d_x;
     int M, Z, K1;
     unsigned short* d_ml16; unsigned short* d_x16; // bf16 twins of d_ml / d_x (nullable)
+    const unsigned short* dG16; const unsigned short* Wg16; const unsigned short* Wml16;  // bf16 twins of the operands (TW)
 };
 
 // H = width of dG (the first generative layer), compile-time
-template <int H>
+// TW: dG, Wg and Wml from their bf16 twins -- all three are k-contiguous here, i.e. straight 16 / 8-byte copies into the
+// images (46 instead of 93 KB per workgroup through the vector-memory path, no conversion)
+template <int H, bool TW>
 __global__ __launch_bounds__(THREADS) void bottleneck_bwd_kernel(BwdArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
@@ -211,30 +282,52 @@ __global__ __launch_bounds__(THREADS) void bottleneck_bwd_kernel(BwdArgs a)
 
     // ---- every load, back to back ---------------------------------------------------------------------
     constexpr int NX = 16 * H / 4 / THREADS;
-    float4 vx[NX];
+    constexpr int NXH = 16 * H / 8 / THREADS;
+    float4 vx[TW ? 1 : NX];
+    uint4 vxh[TW ? NXH : 1];
+    if (TW) {
 #pragma unroll
-    for (int i = 0; i < NX; ++i) {
-        const int t = tid + THREADS * i, row = t / (H / 4), c4 = t % (H / 4);
-        vx[i] = fetch16(a.dG, m0 + row < M, (size_t)(m0 + row) * H + c4 * 4);
+        for (int i = 0; i < NXH; ++i) {
+            const int t = tid + THREADS * i, row = t / (H / 8), c8 = t % (H / 8);
+            vxh[i] = fetch16h(a.dG16, m0 + row < M, (size_t)(m0 + row) * H + c8 * 8);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int t = tid + THREADS * i, row = t / (H / 4), c4 = t % (H / 4);
+            vx[i] = fetch16(a.dG, m0 + row < M, (size_t)(m0 + row) * H + c4 * 4);
+        }
     }
     // Wg [Z, H]: row z is k-contiguous already
     constexpr int NG = 64 * H / 4 / THREADS;      // covers 64 rows; rows >= Z are not loaded
-    float4 vg[NG];
+    constexpr int NGH = 64 * H / 8 / THREADS;
+    float4 vg[TW ? 1 : NG];
+    uint4 vgh[TW ? NGH : 1];
+    if (TW) {
 #pragma unroll
-    for (int i = 0; i < NG; ++i) {
-        const int t = tid + THREADS * i, row = t / (H / 4), c4 = t % (H / 4);
-        vg[i] = fetch16(a.Wg, row < Z, (size_t)row * H + c4 * 4);
+        for (int i = 0; i < NGH; ++i) {
+            const int t = tid + THREADS * i, row = t / (H / 8), c8 = t % (H / 8);
+            vgh[i] = fetch16h(a.Wg16, row < Z, (size_t)row * H + c8 * 8);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const int t = tid + THREADS * i, row = t / (H / 4), c4 = t % (H / 4);
+            vg[i] = fetch16(a.Wg, row < Z, (size_t)row * H + c4 * 4);
+        }
     }
     // Wml [K1, 2Z]: rows j0 .. j0+63, k = 2Z contiguous
     const int NQ = (Z2 + 3) >> 2;                 // float4 per row, <= 32
     const unsigned inv_nq = ((1u << 20) + NQ - 1) / NQ;   // t / NQ == (t * inv_nq) >> 20 for t < 2048, NQ <= 32
     constexpr int NM = 8;                         // 64 rows x <= 32 quads / 256 threads, densely packed: t -> (row t / NQ, quad t % NQ)
-    float4 vm[NM];
+    float4 vm[TW ? 1 : NM];
+    uint2 vmh[TW ? NM : 1];
 #pragma unroll
     for (int i = 0; i < NM; ++i) {
         const int t = tid + THREADS * i;
         const int row = (int)(((unsigned)t * inv_nq) >> 20), c4 = t - row * NQ;
-        vm[i] = fetch16(a.Wml, row < 64 && j0 + row < K1, (size_t)(j0 + row) * Z2 + c4 * 4);
+        if (TW) vmh[i] = fetch8h(a.Wml16, row < 64 && j0 + row < K1, (size_t)(j0 + row) * Z2 + c4 * 4);
+        else vm[i] = fetch16(a.Wml, row < 64 && j0 + row < K1, (size_t)(j0 + row) * Z2 + c4 * 4);
     }
     const int u = wave * 16 + (lane & 15);
     const bool uok = u < Z;
@@ -256,7 +349,19 @@ __global__ __launch_bounds__(THREADS) void bottleneck_bwd_kernel(BwdArgs a)
     for (int i = tid; i < (16 + 64) * L2 / 8; i += THREADS)
         reinterpret_cast<uint4*>(A2)[i] = make_uint4(0u, 0u, 0u, 0u);
 
-    // ---- round to bf16 into the images -----------------------------------------------------------------
+    // ---- into the images (fp32 operands: rounded to bf16 here) --------------------------------------------
+    if (TW) {
+#pragma unroll
+        for (int i = 0; i < NXH; ++i) {
+            const int t = tid + THREADS * i, row = t / (H / 8), c8 = t % (H / 8);
+            *reinterpret_cast<uint4*>(&A1[row * L1 + c8 * 8]) = vxh[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NGH; ++i) {
+            const int t = tid + THREADS * i, row = t / (H / 8), c8 = t % (H / 8);
+            *reinterpret_cast<uint4*>(&B1[row * L1 + c8 * 8]) = vgh[i];
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
         const int t = tid + THREADS * i, row = t / (H / 4), c4 = t % (H / 4);
@@ -271,15 +376,19 @@ __global__ __launch_bounds__(THREADS) void bottleneck_bwd_kernel(BwdArgs a)
         uint2 w; w.x = pack_bf16(x.x, x.y); w.y = pack_bf16(x.z, x.w);
         *reinterpret_cast<uint2*>(&B1[row * L1 + c4 * 4]) = w;
     }
+    }
     __syncthreads();                               // the zero fill is complete before anything lands in A2 / B2
 #pragma unroll
     for (int i = 0; i < NM; ++i) {
         const int t = tid + THREADS * i;
         const int row = (int)(((unsigned)t * inv_nq) >> 20), c4 = t - row * NQ;
         if (row >= 64) continue;
-        const float4 x = zero_unless(j0 + row < K1, vm[i]);       // 2Z % 4 == 0 (Z even): whole quads
-        uint2 w; w.x = pack_bf16(x.x, x.y); w.y = pack_bf16(x.z, x.w);
-        *reinterpret_cast<uint2*>(&B2[row * L2 + c4 * 4]) = w;
+        if (TW) *reinterpret_cast<uint2*>(&B2[row * L2 + c4 * 4]) = vmh[i];
+        else {
+            const float4 x = zero_unless(j0 + row < K1, vm[i]);       // 2Z % 4 == 0 (Z even): whole quads
+            uint2 w; w.x = pack_bf16(x.x, x.y); w.y = pack_bf16(x.z, x.w);
+            *reinterpret_cast<uint2*>(&B2[row * L2 + c4 * 4]) = w;
+        }
     }
 
     // ---- first product: d_z for the units of this wave ----------------------------------------------------
@@ -328,6 +437,7 @@ template <typename K>
 int grant_lds(K kernel, size_t bytes) { return air_grant_lds(reinterpret_cast<const void*>(kernel), bytes); }
 
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+bool al8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
 
 }  // namespace
 
@@ -338,10 +448,15 @@ extern "C" int air_vae_bottleneck_fwd(const air_bottleneck_fwd_t* a, void* strea
     if ((a->Z & 1) || (a->H & 3) || (a->ldx & 3) || !al16(a->X) || !al16(a->Wml) || !al16(a->Wg)) return AIR_EALIGN;
     constexpr int K1 = 256;
     const size_t lds = sizeof(unsigned short) * ((16 + 128) * (K1 + PAD) + (16 + 64) * (64 + PAD));
-    const int rc = grant_lds(bottleneck_fwd_kernel<K1>, lds);
+    // twin operands: all three or none; whole 16-byte pieces of X rows, 8-byte pieces of the weight rows
+    const bool tw = a->X16 && a->Wml16 && a->Wg16 && al16(a->X16) && (a->ldx & 7) == 0 && al8(a->Wml16) && al8(a->Wg16);
+    const int rc = tw ? grant_lds(bottleneck_fwd_kernel<K1, true>, lds) : grant_lds(bottleneck_fwd_kernel<K1, false>, lds);
     if (rc) return rc;
-    FwdArgs k{a->X, a->Wml, a->bml, a->eps, a->Wg, a->bg, a->ml, a->z, a->g, a->M, a->Z, a->H, a->ldx, a->z16, a->g16};
-    hipLaunchKernelGGL(bottleneck_fwd_kernel<K1>, dim3((a->M + 15) / 16, (a->H + 63) / 64), dim3(THREADS), lds, air_stream(stream), k);
+    FwdArgs k{a->X, a->Wml, a->bml, a->eps, a->Wg, a->bg, a->ml, a->z, a->g, a->M, a->Z, a->H, a->ldx, a->z16, a->g16,
+              a->X16, a->Wml16, a->Wg16};
+    const dim3 grid((a->M + 15) / 16, (a->H + 63) / 64);
+    if (tw) hipLaunchKernelGGL((bottleneck_fwd_kernel<K1, true>), grid, dim3(THREADS), lds, air_stream(stream), k);
+    else hipLaunchKernelGGL((bottleneck_fwd_kernel<K1, false>), grid, dim3(THREADS), lds, air_stream(stream), k);
     AIR_CHECK_LAUNCH();
     return 0;
 }
@@ -353,10 +468,14 @@ extern "C" int air_vae_bottleneck_bwd(const air_bottleneck_bwd_t* a, void* strea
     if ((a->Z & 1) || !al16(a->dG) || !al16(a->Wg) || !al16(a->Wml)) return AIR_EALIGN;
     constexpr int H = 256;
     const size_t lds = sizeof(unsigned short) * ((16 + 64) * (H + PAD) + (16 + 64) * (128 + PAD));
-    const int rc = grant_lds(bottleneck_bwd_kernel<H>, lds);
+    const bool tw = a->dG16 && a->Wg16 && a->Wml16 && al16(a->dG16) && al16(a->Wg16) && al8(a->Wml16);
+    const int rc = tw ? grant_lds(bottleneck_bwd_kernel<H, true>, lds) : grant_lds(bottleneck_bwd_kernel<H, false>, lds);
     if (rc) return rc;
-    BwdArgs k{a->dG, a->Wg, a->ml, a->eps, a->att, a->dyn, a->Wml, a->x, a->d_ml, a->d_x, a->M, a->Z, a->K1, a->d_ml16, a->d_x16};
-    hipLaunchKernelGGL(bottleneck_bwd_kernel<H>, dim3((a->M + 15) / 16, (a->K1 + 63) / 64), dim3(THREADS), lds, air_stream(stream), k);
+    BwdArgs k{a->dG, a->Wg, a->ml, a->eps, a->att, a->dyn, a->Wml, a->x, a->d_ml, a->d_x, a->M, a->Z, a->K1, a->d_ml16, a->d_x16,
+              a->dG16, a->Wg16, a->Wml16};
+    const dim3 grid((a->M + 15) / 16, (a->K1 + 63) / 64);
+    if (tw) hipLaunchKernelGGL((bottleneck_bwd_kernel<H, true>), grid, dim3(THREADS), lds, air_stream(stream), k);
+    else hipLaunchKernelGGL((bottleneck_bwd_kernel<H, false>), grid, dim3(THREADS), lds, air_stream(stream), k);
     AIR_CHECK_LAUNCH();
     return 0;
 }
