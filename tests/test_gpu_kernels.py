@@ -689,6 +689,14 @@ def test_vae_bottleneck_forward_matches_the_formulas(H, M, Hd, Z):
     H.check(H.lib().air_gemm(C.byref(g2s), _stream()))
     torch.cuda.synchronize()
     assert (ml - ml2).abs().max() < 1e-5 and (z - z2).abs().max() < 1e-5 and (g - g2).abs().max() < 2e-5
+    # the three operands from their bf16 twins (X16 / Wml16 / Wg16): the same bits in every output
+    ml3, z3, g3 = torch.full_like(ml, float("nan")), torch.full_like(z, float("nan")), torch.full_like(g, float("nan"))
+    tw = [_bf16_twin(H, t[k]) for k in ("X", "Wml", "Wg")]
+    a3 = H.BottleneckFwd(_p(t["X"]), _p(t["Wml"]), _p(t["bml"]), _p(t["eps"]), _p(t["Wg"]), _p(t["bg"]), _p(ml3), _p(z3), _p(g3),
+                         M, K1, Z, Hd, K1, None, None, _p(tw[0]), _p(tw[1]), _p(tw[2]))
+    H.check(H.lib().air_vae_bottleneck_fwd(C.byref(a3), _stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(ml, ml3) and torch.equal(z, z3) and torch.equal(g, g3)
 
 
 @pytest.mark.parametrize("M,K1,Z", [(192, 256, 50), (37, 200, 50), (16, 64, 64), (5, 256, 2)])
@@ -736,6 +744,14 @@ def test_vae_bottleneck_backward_matches_the_formulas(H, M, K1, Z):
     # (d_ml differs in the last fp32 bits between the two accumulation orders; where that flips its bf16
     # rounding as the second product's operand, d_x moves by one bf16 ulp of d_ml times a weight)
     assert (d_ml - d_ml2).abs().max() < 1e-5 and (d_x - d_x2).abs().max() < 3e-4
+    # the three operands from their bf16 twins (dG16 / Wg16 / Wml16): the same bits
+    d_ml3, d_x3 = torch.full_like(d_ml, float("nan")), torch.full_like(d_x, float("nan"))
+    tw = [_bf16_twin(H, t[k]) for k in ("dG", "Wg", "Wml")]
+    a3 = H.BottleneckBwd(_p(t["dG"]), _p(t["Wg"]), _p(t["ml"]), _p(t["eps"]), _p(t["att"]), _p(t["dyn"]), _p(t["Wml"]), _p(t["x"]),
+                         _p(d_ml3), _p(d_x3), M, K1, Z, Hd, None, None, _p(tw[0]), _p(tw[1]), _p(tw[2]))
+    H.check(H.lib().air_vae_bottleneck_bwd(C.byref(a3), _stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(d_ml, d_ml3) and torch.equal(d_x, d_x3)
 
 
 def test_vae_bottleneck_limits(H):
