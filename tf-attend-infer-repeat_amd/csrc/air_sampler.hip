@@ -1375,8 +1375,27 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
         __syncthreads();
         AIR_STAMP_WG(5);
     } else {
+        // one tap per pass: the tap is a compile-time constant of the term loop (its six operand selects fold away)
+        auto stage_one = [&](auto phc) __attribute__((always_inline)) {
+            constexpr int ph = decltype(phc)::value;
+            constexpr bool x1 = ph >> 1, y1 = ph & 1;
+            int i = tid / C, j = tid % C;
+            for (int p = tid; p < CC; p += WB_THREADS) {
+                const Tap tx = sh_tx[j], ty = sh_ty[i];
+                const float gp = z * gsrc[p];
+                const int4 ci = sh_ci[j], ri = sh_ri[i];
+                const float wgt = (x1 ? tx.w1 : tx.w0) * (y1 ? ty.w1 : ty.w0);
+                const int clo = x1 ? ci.z : ci.x, ncols = x1 ? ci.w : ci.y, rlo = y1 ? ri.z : ri.x, nrows = y1 ? ri.w : ri.y;
+                sh_T[rlo * C + nrows * clo + (i - rlo) * ncols + (j - clo)] = wgt * gp;
+                i += di; j += dj;
+                if (j >= C) { j -= C; ++i; }
+            }
+        };
         for (int ph = 0; ph < 4; ++ph) {
-            stage_T(ph, ph + 1);
+            if (ph == 0) stage_one(std::integral_constant<int, 0>{});
+            else if (ph == 1) stage_one(std::integral_constant<int, 1>{});
+            else if (ph == 2) stage_one(std::integral_constant<int, 2>{});
+            else stage_one(std::integral_constant<int, 3>{});
             __syncthreads();
             AIR_STAMP(50 + 3 * ph);
             chains(ph, ph + 1);
