@@ -162,14 +162,30 @@ def cpu_baseline(batch, seconds=15.0):
     im, tg = torch.tensor(images), torch.tensor(targets)
     for _ in range(2):
         tr.step(im, tg, 9.21)
-    n, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < seconds and n < 200:
+    times, t0 = [], time.perf_counter()
+    while time.perf_counter() - t0 < seconds and len(times) < 200:
+        t1 = time.perf_counter()
         tr.step(im, tg, 9.21)
-        n += 1
+        times.append(time.perf_counter() - t1)
     dt = time.perf_counter() - t0
-    return dict(value=round(batch * n / dt, 1), unit="images/sec", cores=threads, kind="port",
-                sample="%d train steps of batch %d (%.1f s) of oracle/air_oracle_torch.CpuTrainer, %d torch threads"
-                       % (n, batch, dt, threads))
+    n = len(times)
+    med = sorted(times)[n // 2]
+    cpu_model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                cpu_model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    # value: from the MEDIAN step time (SURVEY 8(d) protocol); `cores` = the threads actually used, which is the cap --
+    # NOT the box's core count, which is `cores_available`
+    return dict(value=round(batch / med, 1), unit="images/sec", cores=threads, kind="port",
+                threads=threads, thread_cap=16, cores_available=os.cpu_count(), cpu_model=cpu_model,
+                median_step_ms=round(med * 1e3, 2), mean_step_ms=round(dt / n * 1e3, 2), steps_timed=n,
+                sample="%d train steps of batch %d (%.1f s) of oracle/air_oracle_torch.CpuTrainer on %d torch threads (capped: "
+                       "beyond a socket's worth of threads this chain of small ops only slows down) of %s logical cores, %s; "
+                       "median step" % (n, batch, dt, threads, os.cpu_count(), cpu_model))
 
 
 def _free_port():
@@ -285,18 +301,7 @@ def main():
         hp.update(canvas_size=128, max_steps=5, max_digits=4)
         B = 256 if args.batch == 64 else args.batch
     images, targets = synthetic_canvases(B, hp["canvas_size"], hp["max_digits"], seed=1000 + rank)
-    model = am.AIRModel(torch.tensor(images, device=dev), torch.tensor(targets, device=dev), cnn=False,
-                        train=True, scope="air", annealing_schedules=ANNEAL, seed=0, noise_seed=rank,
-                        gemm_precision=args.precision, backward=args.backward, **hp)
-    if world > 1:
-        model.sync_parameters()            # replicas start (and, with one shared all-reduce, stay) identical
-    # several train steps per hipGraph replay (single GPU): amortises the replay's own launch cost
-    gsteps = 1
-    if not args.no_graph:
-        if world == 1:
-            # the largest divisor of the step count up to --graph-steps: exactly args.steps steps are timed
-            gsteps = max(g for g in range(1, max(1, args.graph_steps) + 1) if args.steps % g == 0)
-        model.capture_graph(steps=gsteps)
+    images_d, targets_d = torch.tensor(images, device=dev), torch.tensor(targets, device=dev)
 
     def sync():
         torch.cuda.synchronize()
@@ -304,23 +309,71 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    warm_replays, warm_eager = args.warmup // gsteps, args.warmup % gsteps
-    if warm_replays == 0 and gsteps > 1 and args.warmup > 0:
-        warm_replays, warm_eager = 1, 0                  # the timed region must not hold the graph's first replay: one whole replay (>= W steps)
-    for _ in range(warm_replays):
-        model.training()
-    for _ in range(warm_eager):                     # remainder of the warm-up: single eager steps
-        model.training(eager=True)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps // gsteps):          # one replay = gsteps train steps: exactly args.steps steps
-        model.training()
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
+    def build_and_time(scope, exchange):
+        """one model, W warm-up + exactly K timed train steps (barrier + synchronize on both sides, max over ranks)"""
+        model = am.AIRModel(images_d, targets_d, cnn=False, train=True, scope=scope, annealing_schedules=ANNEAL, seed=0,
+                            noise_seed=rank, gemm_precision=args.precision, backward=args.backward, dp_exchange=exchange, **hp)
+        if world > 1:
+            model.sync_parameters()            # replicas start (and, with one shared all-reduce, stay) identical
+        # several train steps per hipGraph replay: amortises the replay's own launch cost.  Data parallel over RCCL: the
+        # collective is captured between backward and optimizer, so the protocol is the 1-GPU one
+        gsteps, mode = 1, "eager"
+        if not args.no_graph:
+            # the largest divisor of the step count up to --graph-steps: exactly args.steps steps are timed
+            want = max(g for g in range(1, max(1, args.graph_steps) + 1) if args.steps % g == 0)
+            if world > 1 and not model._collectives_capturable():
+                want = 1
+            try:
+                model.capture_graph(steps=want)
+                gsteps = want
+                if world == 1:
+                    mode = "one hipGraph replay = %d train steps" % gsteps
+                elif model._graph[1] is None:
+                    mode = "one hipGraph replay = %d x (fwd+bwd -> gradient exchange -> clip+Adam)" % gsteps
+                else:
+                    mode = "[fwd+bwd graph] -> collective -> [clip+Adam graph]"
+            except Exception as e:                                   # never lose the line over the capture of a collective
+                if world == 1:
+                    raise
+                sys.stderr.write("bench.py: rank %d: capturing the collective failed (%r); collective between two graphs\n" % (rank, e))
+                os.environ["AIR_DP_GRAPH_COLLECTIVE"] = "0"
+                torch.cuda.synchronize()
+                model.release_graph()
+                model.capture_graph(steps=1)
+                gsteps, mode = 1, "[fwd+bwd graph] -> collective -> [clip+Adam graph] (in-graph capture failed)"
+        warm_replays, warm_eager = args.warmup // gsteps, args.warmup % gsteps
+        if warm_replays == 0 and gsteps > 1 and args.warmup > 0:
+            warm_replays, warm_eager = 1, 0              # the timed region must not hold the graph's first replay: one whole replay (>= W steps)
+        for _ in range(warm_replays):
+            model.training()
+        for _ in range(warm_eager):                     # remainder of the warm-up: single eager steps
+            model.training(eager=True)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps // gsteps):          # one replay = gsteps train steps: exactly args.steps steps
+            model.training()
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t)
+        return model, dt, gsteps, mode
+
+    exchange = os.environ.get("AIR_DP_EXCHANGE") or "flat"
+    model, dt, gsteps, graph_mode = build_and_time("air", exchange)
+    exchange_runs = {exchange: round(dt / args.steps * 1e3, 4)}
+    if world > 1 and not os.environ.get("AIR_DP_EXCHANGE"):
+        # both forms of the gradient exchange are complete train steps with the reference's semantics (DESIGN section 6):
+        # time the other one the same way (its own W + K steps) and report the line of the faster, naming it
+        try:
+            other = "factors"
+            m2, dt2, g2, mode2 = build_and_time("air_" + other, other)
+            exchange_runs[other] = round(dt2 / args.steps * 1e3, 4)
+            if dt2 < dt:
+                model, dt, gsteps, graph_mode, exchange = m2, dt2, g2, mode2, other
+        except Exception as e:
+            exchange_runs["factors"] = "failed: %r" % (e,)
     loss = float(model.loss)
     replicas_identical = None
     if world > 1:
@@ -369,7 +422,8 @@ def main():
                                     "256 LSTM, z=50 (training.py:100-122)") if args.workload == "configs[1]" else
                                    "configs[3]: stress, 128x128 canvas, 0-4 objects, batch %d/GPU, 5 steps" % B,
                        "global_batch": world * B,
-                       "hipgraph": not args.no_graph, "steps_per_graph_replay": gsteps, "parallelism": "dp%d" % world,
+                       "hipgraph": not args.no_graph, "steps_per_graph_replay": gsteps, "graph_mode": graph_mode,
+                       "parallelism": "dp%d" % world,
                        "backward": args.backward},
             "per_gpu_images_per_sec": round(value / world, 1), "final_loss": round(loss, 3),
         }
@@ -488,8 +542,11 @@ def main():
             line["distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                                    "rccl_version": nccl_v, "torch": torch.__version__, "hip": getattr(torch.version, "hip", None),
                                    "devices_visible": torch.cuda.device_count(),
-                                   "collective": "one all_reduce(SUM) of the flat fp32 gradient (+ loss/accuracy tail) per step",
-                                   "gradient_exchange": os.environ.get("AIR_DP_EXCHANGE", "flat")}
+                                   "collective": ("one all_reduce(SUM) of the flat fp32 gradient (+ loss/accuracy tail) per step"
+                                                  if exchange == "flat" else
+                                                  "all_gather of the dWx factors (X, sum_t dgates) + all_reduce(SUM) of the other "
+                                                  "gradients (+ loss/accuracy tail) per step"),
+                                   "gradient_exchange": exchange, "ms_per_step_by_exchange": exchange_runs}
             line["replicas_bit_identical"] = replicas_identical
             if same_device or backend != "nccl":
                 line["test_mode"] = "ranks share one device over %s: NOT a scaling measurement" % backend

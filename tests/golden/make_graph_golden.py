@@ -123,7 +123,37 @@ def main():
     print("wrote %d arrays, %.0f KB; loss %.4f (fp64 %.4f), |g| fp32 %.4e fp64 %.4e, T' = %d" %
           (len(out), os.path.getsize(path) / 1024, out["train0/loss"], out["train0/loss_fp64"],
            out["train0/global_norm_fp32"], out["train0/global_norm_fp64"], trips))
+    compose(nodes)
+
+
+# tensors at the interface of the compose kernel (air_write_fwd: the write transformer, the masked canvas accumulation,
+# the VAE KL, the running loss and the Bernoulli cross-entropy; air_model.py:351-366, 429-439, 479-496, 580-593) that
+# graph_b64.npz does not already hold: the posterior mean / log-variance of every step and the loop's exit values
+COMPOSE_FWD_TENSORS = {"rec_mean": gx.W + "vae/rec_mean/BiasAdd", "rec_log_variance": gx.W + "vae/rec_log_variance/BiasAdd"}
+COMPOSE_EXIT_TENSORS = {"running_loss": "air/rnn/while/Exit_5", "loss_per_item": "air/add_1",
+                        "running_recon": "air/rnn/while/Exit_4"}
+
+
+def compose(nodes=None):
+    """tests/golden/graph_b64_compose.npz: the train0 run of main() again (same seeds), first KB images"""
+    if nodes is None:
+        _, nodes = gx.load_graph(META)
+    images, targets, params, noise = inputs()
+    ex = gx.Executor(nodes, gx.air_feeds(nodes, params, images, targets, noise, 0), np.float32)
+    out = {}
+    for k, v in zip(COMPOSE_EXIT_TENSORS, ex.run(list(COMPOSE_EXIT_TENSORS.values()))):
+        out["train0/" + k] = np.asarray(v)[:KB]
+    trips = ex.trip_count(gx.FWD_FRAME)
+    for t in range(trips):
+        for k, v in zip(COMPOSE_FWD_TENSORS, ex.run(list(COMPOSE_FWD_TENSORS.values()), {gx.FWD_FRAME: t})):
+            out["kern/t%d/%s" % (t, k)] = np.asarray(v)[:KB]
+    path = os.path.join(ROOT, "tests", "golden", "graph_b64_compose.npz")
+    np.savez_compressed(path, **out)
+    print("wrote %d arrays, %.0f KB -> %s" % (len(out), os.path.getsize(path) / 1024, path))
 
 
 if __name__ == "__main__":
-    main()
+    if "--compose-only" in sys.argv:
+        compose()
+    else:
+        main()

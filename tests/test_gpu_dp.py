@@ -271,3 +271,84 @@ def test_rccl_collectives_execute_on_the_product_buffers(tmp_path):
     r = subprocess.run([sys.executable, str(script), root, str(_free_port())], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     assert "RCCL" in r.stdout
+
+
+_RCCL_IN_GRAPH = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tf-attend-infer-repeat_amd"))
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[2], RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+                  AIR_DP_FORCE="1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+from oracle import air_oracle as ao
+from oracle.synth import blob_canvases
+from air import air_model as am
+HP = dict(ao.TRAINING_HP)
+images, targets = blob_canvases(64, HP["canvas_size"], HP["max_digits"], seed=23)
+
+def run(exchange, mode, prec):
+    am.reset_default_graph()
+    m = am.AIRModel(torch.tensor(images, device="cuda"), torch.tensor(targets, device="cuda"), cnn=False, train=True,
+                    scope="air", gemm_precision=prec, seed=0, noise_seed=11, dp_exchange=exchange,
+                    annealing_schedules=ao.TRAINING_ANNEALING, **HP)
+    assert m._dp() and m._collectives_capturable()
+    assert [op.kernel for op in m._optimizer_ops()][0] == "grad_sqnorm_kernel"     # the DP optimizer: norm pass after the exchange
+    if mode == "graph":
+        m.capture_graph(steps=4)
+        assert m._graph[1] is None and m._graph_steps == 4          # ONE graph: the collective is inside
+        for _ in range(2):
+            m.training()
+    elif mode == "two_graphs":
+        os.environ["AIR_DP_GRAPH_COLLECTIVE"] = "0"
+        try:
+            m.capture_graph()
+        finally:
+            del os.environ["AIR_DP_GRAPH_COLLECTIVE"]
+        assert m._graph[1] is not None
+        for _ in range(8):
+            m.training()
+    else:
+        for _ in range(8):
+            m.training(eager=True)
+    torch.cuda.synchronize()
+    st = m.store
+    assert int(m.global_step) == 8
+    return [st.params.clone(), st.m.clone(), st.v.clone(), st.grads.clone(), st.gnorm.clone(), m.scalars.clone()]
+
+for prec in ("bf16", "fp32"):
+    for exchange in ("flat", "factors"):
+        ref = run(exchange, "eager", prec)
+        assert float(ref[0].abs().max()) > 0 and np.isfinite(float(ref[4]))
+        for mode in ("graph", "two_graphs"):
+            got = run(exchange, mode, prec)
+            for a, b in zip(ref, got):
+                assert torch.equal(a, b), (prec, exchange, mode)
+    print("in-graph", prec, "ok")
+print("RCCL", ".".join(str(v) for v in torch.cuda.nccl.version()))
+dist.destroy_process_group()
+'''
+
+
+def test_rccl_collective_captured_inside_the_train_step_graph(tmp_path):
+    """Data parallel over RCCL, the protocol of the 1-GPU number: capture_graph(steps=k) records
+    ([fwd+bwd] -> gradient exchange -> [grad_sqnorm + clip + Adam]) x k into ONE hipGraph -- the collective is stream
+    work, torch.cuda.graph captures it -- instead of one step per replay with a host-enqueued collective between two
+    graphs.  On this box's single GPU the process group has one rank (AIR_DP_FORCE=1 makes the model run the DP branch
+    on it): 2 replays of 4 steps == 8 eager DP steps == 8 steps of the two-graph form BIT FOR BIT (variables, Adam
+    slots, gradients, global norm, loss / accuracy), flat and factor exchange, bf16 and fp32
+    (reference semantics: air_model.py:610 reduce_mean over the global batch, :673 clip on the averaged gradient)."""
+    import subprocess
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rccl_in_graph.py"
+    script.write_text(_RCCL_IN_GRAPH)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("AIR_DP_GRAPH_COLLECTIVE", None)
+    r = subprocess.run([sys.executable, str(script), root, str(_free_port())], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "in-graph bf16 ok" in r.stdout and "in-graph fp32 ok" in r.stdout and "RCCL" in r.stdout

@@ -260,3 +260,64 @@ def test_attend_bwd_matches_graph_head_gradients(H, gold):
         for o in range(7):
             scale = max(np.abs(ref[:, o]).max(), 1e-6)
             assert np.abs(got[t, :, o] - ref[:, o]).max() <= 1e-4 * scale, (t, o, got[t, :, o], ref[:, o])
+
+
+def test_compose_reproduces_the_graphs_canvas_bit_for_bit(H, gold, golden_dir):
+    """air_write_fwd (compose) teacher-forced on the graph's OWN per-step tensors (s, x, y, z_pres, masks, vae_recon,
+    posterior mean / log-variance, the three per-step KLs) for the first KB images of the train0 run:
+      * `reconstruction` (write transformer st_backward, x z_pres, masked accumulation over the steps, clip;
+        air_model.py:351-366, 429-439, 580-582; transformer.py:56-117) BIT FOR BIT against the graph's clipped_rec --
+        out-of-range tap residues included;
+      * `reconstruction_loss` (:586-593) <= 1e-5 relative (SURVEY 8(d): "BCE evaluated on the same reconstruction");
+        the order of the 2500-term sum is the only freedom;
+      * the VAE KL (:479-485) and the running loss / ELBO per item <= 1e-5 relative, digit counts exact;
+      * d loss / d reconstruction against the graph's gradient at the canvas (what air_write_bwd is then fed)."""
+    comp = np.load(os.path.join(golden_dir, "graph_b64_compose.npz"))
+    N, Cc, w, Z = int(gold["train0/steps_executed"]), HP["canvas_size"], HP["windows_size"], HP["vae_latent_dimensions"]
+    assert N == HP["max_steps"]
+    images, _, _, _ = _inputs()
+    att = _att(H, gold, N)
+    for t in range(N):
+        att[t, :, H.ATT_KL_Z] = gold["train0/z_pres_kls"][:KB, t]
+        att[t, :, H.ATT_KL_SCALE] = gold["train0/scale_kls"][:KB, t]
+        att[t, :, H.ATT_KL_SHIFT] = gold["train0/shift_kls"][:KB, t]
+        att[t, :, H.ATT_KL_VAE] = 7.0                                  # written by the kernel
+    ml = np.stack([np.concatenate([comp["kern/t%d/rec_mean" % t], comp["kern/t%d/rec_log_variance" % t]], 1) for t in range(N)])
+    vrec = np.stack([gold["kern/t%d/vae_recon" % t] for t in range(N)])
+    dyn = np.zeros(H.DYN_COUNT, np.float32)
+    dyn[H.DYN_VAE_PM], dyn[H.DYN_VAE_PV] = HP["vae_prior_mean"], HP["vae_prior_variance"]
+    dyn[H.DYN_VAE_PLV] = np.log(np.float32(HP["vae_prior_variance"]))
+    dyn[H.DYN_GRAD_SCALE] = 1.0 / 64                                   # the graph's batch: d mean / d item
+    att_d, ml_d, vrec_d, img_d, dyn_d = _cuda(att), _cuda(ml), _cuda(vrec), _cuda(images[:KB]), _cuda(dyn)
+    recon = torch.full((KB, Cc * Cc), 7.0, device="cuda")
+    d_recon = torch.full((KB, Cc * Cc), 7.0, device="cuda")
+    rec_loss, run_loss, loss_item = (torch.full((KB,), 7.0, device="cuda") for _ in range(3))
+    digits = torch.full((KB,), 7, dtype=torch.int32, device="cuda")
+    wf = H.WriteFwd(_p(vrec_d), _p(ml_d), _p(img_d), _p(dyn_d), _p(att_d), _p(recon), _p(rec_loss), _p(d_recon),
+                    _p(run_loss), _p(digits), _p(loss_item), KB, N, Cc, w, Z)
+    H.check(H.lib().air_write_fwd(C.byref(wf), _stream()), "air_write_fwd")
+    torch.cuda.synchronize()
+    ref_rec = gold["train0/reconstruction"][:KB]
+    assert np.array_equal(_np(recon), ref_rec), float(np.abs(_np(recon) - ref_rec).max())
+    # the canvases are not trivial: ink was written, and residues of out-of-range taps survive the clip
+    assert ref_rec.max() > 0.3 and ((ref_rec > 0) & (ref_rec < 1e-5)).sum() > 100
+    rl, rl_ref = _np(rec_loss).astype(np.float64), gold["train0/reconstruction_loss"][:KB].astype(np.float64)
+    assert np.abs(rl - rl_ref).max() / np.abs(rl_ref).max() <= 1e-5 and np.all(np.abs(rl - rl_ref) <= 1e-5 * np.abs(rl_ref))
+    kv = _np(att_d)[:, :, H.ATT_KL_VAE].T
+    np.testing.assert_allclose(kv, gold["train0/vae_kls"][:KB], rtol=1e-5)
+    np.testing.assert_allclose(_np(run_loss), comp["train0/running_loss"], rtol=1e-5)
+    np.testing.assert_allclose(_np(loss_item), comp["train0/loss_per_item"], rtol=1e-5)
+    assert np.array_equal(_np(digits), gold["train0/rec_num_digits"][:KB])
+    # the ELBO of these 16 items given the graph's own per-step tensors
+    assert abs(_np(loss_item).astype(np.float64).mean() - comp["train0/loss_per_item"].astype(np.float64).mean()) \
+        <= 1e-5 * abs(comp["train0/loss_per_item"].astype(np.float64).mean())
+    # d loss / d reconstruction: the graph's gradient at the canvas, for items that were active at some step
+    g_sel = np.zeros((KB, Cc * Cc), np.float32)
+    ever = np.zeros(KB, bool)
+    for t in range(N):
+        act = gold["kern/t%d/mask" % t].astype(bool)
+        g_sel[act] = gold["kern/t%d/g_select" % t].reshape(KB, -1)[act]
+        ever |= act
+    got = _np(d_recon)[ever]
+    assert np.abs(got - g_sel[ever]).max() <= 2e-6 * np.abs(g_sel[ever]).max()
+    assert np.all(np.abs(got - g_sel[ever]) <= 4e-7 * np.abs(g_sel[ever]) + 1e-30)

@@ -529,3 +529,60 @@ def test_deferred_adam_slices_in_multi_step_graphs_are_bit_identical(am, prec, t
             assert torch.equal(st.params16.view(torch.bfloat16), st.params.to(torch.bfloat16))
     for a, b in zip(res["eager"], res["graph"]):
         assert torch.equal(a, b)
+
+
+def test_state_dict_carries_adam_slots_per_variable(am):
+    """state_dict() stores the Adam slots under TensorFlow's slot names (<var>/Adam, <var>/Adam_1), not as the raw flat
+    buffers whose offsets depend on the alignment of this build: a dict taken after two steps restores variables AND
+    optimizer state (the next step is bit-identical), and flat slots of an unknown layout are refused."""
+    model, *_ = _make(am, 16, True)
+    for _ in range(2):
+        model.training()
+    sd = model.state_dict()
+    assert "_adam_m" not in sd and "rnn/kernel/Adam" in sd and "vae/rec_mean/biases/Adam_1" in sd
+    assert tuple(sd["rnn/kernel/Adam"].shape) == tuple(model.variables["rnn/kernel"].shape)
+    assert float(sd["rnn/kernel/Adam_1"].abs().max()) > 0
+    model.training()
+    torch.cuda.synchronize()
+    ref = (model.store.params.clone(), model.store.m.clone(), model.store.v.clone())
+    model.store.m.zero_(); model.store.v.zero_()
+    model.load_state_dict(sd)
+    assert int(model.global_step) == 2
+    model.training()
+    torch.cuda.synchronize()
+    for a, b in zip(ref, (model.store.params, model.store.m, model.store.v)):
+        assert torch.equal(a, b)
+    with pytest.raises(ValueError):
+        model.load_state_dict({**{k: v for k, v in sd.items() if "/Adam" not in k},
+                               "_adam_m": torch.zeros(7), "_adam_v": torch.zeros(7)})
+
+
+@pytest.mark.parametrize("train_kw", [dict(prec="fp32"), dict(prec="bf16", bf16_twins=False),
+                                      dict(prec="bf16", input_weight_gradient="factored")])
+def test_bf16_shadow_follows_a_train_model_that_does_not_maintain_it(am, train_kw):
+    """The bf16 shadow of the variables lives on the shared VariableStore, but only an Adam launch of a model with
+    bf16 twins rewrites it.  A train model WITHOUT twins (fp32 precision, bf16_twins=False, factored dWx) changes the
+    variables every step: a reuse=True evaluation model WITH twins on the same scope (training.py:95-123 builds such a
+    pair) must see the new variables -- its forward equals that of a model without twins, bit for bit, after every
+    train step -- instead of running its GEMMs on a stale shadow."""
+    tr, images, targets, params, noise = _make(am, 16, True, backward="reference", **train_kw)
+    assert not tr._twins
+    dev_img, dev_tg = tr.input_images, tr.target_num_digits
+    kw = dict(cnn=False, train=False, reuse=True, scope="air", gemm_precision="bf16", **HP)
+    ev = am.AIRModel(dev_img, dev_tg, **kw)
+    ev_ref = am.AIRModel(dev_img, dev_tg, bf16_twins=False, **kw)
+    assert ev._twins and not ev_ref._twins and ev.store is tr.store
+    for m in (ev, ev_ref):
+        m.set_noise(noise)
+        m.set_dynamic(z_pres_prior_log_odds=-2.0)
+    losses = []
+    for step in range(3):
+        ev.forward(); ev_ref.forward()
+        torch.cuda.synchronize()
+        assert torch.equal(ev.store.params16.view(torch.bfloat16), ev.store.params.to(torch.bfloat16)), step
+        assert float(ev.loss) == float(ev_ref.loss), step
+        assert torch.equal(ev.reconstruction, ev_ref.reconstruction)
+        losses.append(float(ev.loss))
+        tr.training()
+        assert tr.store.shadow_stale                      # the step changed the variables without touching the shadow
+    assert len(set(losses)) == 3

@@ -176,7 +176,11 @@ class VariableStore:
     def state_dict(self):
         sd = OrderedDict((k, v.detach().cpu().contiguous().clone()) for k, v in self.variables.items())
         sd["global_step"] = self.istate[H.IST_GLOBAL_STEP].cpu().clone()
-        sd["_adam_m"], sd["_adam_v"] = self.m.cpu().clone(), self.v.cpu().clone()
+        # Adam slots per variable under TensorFlow's slot names (<var>/Adam, <var>/Adam_1): independent of the
+        # alignment / order of the flat buffers, which is an implementation detail that has changed between rounds
+        for k in self.variables:
+            sd[k + "/Adam"] = self.adam_m[k].detach().cpu().contiguous().clone()
+            sd[k + "/Adam_1"] = self.adam_v[k].detach().cpu().contiguous().clone()
         return sd
 
     def load_state_dict(self, sd, strict=True):
@@ -187,8 +191,15 @@ class VariableStore:
                 raise KeyError("missing variable %s" % k)
         if "global_step" in sd:
             self.istate[H.IST_GLOBAL_STEP] = int(sd["global_step"])
-        if "_adam_m" in sd:
-            self.m.copy_(torch.as_tensor(sd["_adam_m"])); self.v.copy_(torch.as_tensor(sd["_adam_v"]))
+        for k, v in self.variables.items():
+            if k + "/Adam" in sd:
+                self.adam_m[k].copy_(torch.as_tensor(np.asarray(sd[k + "/Adam"])).to(v.dtype).reshape(v.shape))
+                self.adam_v[k].copy_(torch.as_tensor(np.asarray(sd[k + "/Adam_1"])).to(v.dtype).reshape(v.shape))
+        if "_adam_m" in sd and not any(k + "/Adam" in sd for k in self.variables):
+            # flat slots written by an older build: their offsets are those of THAT build's buffer layout (the alignment
+            # of the flat buffers has changed since) -- refuse loudly rather than load shifted slots
+            raise ValueError("state dict carries flat Adam slots (_adam_m / _adam_v) of an unknown buffer layout; "
+                             "it needs per-variable slots (<var>/Adam, <var>/Adam_1)")
         self.shadow_stale = True
 
 
@@ -343,6 +354,9 @@ class AIRModel:
         if self._dp_exchange not in ("flat", "factors"):
             raise ValueError("dp_exchange must be 'flat' or 'factors'")
         self._dp_factor_ops = None
+        # test hook: run the data-parallel protocol (gradient exchange + separate norm pass + Adam) on a process group of
+        # ONE rank -- all a 1-GPU box can give RCCL -- so that its captured form is exercised on hardware
+        self._dp_force = os.environ.get("AIR_DP_FORCE") == "1"
         self._injected_noise = False
         self._graph = None
         self._dirty = True
@@ -861,6 +875,19 @@ class AIRModel:
             return torch.distributed.get_world_size()
         return 1
 
+    def _dp(self):
+        """True when a train step runs the data-parallel protocol: backward -> gradient exchange -> norm of the
+        exchanged gradient -> clip + Adam (world > 1; or forced on a one-rank group, AIR_DP_FORCE=1)"""
+        if self._world() > 1:
+            return True
+        return self._dp_force and torch.distributed.is_available() and torch.distributed.is_initialized()
+
+    def _collectives_capturable(self):
+        """RCCL collectives are stream work and can be recorded into a hipGraph (torch.cuda.graph captures NCCL calls);
+        gloo moves device tensors through the host and cannot.  AIR_DP_GRAPH_COLLECTIVE=0 keeps the collective outside."""
+        return (self._dp() and torch.distributed.get_backend() == "nccl"
+                and os.environ.get("AIR_DP_GRAPH_COLLECTIVE", "1") != "0")
+
     def sync_parameters(self, src=0):
         """Data parallel: every rank continues from rank `src`'s variables, Adam slots and global_step
         (one broadcast each; DESIGN section 6 needs clip + Adam to run on identical state everywhere).
@@ -876,9 +903,9 @@ class AIRModel:
 
     def _optimizer_ops(self):
         world = self._world()
-        if self._opt_world != world:
+        if self._opt_world != (world, self._dp()):
             st = self.store
-            fused = world == 1
+            fused = not self._dp()
             npart = self._wgrad_blocks if fused else self.lib.air_optim_num_partials(st.n)
             if fused and self._dwx_factors is not None:
                 fx = self._dwx_factors[0]
@@ -893,7 +920,7 @@ class AIRModel:
                                   nbytes=(30 if self._twins else 28) * st.n, tag="adam_clip")
             # data parallel: the norm is that of the all-reduced gradient -> separate pass after the collective
             self._opt = [adam] if fused else [self._sqnorm, adam]
-            self._opt_world = world
+            self._opt_world = (world, self._dp())
         return self._opt
 
     def _adam_riders(self):
@@ -996,7 +1023,7 @@ class AIRModel:
             (self._write_bwd_fin if (i == 0 and fused_finalize) else op)(s)
         # (tried: the VAE weight gradients as their own launch on a side stream beside attend_bwd ->
         # dh_heads -> BPTT.  The big launch takes the CUs the latency-critical chain needs: 217 -> 257 us.)
-        if for_update and self._world() == 1:
+        if for_update and not self._dp():
             self._wgrad_fused(s)
             return
         if for_update and self._dp_exchange == "factors":
@@ -1022,18 +1049,20 @@ class AIRModel:
         if main_only is not None:
             main_only(s)
             return
-        if self._world() > 1 and self._dp_exchange == "factors":
+        if self._dp() and self._dp_exchange == "factors":
             self._dp_factors()["dwx"](s)                         # dWx from the gathered factors, identically on every rank
         for op in self._optimizer_ops():
             op(s)
 
     def capture_graph(self, steps=1, between_steps=None):
-        """Captures the train step into hipGraphs (fixed N, no host sync, no allocation inside):
-        one graph for world_size 1; [fwd+bwd] | RCCL all-reduce | [clip+Adam] for data parallel.
-        steps > 1 (single GPU only): that many consecutive train steps per replay -- noise and
-        schedules are keyed by the device-side global_step, so the steps differ as they would in
-        separate replays; `between_steps(i)` (optional, graph-capturable device work such as the
-        next batch's gather) is captured before step i.  training() then advances `steps` steps."""
+        """Captures the train step into hipGraphs (fixed N, no host sync, no allocation inside).
+        Single GPU: ONE graph of `steps` consecutive train steps.  Data parallel over RCCL: the same -- the gradient
+        exchange is stream work and is recorded between the backward and the optimizer of every step,
+        ([fwd+bwd] -> all_reduce -> [sqnorm + clip + Adam]) x steps in ONE replay, the protocol of the 1-GPU number.
+        Data parallel over a backend whose collectives cannot be captured (gloo): [fwd+bwd] | collective | [clip+Adam],
+        one step per replay.  Noise and schedules are keyed by the device-side global_step, so the steps of a replay
+        differ as they would in separate replays; `between_steps(i)` (optional, graph-capturable device work such as
+        the next batch's gather) is captured before step i.  training() then advances `steps` steps."""
         if not self.train:
             return self._capture_forward_graph()
         self._optimizer_ops()
@@ -1041,39 +1070,55 @@ class AIRModel:
         if self.store.synced_world != world:
             self.sync_parameters()
         self._fresh_shadow()
-        if steps < 1 or (steps > 1 and world > 1):
-            raise ValueError("multi-step graphs need world_size 1")
+        dp = self._dp()
+        in_graph = self._collectives_capturable()
+        if steps < 1 or (steps > 1 and dp and not in_graph):
+            raise ValueError("multi-step graphs need world_size 1 or a backend whose collectives can be captured (nccl)")
         self._graph_steps = steps
+        factors = dp and self._dp_exchange == "factors"
+        if factors:
+            self._dp_factors()                   # buffers + launch lists exist before anything is captured
         torch.cuda.synchronize()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):            # warm-up outside capture (lazy module loads, LDS attributes)
+        with torch.cuda.stream(side):            # warm-up outside capture (lazy module loads, LDS attributes, communicators)
             s = self._stream()
             self._run_forward(s)
-            self._run_backward(s)
+            self._run_backward(s, for_update=factors)
+            if dp:
+                self._dp_exchange_gradients()    # also the first collective of the communicator: never under capture
+                if factors:
+                    self._dp_factors()["dwx"](s)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         # a step that is followed by another one in the same graph defers the VAE part of its Adam into the next
         # step's narrow GEMM launches (_adam_riders); the last step of the replay updates everything itself
-        deferred = self._adam_riders() if (steps > 1 and world == 1) else None
+        deferred = self._adam_riders() if (steps > 1 and not dp) else None
         ga = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(ga):
+        # (thread_local: RCCL's watchdog thread may touch the runtime while this thread captures)
+        with torch.cuda.graph(ga, **({"capture_error_mode": "thread_local"} if dp else {})):
             carried = None
             for i in range(steps):
                 if between_steps is not None:
                     between_steps(i)
                 s = self._stream()
                 self._train_phase_a(s, riders=carried)
-                if world == 1:
+                if not dp:
                     defer = deferred is not None and i < steps - 1
                     self._train_phase_b(s, main_only=deferred[0] if defer else None)
                     carried = deferred[1] if defer else None
+                elif in_graph:
+                    self._dp_exchange_gradients()
+                    self._train_phase_b(self._stream())
+            if dp and in_graph and world > 1:
+                self.scalars[:2].mul_(1.0 / world)       # loss / accuracy rode in the all-reduce as sums over ranks
         gb = None
-        if world > 1:
+        if dp and not in_graph:
             gb = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gb):
                 self._train_phase_b(self._stream())
         self._graph = (ga, gb)
+        self._graph_dp = (dp, in_graph)
         return self
 
     def _capture_forward_graph(self):
@@ -1109,20 +1154,29 @@ class AIRModel:
         if self.store.synced_world != world:
             self.sync_parameters()
         self._fresh_shadow()
+        dp = self._dp()
         if self._graph is not None and not eager:
             ga, gb = self._graph
+            if self._graph_dp[0] != dp:
+                raise RuntimeError("the captured graph was recorded for another process-group state; capture_graph() again")
             ga.replay()
-            if world > 1:
+            if gb is not None:
                 self._dp_exchange_gradients()
                 gb.replay()
+                if world > 1:
+                    self.scalars[:2].mul_(1.0 / world)
         else:
             s = self._stream()
             self._train_phase_a(s)
-            if world > 1:
+            if dp:
                 self._dp_exchange_gradients()
             self._train_phase_b(s)
-        if world > 1:
-            self.scalars[:2].mul_(1.0 / world)
+            if world > 1:
+                self.scalars[:2].mul_(1.0 / world)
+        if not self._twins:
+            # this model's Adam launch does not maintain the bf16 shadow of the (shared) variables: whoever reads it
+            # next -- e.g. a reuse=True model with bf16 twins on the same scope -- has to re-derive it first
+            st.shadow_stale = True
         self._dirty = False
         self._steps_executed = None
 

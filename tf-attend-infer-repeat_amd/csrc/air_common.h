@@ -21,27 +21,32 @@ static inline hipStream_t air_stream(void* s) { return reinterpret_cast<hipStrea
 
 // Opt-in to more than 48 KB of dynamic LDS, ONCE per (kernel function, device): hipFuncSetAttribute is a host-side
 // driver call and must not sit on every launch -- in particular not inside stream capture (callers warm up eagerly).
-// The attribute is per device, so the cache is keyed on the current device as well (one table per translation unit).
+// The attribute is per device, so the cache is one row of kernel functions per device (one table per translation
+// unit).  Thread-safe: a function is published into its device's row (compare-and-swap on a free slot) only AFTER the
+// driver call returned, so a reader that finds it may launch; two threads racing on the same (function, device) both
+// make the call, which is idempotent.  A full row or a device index beyond the table is an error, not a silent
+// per-launch driver call.
 static inline int air_grant_lds(const void* fn, size_t bytes) {
-    struct Slot { std::atomic<const void*> fn; std::atomic<int> dev; };
-    static Slot granted[128];
+    constexpr int MAX_DEV = 32, SLOTS = 64;
+    static std::atomic<const void*> granted[MAX_DEV][SLOTS];
     if (bytes > 160 * 1024) return AIR_ELIMIT;
     if (bytes <= 48 * 1024) return 0;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-    int free_slot = -1;
-    for (int i = 0; i < 128; ++i) {
-        const void* g = granted[i].fn.load(std::memory_order_acquire);
-        if (g == fn && granted[i].dev.load(std::memory_order_relaxed) == dev) return 0;
-        if (!g && free_slot < 0) free_slot = i;
+    if (dev < 0 || dev >= MAX_DEV) return AIR_ELIMIT;
+    std::atomic<const void*>* row = granted[dev];
+    for (int i = 0; i < SLOTS; ++i) {
+        const void* g = row[i].load(std::memory_order_acquire);
+        if (g == fn) return 0;
+        if (!g) break;                                   // slots fill front to back and are never cleared
     }
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
-    if (free_slot >= 0) {
-        granted[free_slot].dev.store(dev, std::memory_order_relaxed);
-        granted[free_slot].fn.store(fn, std::memory_order_release);
+    for (int i = 0; i < SLOTS; ++i) {
+        const void* expect = nullptr;
+        if (row[i].compare_exchange_strong(expect, fn, std::memory_order_acq_rel) || expect == fn) return 0;
     }
-    return 0;
+    return AIR_ELIMIT;
 }
 
 __device__ __forceinline__ float air_sigmoid(float x) {

@@ -1456,10 +1456,11 @@ size_t write_bwd_smem(int C, int w) { return (64 + 8 * C + C + 8 * w + 8 * (w + 
 // ---------------------------------------------------------------------------
 // The bit-for-bit reproduction of the reference's UnsortedSegmentSum rests on a property of gfx950 that no manual
 // states: a same-address ds_add_f32 applies the 64 lanes of an instruction in ascending lane order, and a wave's
-// instructions in program order.  It is probed ONCE per process on the first eager call that needs it (a known-order
-// sum whose value depends on the order; the probe needs a stream synchronise and is therefore skipped -- property
-// assumed -- while the stream is being captured: capture_graph() warms up eagerly first).  A part that orders
-// differently takes the register-chain fallbacks (same results, slower) instead of silently changing gradients.
+// instructions in program order.  It is probed ONCE per process and device on the first eager call that needs it (a
+// known-order sum whose value depends on the order; the probe needs a stream synchronise, so a first call under stream
+// capture takes the register chains -- nothing is assumed -- and says so: capture_graph() warms up eagerly first).  A
+// part that orders differently takes the ring / register-chain fallbacks (same results, slower) instead of silently
+// changing gradients.
 // AIR_LDS_ORDER=0 / 1 forces the answer (tests run both paths against each other).
 // ---------------------------------------------------------------------------
 constexpr int PROBE_N = 8 * 64;
@@ -1485,9 +1486,17 @@ __global__ void lds_order_probe_kernel() {
     if (threadIdx.x == 63) air_probe_out[1] = S;
 }
 
-// bit 0: the LDS atomic pipe is a sequential accumulator on this part; bit 1: so is the lane ring
+// bit 0: the LDS atomic pipe is a sequential accumulator on this part; bit 1: so is the lane ring.
+// Remembered PER DEVICE (a node may mix parts).  A first call that arrives while the stream is being captured cannot
+// probe (the probe synchronises): it takes the conservative answer -- neither property, i.e. the register chains, same
+// bits on any part, slower -- says so once, and remembers nothing, so the first eager call still probes.
 int accumulators(hipStream_t s) {
-    static std::atomic<int> state{0};                    // 0 unknown, else 4 | flags
+    constexpr int MAX_DEV = 32;
+    static std::atomic<int> states[MAX_DEV];             // per device: 0 unknown, else 4 | flags
+    static std::atomic<int> warned{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) dev = 0;
+    std::atomic<int>& state = states[dev];
     int st = state.load(std::memory_order_acquire);
     if (st) return st & 3;
     const char* e0 = getenv("AIR_LDS_ORDER");
@@ -1496,7 +1505,13 @@ int accumulators(hipStream_t s) {
     const bool capturing = hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
     int probed = 3;
     if (!(e0 && e1)) {
-        if (capturing) return (e0 ? (e0[0] != '0') : 1) | (e1 ? (e1[0] != '0') << 1 : 2);   // cannot synchronise here: assumed, not remembered
+        if (capturing) {                                 // cannot synchronise here: nothing assumed, nothing remembered
+            if (!warned.exchange(1))
+                fprintf(stderr, "libair_hip: air_write_bwd / air_transformer_bwd first called under stream capture on device %d: the "
+                                "accumulator probe cannot run, this capture takes the register-chain fallback (same results, slower) -- "
+                                "run the launch once eagerly before capturing\n", dev);
+            return (e0 ? (e0[0] != '0') : 0) | (e1 ? (e1[0] != '0') << 1 : 0);
+        }
         float vals[PROBE_N];
         unsigned x = 12345u;
         float want = 0.0f;
