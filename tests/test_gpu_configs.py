@@ -180,7 +180,8 @@ def test_stress_config_as_benchmarked_bf16_b256(am, monkeypatch):
     assert rep["recon_mean"] <= 2e-3 and rep["recon_frac_over_3e2"] <= 2e-3, rep
     assert rep["elbo_rel"] <= 1e-2 and rep["digits_equal"] == 1.0, rep
     assert rep["rec_scales"] <= 2e-3 and rep["rec_shifts"] <= 5e-3, rep
-    default = three_steps(m)
+    fwd_default = dict(h=m.h.clone(), recon=m.reconstruction.clone(), loss=float(m.loss))
+    three_steps(m)
 
     # the same x.Wx tiling on both sides (latency tiles, 4 slabs): twins on == twins off, bit for bit
     monkeypatch.setenv("AIR_XW_TILE", "4,2,4")
@@ -189,15 +190,22 @@ def test_stress_config_as_benchmarked_bf16_b256(am, monkeypatch):
         mm = make(tw)
         assert mm._twins == tw
         assert not any("gemm_xw_tp_kernel" in op.kernel for op in mm.train_step_ops())
+        if tw:
+            mm.forward()
+            fwd_latency = dict(h=mm.h.clone(), recon=mm.reconstruction.clone(), loss=float(mm.loss))
         res[tw] = three_steps(mm)
     for k in res[False]:
         assert torch.equal(res[False][k], res[True][k]), k
-    # ... and the throughput-tiled default differs from it only by the summation order of x.Wx
+    # ... and the throughput-tiled default differs from it only by the summation order of x.Wx: same forward up to fp32
+    # rounding of a K = 16384 sum (then bf16 rounding of h).  After an update the two runs are not comparable element
+    # by element: the gradient carries the reference's chaotic rounding residue.
     monkeypatch.delenv("AIR_XW_TILE", raising=False)
-    a, b = default, res[True]
-    assert float((a["h"] - b["h"]).abs().max()) <= 2e-2
-    assert float((a["recon"] - b["recon"]).abs().mean()) <= 2e-3
-    assert abs(float(a["gnorm"]) - float(b["gnorm"])) <= 0.5 * float(b["gnorm"])      # residue-dominated
+    dh = float((fwd_default["h"] - fwd_latency["h"]).abs().max())
+    dr = float((fwd_default["recon"] - fwd_latency["recon"]).abs().mean())
+    print("throughput vs latency tiling of x.Wx: |dh| %.2e, mean |d recon| %.2e, loss %.6f vs %.6f" %
+          (dh, dr, fwd_default["loss"], fwd_latency["loss"]))
+    assert dh <= 2e-3 and dr <= 1e-4
+    assert abs(fwd_default["loss"] - fwd_latency["loss"]) <= 1e-3 * abs(fwd_latency["loss"])
 
 
 def test_stress_config_gradients_vs_fp64(am):
