@@ -26,8 +26,10 @@ extern "C" {
 #endif
 
 /* 2: air_gemm_t / air_wgrad_t carry bf16 twins; `literal` of the sampler backward: 0 exact, 1 per-tap order, 2 the
- * reference graph's order (version 1 headers of round 1 called the per-tap order "reference") */
-#define AIR_ABI_VERSION 2
+ * reference graph's order (version 1 headers of round 1 called the per-tap order "reference")
+ * 3: panel-blocked bf16 shadows of the weights (air_panel_t, air_gemm_t.B16p, air_panel_shadow,
+ *    air_adam_clip_step_panels) */
+#define AIR_ABI_VERSION 3
 
 #define AIR_EINVAL   (-1)   /* bad dimension / null pointer            */
 #define AIR_ELIMIT   (-2)   /* size exceeds what the kernel supports    */
@@ -179,6 +181,14 @@ typedef struct {
      * accumulation into q2 only). */
     const uint16_t* A16; const uint16_t* B16;
     uint16_t* C16; uint16_t* q0_16; uint16_t* q2_16;
+    /* PANEL-BLOCKED bf16 twin of an untransposed B = [K, N] (precision 1, nullable; air_panel_t below describes the
+     * layout and who writes it): the same bf16 values as B16, stored as N/16 panels of [K rows][16 columns], so that a
+     * 16-column output tile reads ONE contiguous 32*K-byte block instead of a 32-byte piece of every 2*ldb-byte row
+     * (a quarter of each cache line it pulls through the CU).  For AIR_EPI_LSTM_FWD / AIR_EPI_LSTM_FWD0 (N = 4R gate
+     * columns) the panels are the gate-interleaved ones (air_panel_t.gates = 4): panel p holds units 4p..4p+3, column
+     * gate*4 + u%4 -- the four gates of four units in 32 contiguous bytes per row.  Read instead of B16 by the 16- and
+     * 32-column tiles; results are bit-identical.  B16 may be NULL when B16p is given and the tile supports it. */
+    const uint16_t* B16p;
 } air_gemm_t;
 /* number of K-slabs a ksplit request produces for contraction depth K */
 int air_gemm_slabs(int K, int ksplit);
@@ -189,6 +199,23 @@ int air_gemm_kernel_name(const air_gemm_t* g, char* buf, int n);
 /* dst[i] = bf16(src[i]), round to nearest even: the twin of an array whose producer could not write it (the flat
  * variable buffer after a host-side load -- air_adam_clip_step keeps its shadow fresh afterwards). */
 int air_bf16_twin(const float* src, uint16_t* dst, int64_t n, void* stream);
+
+/* ---- panel-blocked bf16 shadows of row-major [K, N] weight matrices that live in a flat fp32 buffer ----------
+ * Element (k, n) of the matrix at flat offset src_off goes to
+ *   gates == 0:  dst_off + (n / 16) * (K * 16) + k * 16 + n % 16                  (ceil(N / 16) * K * 16 elements)
+ *   gates == 4:  N = 4R gate columns (BasicLSTMCell's i, j, f, o blocks, air_model.py:286), gate = n / R, u = n % R:
+ *                dst_off + (u / 4) * (K * 16) + k * 16 + gate * 4 + u % 4          (K * N elements, R % 4 == 0)
+ * of the panel shadow (what air_gemm_t.B16p points into).  N % 4 == 0, src_off % 4 == 0, dst_off % 4 == 0.
+ * `exclusive` != 0: the row-major bf16 shadow of this range is NOT maintained by air_adam_clip_step_panels (no kernel
+ * reads it: the hoisted x.Wx is the only consumer of Wx and takes the panels). */
+typedef struct {
+    int64_t src_off, dst_off;
+    int32_t K, N, gates, exclusive;
+} air_panel_t;
+#define AIR_MAX_PANELS 16
+/* panel_shadow <- bf16(params), for every described matrix (after a host-side change of the variables) */
+int air_panel_shadow(const float* params, uint16_t* panel_shadow, const air_panel_t* panels /*HOST array, <= 16, ascending src_off*/,
+                     int count, void* stream);
 
 /* ---- grouped weight gradients: every dW = A^T . dY (+ db = column sums of dY) of the
  * step in ONE launch (MatMul_grad / BiasAdd_grad nodes of all variables; weights are shared
@@ -421,6 +448,13 @@ int air_adam_clip_step_blocks(float* params, const float* grads, float* m, float
                               uint16_t* bf16_shadow /*nullable*/, float* gnorm_out /*nullable*/, int max_blocks,
                               float* coef_out /*nullable: [4] floats receiving (clip scale, lr_t, global norm) for deferred slices*/,
                               void* stream);
+/* air_adam_clip_step_blocks (all blocks) that ALSO maintains the panel-blocked shadows: every updated variable that lies
+ * in a described matrix is written to its panel position (and to bf16_shadow unless the matrix is `exclusive`). */
+int air_adam_clip_step_panels(float* params, const float* grads, float* m, float* v, int64_t n,
+                              const float* partials, int npartials, const float* dyn, const int32_t* istate,
+                              float grad_prescale, float beta1, float beta2, float epsilon,
+                              uint16_t* bf16_shadow /*nullable*/, const air_panel_t* panels /*HOST array*/, int npanels,
+                              uint16_t* panel_shadow, float* gnorm_out /*nullable*/, void* stream);
 /* The same step with ONE gradient block taken from its factors instead of from `grads`:
  * `factored` (HOST pointer, one plain problem, db NULL, ldc == N, N % 4 == 0) names a block
  * dW = A^T.dY [M,N] that lies inside the flat buffer (dW points into `grads`; the matching ranges

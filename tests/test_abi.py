@@ -44,7 +44,7 @@ def test_every_declared_symbol_is_exported_and_bound(H):
 
 
 def test_abi_version_and_strerror(H):
-    assert H.lib().air_abi_version() == H.ABI_VERSION == 2
+    assert H.lib().air_abi_version() == H.ABI_VERSION == 3
     assert b"invalid argument" in H.lib().air_strerror(-1)
     assert H.lib().air_strerror(0) == b"success"
 
@@ -58,6 +58,8 @@ def test_struct_layout_matches_c(H, tmp_path):
                     'sizeof(air_attend_fwd_t), offsetof(air_attend_fwd_t, B), sizeof(air_attend_bwd_t),'
                     'sizeof(air_write_fwd_t), sizeof(air_write_bwd_t)); printf("%zu %zu %zu %zu %zu\\n", sizeof(air_colsum_t),'
                     'sizeof(air_bottleneck_fwd_t), offsetof(air_bottleneck_fwd_t, ldx), sizeof(air_bottleneck_bwd_t), offsetof(air_bottleneck_bwd_t, H));'
+                    'printf("%zu %zu %zu %zu %d\\n", sizeof(air_panel_t), offsetof(air_panel_t, K), offsetof(air_panel_t, exclusive), offsetof(air_gemm_t, B16p),'
+                    'AIR_MAX_PANELS);'
                     'return 0;}')
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
@@ -66,7 +68,8 @@ def test_struct_layout_matches_c(H, tmp_path):
     exp = [C.sizeof(H.Gemm), H.Gemm.bias.offset, H.Gemm.aux.offset, H.Gemm.precision.offset, H.Gemm.p0.offset, H.Gemm.q2.offset,
            C.sizeof(H.Schedule), C.sizeof(H.AttendFwd), H.AttendFwd.B.offset, C.sizeof(H.AttendBwd),
            C.sizeof(H.WriteFwd), C.sizeof(H.WriteBwd), C.sizeof(H.Colsum),
-           C.sizeof(H.BottleneckFwd), H.BottleneckFwd.ldx.offset, C.sizeof(H.BottleneckBwd), H.BottleneckBwd.H.offset]
+           C.sizeof(H.BottleneckFwd), H.BottleneckFwd.ldx.offset, C.sizeof(H.BottleneckBwd), H.BottleneckBwd.H.offset,
+           C.sizeof(H.Panel), H.Panel.K.offset, H.Panel.exclusive.offset, H.Gemm.B16p.offset, H.MAX_PANELS]
     assert got == exp, (got, exp)
 
 
@@ -101,6 +104,12 @@ def test_argument_errors_without_gpu(H):
     assert lib.air_wgrad_grouped(nul, 1, 1, None, None, None) == -1
     assert lib.air_wgrad_num_blocks(nul, 1) == 1
     assert lib.air_optim_num_partials(1000) > 0
+    # panel-blocked twins: null buffers, bad descriptors
+    one = (H.Panel * 1)(H.Panel(0, 0, 4, 8, 0, 0))
+    assert lib.air_panel_shadow(None, A, one, 1, None) == -1
+    assert lib.air_panel_shadow(A, A, one, 0, None) == -1
+    assert lib.air_adam_clip_step_panels(A, A, A, A, 32, A, 1, A, A, 1.0, 0.9, 0.999, 1e-8, None, one, 1, None, None, None) == -1
+    assert lib.air_adam_clip_step_panels(A, A, A, A, 16, A, 1, A, A, 1.0, 0.9, 0.999, 1e-8, None, one, 1, A, None, None) == -1   # 4 x 8 > 16
 
 
 def test_no_cpu_fallback(H):

@@ -1239,3 +1239,195 @@ def test_gemm_throughput_tiling_for_the_deep_input_product(H):
     A = torch.zeros(128, 1024, device="cuda"); Ct = torch.zeros(4, 128, 64, device="cuda")
     g = _gemm_struct(H, A, B, Ct, 128, 64, 1024, 1024, 64, 64, 1, ksplit=4, tile_m=8, tile_n=4)
     assert H.lib().air_gemm(C.byref(g), _stream()) == -1
+
+
+# ---- panel-blocked bf16 twins of the weights (air_panel_t): layout, who maintains them, and the GEMMs that read them ----
+
+def _panel_ref(W, gates):
+    """numpy statement of air_panel_t's layout for one row-major [K, N] matrix (include/air_hip.h): bf16 bit patterns as int16"""
+    K, N = W.shape
+    w16 = torch.tensor(W).to(torch.bfloat16).view(torch.int16).numpy()
+    if gates:
+        R = N // 4
+        out = np.zeros((R // 4, K, 16), np.int16)
+        for gate in range(4):
+            blk = w16[:, gate * R:(gate + 1) * R].reshape(K, R // 4, 4)             # [k][panel][unit % 4]
+            out[:, :, gate * 4:gate * 4 + 4] = blk.transpose(1, 0, 2)
+        return out.reshape(-1)
+    P = (N + 15) // 16
+    pad = np.zeros((K, P * 16), np.int16)
+    pad[:, :N] = w16
+    return pad.reshape(K, P, 16).transpose(1, 0, 2).reshape(-1)
+
+
+def _panel_setup(H, rng, mats):
+    """flat fp32 buffer holding `mats` = [(K, N, gates, exclusive)] with gaps (biases) between them, + the descriptors"""
+    off, doff, items, pans = 8, 0, [], []
+    for K, N, gates, excl in mats:
+        items.append((off, doff))
+        pans.append(H.Panel(off, doff, K, N, 4 if gates else 0, 1 if excl else 0))
+        off += (K * N + 7) // 8 * 8 + 24                  # a bias-sized gap that belongs to no matrix
+        doff += ((K * N if gates else (N + 15) // 16 * 16 * K) + 7) // 8 * 8
+    flat = rng.uniform(-1, 1, off).astype(np.float32)
+    return flat, items, (H.Panel * len(pans))(*pans), doff
+
+
+PANEL_MATS = [(2500, 1024, True, True), (256, 1024, True, False), (256, 320, False, False), (784, 512, False, False),
+              (50, 104, False, False), (33, 8, False, False)]
+
+
+def test_panel_shadow_layout_and_adam_maintains_it(H):
+    """air_panel_shadow writes bf16(params) in the documented panel layout (plain 16-column panels, the last one
+    zero-padded; gate-interleaved panels for an LSTM kernel, air_model.py:286 i, j, f, o blocks), and
+    air_adam_clip_step_panels keeps BOTH twins current with the variables it updates: the panel twin everywhere, the
+    row-major twin everywhere except over `exclusive` matrices (left untouched).  ApplyAdam itself is unchanged:
+    variables / slots bit-identical to air_adam_clip_step."""
+    rng = np.random.RandomState(41)
+    flat, items, pans, ptotal = _panel_setup(H, rng, PANEL_MATS)
+    n = flat.size
+    p = torch.tensor(flat, device="cuda")
+    pan = torch.full((ptotal,), 0x7fff, dtype=torch.int16, device="cuda")
+    pan.zero_()
+    H.check(H.lib().air_panel_shadow(_p(p), _p(pan), pans, len(pans), _stream()))
+    torch.cuda.synchronize()
+    got = pan.cpu().numpy()
+    for (K, N, gates, excl), (off, doff) in zip(PANEL_MATS, items):
+        ref = _panel_ref(flat[off:off + K * N].reshape(K, N), gates)
+        assert np.array_equal(got[doff:doff + ref.size], ref), (K, N, gates)
+    # one Adam step with real gradients, twice: with and without the panel tables
+    g = torch.tensor(rng.uniform(-1, 1, n).astype(np.float32), device="cuda")
+    dyn = np.zeros(H.DYN_COUNT, np.float32)
+    dyn[H.DYN_LEARNING_RATE], dyn[H.DYN_CLIP_NORM] = 1e-2, 1.0
+    dyn_d = torch.tensor(dyn, device="cuda")
+    res = {}
+    for mode in ("plain", "panels"):
+        pp, m, v = p.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        ist = torch.zeros(H.IST_COUNT, dtype=torch.int32, device="cuda")
+        npart = H.lib().air_optim_num_partials(n)
+        part = torch.zeros(npart, device="cuda")
+        gn = torch.zeros(1, device="cuda")
+        sh = torch.full((n,), 0x1234, dtype=torch.int16, device="cuda")
+        pn = torch.full((ptotal,), 0x1234, dtype=torch.int16, device="cuda")
+        H.check(H.lib().air_grad_sqnorm(_p(g), n, _p(part), _p(ist), _stream()))
+        if mode == "plain":
+            H.check(H.lib().air_adam_clip_step(_p(pp), _p(g), _p(m), _p(v), n, _p(part), npart, _p(dyn_d), _p(ist), 1.0, 0.9, 0.999, 1e-8,
+                                               _p(sh), _p(gn), _stream()))
+        else:
+            H.check(H.lib().air_adam_clip_step_panels(_p(pp), _p(g), _p(m), _p(v), n, _p(part), npart, _p(dyn_d), _p(ist), 1.0, 0.9, 0.999,
+                                                      1e-8, _p(sh), pans, len(pans), _p(pn), _p(gn), _stream()))
+        torch.cuda.synchronize()
+        res[mode] = (pp, m, v, sh, pn, float(gn))
+    for a, b in zip(res["plain"][:3], res["panels"][:3]):
+        assert torch.equal(a, b)
+    assert res["plain"][5] == res["panels"][5]
+    pp, sh, pn = res["panels"][0].cpu().numpy(), res["panels"][3].cpu().numpy(), res["panels"][4].cpu().numpy()
+    assert not np.array_equal(pp, flat)
+    flat16 = torch.tensor(pp).to(torch.bfloat16).view(torch.int16).numpy()
+    assert np.array_equal(res["plain"][3].cpu().numpy(), flat16)                    # the plain call: the whole row-major twin
+    keep = np.ones(n, bool)
+    for (K, N, gates, excl), (off, doff) in zip(PANEL_MATS, items):
+        ref = _panel_ref(pp[off:off + K * N].reshape(K, N), gates)
+        sl = pn[doff:doff + ref.size]
+        if gates or N % 16 == 0:
+            assert np.array_equal(sl, ref), (K, N, gates)
+        else:                                             # the pad columns of the last panel are never written
+            P = (N + 15) // 16
+            m_ = np.zeros((K, P * 16), bool); m_[:, :N] = True
+            m_ = m_.reshape(K, P, 16).transpose(1, 0, 2).reshape(-1)
+            assert np.array_equal(sl[m_], ref[m_]) and np.all(sl[~m_] == 0x1234)
+        if excl:
+            keep[off:off + K * N] = False
+            assert np.all(sh[off:off + K * N] == 0x1234)                             # exclusive: the row-major twin is left alone
+    assert np.array_equal(sh[keep], flat16[keep])
+    # argument errors: overlapping / unordered matrices, unaligned offsets, too many
+    bad = (H.Panel * 2)(H.Panel(0, 0, 4, 8, 0, 0), H.Panel(16, 64, 4, 8, 0, 0))
+    assert H.lib().air_panel_shadow(_p(p), _p(pan), bad, 2, _stream()) == -1
+    bad = (H.Panel * 1)(H.Panel(2, 0, 4, 8, 0, 0))
+    assert H.lib().air_panel_shadow(_p(p), _p(pan), bad, 1, _stream()) == -3
+    bad = (H.Panel * 1)(H.Panel(0, 0, 4, 24, 4, 0))                                   # gates: N % 16
+    assert H.lib().air_panel_shadow(_p(p), _p(pan), bad, 1, _stream()) == -1
+    assert H.lib().air_panel_shadow(_p(p), _p(pan), pans, 17, _stream()) == -2
+
+
+def _panels_of(H, W, gates):
+    """device panel twin of one device matrix through the ABI"""
+    K, N = W.shape
+    size = K * N if gates else (N + 15) // 16 * 16 * K
+    out = torch.zeros(size, dtype=torch.int16, device="cuda")
+    pd = (H.Panel * 1)(H.Panel(0, 0, K, N, 4 if gates else 0, 0))
+    H.check(H.lib().air_panel_shadow(_p(W), _p(out), pd, 1, _stream()))
+    return out
+
+
+@pytest.mark.parametrize("M,N,K,tile", [(192, 320, 256, (0, 0)), (192, 512, 784, (0, 0)), (192, 256, 512, (0, 0)), (192, 784, 512, (0, 0)),
+                                        (1280, 512, 784, (0, 0)), (50, 104, 2048, (1, 1)), (37, 200, 1160, (2, 2)),
+                                        (64, 1024, 2496, (2, 2))])
+def test_gemm_reads_panel_blocked_weights_bit_identically(H, M, N, K, tile):
+    """air_gemm_t.B16p: the same product from the panel-blocked twin of B (16- and 32-column tiles) as from the row-major
+    twin -- same bf16 values, same k order, same reduction: BIT-IDENTICAL, with or without the row-major twin present."""
+    rng = np.random.RandomState(M + N + K)
+    A = torch.tensor(rng.uniform(-1, 1, (M, K)).astype(np.float32), device="cuda")
+    B = torch.tensor(rng.uniform(-1, 1, (K, N)).astype(np.float32), device="cuda")
+    bias = torch.tensor(rng.uniform(-1, 1, N).astype(np.float32), device="cuda")
+    A16, B16, B16p = _bf16_twin(H, A), _bf16_twin(H, B), _panels_of(H, B, False)
+    outs = []
+    for kw in (dict(B16=B16), dict(B16p=B16p), dict(B16=B16, B16p=B16p)):
+        Ct = torch.full((M, N), float("nan"), device="cuda")
+        g = _gemm_struct(H, A, B, Ct, M, N, K, K, N, N, 1, tile_m=tile[0], tile_n=tile[1], bias=bias, act=H.ACT_SOFTPLUS, A16=A16, **kw)
+        assert _kernel_name(H, g).startswith("gemm_bf16tw_kernel")
+        H.check(H.lib().air_gemm(C.byref(g), _stream()))
+        torch.cuda.synchronize()
+        outs.append(Ct)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert bool(torch.isfinite(outs[0]).all())
+
+
+def test_gemm_lstm_tiles_read_gate_interleaved_panels_bit_identically(H):
+    """The four-unit x four-gate tiles (AIR_EPI_LSTM_FWD; AIR_EPI_LSTM_FWD0 = the hoisted x.Wx carrying the first step)
+    on the gate-interleaved panel twin of the LSTM kernel: every output bit-identical to the row-major twin and to the
+    fp32-operand kernels; x.Wx as fp32 A (the caller's image batch) and as a bf16 twin; one x.Wx slab as the addend of
+    the later steps."""
+    dev, lib = "cuda", H.lib()
+    rng = np.random.RandomState(43)
+    f = lambda *s: torch.tensor(rng.uniform(-1, 1, s).astype(np.float32), device=dev)  # noqa: E731
+    i16 = lambda *s: torch.zeros(*s, dtype=torch.int16, device=dev)  # noqa: E731
+    for Bn, R, D in ((64, 256, 2500), (48, 64, 520)):
+        X, Wx, Wh, bias = f(Bn, D).abs(), f(D, 4 * R) * 0.05, f(R, 4 * R) * 0.1, f(4 * R) * 0.1
+        Wx16, WxP, Wh16, WhP, X16 = _bf16_twin(H, Wx), _panels_of(H, Wx, True), _bf16_twin(H, Wh), _panels_of(H, Wh, True), _bf16_twin(H, X)
+        res = []
+        for kw in (dict(), dict(B16=Wx16), dict(B16p=WxP), dict(B16p=WxP, A16=X16)):
+            xw, acts, c1, h1, h16 = f(Bn, 4 * R), f(Bn, 4 * R), f(Bn, R), f(Bn, R), i16(Bn, R)
+            g = _gemm_struct(H, X, Wx, xw, Bn, 4 * R, D, D, 4 * R, 4 * R, 1, bias=bias, epi=H.EPI_LSTM_FWD0, q0=acts, q1=c1, q2=h1,
+                             q2_16=h16, **kw)
+            name = _kernel_name(H, g)
+            if not kw:
+                assert name.startswith("gemm_bf16v2_kernel"), name
+            elif D % 8 or "A16" not in kw:
+                assert name.startswith("gemm_bf16tw_kernel<1, 1, false, 6, true, ") or (D % 8 and "A16" in kw), name
+            H.check(lib.air_gemm(C.byref(g), _stream()))
+            torch.cuda.synchronize()
+            assert torch.equal(h16.view(torch.bfloat16), h1.to(torch.bfloat16))
+            res.append((xw, acts, c1, h1))
+        for other in res[1:]:
+            for a0, a1 in zip(res[0], other):
+                assert torch.equal(a0, a1)
+        xw0, _, c_prev, h_prev = res[0]
+        # a later step: h.Wh + the ONE slab of x.Wx + bias -> gates
+        h16_in = _bf16_twin(H, h_prev)
+        res2 = []
+        for kw in (dict(B16=Wh16), dict(B16p=WhP), dict(B16=Wh16, B16p=WhP)):
+            acts, c1, h1, dummy, h16 = f(Bn, 4 * R), f(Bn, R), f(Bn, R), f(Bn, 4 * R), i16(Bn, R)
+            g = _gemm_struct(H, h_prev, Wh, dummy, Bn, 4 * R, R, R, 4 * R, 4 * R, 1, bias=bias, addend=xw0, ldadd=4 * R, addend_slabs=1,
+                             epi=H.EPI_LSTM_FWD, p0=c_prev, q0=acts, q1=c1, q2=h1, q2_16=h16, A16=h16_in, **kw)
+            assert "tw_kernel" in _kernel_name(H, g)
+            H.check(lib.air_gemm(C.byref(g), _stream()))
+            torch.cuda.synchronize()
+            res2.append((acts, c1, h1))
+        for other in res2[1:]:
+            for a0, a1 in zip(res2[0], other):
+                assert torch.equal(a0, a1)
+        # ... against the float64 statement of BasicLSTMCell on the bf16-rounded operands
+        pre = _bf16_round(h_prev.cpu().numpy()) @ _bf16_round(Wh.cpu().numpy()) + xw0.cpu().numpy().astype(np.float64) + bias.cpu().numpy()
+        sig = lambda v: 1.0 / (1.0 + np.exp(-v))  # noqa: E731
+        cn = c_prev.cpu().numpy() * sig(pre[:, 2 * R:3 * R] + 1.0) + sig(pre[:, :R]) * np.tanh(pre[:, R:2 * R])
+        np.testing.assert_allclose(res2[0][1].cpu().numpy(), cn, atol=5e-5)

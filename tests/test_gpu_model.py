@@ -446,6 +446,27 @@ def test_first_lstm_step_in_the_xwx_launch_matches_the_default_path(am, monkeypa
     assert abs(outs[False][3] - outs[True][3]) / abs(outs[False][3]) < 1e-5
 
 
+def _assert_panels_current(st):
+    """the panel-blocked twins on the store hold bf16 of the CURRENT variables in air_panel_t's layout"""
+    pan = st.params16p.cpu().numpy()
+    flat = st.params.cpu()
+    assert len(st.panels) >= 2
+    for q in st.panels:
+        W = flat[q.src_off:q.src_off + q.K * q.N].reshape(q.K, q.N)
+        w16 = W.to(torch.bfloat16).view(torch.int16).numpy()
+        if q.gates:
+            R = q.N // 4
+            ref = np.zeros((R // 4, q.K, 16), np.int16)
+            for gate in range(4):
+                ref[:, :, gate * 4:gate * 4 + 4] = w16[:, gate * R:(gate + 1) * R].reshape(q.K, R // 4, 4).transpose(1, 0, 2)
+        else:
+            P = (q.N + 15) // 16
+            pad = np.zeros((q.K, P * 16), np.int16)
+            pad[:, :q.N] = w16
+            ref = pad.reshape(q.K, P, 16).transpose(1, 0, 2)
+        assert np.array_equal(pan[q.dst_off:q.dst_off + ref.size], ref.reshape(-1)), (q.src_off, q.K, q.N, q.gates)
+
+
 @pytest.mark.parametrize("hp_over,B", [({}, 64), (dict(canvas_size=128, max_steps=5, max_digits=4), 32)])
 def test_bf16_twins_are_bit_identical_to_fp32_operands(am, hp_over, B):
     """bf16_twins=True (default on the bf16 path): every GEMM / weight-gradient operand is read from a bf16
@@ -469,7 +490,10 @@ def test_bf16_twins_are_bit_identical_to_fp32_operands(am, hp_over, B):
                        ml=model.ml.clone(), vrec=model.vrec.clone(), h=model.h.clone())
         if tw:
             # the shadow Adam maintains IS bf16(variables); activation twins are bf16 of their fp32 arrays
-            assert torch.equal(st.params16.view(torch.bfloat16), st.params.to(torch.bfloat16))
+            # (the row-major twin of the Wx rows is dropped where the panel twin is its only reader: "exclusive")
+            lo = model.store.dims["D"] * 4 * model.store.dims["R"] if st.wx_exclusive else 0
+            assert torch.equal(st.params16[lo:].view(torch.bfloat16), st.params[lo:].to(torch.bfloat16))
+            _assert_panels_current(st)
             assert torch.equal(model.h16.view(torch.bfloat16), model.h.to(torch.bfloat16))
             assert torch.equal(model.window16.view(torch.bfloat16), model.window.to(torch.bfloat16))
             assert torch.equal(model.d_hid16.view(torch.bfloat16), model.d_hid.to(torch.bfloat16))
@@ -494,7 +518,9 @@ def test_bf16_shadow_follows_host_side_changes_of_the_variables(am):
     model.forward()
     torch.cuda.synchronize()
     assert not model.store.shadow_stale
-    assert torch.equal(model.store.params16.view(torch.bfloat16), model.store.params.to(torch.bfloat16))
+    lo = model.store.dims["D"] * 4 * model.store.dims["R"] if model.store.wx_exclusive else 0
+    assert torch.equal(model.store.params16[lo:].view(torch.bfloat16), model.store.params[lo:].to(torch.bfloat16))
+    _assert_panels_current(model.store)
     ref, *_ = _make(am, 16, False, prec="bf16", bf16_twins=False)
     ref.use_device_rng()
     ref.load_state_dict(p2)
@@ -509,6 +535,7 @@ def test_deferred_adam_slices_in_multi_step_graphs_are_bit_identical(am, prec, t
     launches with the recorded clip scale / lr_t (air_step_job_t.ad_*).  Variables, Adam slots, bf16 shadow and
     global_step after 2 replays of 4 steps must equal 8 eager steps BIT FOR BIT (ApplyAdam, air_model.py:673-694)."""
     monkeypatch.setenv("AIR_ADAM_RIDERS", "1")        # off by default: measured no faster (air_model.py::_adam_riders)
+    monkeypatch.setenv("AIR_NO_PANELS", "1")          # ... and the slices maintain the row-major twin only
     res = {}
     for mode in ("eager", "graph"):
         model, *_ = _make(am, 64, True, prec=prec, backward="reference", bf16_twins=twins)
@@ -579,7 +606,9 @@ def test_bf16_shadow_follows_a_train_model_that_does_not_maintain_it(am, train_k
     for step in range(3):
         ev.forward(); ev_ref.forward()
         torch.cuda.synchronize()
-        assert torch.equal(ev.store.params16.view(torch.bfloat16), ev.store.params.to(torch.bfloat16)), step
+        lo = ev.store.dims["D"] * 4 * ev.store.dims["R"] if ev.store.wx_exclusive else 0
+        assert torch.equal(ev.store.params16[lo:].view(torch.bfloat16), ev.store.params[lo:].to(torch.bfloat16)), step
+        _assert_panels_current(ev.store)
         assert float(ev.loss) == float(ev_ref.loss), step
         assert torch.equal(ev.reconstruction, ev_ref.reconstruction)
         losses.append(float(ev.loss))

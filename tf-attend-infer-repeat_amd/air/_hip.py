@@ -15,7 +15,7 @@ import torch  # noqa: F401  -- FIRST: torch brings its own libamdhip64; loading 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AIR_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "libair_hip.so")   # override: A/B builds in tools/
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # enums (keep in sync with include/air_hip.h)
 DYN_PRIOR_LOG_ODDS, DYN_TEMPERATURE, DYN_STOP_THRESHOLD, DYN_LEARNING_RATE, DYN_CLIP_NORM = 0, 1, 2, 3, 4
@@ -58,7 +58,15 @@ class Gemm(C.Structure):
                 ("epi", _i), ("tile_m", _i), ("tile_n", _i), ("ksplit", _i), ("addend_slabs", _i), ("i0", _i),
                 ("p0", _p), ("p1", _p), ("p2", _p), ("p3", _p), ("q0", _p), ("q1", _p), ("q2", _p),
                 ("step_job", C.POINTER(StepJob)),
-                ("A16", _p), ("B16", _p), ("C16", _p), ("q0_16", _p), ("q2_16", _p)]
+                ("A16", _p), ("B16", _p), ("C16", _p), ("q0_16", _p), ("q2_16", _p), ("B16p", _p)]
+
+
+class Panel(C.Structure):
+    """air_panel_t: one row-major [K, N] matrix of the flat variable buffer and where its panel-blocked bf16 twin lives"""
+    _fields_ = [("src_off", C.c_int64), ("dst_off", C.c_int64), ("K", _i), ("N", _i), ("gates", _i), ("exclusive", _i)]
+
+
+MAX_PANELS = 16
 
 
 class Colsum(C.Structure):
@@ -118,6 +126,9 @@ _SIGNATURES = {
     "air_gemm_kernel_name": (C.c_int, [C.POINTER(Gemm), C.c_char_p, C.c_int]),
     "air_gemm_slabs": (C.c_int, [C.c_int, C.c_int]),
     "air_bf16_twin": (C.c_int, [_p, _p, C.c_int64, _p]),
+    "air_panel_shadow": (C.c_int, [_p, _p, C.POINTER(Panel), C.c_int, _p]),
+    "air_adam_clip_step_panels": (C.c_int, [_p, _p, _p, _p, C.c_int64, _p, C.c_int, _p, _p, _f, _f, _f, _f, _p,
+                                            C.POINTER(Panel), C.c_int, _p, _p, _p]),
     "air_colsum": (C.c_int, [C.POINTER(Colsum), C.c_int, _p]),
     "air_wgrad_num_blocks": (C.c_int, [C.POINTER(Wgrad), C.c_int]),
     "air_wgrad_grouped": (C.c_int, [C.POINTER(Wgrad), C.c_int, C.c_int, _p, _p, _p]),

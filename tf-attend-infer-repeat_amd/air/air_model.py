@@ -111,6 +111,35 @@ class VariableStore:
         # `variables[...]` views directly must call touch().
         self.params16 = torch.zeros(self.n, dtype=torch.int16, device=device)
         self.shadow_stale = True
+        # PANEL-BLOCKED bf16 twins (air_panel_t) of the weights the forward (untransposed) products read: 16-column
+        # panels of [K][16], so that a 16-column GEMM tile fetches whole cache lines; the LSTM kernel in gate-interleaved
+        # panels (the four gates of four units in 32 contiguous bytes per row), in two pieces (Wx rows, Wh rows).
+        # Maintained by Adam next to the row-major shadow (which the transposed data-gradient products keep reading);
+        # Wx has no other reader than the hoisted x.Wx, so its row-major shadow is dropped ("exclusive") unless the
+        # canvas is large (the throughput tiling of D > 4096 reads row-major lines) or the first-step fusion is off.
+        self.fuse_step0 = os.environ.get("AIR_STEP0_FUSION", "1") != "0"
+        pan, poff = [], 0
+        self.panel_off = {}
+
+        def add_panel(key, src_off, K, N, gates, exclusive=False):
+            nonlocal poff
+            if N % 8 or src_off % 4 or (gates and (N // 4) % 4):
+                return
+            self.panel_off[key] = poff
+            pan.append(H.Panel(src_off, poff, K, N, 4 if gates else 0, 1 if exclusive else 0))
+            poff += _align8(K * N if gates else ((N + 15) // 16) * 16 * K)
+        o = self.offsets["lstm_kernel"]
+        add_panel("Wx", o, D, 4 * R, True, exclusive=(self.fuse_step0 and D <= 4096))
+        add_panel("Wh", o + D * 4 * R, R, 4 * R, True)
+        for k, shp in fused.items():
+            if k.endswith("_w") and k not in ("ml_w", "gen0_w") or k == "whid":
+                add_panel(k, self.offsets[k], shp[0], shp[1], False)
+        pan = pan[:H.MAX_PANELS]
+        self.panels = (H.Panel * len(pan))(*pan)
+        self.panel_off = {k: v for k, v in self.panel_off.items() if any(q.dst_off == v for q in pan)}
+        # True: params16 is NOT maintained over the Wx rows of the LSTM kernel (only its panel twin is)
+        self.wx_exclusive = "Wx" in self.panel_off and bool(pan[0].exclusive)
+        self.params16p = torch.zeros(max(poff, 8), dtype=torch.int16, device=device)
 
         def views(buf):
             return OrderedDict((k, buf[self.offsets[k]:self.offsets[k] + int(np.prod(s))].view(*s))
@@ -171,7 +200,16 @@ class VariableStore:
         if stream is None:
             stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         H.check(H.lib().air_bf16_twin(_ptr(self.params), _ptr(self.params16), self.n, stream), "air_bf16_twin")
+        if len(self.panels):
+            H.check(H.lib().air_panel_shadow(_ptr(self.params), _ptr(self.params16p), self.panels, len(self.panels), stream),
+                    "air_panel_shadow")
         self.shadow_stale = False
+
+    def panel(self, key):
+        """device pointer (as int16 tensor view) of the panel-blocked twin of matrix `key`, or None"""
+        if key not in self.panel_off:
+            return None
+        return self.params16p[self.panel_off[key]:]
 
     def state_dict(self):
         sd = OrderedDict((k, v.detach().cpu().contiguous().clone()) for k, v in self.variables.items())
@@ -432,11 +470,16 @@ class AIRModel:
         if os.environ.get("AIR_XW_TILE"):                    # tuning hook: "tm,tn,ksplit" (ksplit <= 8 slabs)
             tm_, tn_, ks_ = (int(v) for v in os.environ["AIR_XW_TILE"].split(","))
             self._xw_ksplit, self._xw_tile = ks_, (tm_, tn_)
-        # AIR_STEP0_FUSION=1: ONE launch computes x.Wx (no split-K) and, in its epilogue, the first LSTM step (zero
-        # state: no h.Wh) -- AIR_EPI_LSTM_FWD0.  Measured slower and therefore off: its tiles are four units x four
-        # gates, i.e. 16-byte row segments of Wx (one eighth of every cache line fetched), 16.0 us against
-        # 7.8 + 3.4 us for the split-K product + the pointwise first step (0.198 vs 0.194-0.195 ms per step).
-        self._fuse_step0 = (os.environ.get("AIR_STEP0_FUSION") == "1" and R % 4 == 0 and D % 2 == 0
+        # ONE launch computes x.Wx (no split-K) and, in its epilogue, the first LSTM step (zero state: no h.Wh) --
+        # AIR_EPI_LSTM_FWD0 on four-unit x four-gate tiles.  On the row-major shadow of Wx such a tile reads 8-byte pieces
+        # of every row (one sixteenth of each cache line it pulls through the CU): 16.0 us against 7.8 + 3.4 us for the
+        # split-K product + the pointwise first step, which is why round 2 kept it off.  On the gate-interleaved PANEL twin
+        # (VariableStore.panels) the tile's rows are 32 contiguous bytes: default for the bf16 path now (and for its
+        # twins-off form, so that the two stay bit-identical); the fp32 path keeps the split-K product.
+        # AIR_STEP0_FUSION=0 / 1 forces it off / on.
+        env0 = os.environ.get("AIR_STEP0_FUSION")
+        want0 = (env0 == "1") if env0 in ("0", "1") else (self._prec == 1 and D <= 4096)
+        self._fuse_step0 = (want0 and self.store.fuse_step0 and R % 4 == 0 and D % 4 == 0
                             and not os.environ.get("AIR_XW_TILE"))
         self._xw_slabs = 1 if self._fuse_step0 else self.lib.air_gemm_slabs(D, self._xw_ksplit)
         self.xw = f(self._xw_slabs, B, 4 * R)            # x.Wx (split-K slabs when not fused)
@@ -495,7 +538,7 @@ class AIRModel:
     def _gemm(self, A, Bm, Cm, M, N, K, lda, ldb, ldc, ta=0, tb=0, bias=None, addend=None, ldadd=0,
               aux=None, ldaux=0, aux_scale=0.0, act=H.ACT_NONE, actgrad=H.GRAD_NONE, accumulate=0, tag="gemm",
               epi=H.EPI_GENERIC, tile=(0, 0), ksplit=0, addend_slabs=0, i0=0, p=(), q=(), extra_bytes=0, step_job=None,
-              A16=None, B16=None, C16=None, q0_16=None, q2_16=None):
+              A16=None, B16=None, C16=None, q0_16=None, q2_16=None, B16p=None):
         p = list(p) + [None] * (4 - len(p))
         q = list(q) + [None] * (3 - len(q))
         if epi == H.EPI_GENERIC and tile == (0, 0) and os.environ.get("AIR_EXP_TILES"):      # tuning hook: "N:tm,tn;N:tm,tn"
@@ -508,21 +551,21 @@ class AIRModel:
                    epi, tile[0], tile[1], ksplit, addend_slabs, i0,
                    _ptr(p[0]), _ptr(p[1]), _ptr(p[2]), _ptr(p[3]), _ptr(q[0]), _ptr(q[1]), _ptr(q[2]),
                    C.pointer(step_job) if step_job is not None else None,
-                   _ptr(A16), _ptr(B16), _ptr(C16), _ptr(q0_16), _ptr(q2_16))
+                   _ptr(A16), _ptr(B16), _ptr(C16), _ptr(q0_16), _ptr(q2_16), _ptr(B16p))
         fn = self.lib.air_gemm
         kbuf = C.create_string_buffer(96)
         H.check(self.lib.air_gemm_kernel_name(C.byref(g), kbuf, 96), "air_gemm_kernel_name")
         extra = (addend is not None) * max(1, addend_slabs) + (aux is not None) + (1 if accumulate else 0)
         return _Op("%s[%dx%dx%d%s]" % (tag, M, N, K, "t" if ta else ("n" + ("t" if tb else "n"))),
                    lambda s, g=g, fn=fn, keep=step_job: H.check(fn(C.byref(g), s), "air_gemm"),
-                   nbytes=(2 if A16 is not None else 4) * M * K + (2 if B16 is not None else 4) * K * N
+                   nbytes=(2 if A16 is not None else 4) * M * K + (2 if (B16 is not None or B16p is not None) else 4) * K * N
                    + 4 * M * N * (1 + extra) + (2 * M * N if C16 is not None else 0) + (4 * N if bias is not None else 0) + extra_bytes,
                    flops=2 * M * N * K, kernel=kbuf.value.decode())
 
     _KERNEL_OF = {"air_lstm_first_step": "lstm_first_step_kernel", "air_step_begin": "step_begin_kernel", "air_attend_fwd": "attend_fwd_kernel",
                   "air_attend_bwd": "attend_bwd_kernel", "air_write_fwd": "write_fwd_kernel",
                   "air_write_bwd": "write_bwd_kernel", "air_finalize": "finalize_kernel",
-                  "air_grad_sqnorm": "grad_sqnorm_kernel", "air_adam_clip_step": "adam_clip_kernel",
+                  "air_grad_sqnorm": "grad_sqnorm_kernel", "air_adam_clip_step": "adam_clip_kernel<false>",
                   "air_vae_bottleneck_fwd": "bottleneck_fwd_kernel<256>", "air_vae_bottleneck_bwd": "bottleneck_bwd_kernel<256>"}
 
     def _call(self, name, *args, nbytes=0, flops=0, tag=None):
@@ -552,6 +595,10 @@ class AIRModel:
         tw = self._twins
         P16 = st.P16
         T = (lambda k: P16[k]) if tw else (lambda k: None)  # noqa: E731
+        # panel-blocked twins (forward products only; AIR_NO_PANELS=1 keeps every product on the row-major shadow)
+        use_pan = tw and os.environ.get("AIR_NO_PANELS") != "1"
+        TP = (lambda k: st.panel(k)) if use_pan else (lambda k: None)  # noqa: E731
+        self._use_panels = use_pan
         Wx16, Wh16 = (P16["lstm_kernel"][:D], P16["lstm_kernel"][D:]) if tw else (None, None)
         o16 = lambda t, i=None: (None if t is None else (t if i is None else t[i]))  # noqa: E731
         imgs = self.input_images
@@ -572,20 +619,25 @@ class AIRModel:
         noise_bytes = 4 * (self.normals.numel() + self.uniforms.numel())
         if self._fuse_step0:
             # the first step rides in the x.Wx launch: h_0 = c_0 = 0 (zero_state, :540), so its gates are x.Wx + b
+            # (twins: the panel twin of Wx is the ONLY bf16 form of Wx that is maintained when the store made it exclusive)
+            wx_pan = TP("Wx")
             step0 = dict(bias=P["lstm_bias"], epi=H.EPI_LSTM_FWD0, q=(self.acts[0], self.c[1], self.h[1]),
-                         extra_bytes=4 * B * R * 6, q2_16=o16(self.h16, 1))
+                         extra_bytes=4 * B * R * 6, q2_16=o16(self.h16, 1), B16p=wx_pan,
+                         B16=(Wx16 if (wx_pan is None and not st.wx_exclusive) else None))
             fwd.append(self._gemm(imgs, Wx, self.xw, B, 4 * R, D, D, 4 * R, 4 * R, tag="xWx+lstm0", **step0))
             step0["extra_bytes"] += noise_bytes
-            self._xwx_with_begin = self._gemm(imgs, Wx, self.xw, B, 4 * R, D, D, 4 * R, 4 * R,
-                                              tag="xWx+lstm0+step_begin", step_job=job, **step0)
+            self._begin_host = (0, self._gemm(imgs, Wx, self.xw, B, 4 * R, D, D, 4 * R, 4 * R,
+                                              tag="xWx+lstm0+step_begin", step_job=job, **step0))
         else:
+            if st.wx_exclusive:
+                Wx16 = None         # (the row-major shadow of Wx is not maintained on this scope: fp32 operand)
             fwd.append(self._gemm(imgs, Wx, self.xw, B, 4 * R, D, D, 4 * R, 4 * R, ksplit=self._xw_ksplit,
                                   tile=self._xw_tile, tag="xWx", B16=Wx16))
             # the same launch carrying the step prologue (schedules + Philox noise) as an extra plane of
             # workgroups: x.Wx reads neither, so the train step needs no prologue launch of its own
-            self._xwx_with_begin = self._gemm(imgs, Wx, self.xw, B, 4 * R, D, D, 4 * R, 4 * R, ksplit=self._xw_ksplit,
+            self._begin_host = (0, self._gemm(imgs, Wx, self.xw, B, 4 * R, D, D, 4 * R, 4 * R, ksplit=self._xw_ksplit,
                                               tile=self._xw_tile, tag="xWx+step_begin", step_job=job,
-                                              extra_bytes=noise_bytes, B16=Wx16)
+                                              extra_bytes=noise_bytes, B16=Wx16))
             # step 0 starts from zero_state (:540): h_0 . Wh = 0, the gates are x.Wx + b -- a pointwise launch
             fwd.append(self._call("air_lstm_first_step", _ptr(self.xw), self._xw_slabs, _ptr(P["lstm_bias"]),
                                   _ptr(self.acts[0]), _ptr(self.c[1]), _ptr(self.h[1]), _ptr(o16(self.h16, 1)), B, R,
@@ -593,14 +645,21 @@ class AIRModel:
         # the recurrence: the remaining LSTM steps, chained (the only sequential part of the loop -- the LSTM
         # sees the same image every step and nothing downstream feeds back into it, :286/:535)
         for t in range(1, N):
-            host_gemm(self.h[t], Wh, self.gates_pre, B, 4 * R, R, R, 4 * R, 4 * R,
-                      bias=P["lstm_bias"], addend=self.xw, ldadd=4 * R, addend_slabs=self._xw_slabs,
-                      epi=H.EPI_LSTM_FWD, p=(self.c[t],), q=(self.acts[t], self.c[t + 1], self.h[t + 1]),
-                      extra_bytes=4 * B * R * 7, tag="lstm_fwd",
-                      A16=o16(self.h16, t), B16=Wh16, q2_16=o16(self.h16, t + 1))
+            lstm_kw = dict(bias=P["lstm_bias"], addend=self.xw, ldadd=4 * R, addend_slabs=self._xw_slabs,
+                           epi=H.EPI_LSTM_FWD, p=(self.c[t],), q=(self.acts[t], self.c[t + 1], self.h[t + 1]),
+                           extra_bytes=4 * B * R * 7, tag="lstm_fwd",
+                           A16=o16(self.h16, t), B16=Wh16, q2_16=o16(self.h16, t + 1), B16p=TP("Wh"))
+            host_gemm(self.h[t], Wh, self.gates_pre, B, 4 * R, R, R, 4 * R, 4 * R, **lstm_kw)
+            if t == 1 and self._fuse_step0 and use_pan and os.environ.get("AIR_BEGIN_HOST", "lstm") == "lstm":   # (deferred Adam riders never coexist with panels)
+                # With the first step fused into it, x.Wx is ONE round of 160 KB of LDS per workgroup: prologue workgroups in
+                # that launch would each take a whole CU.  The LSTM steps read neither the noise, nor dyn, nor the image
+                # twin (their first consumer is attend_fwd): the prologue rides in the first of them instead (16 KB of LDS)
+                lstm_kw = dict(lstm_kw, extra_bytes=lstm_kw["extra_bytes"] + noise_bytes, tag="lstm_fwd+step_begin")
+                self._begin_host = (len(fwd) - 1, self._gemm(self.h[t], Wh, self.gates_pre, B, 4 * R, R, R, 4 * R, 4 * R,
+                                                             step_job=job, **lstm_kw))
         # everything else runs ONCE over all N*B (step, image) rows
         host_gemm(self.h[1], P["whid"], self.hid, NB, HT, R, R, HT, HT, bias=P["bhid"],
-                  act=H.ACT_RELU, tag="heads_hid", A16=o16(self.h16, 1), B16=T("whid"), C16=self.hid16)
+                  act=H.ACT_RELU, tag="heads_hid", A16=o16(self.h16, 1), B16=T("whid"), C16=self.hid16, B16p=TP("whid"))
         a = H.AttendFwd(_ptr(self.hid), _ptr(P["wout"]), _ptr(P["bout"]), _ptr(imgs),
                         _ptr(self.eps_scale), _ptr(self.eps_shift), _ptr(self.u), _ptr(self.dyn),
                         _ptr(self.out7), _ptr(self.att), _ptr(self.window),
@@ -612,7 +671,7 @@ class AIRModel:
             (host_gemm if i == 0 else (lambda *a_, **k_: fwd.append(self._gemm(*a_, **k_))))(
                 x, P["rec%d_w" % i], self.rec_act[i], NB, u, k, k, u, u,
                 bias=P["rec%d_b" % i], act=H.ACT_SOFTPLUS, tag="vae_rec",
-                A16=x16, B16=T("rec%d_w" % i), C16=self.rec_act16[i])
+                A16=x16, B16=T("rec%d_w" % i), C16=self.rec_act16[i], B16p=TP("rec%d_w" % i))
             x, x16, k = self.rec_act[i], self.rec_act16[i], u
         # the bottleneck (last recognition product -> reparameterised sample -> first generative layer) is
         # ONE launch where the fused kernel's limits hold (bf16 operands; vae.py:16-30); else two GEMMs
@@ -638,11 +697,11 @@ class AIRModel:
             u = gen_u[i]
             fwd.append(self._gemm(x, P["gen%d_w" % i], self.gen_act[i], NB, u, k, k, u, u,
                                   bias=P["gen%d_b" % i], act=H.ACT_SOFTPLUS, tag="vae_gen",
-                                  A16=x16, B16=T("gen%d_w" % i), C16=self.gen_act16[i]))
+                                  A16=x16, B16=T("gen%d_w" % i), C16=self.gen_act16[i], B16p=TP("gen%d_w" % i)))
             x, x16, k = self.gen_act[i], self.gen_act16[i], u
         fwd.append(self._gemm(x, P["out_w"], self.vrec, NB, d, k, k, d, d, bias=P["out_b"],
                               act=H.ACT_SIGMOID_NOISE, aux=self.eps_x, ldaux=d,
-                              aux_scale=float(self.vae_likelihood_std), tag="vae_out", A16=x16, B16=T("out_w")))
+                              aux_scale=float(self.vae_likelihood_std), tag="vae_out", A16=x16, B16=T("out_w"), B16p=TP("out_w")))
         wf = H.WriteFwd(_ptr(self.vrec), _ptr(self.ml), _ptr(imgs), _ptr(self.dyn), _ptr(self.att),
                         _ptr(self._recon), _ptr(self._rec_loss), _ptr(self.d_recon if self.train else None),
                         _ptr(self.run_loss), _ptr(self.run_digits), _ptr(self._loss_item), B, N, Cc, w, Z)
@@ -853,9 +912,9 @@ class AIRModel:
             for i, op in enumerate(self._fwd):
                 pick(i, op)(s)
         else:
-            self._xwx_with_begin(s)
-            for i, op in enumerate(self._fwd[1:], 1):
-                pick(i, op)(s)
+            hi, hop = self._begin_host               # the launch that carries the step prologue as extra workgroups
+            for i, op in enumerate(self._fwd):
+                (hop if i == hi else pick(i, op))(s)
         if finalize:
             self._finalize(s)
 
@@ -913,6 +972,13 @@ class AIRModel:
                                   st.n, self._dwx_factors, self._prec, _ptr(st.partials), npart, _ptr(self.dyn),
                                   _ptr(st.istate), 1.0, 0.9, 0.999, 1e-8, _ptr(st.gnorm),
                                   nbytes=28 * st.n - 4 * fx.M * fx.N, flops=2 * fx.M * fx.N * fx.K, tag="adam_clip")
+            elif self._twins and len(st.panels) and os.environ.get("AIR_NO_PANELS") != "1":
+                # (with the panels whether or not THIS model reads them: another model on the scope may)
+                adam = self._call("air_adam_clip_step_panels", _ptr(st.params), _ptr(st.grads), _ptr(st.m), _ptr(st.v),
+                                  st.n, _ptr(st.partials), npart, _ptr(self.dyn), _ptr(st.istate), 1.0 / world,
+                                  0.9, 0.999, 1e-8, _ptr(st.params16), st.panels, len(st.panels), _ptr(st.params16p),
+                                  _ptr(st.gnorm), nbytes=30 * st.n, tag="adam_clip")
+                adam.kernel = "adam_clip_kernel<true>" if os.environ.get("AIR_ADAM_PANELS_SWEEP") else "adam_panels_kernel"
             else:
                 adam = self._call("air_adam_clip_step", _ptr(st.params), _ptr(st.grads), _ptr(st.m), _ptr(st.v),
                                   st.n, _ptr(st.partials), npart, _ptr(self.dyn), _ptr(st.istate), 1.0 / world,
@@ -938,7 +1004,8 @@ class AIRModel:
         # OFF by default -- measured on MI355X (tools/ab_bench.sh, 400 steps, 20 per replay): 0.1838 ms/step with the slices
         # carried, 0.1832 without.  The slice is HBM work whatever launch it sits in: the carrying GEMMs last as long as their
         # riders and lose what the Adam launch saved.  AIR_ADAM_RIDERS=1 enables it (tests keep the path bit-identical).
-        if (not self.train or self._dwx_factors is not None or os.environ.get("AIR_ADAM_RIDERS") != "1" or not self._fwd_hosts):
+        if (not self.train or self._dwx_factors is not None or os.environ.get("AIR_ADAM_RIDERS") != "1" or not self._fwd_hosts
+                or (self._twins and self._use_panels)):    # (the deferred slices do not maintain the panel-blocked twins)
             return None
         lo, hi = st.offsets["rec0_w"], st.n                      # the VAE variables: contiguous tail of the flat buffer
         first_free = st.offsets.get("rec1_w", st.offsets["ml_w"])   # the first recognition GEMM reads rec0_w / rec0_b itself
@@ -967,7 +1034,7 @@ class AIRModel:
                           lo, _ptr(st.partials), npart, _ptr(self.dyn), _ptr(st.istate), 1.0, 0.9, 0.999, 1e-8,
                           _ptr(st.params16) if self._twins else None, _ptr(st.gnorm), 0, _ptr(st.adam_coef),
                           nbytes=(30 if self._twins else 28) * lo, tag="adam_clip_main")
-        main.kernel = "adam_clip_kernel"
+        main.kernel = "adam_clip_kernel<false>"
         self._fwd_riders = (main, riders)
         return self._fwd_riders
 
@@ -1035,8 +1102,9 @@ class AIRModel:
 
     def train_step_ops(self):
         """The launches of one single-GPU train step, in order (bench / profiling tools)."""
-        return ([self._xwx_with_begin] + self._fwd[1:] + [self._write_bwd_fin] + self._bwd[1:] + [self._wgrad_fused]
-                + self._optimizer_ops())
+        hi, hop = self._begin_host
+        return ([(hop if i == hi else op) for i, op in enumerate(self._fwd)] + [self._write_bwd_fin] + self._bwd[1:]
+                + [self._wgrad_fused] + self._optimizer_ops())
 
     def _train_phase_a(self, s, riders=None):
         """step prologue + forward + loss + backward (+ weight grads) into the flat grad buffer"""

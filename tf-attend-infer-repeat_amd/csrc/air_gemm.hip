@@ -1046,6 +1046,7 @@ static int fill_args(const air_gemm_t* g, Args& a) {
     a.q0 = g->q0; a.q1 = g->q1; a.q2 = g->q2; a.q3 = nullptr;
     a.i0 = g->i0; a.i1 = 0;
     a.A16 = g->A16; a.B16 = g->B16; a.C16 = g->C16; a.q0_16 = g->q0_16; a.q2_16 = g->q2_16;
+    a.B16p = (g->precision == 1 && !g->transA && !g->transB) ? g->B16p : nullptr;
     a.job_on = 0;
     if (g->step_job) {
         const air_step_job_t& j = *g->step_job;

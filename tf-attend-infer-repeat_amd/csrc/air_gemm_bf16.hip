@@ -75,7 +75,7 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16tw_kernel(Args a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int tile_m, tile_n;
     xcd_tile(tile_m, tile_n);
-    constexpr bool QUAD = EPI_ == EPI_LSTM_FWD_Q;         // 16 columns = 4 gates x 4 units (TN == 1, untransposed B)
+    constexpr bool QUAD = EPI_ == EPI_LSTM_FWD_Q || EPI_ == AIR_EPI_LSTM_FWD0;   // 16 columns = 4 gates x 4 units (TN == 1, untransposed B)
     const int m0 = tile_m * BM, n0 = QUAD ? tile_n * 4 : tile_n * BN / TN * (a.gstride == 16 ? TN : 1);
     const int kbeg = zslab * a.kslab;
     const int kend = min(a.K, kbeg + a.kslab);
@@ -90,7 +90,12 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16tw_kernel(Args a)
     Pre<TM, TN> pre;
 
     const char* Ab = AF32 ? reinterpret_cast<const char*>(a.A) : reinterpret_cast<const char*>(a.A16);
-    const char* Bb = reinterpret_cast<const char*>(a.B16);
+    // B from its panel-blocked twin when the caller has one (untransposed B only): a 16-column tile's rows are then
+    // 32 contiguous bytes each, consecutive k contiguous -- whole cache lines instead of a quarter (plain panels) or
+    // a sixteenth (four 8-byte gate pieces per row of a row-major LSTM kernel) of every line pulled through the CU
+    const bool pnl = !TB && a.B16p != nullptr;
+    const char* Bb = reinterpret_cast<const char*>(pnl ? a.B16p : a.B16);
+    const unsigned pK16 = (unsigned)a.K * 16u;
     // tasks of one round, 16 bytes each.  k-contiguous bf16 operand: (image, row, slot g of 8 k) -- eight
     // consecutive lanes read one whole 128-byte row of an image.  fp32 A: (image, row, 4 k), rounded on the
     // way into LDS as the fp32-operand kernel does.  n-contiguous B: (image, k, 8 columns).
@@ -130,7 +135,9 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16tw_kernel(Args a)
                 const int c = t / (KB * 4), k = (t >> 2) % KB, gate = t & 3;
                 const int gn = gate * a.gstride + n0, gk = kr + c * KB + k;
                 const bool ok = (t < R * KB * 4) && n0 < a.gwidth && gk < kend;
-                vq[i] = ldg8u(Bb, ((unsigned)gk * (unsigned)a.ldb + (unsigned)gn) * 2u, ok);
+                const unsigned off = pnl ? (unsigned)(n0 >> 2) * pK16 + (unsigned)gk * 16u + (unsigned)gate * 4u
+                                         : (unsigned)gk * (unsigned)a.ldb + (unsigned)gn;
+                vq[i] = ldg8u(Bb, off * 2u, ok);
             }
         } else if (TB) {
 #pragma unroll
@@ -152,7 +159,9 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16tw_kernel(Args a)
                 const int gn = n0 + j * a.gstride + cc, cg = n0 + cc + (a.gstride == 16 ? j * 16 : 0);
                 const int gk = kr + c * KB + k;
                 const bool ok = (t < R * KB * (BN / 8)) && cg < a.gwidth && gn < a.N && gk < kend;
-                vb[i] = ldg16u(Bb, ((unsigned)gk * (unsigned)a.ldb + (unsigned)gn) * 2u, ok);
+                const unsigned off = pnl ? (unsigned)(gn >> 4) * pK16 + (unsigned)gk * 16u + (unsigned)(gn & 15)
+                                         : (unsigned)gk * (unsigned)a.ldb + (unsigned)gn;
+                vb[i] = ldg16u(Bb, off * 2u, ok);
             }
         }
     };
@@ -421,18 +430,27 @@ namespace airg {
 // Which (tile, epilogue, layout) combinations exist as twin kernels, and with how many images per round.
 // Returns R (> 0) or 0 when this descriptor has to take the fp32-operand kernels.
 int twin_rounds(const Args& a, int tm, int tn, bool ta, bool tb) {
-    if (ta || !a.B16 || getenv("AIR_GEMM_NO_TWINS") != nullptr) return 0;
+    // (a panel-blocked B twin serves the untransposed 16- / 32-column tiles and the four-unit LSTM tiles; everything
+    // else needs the row-major twin)
+    const bool pnl_tile = !tb && a.B16p != nullptr && ((tm == 1 && tn == 1) || (tm == 2 && tn == 2) || (tm == 1 && tn == 4));
+    if (ta || (!a.B16 && !pnl_tile) || getenv("AIR_GEMM_NO_TWINS") != nullptr) return 0;
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const bool af32 = a.A16 == nullptr;
     // whole 16-byte pieces only: the ragged shapes keep the fp32-operand kernels
     if (af32) { if (!al16(a.A) || (a.lda & 3) || (a.K & 3) || (a.kslab & 3)) return 0; }
     else if (!al16(a.A16) || (a.lda & 7) || (a.K & 7) || (a.kslab & 7)) return 0;
-    if (!al16(a.B16) || (a.ldb & 7)) return 0;
+    if (pnl_tile) { if (!al16(a.B16p)) return 0; }
+    else if (!al16(a.B16) || (a.ldb & 7)) return 0;
     if (tb) { if ((a.K & 7) || (a.kslab & 7)) return 0; }
     else if ((a.N & 7) || (a.gstride & 7) || (a.gwidth & 7)) return 0;
     const int nimg = images_of(a);
     const int e = a.epi;
     if (tm == 1 && tn == 1) {
+        // the hoisted x.Wx carrying the first LSTM step: four-unit tiles over the WHOLE contraction, fp32 or twin A
+        // (K <= 2560: all 40 images in ONE round -- one memory round trip, 160 KB of LDS, one workgroup per CU)
+        if (e == AIR_EPI_LSTM_FWD0)
+            return (!tb && (a.gwidth & 3) == 0 && (int)((a.K + a.kslab - 1) / a.kslab) == 1)
+                       ? ((nimg <= 40 && nimg > 16 && getenv("AIR_FWD0_ROUNDS") == nullptr) ? 40 : 16) : 0;
         if (af32) return 0;
         if (e == AIR_EPI_GENERIC || ((e == AIR_EPI_LSTM_BWD || e == AIR_EPI_LSTM_BWD_TAIL) && tb)) return nimg <= 4 ? 4 : (nimg <= 8 ? 8 : 16);
         return 0;
@@ -449,6 +467,11 @@ int twin_launch(const Args& a, int tm, int tn, bool tb, dim3 grid, hipStream_t s
     const bool af32 = a.A16 == nullptr;
     const int e = a.epi;
 #define TW(TM_, TN_, TB_, EPI__, AF_, R_) return launch_one<TM_, TN_, TB_, EPI__, AF_, R_>(a, grid, s)
+    if (tm == 1 && tn == 1 && e == AIR_EPI_LSTM_FWD0) {
+        if (r == 40) { if (af32) TW(1, 1, false, AIR_EPI_LSTM_FWD0, true, 40); TW(1, 1, false, AIR_EPI_LSTM_FWD0, false, 40); }
+        if (af32) TW(1, 1, false, AIR_EPI_LSTM_FWD0, true, 16);
+        TW(1, 1, false, AIR_EPI_LSTM_FWD0, false, 16);
+    }
     if (tm == 1 && tn == 1) {
         if (e == AIR_EPI_GENERIC) {
             if (tb) { if (r == 4) TW(1, 1, true, AIR_EPI_GENERIC, false, 4); if (r == 8) TW(1, 1, true, AIR_EPI_GENERIC, false, 8); TW(1, 1, true, AIR_EPI_GENERIC, false, 16); }
@@ -469,7 +492,11 @@ int twin_launch(const Args& a, int tm, int tn, bool tb, dim3 grid, hipStream_t s
             }
             return launch_one<1, 1, false, EPI_LSTM_FWD_Q, false, 4>(b, gq, s);
         }
-        TW(1, 4, false, AIR_EPI_LSTM_FWD, false, 4);
+        // (the wide tiles read the row-major twin: a gate-interleaved panel twin is laid out for the four-unit tiles only)
+        if (!a.B16) return AIR_EINVAL;
+        Args w = a;
+        w.B16p = nullptr;
+        return launch_one<1, 4, false, AIR_EPI_LSTM_FWD, false, 4>(w, grid, s);
     }
     if (tm == 2 && tn == 2) {
         if (af32) TW(2, 2, false, AIR_EPI_GENERIC, true, 8);
@@ -511,6 +538,11 @@ int xw_tp_launch(const Args& a0, int job_planes_hint, hipStream_t s) {
 void twin_kernel_name(const Args& a, int tm, int tn, bool tb, char* buf, int n) {
     if (tm == 1 && tn == 4 && (a.gwidth & 3) == 0 && getenv("AIR_LSTM_FWD_WIDE") == nullptr) {
         snprintf(buf, n, "gemm_bf16tw_kernel<1, 1, false, %d, false, 4>", EPI_LSTM_FWD_Q);
+        return;
+    }
+    if (tm == 1 && tn == 1 && a.epi == AIR_EPI_LSTM_FWD0) {
+        snprintf(buf, n, "gemm_bf16tw_kernel<1, 1, false, %d, %s, %d>", AIR_EPI_LSTM_FWD0, a.A16 == nullptr ? "true" : "false",
+                 twin_rounds(a, tm, tn, false, tb));
         return;
     }
     snprintf(buf, n, "gemm_bf16tw_kernel<%d, %d, %s, %d, %s, %d>", tm, tn, tb ? "true" : "false", a.epi,

@@ -52,6 +52,9 @@ struct Args {
     // to C / q0 / q2 for the GEMMs that consume its output.
     const unsigned short* A16; const unsigned short* B16;
     unsigned short* C16; unsigned short* q0_16; unsigned short* q2_16;
+    // panel-blocked twin of an untransposed B (air_gemm_t.B16p): element (k, n) at (n / 16) * K * 16 + k * 16 + n % 16;
+    // gate-interleaved panels (unit quad p: [k][gate][4 units]) for the four-unit LSTM tiles
+    const unsigned short* B16p;
     // optional step prologue (schedules + Philox noise) carried by the workgroups of an extra grid.z
     // plane: the hoisted x.Wx launch needs neither, so the prologue costs no launch of its own
     int job_on; AirStepJob job;   // job_on = number of grid.z planes given to the prologue (0 = none)
@@ -129,6 +132,9 @@ __device__ __forceinline__ void epilogue_prefetch(const Args& a, Pre<TM, TN>& pr
                 for (int k = 0; k < 4; ++k)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) pre.f[j * 8 + k] = a.addend[k * a.add_slab_stride + base + (size_t)j * R];
+            } else if (a.add_slabs == 1) {                 // x.Wx left whole by the launch that also ran the first step
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pre.f[j * 8] = a.addend[base + (size_t)j * R];
             } else {
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
