@@ -22,7 +22,7 @@ def H():
 
 
 def _p(t):
-    return C.c_void_p(t.data_ptr())
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
 def _stream():
@@ -1431,3 +1431,144 @@ def test_gemm_lstm_tiles_read_gate_interleaved_panels_bit_identically(H):
         sig = lambda v: 1.0 / (1.0 + np.exp(-v))  # noqa: E731
         cn = c_prev.cpu().numpy() * sig(pre[:, 2 * R:3 * R] + 1.0) + sig(pre[:, :R]) * np.tanh(pre[:, R:2 * R])
         np.testing.assert_allclose(res2[0][1].cpu().numpy(), cn, atol=5e-5)
+
+
+@pytest.mark.parametrize("Cc,w,N,B,Z", [(50, 28, 3, 6, 50), (128, 28, 5, 4, 50), (33, 17, 4, 5, 7)])
+def test_compose_in_bands_is_bit_identical_to_one_workgroup_per_image(H, Cc, w, N, B, Z):
+    """air_write_fwd with rec_part (an image's 1024 virtual threads as four workgroups of 256, grid B x 4) + the sums
+    completed by the next launch (air_finalize_parts after a plain forward; air_write_bwd's finisher in a train step)
+    == the one-workgroup launch + air_finalize, BIT FOR BIT: reconstruction, its gradient, KLs, running loss, digit
+    counts, reconstruction_loss, per-item ELBO and the batch means (air_model.py:351-366, 429-439, 580-611)."""
+    rng = np.random.RandomState(Cc + N)
+    lib = H.lib()
+    att = np.zeros((N, B, H.ATT_STRIDE), np.float32)
+    att[:, :, H.ATT_S] = rng.uniform(0.2, 0.7, (N, B)); att[:, :, H.ATT_X] = rng.uniform(-0.7, 0.7, (N, B))
+    att[:, :, H.ATT_Y] = rng.uniform(-0.7, 0.7, (N, B)); att[:, :, H.ATT_Z] = rng.uniform(0.2, 1.0, (N, B))
+    alive = np.cumprod(rng.uniform(0, 1, (N, B)) < 0.8, axis=0).astype(np.float32)
+    att[:, :, H.ATT_MASK] = alive
+    att[1:, :, H.ATT_MASK_PREV] = alive[:-1]; att[0, :, H.ATT_MASK_PREV] = 1.0
+    for k in (H.ATT_KL_Z, H.ATT_KL_SCALE, H.ATT_KL_SHIFT):
+        att[:, :, k] = rng.uniform(0, 3, (N, B))
+    vrec = rng.uniform(0, 1, (N, B, w * w)).astype(np.float32)
+    ml = rng.uniform(-1, 1, (N, B, 2 * Z)).astype(np.float32)
+    images = (rng.uniform(0, 1, (B, Cc * Cc)) * (rng.uniform(0, 1, (B, Cc * Cc)) < 0.2)).astype(np.float32)
+    targets = rng.randint(0, N + 1, B).astype(np.int32)
+    dyn = np.zeros(H.DYN_COUNT, np.float32)
+    dyn[H.DYN_VAE_PM], dyn[H.DYN_VAE_PV], dyn[H.DYN_VAE_PLV], dyn[H.DYN_GRAD_SCALE] = 0.0, 1.0, 0.0, 1.0 / B
+    t = lambda a_, dt=torch.float32: torch.tensor(a_, dtype=dt, device="cuda")  # noqa: E731
+    vrec_d, ml_d, img_d, dyn_d, tg_d = t(vrec), t(ml), t(images), t(dyn), t(targets, torch.int32)
+    res = {}
+    for mode in ("one", "bands", "bands2", "bands_train"):
+        att_d = t(att)
+        recon, d_recon = torch.full((B, Cc * Cc), 7.0, device="cuda"), torch.full((B, Cc * Cc), 7.0, device="cuda")
+        rec_loss, run_loss, loss_item, scal = (torch.full((n_,), 7.0, device="cuda") for n_ in (B, B, B, 4))
+        digits = torch.full((B,), 7, dtype=torch.int32, device="cuda")
+        part = torch.full((B, 16), 7.0, device="cuda") if mode != "one" else None
+        wf = H.WriteFwd(_p(vrec_d), _p(ml_d), _p(img_d), _p(dyn_d), _p(att_d), _p(recon), _p(rec_loss), _p(d_recon),
+                        _p(run_loss), _p(digits), _p(loss_item), B, N, Cc, w, Z, _p(part), 2 if mode == "bands2" else 0)
+        H.check(lib.air_write_fwd(C.byref(wf), _stream()), "air_write_fwd")
+        if mode == "one":
+            H.check(lib.air_finalize(_p(run_loss), _p(rec_loss), _p(tg_d), _p(digits), _p(loss_item), _p(scal), B, _stream()))
+        elif mode in ("bands", "bands2"):
+            torch.cuda.synchronize()
+            assert float(rec_loss[0]) == 7.0 and float(loss_item[0]) == 7.0        # not written by the banded launch itself
+            H.check(lib.air_finalize_parts(_p(run_loss), _p(part), _p(rec_loss), _p(tg_d), _p(digits), _p(loss_item), _p(scal), B, _stream()))
+        else:
+            dgen, dsx = torch.zeros(N, B, w * w, device="cuda"), torch.zeros(N, B, 4, device="cuda")
+            wb = H.WriteBwd(_p(d_recon), _p(vrec_d), _p(att_d), _p(dgen), _p(dsx), B, N, Cc, w, 2, None, _p(tg_d), _p(digits), _p(scal),
+                            None, _p(part), _p(run_loss), _p(rec_loss), _p(loss_item))
+            H.check(lib.air_write_bwd(C.byref(wb), _stream()), "air_write_bwd")
+        torch.cuda.synchronize()
+        res[mode] = [recon, d_recon, rec_loss, run_loss, loss_item, digits, scal[:2].clone(), att_d]
+    for mode in ("bands", "bands2", "bands_train"):
+        for a0, a1 in zip(res["one"], res[mode]):
+            assert torch.equal(a0, a1), mode
+    assert float(res["one"][2].abs().min()) > 0 and bool(torch.isfinite(res["one"][6]).all())
+    # a finisher that is given the partials but not the buffers to complete is refused
+    wb = H.WriteBwd(_p(d_recon), _p(vrec_d), _p(att_d), _p(dgen), _p(dsx), B, N, Cc, w, 2, None, _p(tg_d), _p(digits), _p(scal),
+                    None, _p(part), None, None, None)
+    assert lib.air_write_bwd(C.byref(wb), _stream()) == -1
+
+
+def test_weight_gradient_tiles_ride_in_the_bptt_gemm_launches(H):
+    """air_gemm_t.rider_table: trailing workgroups of an AIR_EPI_LSTM_BWD / LSTM_BWD_TAIL launch compute tiles of a grouped
+    weight-gradient table; air_wgrad_grouped_skip then runs the rest.  dW, db and every global-norm partial slot are
+    BIT-IDENTICAL to the one grouped launch, the carrying product is unchanged, and launches that cannot carry riders
+    refuse them (MatMul_grad / BiasAdd_grad of the VAE variables, air_model.py:651-694 via vae.py:13-34)."""
+    dev, lib = "cuda", H.lib()
+    rng = np.random.RandomState(51)
+    f = lambda *s: torch.tensor(rng.uniform(-1, 1, s).astype(np.float32), device=dev)  # noqa: E731
+    i16 = lambda *s: torch.zeros(*s, dtype=torch.int16, device=dev)  # noqa: E731
+    K = 192
+    shapes = [(256, 1024), (784, 512), (512, 256), (256, 100), (512, 784), (50, 256)]        # (M, N): first and last do not ride
+    ops = []
+    for M, N in shapes:
+        A, dY = f(K, M), f(K, N)
+        ops.append((A, dY, _bf16_twin(H, A), _bf16_twin(H, dY)))
+
+    def problems(outs):
+        return (H.Wgrad * len(shapes))(*[H.Wgrad(_p(A), _p(dY), _p(dW), _p(db), M, N, K, M, N, N, 0, 0, 0, 0, _p(A16), _p(dY16))
+                                         for (M, N), (A, dY, A16, dY16), (dW, db) in zip(shapes, ops, outs)])
+    mk = lambda: [(torch.full((M, N), 7.0, device=dev), torch.full((N,), 7.0, device=dev)) for M, N in shapes]  # noqa: E731
+    ref, got = mk(), mk()
+    total = lib.air_wgrad_num_blocks(problems(ref), len(shapes))
+    p_ref, p_got = torch.full((total,), 7.0, device=dev), torch.full((total,), 7.0, device=dev)
+    ist = torch.zeros(H.IST_COUNT, dtype=torch.int32, device=dev)
+    H.check(lib.air_wgrad_grouped(problems(ref), len(shapes), 1, _p(p_ref), _p(ist), _stream()))
+    # riders: problems 1..4 (contiguous tile range), carried by two GEMM launches; the rest by the skip launch
+    pr = problems(got)
+    f0, n0, f1, n1 = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    H.check(lib.air_wgrad_problem_blocks(pr, len(shapes), 1, C.byref(f0), C.byref(n0)))
+    H.check(lib.air_wgrad_problem_blocks(pr, len(shapes), 4, C.byref(f1), C.byref(n1)))
+    first, count = f0.value, f1.value + n1.value - f0.value
+    assert first == 64 and count == 13 * 8 + 8 * 4 + 4 * 2 + 8 * 13
+    host = C.create_string_buffer(lib.air_wgrad_table_bytes())
+    assert lib.air_wgrad_table_fill(pr, len(shapes), host) == total
+    table = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(dev)
+    # the carrying products: a BPTT step (64 workgroups of its own) and the heads' d h with the last step's cell backward
+    Bn, R, HT = 64, 256, 320
+    acts, c_prev, c0, dc_in = f(Bn, 4 * R).abs() * 0.5, f(Bn, R), f(Bn, R), f(Bn, R)
+    dgn, dh_heads, Wh = f(Bn, 4 * R), f(Bn, R), f(R, 4 * R) * 0.1
+    dgn16, Wh16 = _bf16_twin(H, dgn), _bf16_twin(H, Wh)
+    d_hid, Whid = f(3 * Bn, HT), f(R, HT) * 0.1
+    d_hid16, Whid16 = _bf16_twin(H, d_hid), _bf16_twin(H, Whid)
+    half = count // 3
+    res = {}
+    for ride in (False, True):
+        # (C of the fused BPTT launch is scratch the epilogue does not write: zeros on both sides)
+        dh, dg, dcp, ds = torch.zeros(Bn, R, device=dev), f(Bn, 4 * R), f(Bn, R), torch.zeros(Bn, 4 * R, device=dev)
+        kw = dict(transB=1, addend=dh_heads, ldadd=R, epi=H.EPI_LSTM_BWD, p0=acts, p1=c_prev, p2=c0, p3=dc_in, q0=dg, q1=dcp, q2=ds, i0=0,
+                  A16=dgn16, B16=Wh16)
+        if ride:
+            kw.update(rider_table=table, rider_first=first, rider_count=half, rider_sq=p_got)
+        g1 = _gemm_struct(H, dgn, Wh, dh, Bn, R, 4 * R, 4 * R, 4 * R, R, 1, **kw)
+        assert "tw_kernel" in _kernel_name(H, g1)
+        H.check(lib.air_gemm(C.byref(g1), _stream()))
+        dhh, dg2, dcp2, ds2 = f(3 * Bn, R), f(Bn, 4 * R), f(Bn, R), f(Bn, 4 * R)
+        kw = dict(transB=1, epi=H.EPI_LSTM_BWD_TAIL, i0=2 * Bn, p0=acts, p1=c_prev, p2=c0, q0=dg2, q1=dcp2, q2=ds2, A16=d_hid16, B16=Whid16)
+        if ride:
+            kw.update(rider_table=table, rider_first=first + half, rider_count=count - half, rider_sq=p_got)
+        g2 = _gemm_struct(H, d_hid, Whid, dhh, 3 * Bn, R, HT, HT, HT, R, 1, **kw)
+        H.check(lib.air_gemm(C.byref(g2), _stream()))
+        torch.cuda.synchronize()
+        res[ride] = (dh, dg, dcp, ds, dhh[:2 * Bn].clone(), dg2, dcp2, ds2)
+    for a0, a1 in zip(res[False], res[True]):
+        assert torch.equal(a0, a1)                                   # the carrying products do not notice their riders
+    ist2 = torch.zeros(H.IST_COUNT, dtype=torch.int32, device=dev)
+    H.check(lib.air_wgrad_grouped_skip(pr, len(shapes), 1, _p(p_got), _p(ist2), first, count, _stream()))
+    torch.cuda.synchronize()
+    assert int(ist2[0]) == 1 and int(ist[0]) == 1
+    assert torch.equal(p_ref, p_got) and float(p_ref.min()) > 0 and not bool((p_ref == 7.0).any())
+    for (dW0, db0), (dW1, db1) in zip(ref, got):
+        assert torch.equal(dW0, dW1) and torch.equal(db0, db1)
+    # refused: riders on a launch that has no rider code, a skip range that holds tile 0, riders without twin operands
+    Ct = torch.zeros(Bn, R, device=dev)
+    g = _gemm_struct(H, dgn, Wh, Ct, Bn, R, 4 * R, 4 * R, 4 * R, R, 1, transB=1, A16=dgn16, B16=Wh16, rider_table=table, rider_first=first,
+                     rider_count=4, rider_sq=p_got)
+    assert lib.air_gemm(C.byref(g), _stream()) == -1
+    kw = dict(transB=1, addend=dh_heads, ldadd=R, epi=H.EPI_LSTM_BWD, p0=acts, p1=c_prev, p2=c0, p3=dc_in, q0=dg, q1=dcp, q2=ds, i0=0,
+              rider_table=table, rider_first=first, rider_count=4, rider_sq=p_got)
+    g = _gemm_struct(H, dgn, Wh, dh, Bn, R, 4 * R, 4 * R, 4 * R, R, 1, **kw)            # fp32 operands: the fp32-operand kernel
+    assert lib.air_gemm(C.byref(g), _stream()) == -1
+    assert lib.air_wgrad_grouped_skip(pr, len(shapes), 1, _p(p_got), _p(ist2), 0, 8, _stream()) == -1
+    assert lib.air_wgrad_grouped_skip(pr, len(shapes), 1, _p(p_got), _p(ist2), total - 4, 8, _stream()) == -1

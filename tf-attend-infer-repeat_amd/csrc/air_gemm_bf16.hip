@@ -22,6 +22,7 @@
 // the fp32-operand bf16 path (tests/test_gpu_kernels.py::test_gemm_bf16_twins_bit_identical).
 // A may stay fp32 (AF32: the hoisted x.Wx reads the caller's fp32 image batch).
 #include "air_gemm_common.h"
+#include "air_wgrad_tile.h"
 #include <atomic>
 #include <cstdlib>
 #include <cstdio>
@@ -70,7 +71,19 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16tw_kernel(Args a)
         air_step_job_run(a.job, blockIdx.z * plane + (long)blockIdx.y * gridDim.x + blockIdx.x, plane * a.job_on);
         return;
     }
-    const int nslab = (int)gridDim.z - a.job_on;
+    // weight-gradient riders: the last planes (dispatched behind the product's own workgroups).  Only the kernels at
+    // the end of the backward chain are instantiated with the code (the launcher refuses riders elsewhere).
+    constexpr bool RIDES = TM == 1 && TN == 1 && TB && (EPI_ == AIR_EPI_LSTM_BWD || EPI_ == AIR_EPI_LSTM_BWD_TAIL);
+    if (RIDES && (int)blockIdx.z >= (int)gridDim.z - a.rider_planes) {
+        const int plane = (int)(gridDim.x * gridDim.y);
+        const int r = ((int)blockIdx.z - ((int)gridDim.z - a.rider_planes)) * plane + (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
+        if (r < a.rider_count)
+            airw::run_tile_bf16(*reinterpret_cast<const airw::Table*>(a.rider_tab), a.rider_first + r,
+                                reinterpret_cast<unsigned short*>(Lds), a.rider_sq, nullptr,
+                                reinterpret_cast<float*>(Lds + sizeof(unsigned short) * 2 * airw::NIMG_W * airw::BT * airw::KB));
+        return;
+    }
+    const int nslab = (int)gridDim.z - a.job_on - (RIDES ? a.rider_planes : 0);
     const int zslab = (int)blockIdx.z - a.job_on;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int tile_m, tile_n;
@@ -310,15 +323,23 @@ __global__ __launch_bounds__(THREADS) void gemm_xw_tp_kernel(Args a)
         return;
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // XCD-aware map for the BIG operand: the image batch (16.8 MB fp32) does not fit an L2 (4 MB per XCD), but the
-    // [64 rows x K-slab] panel one (row tile, slab) pair needs does (0.5 MB) -- so all column tiles of a pair run on ONE
-    // XCD (workgroup b runs on XCD b % 8): the panel is fetched from memory once and its 16 users hit in that L2
+    // XCD-aware map (workgroup b runs on XCD b % 8, each XCD with its own 4 MB L2).  Round 3 kept all column tiles of a
+    // (row tile, slab) pair on one XCD: the fp32 A panel of the pair came from memory once -- but the four row tiles that
+    // share a B panel (the bf16 shadow of Wx: 33.5 MB, the BIGGER operand) then sat on four different XCDs, and the
+    // counters showed it: 167 MB read for 50 MB of operands.  Now a K SLAB is an XCD's: all (row tile, column tile) pairs
+    // of slab z run on XCD z % 8, stepping through k together (two workgroups per CU, 64 per XCD at the stress shape), so
+    // every line of BOTH operands is fetched from memory by one L2 only and its other users hit there.
+    // AIR_XW_TP_MAP=pair restores the old map (A/B).
     int tile_m = blockIdx.y, tile_n = blockIdx.x, zslab = (int)blockIdx.z;
     {
         const int nx = gridDim.x, ny = gridDim.y, pairs = ny * nz;
-        if ((pairs & 7) == 0) {
-            const int lin = (zslab * ny + (int)blockIdx.y) * nx + (int)blockIdx.x;
-            const int xcd = lin & 7, slot = lin >> 3;
+        const int lin = (zslab * ny + (int)blockIdx.y) * nx + (int)blockIdx.x;
+        const int xcd = lin & 7, slot = lin >> 3;
+        if (a.i1 == 0 && (nz & 7) == 0) {
+            zslab = xcd + 8 * (slot / (nx * ny));
+            const int rem = slot % (nx * ny);
+            tile_n = rem % nx; tile_m = rem / nx;
+        } else if ((pairs & 7) == 0) {
             const int pair = xcd + 8 * (slot / nx);
             tile_n = slot % nx; tile_m = pair % ny; zslab = pair / ny;
         }
@@ -411,12 +432,24 @@ __global__ __launch_bounds__(THREADS) void gemm_xw_tp_kernel(Args a)
 }
 
 template <int TM, int TN, bool TB, int EPI_, bool AF32, int R>
-int launch_one(const Args& a, dim3 grid, hipStream_t s) {
+int launch_one(const Args& a0, dim3 grid, hipStream_t s) {
     using Cfg = TwCfg<TM, TN, R>;
     auto kern = gemm_bf16tw_kernel<TM, TN, TB, EPI_, AF32, R>;
-    const int rc = air_grant_lds(reinterpret_cast<const void*>(kern), Cfg::BYTES);
+    Args a = a0;
+    size_t lds = Cfg::BYTES;
+    a.rider_planes = 0;
+    if (a.rider_count > 0) {
+        constexpr bool RIDES = TM == 1 && TN == 1 && TB && (EPI_ == AIR_EPI_LSTM_BWD || EPI_ == AIR_EPI_LSTM_BWD_TAIL);
+        if (!RIDES || !a.rider_tab) return AIR_EINVAL;
+        const int plane = (int)(grid.x * grid.y);
+        a.rider_planes = (a.rider_count + plane - 1) / plane;
+        grid.z += a.rider_planes;
+        const size_t need = sizeof(unsigned short) * 2 * airw::NIMG_W * airw::BT * airw::KB + 16;    // the tile's images / fp32 output tile + the norm reduction
+        if (lds < need) lds = need;
+    }
+    const int rc = air_grant_lds(reinterpret_cast<const void*>(kern), lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(kern, grid, dim3(THREADS), Cfg::BYTES, s, a);
+    hipLaunchKernelGGL(kern, grid, dim3(THREADS), lds, s, a);
     AIR_CHECK_LAUNCH();
     return 0;
 }
@@ -530,6 +563,7 @@ int xw_tp_launch(const Args& a0, int job_planes_hint, hipStream_t s) {
     (void)job_planes_hint;
     grid.z = (a.K + a.kslab - 1) / a.kslab + a.job_on;
     a.slab_stride = (long)a.M * a.ldc;
+    { const char* e = getenv("AIR_XW_TP_MAP"); a.i1 = (e && e[0] == 'p') ? 1 : 0; }      // (i1: unused by this kernel otherwise)
     hipLaunchKernelGGL(gemm_xw_tp_kernel, grid, dim3(THREADS), 0, s, a);
     AIR_CHECK_LAUNCH();
     return 0;

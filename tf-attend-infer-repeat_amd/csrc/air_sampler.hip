@@ -625,13 +625,22 @@ __global__ __launch_bounds__(THREADS) void attend_bwd_kernel(air_attend_bwd_t a)
 // reconstruction loss + its gradient (air_model.py:351-366, 409-439, 479-496,
 // 580-593).  One workgroup per image.
 // ---------------------------------------------------------------------------
-// 16 waves per workgroup (one workgroup per image): the pixel loop is a chain of dependent LDS
-// gathers and two logf per pixel; 4 waves per SIMD hide that latency
+// 16 waves per image: the pixel loop is a chain of dependent LDS gathers and two logf per pixel; 4 waves per SIMD hide
+// that latency.  BANDS = false: ONE workgroup of 1024 threads per image (any caller of the C ABI).  BANDS = true (the
+// model's launch, a.rec_part given): the same 1024 "virtual threads" of an image are FOUR workgroups of 256 (grid
+// B x 4) -- 256 workgroups at B = 64 instead of 64, one per CU.  Virtual thread v = band * 256 + tid owns the pixels
+// v, v + 1024, ... exactly as before, so every per-thread and per-wave partial sum of the Bernoulli cross-entropy is
+// unchanged; the 16 wave partials go to rec_part[b][16] and whoever runs next (air_write_bwd's finisher, air_finalize)
+// adds them in the old order: reconstruction_loss and the ELBO are BIT-IDENTICAL to the one-workgroup form.  Band 0
+// also does the per-image bookkeeping (KLs, running loss, digit count).
 constexpr int CF_THREADS = 1024;
-__global__ __launch_bounds__(CF_THREADS) void write_fwd_kernel(air_write_fwd_t a)
+constexpr int CF_BANDS = 4;
+template <int NT, bool BANDS>
+__global__ __launch_bounds__(NT) void write_fwd_kernel(air_write_fwd_t a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, band = BANDS ? (int)blockIdx.y : 0, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int vt = band * NT + tid;                                       // virtual thread of the image, 0 .. 1023
     const int C = a.C, w = a.w, Z = a.Z, N = a.N, B = a.B;
     float* sh_red = smem;                                    // [16]
     float* sh_z = smem + 16;                                 // [MAX_STEPS] z_pres
@@ -642,22 +651,34 @@ __global__ __launch_bounds__(CF_THREADS) void write_fwd_kernel(air_write_fwd_t a
     Tap* sh_ty = sh_tx + (size_t)N * C;                                    // [N][C]
     float* sh_win = reinterpret_cast<float*>(sh_ty + (size_t)N * C);      // [N][w*w]
     const float* dyn = a.dyn;
+    const size_t base = (size_t)b * C * C;
+    const int CC = C * C;
+
+    // the image pixels of this thread do not depend on anything computed here: on small canvases (<= 4 per thread) their
+    // loads go out with phase A's -- one memory round trip instead of two
+    constexpr int XPRE = 4;
+    const bool xpre = CC <= XPRE * CF_THREADS;
+    float xs[XPRE];
+#pragma unroll
+    for (int k = 0; k < XPRE; ++k) { const int p = vt + k * CF_THREADS; xs[k] = a.images[base + ((xpre && p < CC) ? p : 0)]; }
 
     // phase A -- everything that only needs the per-step records, for all steps at once
     // (independent loads: one memory round trip instead of one per step)
-    for (int t = wave; t < N; t += CF_THREADS / 64) {
-        // VAE KL :479-493 (a public output whether or not the item is still active): one wave per step
-        const float* ml = a.ml + ((size_t)t * B + b) * 2 * Z;
-        const float pv = dyn[AIR_DYN_VAE_PV], pm = dyn[AIR_DYN_VAE_PM], plv = dyn[AIR_DYN_VAE_PLV];
-        float klt = 0.0f;
-        for (int j = lane; j < Z; j += 64) {
-            const float lv = ml[Z + j];
-            klt += gauss_kl_term(plv, lv, expf(lv), pv, ml[j], pm);
+    if (band == 0) {
+        for (int t = wave; t < N; t += NT / 64) {
+            // VAE KL :479-493 (a public output whether or not the item is still active): one wave per step
+            const float* ml = a.ml + ((size_t)t * B + b) * 2 * Z;
+            const float pv = dyn[AIR_DYN_VAE_PV], pm = dyn[AIR_DYN_VAE_PM], plv = dyn[AIR_DYN_VAE_PLV];
+            float klt = 0.0f;
+            for (int j = lane; j < Z; j += 64) {
+                const float lv = ml[Z + j];
+                klt += gauss_kl_term(plv, lv, expf(lv), pv, ml[j], pm);
+            }
+            klt = air_wave_sum(klt);
+            if (lane == 0) sh_kl[t] = 0.5f * klt;
         }
-        klt = air_wave_sum(klt);
-        if (lane == 0) sh_kl[t] = 0.5f * klt;
     }
-    for (int it = tid; it < N * C; it += CF_THREADS) {
+    for (int it = tid; it < N * C; it += NT) {
         const int t = it / C, j = it % C;
         const float* at = a.att + ((size_t)t * B + b) * AIR_ATT_STRIDE;
         // theta_recon :353-356
@@ -666,7 +687,7 @@ __global__ __launch_bounds__(CF_THREADS) void write_fwd_kernel(air_write_fwd_t a
         sh_tx[it] = axis_tap(j, C, w, ia, bx);
         sh_ty[it] = axis_tap(j, C, w, ia, by);
     }
-    for (int it = tid; it < N * w * w; it += CF_THREADS) {
+    for (int it = tid; it < N * w * w; it += NT) {
         const int t = it / (w * w);
         sh_win[it] = a.vrec[((size_t)t * B + b) * w * w + (it - t * w * w)];
     }
@@ -682,7 +703,7 @@ __global__ __launch_bounds__(CF_THREADS) void write_fwd_kernel(air_write_fwd_t a
     }
     __syncthreads();
     float Lkeep = 0.0f;
-    if (tid == 0) {
+    if (tid == 0 && band == 0) {
         // running loss in the reference order: z KL (old mask), scale, shift, VAE KL (new mask) :411-493
         float L = 0.0f;
         int digits = 0;
@@ -703,12 +724,17 @@ __global__ __launch_bounds__(CF_THREADS) void write_fwd_kernel(air_write_fwd_t a
 
     // phase B -- canvas + Bernoulli cross-entropy, pixel by pixel
     const float gsc = dyn[AIR_DYN_GRAD_SCALE];
-    const size_t base = (size_t)b * C * C;
     float acc = 0.0f;
     const int di = CF_THREADS / C, dj = CF_THREADS % C;
-    int i = tid / C, j = tid % C;
-    for (int p = tid; p < C * C; p += CF_THREADS) {
-        const float x = a.images[base + p];
+    int i = vt / C, j = vt % C;
+    int k = 0;
+    for (int p = vt; p < CC; p += CF_THREADS, ++k) {
+        float x;
+        if (xpre) {                                                 // (k < XPRE whenever xpre: a compile-time-indexed pick)
+            x = xs[0];
+#pragma unroll
+            for (int q = 1; q < XPRE; ++q) x = (k == q) ? xs[q] : x;
+        } else x = a.images[base + p];
         float R = 0.0f;                                             // running_recon :552
         for (int t = 0; t < N; ++t) {
             if (!sh_act[t]) continue;                               // where(active, z*w, 0) :433-439
@@ -729,7 +755,13 @@ __global__ __launch_bounds__(CF_THREADS) void write_fwd_kernel(air_write_fwd_t a
             a.d_recon[base + p] = pass ? -gsc * (x / p1 - (1.0f - x) / p0) : 0.0f;
         }
     }
-    acc = air_block_sum_n<CF_THREADS / 64>(acc, sh_red);
+    if (BANDS) {
+        // this band's four wave sums; the 16 of an image are added ((w0 + w1) + ...) + w15 by the consumer
+        acc = air_wave_sum(acc);
+        if (lane == 0) a.rec_part[(size_t)b * 16 + (vt >> 6)] = acc;
+        return;
+    }
+    acc = air_block_sum_n<NT / 64>(acc, sh_red);
     if (tid == 0) {
         const float rl = -acc;
         a.rec_loss[b] = rl;
@@ -765,7 +797,8 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_kernel(air_write_bwd_t a
         // loss = mean(loss_item) :593,610; accuracy = mean(target == digits) :597-611 (air_finalize)
         float r4[4] = {0.f, 0.f, 0.f, 0.f};
         for (int i = tid; i < a.B; i += WB_THREADS) {
-            r4[0] += a.fin_loss_item[i];
+            // (banded compose: the per-image sums are finished here, air_write_fwd_t.rec_part)
+            r4[0] += a.fin_rec_part ? air_compose_finish(a.fin_rec_part, a.fin_run_loss, a.fin_rec_loss, a.fin_loss_item_out, i) : a.fin_loss_item[i];
             r4[1] += (a.fin_targets[i] == a.fin_digits[i]) ? 1.0f : 0.0f;
         }
         air_block_sum4<WB_THREADS / 64>(r4, sh_red);
@@ -1051,8 +1084,10 @@ template <bool ALLPH>
 __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_bwd_t a, int seq_flags)
 {
     // seq_flags (accumulators(), below): bit 0 the LDS atomic pipe applies lanes in order, bit 1 the lane-ring accumulator
-    // is exact on this part (used when the pipe is not)
+    // is exact on this part (used when the pipe is not); bits 8..15: pipe / ring MIX factor c in sixteenths (0 = every
+    // corner on the pipe), see pipe_mask below
     const bool lds_ordered = seq_flags & 1, ring_ok = seq_flags & 2;
+    const int mix16 = (seq_flags >> 8) & 0xff;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x, t = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NW = WB_THREADS / 64;
@@ -1078,7 +1113,8 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
     if (a.fin_scalars && b == 0 && t == 0) {
         float r4[4] = {0.f, 0.f, 0.f, 0.f};
         for (int i = tid; i < a.B; i += WB_THREADS) {
-            r4[0] += a.fin_loss_item[i];
+            // (banded compose: the per-image sums are finished here, air_write_fwd_t.rec_part)
+            r4[0] += a.fin_rec_part ? air_compose_finish(a.fin_rec_part, a.fin_run_loss, a.fin_rec_loss, a.fin_loss_item_out, i) : a.fin_loss_item[i];
             r4[1] += (a.fin_targets[i] == a.fin_digits[i]) ? 1.0f : 0.0f;
         }
         air_block_sum4<NW>(r4, sh_red);
@@ -1150,8 +1186,47 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
         const int* r1 = sh_run + ((2 * ax + 1) * w + tp.i1) * 2;
         (ax ? sh_ri : sh_ci)[J] = make_int4(r0[0], r0[1] - r0[0] + 1, r1[0], r1[1] - r1[0] + 1);
     }
+    // terms of corner slot c over its four taps (sh_red[64 + 8 * NW ..] is free until the pixel loop's partials are combined)
+    int* sh_cn = reinterpret_cast<int*>(sh_acc) + 4;       // [4] (the pad words behind the four accumulators)
+    if (tid < 4) {
+        int tot = 0;
+        for (int ph = 0; ph < 4; ++ph) {
+            const int xa = ph >> 1, ya = 2 + (ph & 1), q = (tid & 1) ? w - 1 : 0, pp = (tid & 2) ? w - 1 : 0;
+            const int ncols = sh_run[(xa * w + q) * 2 + 1] - sh_run[(xa * w + q) * 2] + 1;
+            const int nrows = sh_run[(ya * w + pp) * 2 + 1] - sh_run[(ya * w + pp) * 2] + 1;
+            tot += max(nrows, 0) * max(ncols, 0);
+        }
+        sh_cn[tid] = tot;
+    }
     __syncthreads();
     AIR_STAMP(42);
+    // Which corners go through the LDS atomic pipe and which through lane rings (block-uniform, bit c = corner c on the
+    // pipe).  The pipe is ONE per CU -- every resident workgroup's corner streams queue on it at ~4 cycles per term --
+    // while a ring is private to its wave at ~12 cycles per term: with several workgroups per CU (large canvases: five per
+    // CU, two resident) the pipe is the launch's bottleneck (245 of 252 us at 128 x 128) although the rings would be idle.
+    // Cost model of one workgroup: pipe time = c * 4 * (terms on the pipe), c > 1 pricing the other workgroups' share of
+    // it; ring time = 12 * (its longest ring stream).  Corners sorted by size, the k largest on the pipe, k = argmin of
+    // max(pipe, ring).  Either accumulator adds a corner's terms in the same order: bit-identical whatever the split.
+    int pipe_mask = lds_ordered ? 0xf : 0;
+    if (lds_ordered && ring_ok && mix16 > 0) {
+        int n[4] = {sh_cn[0], sh_cn[1], sh_cn[2], sh_cn[3]}, id[4] = {0, 1, 2, 3};
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3 - i; ++j)
+                if (n[j] < n[j + 1]) { const int tn = n[j]; n[j] = n[j + 1]; n[j + 1] = tn; const int ti = id[j]; id[j] = id[j + 1]; id[j + 1] = ti; }
+        long best = -1; int bk = 4, onp = 0;
+        pipe_mask = 0;
+        int mask_k = 0;
+#pragma unroll
+        for (int k = 0; k <= 4; ++k) {
+            const long pipe_t = (long)mix16 * 4 * onp, ring_t = (long)16 * 12 * (k < 4 ? n[k] : 0);   // (both x 16)
+            const long cst = pipe_t > ring_t ? pipe_t : ring_t;
+            if (best < 0 || cst < best) { best = cst; bk = k; pipe_mask = mask_k; }
+            if (k < 4) { onp += n[k]; mask_k |= 1 << id[k]; }
+        }
+        (void)bk;
+    }
 
     // tap ph = a, b, c, d <-> (y0,x0), (y1,x0), (y0,x1), (y1,x1)
     const int di = WB_THREADS / C, dj = WB_THREADS % C;
@@ -1367,7 +1442,7 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
         AIR_STAMP(44);
         AIR_STAMP_WG(3);
         if (wave < 4) {
-            if (lds_ordered) feed_corner(wave, 0, 4);
+            if ((pipe_mask >> wave) & 1) feed_corner(wave, 0, 4);
             else if (ring_ok) ring_corner(wave, 0, 4);
         } else theta_loop(TH0, THN);
         AIR_STAMP(48);
@@ -1402,7 +1477,7 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
             __syncthreads();
             AIR_STAMP(51 + 3 * ph);
             if (wave < 4) {
-                if (lds_ordered) feed_corner(wave, ph, ph + 1);
+                if ((pipe_mask >> wave) & 1) feed_corner(wave, ph, ph + 1);
                 else if (ring_ok) ring_corner(wave, ph, ph + 1);
             } else if (ph == 0) theta_loop(TH0, THN);
             __syncthreads();
@@ -1610,9 +1685,21 @@ extern "C" int air_write_fwd(const air_write_fwd_t* a, void* stream) {
     if (a->B <= 0 || a->N <= 0 || a->C < 2 || a->w < 2 || a->Z <= 0) return AIR_EINVAL;
     if (a->N > MAX_STEPS) return AIR_ELIMIT;
     const size_t lds = write_smem(a->N, a->C, a->w);
-    int rc = ensure_lds(write_fwd_kernel, lds);
-    if (rc) return rc;
-    hipLaunchKernelGGL(write_fwd_kernel, dim3(a->B), dim3(CF_THREADS), lds, air_stream(stream), *a);
+    if (a->rec_part && a->bands == 2) {
+        int rc = ensure_lds(write_fwd_kernel<CF_THREADS / 2, true>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((write_fwd_kernel<CF_THREADS / 2, true>), dim3(a->B, 2), dim3(CF_THREADS / 2), lds, air_stream(stream), *a);
+    } else if (a->rec_part) {
+        if (a->bands != 0 && a->bands != CF_BANDS) return AIR_EINVAL;
+        int rc = ensure_lds(write_fwd_kernel<CF_THREADS / CF_BANDS, true>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((write_fwd_kernel<CF_THREADS / CF_BANDS, true>), dim3(a->B, CF_BANDS), dim3(CF_THREADS / CF_BANDS), lds,
+                           air_stream(stream), *a);
+    } else {
+        int rc = ensure_lds(write_fwd_kernel<CF_THREADS, false>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((write_fwd_kernel<CF_THREADS, false>), dim3(a->B), dim3(CF_THREADS), lds, air_stream(stream), *a);
+    }
     AIR_CHECK_LAUNCH();
     return 0;
 }
@@ -1629,6 +1716,7 @@ extern "C" int air_write_bwd_kernel_name(const air_write_bwd_t* a, char* buf, in
 extern "C" int air_write_bwd(const air_write_bwd_t* a, void* stream) {
     if (!a || !a->d_recon || !a->vrec || !a->att || !a->d_gen_pre || !a->d_sxy_write) return AIR_EINVAL;
     if (a->B <= 0 || a->N <= 0 || a->C < 2 || a->w < 2) return AIR_EINVAL;
+    if (a->fin_rec_part && (!a->fin_scalars || !a->fin_run_loss || !a->fin_rec_loss || !a->fin_loss_item_out)) return AIR_EINVAL;
     if (2 * a->w > THREADS) return AIR_ELIMIT;
     if (a->literal == 2) {
         if (a->w * a->w > WB_THREADS) return AIR_ELIMIT;
@@ -1637,7 +1725,14 @@ extern "C" int air_write_bwd(const air_write_bwd_t* a, void* stream) {
         const size_t lds = write_bwd_graph_smem(a->C, a->w, allph);
         int rc = allph ? ensure_lds(write_bwd_graph_kernel<true>, lds) : ensure_lds(write_bwd_graph_kernel<false>, lds);
         if (rc) return rc;
-        const int flags = accumulators(air_stream(stream));
+        int flags = accumulators(air_stream(stream));
+        // pipe / ring mix (write_bwd_graph_kernel::pipe_mask): c in sixteenths.  Large canvases -- several workgroups per
+        // CU share the one atomic pipe -- default to c = 2; one workgroup per CU (all taps resident) keeps the pipe.
+        // AIR_WB_MIX=<float> overrides (0 = pipe only).
+        static const int mix_env = [] { const char* e = getenv("AIR_WB_MIX"); return e ? (int)(atof(e) * 16.0 + 0.5) : -1; }();
+        int mix16 = mix_env >= 0 ? mix_env : (allph ? 0 : 32);
+        if (mix16 > 255) mix16 = 255;
+        if ((flags & 3) == 3) flags |= mix16 << 8;
         if (allph) hipLaunchKernelGGL(write_bwd_graph_kernel<true>, dim3(a->B, a->N), dim3(WB_THREADS), lds, air_stream(stream), *a, flags);
         else hipLaunchKernelGGL(write_bwd_graph_kernel<false>, dim3(a->B, a->N), dim3(WB_THREADS), lds, air_stream(stream), *a, flags);
         AIR_CHECK_LAUNCH();

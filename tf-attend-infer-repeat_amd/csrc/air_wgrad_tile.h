@@ -1,0 +1,521 @@
+// Device code of the weight-gradient tiles (dW = A^T . dY, one 64 x 64 output tile per workgroup), shared by the grouped
+// weight-gradient launch (air_wgrad.hip) and by the GEMM kernels that carry tiles as RIDERS (air_gemm_bf16.hip): trailing
+// workgroups of the narrow launches at the end of the backward chain compute weight gradients whose operands already exist.
+#pragma once
+#include "air_common.h"
+#include <type_traits>
+
+namespace airw {
+
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int THREADS = 256;
+constexpr int BT = 64;          // output tile (both dims)
+constexpr int KC = 32;          // rows per staged chunk
+constexpr int LS = BT + 16;     // LDS row stride: = 16 (mod 32) dwords -> conflict-free fragment reads, 16-B aligned
+constexpr int MAXP = 12;
+
+struct Prob {
+    const float* A; const float* dY; float* dW; float* db;
+    const unsigned short* A16; const unsigned short* dY16;      // bf16 twins of A / dY (nullable): see tile_bf16_tw
+    int M, N, K, lda, ldb, ldc;
+    int head_pack, Hs, Hh, Hz;
+    int tiles_n, first_block;
+};
+// first[i] = first workgroup of problem i (INT_MAX past `count`): kept apart from the descriptors so that
+// ONE wide scalar load fetches all of them and the owner is found without a chain of dependent loads
+struct Table { int count; int total_blocks; int first[MAXP]; Prob p[MAXP]; };
+
+// One float4 of a row-major operand, zero outside [rows x cols], in two branch-free halves: fetch4
+// issues the load(s) with out-of-range accesses redirected to element 0, mask4 zeroes what was out of
+// range.  Callers issue ALL fetches of a batch before the first mask: a run-time branch around a
+// load (or a consumer right behind it) makes the compiler wait on the spot, which serialises the
+// 16-24 loads a thread should have in flight (12 us instead of 3 for the ragged-edge tiles).
+// VEC: base 16-byte aligned and ld % 4 == 0 -- a quad that starts inside a row then lies inside
+// the padded row, so the 16-byte load is issued even when its last columns are past `cols`.
+template <bool VEC>
+__device__ __forceinline__ float4 fetch4(const float* __restrict__ base, int ld, int row, int col, int rows, int cols) {
+    const bool okr = row < rows;
+    const unsigned at = (unsigned)row * (unsigned)ld + (unsigned)col;
+    if (VEC) return *reinterpret_cast<const float4*>(base + ((okr && col < cols) ? at : 0u));
+    float4 v;
+    v.x = base[(okr && col < cols) ? at : 0u];
+    v.y = base[(okr && col + 1 < cols) ? at + 1u : 0u];
+    v.z = base[(okr && col + 2 < cols) ? at + 2u : 0u];
+    v.w = base[(okr && col + 3 < cols) ? at + 3u : 0u];
+    return v;
+}
+__device__ __forceinline__ float4 mask4(float4 t, int row, int col, int rows, int cols) {
+    const bool okr = row < rows;
+    float4 v;
+    v.x = (okr && col < cols) ? t.x : 0.f;
+    v.y = (okr && col + 1 < cols) ? t.y : 0.f;
+    v.z = (okr && col + 2 < cols) ? t.z : 0.f;
+    v.w = (okr && col + 3 < cols) ? t.w : 0.f;
+    return v;
+}
+
+
+// sum of squares of everything this workgroup stored (tf.global_norm terms): one partial per
+// workgroup, reduced again in fixed order by the Adam kernel; workgroup 0 also counts the step
+// (apply_gradients(global_step=...), air_model.py:692-694)
+// (sq_red: 4 floats of LDS supplied by the kernel -- a carrying GEMM kernel must not own static LDS: it could no longer
+// be granted the whole 160 KB as dynamic LDS, hipFuncSetAttribute refuses static + dynamic > 160 KB)
+__device__ __forceinline__ void publish_sq(float sq, float* sq_partials, int32_t* istate, int block, float* sq_red) {
+    sq = air_block_sum_256(sq, sq_red);
+    if (threadIdx.x == 0) {
+        sq_partials[block] = sq;
+        if (block == 0 && istate) istate[AIR_IST_GLOBAL_STEP] += 1;
+    }
+}
+
+// Epilogue of the weight-gradient kernels: the tile in Ct goes to pr.dW (whole rows per store
+// instruction) and its sum of squares to the caller.  pr.dW == NULL: nothing is stored, only the
+// sum of squares is taken (a gradient that air_adam_clip_step_factored rebuilds from its factors).
+__device__ __forceinline__ float store_tile(const Prob& pr, int m0, int n0, const float* Ct, float sq)
+{
+    const int tid = threadIdx.x;
+    const int M = pr.M, N = pr.N, ldc = pr.ldc;
+    float* dW = pr.dW;
+    if (!pr.head_pack) {
+        const bool vecC = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(dW) & 15) == 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = (tid >> 4) + 16 * r, col = (tid & 15) * 4;
+            const int m = m0 + row, n = n0 + col;
+            if (m >= M) continue;
+            const float4 t = *reinterpret_cast<const float4*>(&Ct[row * LS + col]);
+            float* dst = dW + (size_t)m * ldc + n;
+            if (vecC && n + 3 < N) { if (dW) *reinterpret_cast<float4*>(dst) = t; sq += (t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w); }
+            else {
+                if (n < N) { if (dW) dst[0] = t.x; sq += t.x * t.x; }
+                if (n + 1 < N) { if (dW) dst[1] = t.y; sq += t.y * t.y; }
+                if (n + 2 < N) { if (dW) dst[2] = t.z; sq += t.z * t.z; }
+                if (n + 3 < N) { if (dW) dst[3] = t.w; sq += t.w * t.w; }
+            }
+        }
+    } else {
+        // head output units (air_model.py:294-316, 376): A = d_out7 [K,8], dY = hid [K,HT];
+        // unit o only owns the hidden segment of its head: dW = wout[o][n - off], db = bout[o] = sum_k d_out7[k][o]
+        const int wid[5] = {pr.Hs, pr.Hs, pr.Hh, pr.Hh, pr.Hz};
+        const int head[7] = {0, 1, 2, 2, 3, 3, 4};
+        for (int it = tid; it < 7 * BT; it += THREADS) {
+            const int o = it / BT, col = it % BT, n = n0 + col;
+            int off = 0;
+            for (int h = 0; h < head[o]; ++h) off += wid[h];
+            if (m0 == 0 && n < N && n >= off && n < off + wid[head[o]]) {
+                const float t = Ct[o * LS + col];
+                dW[(size_t)o * ldc + (n - off)] = t;
+                sq += t * t;
+            }
+        }
+    }
+    return sq;
+}
+
+__device__ __forceinline__ const Prob& find_tile(const Table& tab, int block, int& m0, int& n0) {
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < MAXP; ++i) pi += (block >= tab.first[i]) ? 1 : 0;
+    const Prob& pr = tab.p[pi];
+    const int local = block - pr.first_block;
+    m0 = (local / pr.tiles_n) * BT; n0 = (local % pr.tiles_n) * BT;
+    return pr;
+}
+
+// ---------------------------------------------------------------------------
+// bf16-operand variant (precision 1): operands are rounded to bf16 (RNE,
+// v_cvt_pk_bf16_f32) on their way into LDS, products run on
+// v_mfma_f32_16x16x32_bf16 with fp32 accumulation.  K sits on the slow (row)
+// axis of both operands, the MFMA wants 8 consecutive k per lane: a thread
+// loads the same 4 columns of 8 consecutive rows (8 x 16-B loads), packs one
+// 16-B k-run per column and stores it into a [column][k] image whose 16-B slots
+// are XOR-swizzled by the column index -- conflict-free for the 8-lane
+// ds_write_b128 groups and for the 16-lane ds_read_b128 fragment groups.  All
+// loads of up to 192 rows are in flight at once, one barrier before the MFMAs
+// (no per-chunk barriers); the bias column sums are taken from the fp32
+// registers before rounding.
+// ---------------------------------------------------------------------------
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+constexpr int KB = 64;          // rows per LDS image
+constexpr int NIMG_W = 3;       // images resident per round in the weight-gradient kernel: K <= 192 needs one round
+
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+
+// bf16 tile: as tile_f32, operands rounded to bf16; Img = [operand][image][column][k] shorts of LDS,
+// the fp32 tile is left at its start (64 rows of LS floats, barrier-synchronised).
+template <int NIMG>     // LDS images (64 rows each) resident per round; Img holds max(2 * NIMG * 8 KB, 20 KB)
+__device__ __forceinline__ float tile_bf16(const Prob& pr, int m0, int n0, unsigned short* Img)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const float* __restrict__ Ap = pr.A;
+    const float* __restrict__ Yp = pr.dY;
+    const int M = pr.M, N = pr.N, K = pr.K, lda = pr.lda, ldb = pr.ldb;
+    float* db = pr.db;
+    const int head_pack = pr.head_pack;
+
+    // staging role: threads 0..127 own operand A, 128..255 own dY; g = k-run (8 rows), q = column quad
+    const int op = tid >> 7, g = tid & 7, q = (tid & 127) >> 3;
+    const float* src = op ? Yp : Ap;
+    const int ld = op ? ldb : lda, cols = op ? N : M, c0 = (op ? n0 : m0) + 4 * q;
+    const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+    unsigned short* img = Img + (size_t)op * NIMG * BT * KB;
+    const bool bias_block = (db != nullptr) && (head_pack ? (n0 == 0) : (m0 == 0));
+    const bool bias_thread = bias_block && (op == (head_pack ? 0 : 1));
+    float csum[4] = {0.f, 0.f, 0.f, 0.f};
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    AIR_STAMP(1);
+    for (int kr = 0; kr < K; kr += NIMG * KB) {
+        if (kr > 0) __syncthreads();                     // every wave is done reading the previous images
+        float4 v[NIMG][8];
+        // wave-uniform choices, each ONE branch around the whole batch of loads
+        const bool inside = (op ? n0 : m0) + BT <= cols;                  // no ragged column edge
+        if (vec && inside && (K % KB) == 0) {
+            // interior tile, whole images: uniform base + 32-bit byte offsets, nothing to mask
+            const char* base = reinterpret_cast<const char*>(src);
+            const unsigned step = (unsigned)ld * 4u;
+            const unsigned off0 = (unsigned)(kr + g * 8) * step + (unsigned)c0 * 4u;
+#pragma unroll
+            for (int c = 0; c < NIMG; ++c)
+                if (kr + c * KB < K) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r)
+                        v[c][r] = *reinterpret_cast<const float4*>(base + (off0 + (unsigned)(c * KB + r) * step));
+                }
+        } else if (vec) {
+#pragma unroll
+            for (int c = 0; c < NIMG; ++c)
+                if (kr + c * KB < K) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[c][r] = fetch4<true>(src, ld, kr + c * KB + g * 8 + r, c0, K, cols);
+                }
+        } else {
+#pragma unroll
+            for (int c = 0; c < NIMG; ++c)
+                if (kr + c * KB < K) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[c][r] = fetch4<false>(src, ld, kr + c * KB + g * 8 + r, c0, K, cols);
+                }
+        }
+        AIR_STAMP(2);
+        if (!(vec && inside && (K % KB) == 0)) {
+#pragma unroll
+            for (int c = 0; c < NIMG; ++c)
+                if (kr + c * KB < K) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[c][r] = mask4(v[c][r], kr + c * KB + g * 8 + r, c0, K, cols);
+                }
+        }
+#pragma unroll
+        for (int c = 0; c < NIMG; ++c)
+            if (kr + c * KB < K) {
+                if (bias_thread) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) { csum[0] += v[c][r].x; csum[1] += v[c][r].y; csum[2] += v[c][r].z; csum[3] += v[c][r].w; }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int col = 4 * q + j;
+                    auto e = [&](int r) { const float4& t = v[c][r]; return j == 0 ? t.x : j == 1 ? t.y : j == 2 ? t.z : t.w; };
+                    uint4 w;
+                    w.x = pack_bf16(e(0), e(1)); w.y = pack_bf16(e(2), e(3));
+                    w.z = pack_bf16(e(4), e(5)); w.w = pack_bf16(e(6), e(7));
+                    *reinterpret_cast<uint4*>(&img[(size_t)c * BT * KB + col * KB + ((g ^ (col & 7)) << 3)]) = w;
+                }
+            }
+        AIR_STAMP(3);
+        __syncthreads();
+        AIR_STAMP(4);
+#pragma unroll
+        for (int c = 0; c < NIMG; ++c)
+            if (kr + c * KB < K) {
+                const unsigned short* ai = Img + (size_t)c * BT * KB;
+                const unsigned short* bi = Img + (size_t)(NIMG + c) * BT * KB;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int slot = ks * 4 + (lane >> 4);
+                    bf16x8 av[2], bv[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int col = wm + i * 16 + (lane & 15);
+                        av[i] = *reinterpret_cast<const bf16x8*>(&ai[col * KB + ((slot ^ (col & 7)) << 3)]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int col = wn + j * 16 + (lane & 15);
+                        bv[j] = *reinterpret_cast<const bf16x8*>(&bi[col * KB + ((slot ^ (col & 7)) << 3)]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+                }
+            }
+    }
+
+    float sq = 0.0f;
+    // bias: reduce the 8 k-runs (lanes g = 0..7 are contiguous) of each column quad
+    if (bias_block) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s = csum[j];
+            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+            csum[j] = s;
+        }
+        if (bias_thread && g == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = 4 * q + j;
+                if (!head_pack) { if (n0 + col < N) { db[n0 + col] = csum[j]; sq += csum[j] * csum[j]; } }
+                else if (col < 7) { db[col] = csum[j]; sq += csum[j] * csum[j]; }
+            }
+        }
+    }
+
+    // epilogue through LDS: whole 256-byte rows per store instruction
+    AIR_STAMP(5);
+    __syncthreads();
+    float* Ct = reinterpret_cast<float*>(Img);           // 64 x LS floats = 20 KB <= 48 KB
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+                Ct[(wm + i * 16 + (lane >> 4) * 4 + qq) * LS + wn + j * 16 + (lane & 15)] = acc[i][j][qq];
+    __syncthreads();
+    return sq;
+}
+
+// bf16-TWIN tile: both operands are read from the bf16 twins their producers wrote (air_wgrad_t.A16 / dY16).
+// K is the slow axis of both, i.e. both are "n-contiguous" for the MFMA: a 64-row image of an operand is
+// copied as it lies into a [k][64 columns] LDS image (16- or 8-byte pieces, lane-linear rows of 128 bytes,
+// no conversion, no register transpose) and the MFMA fragments -- 8 consecutive k per lane -- come out of
+// gfx950's transpose read ds_read_b64_tr_b16 (tools/exp/tr_read.hip; the same scheme as the forward GEMM's
+// row-major weights, air_gemm_bf16.hip).  Same bf16 values, same k order per wave as tile_bf16: the tile is
+// bit-identical.  The bias gradient still comes from the fp32 dY (column sums before rounding, in tile_bf16's
+// order) -- only the m0 == 0 tiles pay those loads.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ bool twin_ok(const Prob& pr) {
+    auto a8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; };
+    return pr.A16 && pr.dY16 && !pr.head_pack && a8(pr.A16) && a8(pr.dY16) && (pr.lda & 3) == 0 && (pr.ldb & 3) == 0 &&
+           (pr.M & 3) == 0 && (pr.N & 3) == 0;
+}
+
+template <int NIMG>
+__device__ __forceinline__ float tile_bf16_tw(const Prob& pr, int m0, int n0, unsigned short* Img)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int M = pr.M, N = pr.N, K = pr.K, lda = pr.lda, ldb = pr.ldb;
+    float* db = pr.db;
+    const char* Ab = reinterpret_cast<const char*>(pr.A16);
+    const char* Yb = reinterpret_cast<const char*>(pr.dY16);
+    unsigned short* ImgA = Img;                              // [NIMG][64 k][64 m]
+    unsigned short* ImgB = Img + NIMG * KB * BT;             // [NIMG][64 k][64 n]
+    // 16-byte pieces when rows start 16-byte aligned (ld % 8 == 0), else 8-byte pieces (ld % 4 == 0)
+    const bool a16 = (lda & 7) == 0 && (reinterpret_cast<uintptr_t>(pr.A16) & 15) == 0 && (M & 7) == 0;
+    const bool b16 = (ldb & 7) == 0 && (reinterpret_cast<uintptr_t>(pr.dY16) & 15) == 0 && (N & 7) == 0;
+    const bool bias_block = (db != nullptr) && (m0 == 0);
+    // the bias threads' fp32 view of dY: g = k-run (8 rows), q = column quad -- tile_bf16's staging role of operand dY
+    const int bg = tid & 7, bq = (tid & 127) >> 3;
+    const bool bias_thread = bias_block && tid >= 128;
+    float csum[4] = {0.f, 0.f, 0.f, 0.f};
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int T8 = NIMG * KB * 16 / THREADS;             // 8-byte pieces per thread per operand (two of them = one 16-byte piece)
+    uint2 ra[T8], rb[T8];
+    // all operand loads of one round, one wave-uniform branch per operand.  Rounds are software-pipelined: the loads of
+    // round r+1 are issued as soon as round r's registers are in LDS, i.e. under its barrier and MFMAs (K > 192: the
+    // 128x128 configuration contracts over 256 rows)
+    auto issue_round = [&](int kr) __attribute__((always_inline)) {
+        if (a16) {
+#pragma unroll
+            for (int i = 0; i < T8 / 2; ++i) {
+                const int t = tid + THREADS * i, k = kr + (t >> 3), col = m0 + (t & 7) * 8;
+                const bool ok = k < K && col < M;
+                const uint4 x = *reinterpret_cast<const uint4*>(Ab + (ok ? ((unsigned)k * (unsigned)lda + (unsigned)col) * 2u : 0u));
+                ra[2 * i] = ok ? make_uint2(x.x, x.y) : make_uint2(0u, 0u);
+                ra[2 * i + 1] = ok ? make_uint2(x.z, x.w) : make_uint2(0u, 0u);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < T8; ++i) {
+                const int t = tid + THREADS * i, k = kr + (t >> 4), col = m0 + (t & 15) * 4;
+                const bool ok = k < K && col < M;
+                const uint2 x = *reinterpret_cast<const uint2*>(Ab + (ok ? ((unsigned)k * (unsigned)lda + (unsigned)col) * 2u : 0u));
+                ra[i] = ok ? x : make_uint2(0u, 0u);
+            }
+        }
+        if (b16) {
+#pragma unroll
+            for (int i = 0; i < T8 / 2; ++i) {
+                const int t = tid + THREADS * i, k = kr + (t >> 3), col = n0 + (t & 7) * 8;
+                const bool ok = k < K && col < N;
+                const uint4 x = *reinterpret_cast<const uint4*>(Yb + (ok ? ((unsigned)k * (unsigned)ldb + (unsigned)col) * 2u : 0u));
+                rb[2 * i] = ok ? make_uint2(x.x, x.y) : make_uint2(0u, 0u);
+                rb[2 * i + 1] = ok ? make_uint2(x.z, x.w) : make_uint2(0u, 0u);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < T8; ++i) {
+                const int t = tid + THREADS * i, k = kr + (t >> 4), col = n0 + (t & 15) * 4;
+                const bool ok = k < K && col < N;
+                const uint2 x = *reinterpret_cast<const uint2*>(Yb + (ok ? ((unsigned)k * (unsigned)ldb + (unsigned)col) * 2u : 0u));
+                rb[i] = ok ? x : make_uint2(0u, 0u);
+            }
+        }
+    };
+    AIR_STAMP(1);
+    issue_round(0);
+    AIR_STAMP(2);
+    for (int kr = 0; kr < K; kr += NIMG * KB) {
+        if (kr > 0) __syncthreads();
+        // ---- straight into the [k][64] images (lane-linear rows)
+        if (a16) {
+#pragma unroll
+            for (int i = 0; i < T8 / 2; ++i)
+                *reinterpret_cast<uint4*>(&ImgA[(tid + THREADS * i) * 8]) = make_uint4(ra[2 * i].x, ra[2 * i].y, ra[2 * i + 1].x, ra[2 * i + 1].y);
+        } else {
+#pragma unroll
+            for (int i = 0; i < T8; ++i) *reinterpret_cast<uint2*>(&ImgA[(tid + THREADS * i) * 4]) = ra[i];
+        }
+        if (b16) {
+#pragma unroll
+            for (int i = 0; i < T8 / 2; ++i)
+                *reinterpret_cast<uint4*>(&ImgB[(tid + THREADS * i) * 8]) = make_uint4(rb[2 * i].x, rb[2 * i].y, rb[2 * i + 1].x, rb[2 * i + 1].y);
+        } else {
+#pragma unroll
+            for (int i = 0; i < T8; ++i) *reinterpret_cast<uint2*>(&ImgB[(tid + THREADS * i) * 4]) = rb[i];
+        }
+        AIR_STAMP(3);
+        if (kr + NIMG * KB < K) issue_round(kr + NIMG * KB);
+        __syncthreads();
+        AIR_STAMP(4);
+        // ---- MFMAs: fragments through the transpose read (lane i of a 16-lane group hands in row 8g + i/4 (+4), column quad i%4)
+        const int il = lane & 15;
+#pragma unroll
+        for (int c = 0; c < NIMG; ++c)
+            if (kr + c * KB < K) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int krow = c * KB + ks * 32 + (lane >> 4) * 8 + (il >> 2);
+                    const unsigned short* pa = &ImgA[krow * BT + wm + (il & 3) * 4];
+                    const unsigned short* pb = &ImgB[krow * BT + wn + (il & 3) * 4];
+                    bf16x8 av[2], bv[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pa + i * 16));
+                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pa + i * 16 + 4 * BT));
+                        av[i] = bf16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pb + j * 16));
+                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pb + j * 16 + 4 * BT));
+                        bv[j] = bf16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+                }
+            }
+    }
+    AIR_STAMP(5);
+    if (bias_thread) {
+        // fp32 column sums of dY (m0 == 0 tiles only) in tile_bf16's order: per k-run g the rows g*8 + r of image c, images
+        // in order; the xor-tree over g follows.  After the MFMAs (the operand registers are free), the next image's 8 loads
+        // in flight while this one is summed: ONE exposed round trip per tile (three sequential ones per round made the
+        // bias tiles the long pole of the launch: 41 us at K = 1280).
+        const bool vec = ((ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(pr.dY) & 15) == 0);
+        const int nimg = (K + KB - 1) / KB;
+        float4 cur[8], nxt[8];
+        auto fetch_img = [&](float4 (&v)[8], int c) __attribute__((always_inline)) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                v[r] = vec ? fetch4<true>(pr.dY, ldb, c * KB + bg * 8 + r, n0 + 4 * bq, K, N)
+                           : fetch4<false>(pr.dY, ldb, c * KB + bg * 8 + r, n0 + 4 * bq, K, N);
+        };
+        fetch_img(cur, 0);
+        for (int c = 0; c < nimg; ++c) {
+            if (c + 1 < nimg) fetch_img(nxt, c + 1);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float4 t = mask4(cur[r], c * KB + bg * 8 + r, n0 + 4 * bq, K, N);
+                csum[0] += t.x; csum[1] += t.y; csum[2] += t.z; csum[3] += t.w;
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) cur[r] = nxt[r];
+        }
+    }
+
+    float sq = 0.0f;
+    if (bias_block) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s = csum[j];
+            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+            csum[j] = s;
+        }
+        if (bias_thread && bg == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = 4 * bq + j;
+                if (n0 + col < N) { db[n0 + col] = csum[j]; sq += csum[j] * csum[j]; }
+            }
+        }
+    }
+    __syncthreads();
+    float* Ct = reinterpret_cast<float*>(Img);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+                Ct[(wm + i * 16 + (lane >> 4) * 4 + qq) * LS + wn + j * 16 + (lane & 15)] = acc[i][j][qq];
+    __syncthreads();
+    return sq;
+}
+
+
+// One rider / grouped-launch workgroup of the bf16 path: tile `block` of the table; Img = 48 KB of LDS (16-byte aligned),
+// sq_red = 4 more floats.  sq_partials == NULL: no global-norm partial is published.
+__device__ __forceinline__ void run_tile_bf16(const Table& tab, int block, unsigned short* Img, float* __restrict__ sq_partials,
+                                              int32_t* __restrict__ istate, float* sq_red)
+{
+    int m0, n0;
+    const Prob& pr = find_tile(tab, block, m0, n0);
+    AIR_STAMP(0);
+    // block-uniform: operands from their bf16 twins where the problem supplies usable ones
+    const float bias_sq = twin_ok(pr) ? tile_bf16_tw<NIMG_W>(pr, m0, n0, Img) : tile_bf16<NIMG_W>(pr, m0, n0, Img);
+    AIR_STAMP(6);
+    const float sq = store_tile(pr, m0, n0, reinterpret_cast<const float*>(Img), bias_sq);
+    AIR_STAMP(7);
+    if (sq_partials) publish_sq(sq, sq_partials, istate, block, sq_red);
+    AIR_STAMP(8);
+}
+
+}  // namespace airw

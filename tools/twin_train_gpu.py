@@ -2,7 +2,7 @@
 (oracle/air_oracle_torch.py: un-fused fp32 ops, autograd's own residue-carrying gradients) with
 torch-ROCm kernels on the same data, annealing and optimizer as training.py -- an independent
 implementation of "the reference's fp32 autodiff" to compare success rates with.
-  python tools/twin_train_gpu.py <seed> <iterations> [<backgrounds.npz>:<key>]   (clutter: BASELINE configs[4])"""
+  python tools/twin_train_gpu.py <seed> <iterations> [<backgrounds.npz>:<key> [<max intensity>]]   (clutter: BASELINE configs[4])"""
 import json, math, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tf-attend-infer-repeat_amd"))
@@ -17,6 +17,8 @@ bg = None
 if len(sys.argv) > 3:                                      # clutter background, already scaled (tests/golden/backgrounds.npz)
     f_, key_ = sys.argv[3].rsplit(":", 1)
     bg = np.load(f_)[key_].astype(np.float32)
+    if len(sys.argv) > 4 and bg.max() > 0:                 # rescaled to a maximum intensity, as training.py --bg-max-intensity does
+        bg = bg / bg.max() * min(float(sys.argv[4]), 1.0)
 ds = generate_dataset(bg=bg)
 te_im, te_dg = shift_zero_digits_images(ds["test_images"], ds["test_digits"])
 tr_im, tr_dg = torch.tensor(ds["train_images"]), torch.tensor(ds["train_digits"].astype(np.int32))
