@@ -189,13 +189,6 @@ typedef struct {
      * gate*4 + u%4 -- the four gates of four units in 32 contiguous bytes per row.  Read instead of B16 by the 16- and
      * 32-column tiles; results are bit-identical.  B16 may be NULL when B16p is given and the tile supports it. */
     const uint16_t* B16p;
-    /* optional weight-gradient RIDERS (precision 1, transB, AIR_EPI_LSTM_BWD / AIR_EPI_LSTM_BWD_TAIL on twin operands only;
-     * AIR_EINVAL elsewhere): rider_table = DEVICE copy of a grouped weight-gradient table (air_wgrad_table_fill);
-     * trailing workgroups of this launch compute its tiles rider_first .. rider_first + rider_count - 1 (bf16 path) and
-     * publish their global-norm partials into rider_sq[tile] (nullable) -- tiles whose operands exist before this launch
-     * starts, on the CUs a narrow launch leaves idle.  The grouped launch that follows names the range as its skip range
-     * (air_wgrad_grouped_skip).  Same tile code, same slot numbering: gradients and global norm are bit-identical. */
-    const void* rider_table; int32_t rider_first, rider_count; float* rider_sq;
 } air_gemm_t;
 /* number of K-slabs a ksplit request produces for contraction depth K */
 int air_gemm_slabs(int K, int ksplit);
@@ -249,16 +242,6 @@ typedef struct {
 int air_wgrad_num_blocks(const air_wgrad_t* probs, int count);
 int air_wgrad_grouped(const air_wgrad_t* probs /*HOST array, <= 12*/, int count, int precision,
                       float* sq_partials, int32_t* istate, void* stream);
-/* The same launch WITHOUT the tiles [skip_first, skip_first + skip_count) of the table (skip_first > 0), which riders of
- * earlier launches have computed (air_gemm_t.rider_table); every remaining tile keeps its number = its sq_partials slot. */
-int air_wgrad_grouped_skip(const air_wgrad_t* probs, int count, int precision, float* sq_partials, int32_t* istate,
-                           int skip_first, int skip_count, void* stream);
-/* The descriptor table of a grouped launch as the kernels read it: air_wgrad_table_bytes() bytes, filled into HOST memory
- * (returns the number of tiles); the caller copies it to the device for air_gemm_t.rider_table. */
-int air_wgrad_table_bytes(void);
-int air_wgrad_table_fill(const air_wgrad_t* probs, int count, void* host_dst);
-/* first tile and number of tiles of problem `problem` in the table's numbering */
-int air_wgrad_problem_blocks(const air_wgrad_t* probs, int count, int problem, int* first, int* nblocks);
 
 /* column sums db[n] = sum_r dY[r*ld + n]  (BiasAdd_grad nodes) for `count` problems */
 typedef struct { const float* src; float* dst; int32_t rows, cols, ld, accumulate; } air_colsum_t;
@@ -376,6 +359,10 @@ typedef struct {
      * air_write_bwd (fin_rec_part ...) in a train step, air_finalize_parts after a plain forward.  Bit-identical. */
     float* rec_part;
     int32_t bands;                       /* with rec_part: 4 (0 = 4) workgroups of 256 threads, or 2 of 512, per image */
+    /* nullable, [N*B] (N*B <= 4096): one extra workgroup of this launch sorts the (image, step) items by the work the
+     * graph-order write backward will have with them (its corner terms; inactive items last) and leaves the permutation
+     * here -- air_write_bwd_t.order.  Worth it when there are more items than CUs (128 x 128, b = 256: 1280 items). */
+    int32_t* wb_order;
 } air_write_fwd_t;
 int air_write_fwd(const air_write_fwd_t* a, void* stream);
 
@@ -396,6 +383,10 @@ typedef struct {
      * per-image sums -- rec_loss[i] = -(sum of the 16 partials), loss_item[i] = run_loss[i] + rec_loss[i] -- and writes
      * them (fin_loss_item is then not read).  All four nullable together. */
     const float* fin_rec_part; const float* fin_run_loss; float* fin_rec_loss; float* fin_loss_item_out;
+    /* nullable (literal 2 only): workgroup i of the launch computes item order[i] = t * B + b instead of item i -- the
+     * longest-first permutation of air_write_fwd_t.wb_order (the hardware hands workgroups out in launch order).  Results
+     * do not depend on it.  With `order` the batch-mean finisher is the LAST workgroup of the launch. */
+    const int32_t* order;
 } air_write_bwd_t;
 int air_write_bwd(const air_write_bwd_t* a, void* stream);
 /* the kernel function air_write_bwd dispatches this descriptor to, as rocprofv3 prints it (profiling tools) */

@@ -1490,85 +1490,69 @@ def test_compose_in_bands_is_bit_identical_to_one_workgroup_per_image(H, Cc, w, 
     assert lib.air_write_bwd(C.byref(wb), _stream()) == -1
 
 
-def test_weight_gradient_tiles_ride_in_the_bptt_gemm_launches(H):
-    """air_gemm_t.rider_table: trailing workgroups of an AIR_EPI_LSTM_BWD / LSTM_BWD_TAIL launch compute tiles of a grouped
-    weight-gradient table; air_wgrad_grouped_skip then runs the rest.  dW, db and every global-norm partial slot are
-    BIT-IDENTICAL to the one grouped launch, the carrying product is unchanged, and launches that cannot carry riders
-    refuse them (MatMul_grad / BiasAdd_grad of the VAE variables, air_model.py:651-694 via vae.py:13-34)."""
-    dev, lib = "cuda", H.lib()
-    rng = np.random.RandomState(51)
-    f = lambda *s: torch.tensor(rng.uniform(-1, 1, s).astype(np.float32), device=dev)  # noqa: E731
-    i16 = lambda *s: torch.zeros(*s, dtype=torch.int16, device=dev)  # noqa: E731
-    K = 192
-    shapes = [(256, 1024), (784, 512), (512, 256), (256, 100), (512, 784), (50, 256)]        # (M, N): first and last do not ride
-    ops = []
-    for M, N in shapes:
-        A, dY = f(K, M), f(K, N)
-        ops.append((A, dY, _bf16_twin(H, A), _bf16_twin(H, dY)))
-
-    def problems(outs):
-        return (H.Wgrad * len(shapes))(*[H.Wgrad(_p(A), _p(dY), _p(dW), _p(db), M, N, K, M, N, N, 0, 0, 0, 0, _p(A16), _p(dY16))
-                                         for (M, N), (A, dY, A16, dY16), (dW, db) in zip(shapes, ops, outs)])
-    mk = lambda: [(torch.full((M, N), 7.0, device=dev), torch.full((N,), 7.0, device=dev)) for M, N in shapes]  # noqa: E731
-    ref, got = mk(), mk()
-    total = lib.air_wgrad_num_blocks(problems(ref), len(shapes))
-    p_ref, p_got = torch.full((total,), 7.0, device=dev), torch.full((total,), 7.0, device=dev)
-    ist = torch.zeros(H.IST_COUNT, dtype=torch.int32, device=dev)
-    H.check(lib.air_wgrad_grouped(problems(ref), len(shapes), 1, _p(p_ref), _p(ist), _stream()))
-    # riders: problems 1..4 (contiguous tile range), carried by two GEMM launches; the rest by the skip launch
-    pr = problems(got)
-    f0, n0, f1, n1 = C.c_int(), C.c_int(), C.c_int(), C.c_int()
-    H.check(lib.air_wgrad_problem_blocks(pr, len(shapes), 1, C.byref(f0), C.byref(n0)))
-    H.check(lib.air_wgrad_problem_blocks(pr, len(shapes), 4, C.byref(f1), C.byref(n1)))
-    first, count = f0.value, f1.value + n1.value - f0.value
-    assert first == 64 and count == 13 * 8 + 8 * 4 + 4 * 2 + 8 * 13
-    host = C.create_string_buffer(lib.air_wgrad_table_bytes())
-    assert lib.air_wgrad_table_fill(pr, len(shapes), host) == total
-    table = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(dev)
-    # the carrying products: a BPTT step (64 workgroups of its own) and the heads' d h with the last step's cell backward
-    Bn, R, HT = 64, 256, 320
-    acts, c_prev, c0, dc_in = f(Bn, 4 * R).abs() * 0.5, f(Bn, R), f(Bn, R), f(Bn, R)
-    dgn, dh_heads, Wh = f(Bn, 4 * R), f(Bn, R), f(R, 4 * R) * 0.1
-    dgn16, Wh16 = _bf16_twin(H, dgn), _bf16_twin(H, Wh)
-    d_hid, Whid = f(3 * Bn, HT), f(R, HT) * 0.1
-    d_hid16, Whid16 = _bf16_twin(H, d_hid), _bf16_twin(H, Whid)
-    half = count // 3
+@pytest.mark.parametrize("Cc,w,N,B", [(128, 28, 5, 64), (50, 28, 3, 16)])
+def test_write_bwd_takes_its_items_longest_first_without_changing_results(H, Cc, w, N, B):
+    """air_write_fwd_t.wb_order: one extra workgroup of the compose launch sorts the (image, step) items by the corner
+    terms the graph-order write backward will accumulate for them (inactive items last) -- a permutation of 0 .. N*B-1,
+    non-increasing in the cost class (1024 terms); air_write_bwd_t.order: the backward computes item order[i] in workgroup i.  Gradients wrt
+    the decoder output and wrt (s, x, y, z) and the batch means are BIT-IDENTICAL with and without the order
+    (transformer.py:56-117 under tf.gradients; air_model.py:595-611)."""
+    rng = np.random.RandomState(Cc + B)
+    lib = H.lib()
+    Z, NB = 50, N * B
+    att = np.zeros((N, B, H.ATT_STRIDE), np.float32)
+    att[:, :, H.ATT_S] = rng.uniform(0.08, 0.9, (N, B)); att[:, :, H.ATT_X] = rng.uniform(-0.9, 0.9, (N, B))
+    att[:, :, H.ATT_Y] = rng.uniform(-0.9, 0.9, (N, B)); att[:, :, H.ATT_Z] = rng.uniform(0.2, 1.0, (N, B))
+    alive = np.cumprod(rng.uniform(0, 1, (N, B)) < 0.75, axis=0).astype(np.float32)
+    att[:, :, H.ATT_MASK] = alive
+    att[1:, :, H.ATT_MASK_PREV] = alive[:-1]; att[0, :, H.ATT_MASK_PREV] = 1.0
+    vrec = rng.uniform(0.05, 0.95, (N, B, w * w)).astype(np.float32)
+    ml = rng.uniform(-1, 1, (N, B, 2 * Z)).astype(np.float32)
+    images = (rng.uniform(0, 1, (B, Cc * Cc)) * (rng.uniform(0, 1, (B, Cc * Cc)) < 0.2)).astype(np.float32)
+    targets = rng.randint(0, N + 1, B).astype(np.int32)
+    dyn = np.zeros(H.DYN_COUNT, np.float32)
+    dyn[H.DYN_VAE_PV], dyn[H.DYN_GRAD_SCALE] = 1.0, 1.0 / B
+    t = lambda a_, dt=torch.float32: torch.tensor(a_, dtype=dt, device="cuda")  # noqa: E731
+    vrec_d, ml_d, img_d, dyn_d, tg_d = t(vrec), t(ml), t(images), t(dyn), t(targets, torch.int32)
     res = {}
-    for ride in (False, True):
-        # (C of the fused BPTT launch is scratch the epilogue does not write: zeros on both sides)
-        dh, dg, dcp, ds = torch.zeros(Bn, R, device=dev), f(Bn, 4 * R), f(Bn, R), torch.zeros(Bn, 4 * R, device=dev)
-        kw = dict(transB=1, addend=dh_heads, ldadd=R, epi=H.EPI_LSTM_BWD, p0=acts, p1=c_prev, p2=c0, p3=dc_in, q0=dg, q1=dcp, q2=ds, i0=0,
-                  A16=dgn16, B16=Wh16)
-        if ride:
-            kw.update(rider_table=table, rider_first=first, rider_count=half, rider_sq=p_got)
-        g1 = _gemm_struct(H, dgn, Wh, dh, Bn, R, 4 * R, 4 * R, 4 * R, R, 1, **kw)
-        assert "tw_kernel" in _kernel_name(H, g1)
-        H.check(lib.air_gemm(C.byref(g1), _stream()))
-        dhh, dg2, dcp2, ds2 = f(3 * Bn, R), f(Bn, 4 * R), f(Bn, R), f(Bn, 4 * R)
-        kw = dict(transB=1, epi=H.EPI_LSTM_BWD_TAIL, i0=2 * Bn, p0=acts, p1=c_prev, p2=c0, q0=dg2, q1=dcp2, q2=ds2, A16=d_hid16, B16=Whid16)
-        if ride:
-            kw.update(rider_table=table, rider_first=first + half, rider_count=count - half, rider_sq=p_got)
-        g2 = _gemm_struct(H, d_hid, Whid, dhh, 3 * Bn, R, HT, HT, HT, R, 1, **kw)
-        H.check(lib.air_gemm(C.byref(g2), _stream()))
+    for ordered in (False, True):
+        att_d = t(att)
+        recon, d_recon = torch.zeros(B, Cc * Cc, device="cuda"), torch.zeros(B, Cc * Cc, device="cuda")
+        rec_loss, run_loss, loss_item, scal = (torch.full((n_,), 7.0, device="cuda") for n_ in (B, B, B, 4))
+        digits = torch.zeros(B, dtype=torch.int32, device="cuda")
+        order = torch.full((NB,), -1, dtype=torch.int32, device="cuda") if ordered else None
+        wf = H.WriteFwd(_p(vrec_d), _p(ml_d), _p(img_d), _p(dyn_d), _p(att_d), _p(recon), _p(rec_loss), _p(d_recon),
+                        _p(run_loss), _p(digits), _p(loss_item), B, N, Cc, w, Z, None, 0, _p(order))
+        H.check(lib.air_write_fwd(C.byref(wf), _stream()), "air_write_fwd")
+        dgen, dsx = torch.full((N, B, w * w), 7.0, device="cuda"), torch.full((N, B, 4), 7.0, device="cuda")
+        wb = H.WriteBwd(_p(d_recon), _p(vrec_d), _p(att_d), _p(dgen), _p(dsx), B, N, Cc, w, 2, _p(loss_item), _p(tg_d), _p(digits), _p(scal),
+                        None, None, None, None, None, _p(order))
+        H.check(lib.air_write_bwd(C.byref(wb), _stream()), "air_write_bwd")
         torch.cuda.synchronize()
-        res[ride] = (dh, dg, dcp, ds, dhh[:2 * Bn].clone(), dg2, dcp2, ds2)
+        res[ordered] = (recon, d_recon, rec_loss, loss_item, dgen, dsx, scal[:2].clone())
+        if ordered:
+            o = order.cpu().numpy()
+            assert sorted(o.tolist()) == list(range(NB))                                   # a permutation
+            act = alive.reshape(-1)[o] != 0
+            n_act = int(act.sum())
+            assert act[:n_act].all() and not act[n_act:].any()                             # inactive items last
+            # the cost the sort used, restated: out-of-range columns x rows of the write transformer (transformer.py:75-87)
+            def oob(sv, shift):
+                tt = np.linspace(-1, 1, Cc, dtype=np.float32)
+                X = ((np.float32(1.0) / sv * tt + (-shift) / sv) + np.float32(1.0)) * np.float32(w - 1.001) / np.float32(2.0)
+                f0 = np.floor(X)
+                return int((np.clip(f0, 0, w - 1) == np.clip(f0 + 1, 0, w - 1)).sum())
+            cost = []
+            for it in o[:n_act]:
+                a_ = att.reshape(NB, -1)[it]
+                cost.append(oob(a_[H.ATT_S], a_[H.ATT_X]) * oob(a_[H.ATT_S], a_[H.ATT_Y]))
+            # ... in classes of 1024 terms (a counting sort: within a class the order is free)
+            klass = [(4 * c_ + 12000) >> 10 for c_ in cost]
+            assert all(c0 >= c1 for c0, c1 in zip(klass, klass[1:])), "items are not longest first"
+            assert klass[0] > klass[-1]
     for a0, a1 in zip(res[False], res[True]):
-        assert torch.equal(a0, a1)                                   # the carrying products do not notice their riders
-    ist2 = torch.zeros(H.IST_COUNT, dtype=torch.int32, device=dev)
-    H.check(lib.air_wgrad_grouped_skip(pr, len(shapes), 1, _p(p_got), _p(ist2), first, count, _stream()))
-    torch.cuda.synchronize()
-    assert int(ist2[0]) == 1 and int(ist[0]) == 1
-    assert torch.equal(p_ref, p_got) and float(p_ref.min()) > 0 and not bool((p_ref == 7.0).any())
-    for (dW0, db0), (dW1, db1) in zip(ref, got):
-        assert torch.equal(dW0, dW1) and torch.equal(db0, db1)
-    # refused: riders on a launch that has no rider code, a skip range that holds tile 0, riders without twin operands
-    Ct = torch.zeros(Bn, R, device=dev)
-    g = _gemm_struct(H, dgn, Wh, Ct, Bn, R, 4 * R, 4 * R, 4 * R, R, 1, transB=1, A16=dgn16, B16=Wh16, rider_table=table, rider_first=first,
-                     rider_count=4, rider_sq=p_got)
-    assert lib.air_gemm(C.byref(g), _stream()) == -1
-    kw = dict(transB=1, addend=dh_heads, ldadd=R, epi=H.EPI_LSTM_BWD, p0=acts, p1=c_prev, p2=c0, p3=dc_in, q0=dg, q1=dcp, q2=ds, i0=0,
-              rider_table=table, rider_first=first, rider_count=4, rider_sq=p_got)
-    g = _gemm_struct(H, dgn, Wh, dh, Bn, R, 4 * R, 4 * R, 4 * R, R, 1, **kw)            # fp32 operands: the fp32-operand kernel
-    assert lib.air_gemm(C.byref(g), _stream()) == -1
-    assert lib.air_wgrad_grouped_skip(pr, len(shapes), 1, _p(p_got), _p(ist2), 0, 8, _stream()) == -1
-    assert lib.air_wgrad_grouped_skip(pr, len(shapes), 1, _p(p_got), _p(ist2), total - 4, 8, _stream()) == -1
+        assert torch.equal(a0, a1)
+    assert float(res[True][4].abs().max()) > 0 and not bool((res[True][5] == 7.0).any())
+    # refused: an order with a backward that is not the graph-order one; too many items to sort
+    wb = H.WriteBwd(_p(d_recon), _p(vrec_d), _p(att_d), _p(dgen), _p(dsx), B, N, Cc, w, 0, None, None, None, None, None, None, None, None, None, _p(order))
+    assert lib.air_write_bwd(C.byref(wb), _stream()) == -1

@@ -615,35 +615,3 @@ def test_bf16_shadow_follows_a_train_model_that_does_not_maintain_it(am, train_k
         tr.training()
         assert tr.store.shadow_stale                      # the step changed the variables without touching the shadow
     assert len(set(losses)) == 3
-
-
-@pytest.mark.parametrize("hp_over,B", [({}, 64), (dict(canvas_size=128, max_steps=5, max_digits=4), 32), (dict(max_steps=1), 16)])
-def test_weight_gradient_riders_are_bit_identical_to_the_grouped_launch(am, monkeypatch, hp_over, B):
-    """The VAE weight-gradient tiles ride as trailing workgroups of dh_heads and the BPTT steps (their operands exist once
-    the data gradient has reached the glimpse); the grouped launch at the end runs the others (AIR_WGRAD_RIDERS=1; the
-    default keeps every tile in the grouped launch): all 36 gradients, the global norm, variables and Adam slots after three
-    steps are BIT-IDENTICAL (same tile code, same slot of the global-norm partials)."""
-    hp = dict(HP, **hp_over)
-    res = {}
-    for riders in (True, False):
-        monkeypatch.setenv("AIR_WGRAD_RIDERS", "1" if riders else "0")      # (off by default: measured slower, air_model.py)
-        model, *_ = _make(am, B, True, prec="bf16", backward="reference", hp=hp)
-        assert (model._ride_count > 0) == riders
-        if riders:
-            names = [op.name for op in model.train_step_ops()]
-            assert model._ride_count >= 200 and model._ride_first == 84 if not hp_over else model._ride_count > 0
-        for _ in range(3):
-            model.training()
-        torch.cuda.synchronize()
-        st = model.store
-        res[riders] = dict(params=st.params.clone(), m=st.m.clone(), v=st.v.clone(), grads=st.grads.clone(), gnorm=st.gnorm.clone(),
-                           partials=st.partials[:model._wgrad_blocks].clone())
-        # also the un-fused backward (gradients only: no partials, no step count) as tests and DP use it
-        s = model._stream()
-        model._run_forward(s)
-        model._run_backward(s)
-        torch.cuda.synchronize()
-        res[riders]["grads_plain"] = st.grads.clone()
-    for k in res[True]:
-        assert torch.equal(res[True][k], res[False][k]), k
-    assert float(res[True]["grads"].abs().max()) > 0

@@ -58,8 +58,7 @@ class Gemm(C.Structure):
                 ("epi", _i), ("tile_m", _i), ("tile_n", _i), ("ksplit", _i), ("addend_slabs", _i), ("i0", _i),
                 ("p0", _p), ("p1", _p), ("p2", _p), ("p3", _p), ("q0", _p), ("q1", _p), ("q2", _p),
                 ("step_job", C.POINTER(StepJob)),
-                ("A16", _p), ("B16", _p), ("C16", _p), ("q0_16", _p), ("q2_16", _p), ("B16p", _p),
-                ("rider_table", _p), ("rider_first", _i), ("rider_count", _i), ("rider_sq", _p)]
+                ("A16", _p), ("B16", _p), ("C16", _p), ("q0_16", _p), ("q2_16", _p), ("B16p", _p)]
 
 
 class Panel(C.Structure):
@@ -99,14 +98,14 @@ class AttendBwd(C.Structure):
 class WriteFwd(C.Structure):
     _fields_ = [("vrec", _p), ("ml", _p), ("images", _p), ("dyn", _p), ("att", _p), ("recon", _p),
                 ("rec_loss", _p), ("d_recon", _p), ("run_loss", _p), ("run_digits", _p), ("loss_item", _p),
-                ("B", _i), ("N", _i), ("C", _i), ("w", _i), ("Z", _i), ("rec_part", _p), ("bands", _i)]
+                ("B", _i), ("N", _i), ("C", _i), ("w", _i), ("Z", _i), ("rec_part", _p), ("bands", _i), ("wb_order", _p)]
 
 
 class WriteBwd(C.Structure):
     _fields_ = [("d_recon", _p), ("vrec", _p), ("att", _p), ("d_gen_pre", _p), ("d_sxy_write", _p),
                 ("B", _i), ("N", _i), ("C", _i), ("w", _i), ("literal", _i),
                 ("fin_loss_item", _p), ("fin_targets", _p), ("fin_digits", _p), ("fin_scalars", _p), ("d_gen_pre16", _p),
-                ("fin_rec_part", _p), ("fin_run_loss", _p), ("fin_rec_loss", _p), ("fin_loss_item_out", _p)]
+                ("fin_rec_part", _p), ("fin_run_loss", _p), ("fin_rec_loss", _p), ("fin_loss_item_out", _p), ("order", _p)]
 
 
 class BottleneckFwd(C.Structure):
@@ -134,10 +133,6 @@ _SIGNATURES = {
     "air_colsum": (C.c_int, [C.POINTER(Colsum), C.c_int, _p]),
     "air_wgrad_num_blocks": (C.c_int, [C.POINTER(Wgrad), C.c_int]),
     "air_wgrad_grouped": (C.c_int, [C.POINTER(Wgrad), C.c_int, C.c_int, _p, _p, _p]),
-    "air_wgrad_grouped_skip": (C.c_int, [C.POINTER(Wgrad), C.c_int, C.c_int, _p, _p, C.c_int, C.c_int, _p]),
-    "air_wgrad_table_bytes": (C.c_int, []),
-    "air_wgrad_table_fill": (C.c_int, [C.POINTER(Wgrad), C.c_int, _p]),
-    "air_wgrad_problem_blocks": (C.c_int, [C.POINTER(Wgrad), C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "air_lstm_gates_fwd": (C.c_int, [_p, _p, _p, _p, _p, C.c_int, C.c_int, _p]),
     "air_lstm_first_step": (C.c_int, [_p, C.c_int, _p, _p, _p, _p, _p, C.c_int, C.c_int, _p]),
     "air_lstm_gates_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, C.c_int, C.c_int, C.c_int, _p]),

@@ -129,7 +129,8 @@ class VariableStore:
             pan.append(H.Panel(src_off, poff, K, N, 4 if gates else 0, 1 if exclusive else 0))
             poff += _align8(K * N if gates else ((N + 15) // 16) * 16 * K)
         o = self.offsets["lstm_kernel"]
-        add_panel("Wx", o, D, 4 * R, True, exclusive=(self.fuse_step0 and D <= 4096))
+        if self.fuse_step0 and D <= 4096:       # (its one reader is the x.Wx launch that also runs the first step; the throughput
+            add_panel("Wx", o, D, 4 * R, True, exclusive=True)     # tiling of a large canvas reads row-major lines: no panel twin there)
         add_panel("Wh", o + D * 4 * R, R, 4 * R, True)
         for k, shp in fused.items():
             if k.endswith("_w") and k not in ("ml_w", "gen0_w") or k == "whid":
@@ -538,8 +539,7 @@ class AIRModel:
     def _gemm(self, A, Bm, Cm, M, N, K, lda, ldb, ldc, ta=0, tb=0, bias=None, addend=None, ldadd=0,
               aux=None, ldaux=0, aux_scale=0.0, act=H.ACT_NONE, actgrad=H.GRAD_NONE, accumulate=0, tag="gemm",
               epi=H.EPI_GENERIC, tile=(0, 0), ksplit=0, addend_slabs=0, i0=0, p=(), q=(), extra_bytes=0, step_job=None,
-              A16=None, B16=None, C16=None, q0_16=None, q2_16=None, B16p=None,
-              rider_table=None, rider_first=0, rider_count=0, rider_sq=None):
+              A16=None, B16=None, C16=None, q0_16=None, q2_16=None, B16p=None):
         p = list(p) + [None] * (4 - len(p))
         q = list(q) + [None] * (3 - len(q))
         if epi == H.EPI_GENERIC and tile == (0, 0) and os.environ.get("AIR_EXP_TILES"):      # tuning hook: "N:tm,tn;N:tm,tn"
@@ -552,8 +552,7 @@ class AIRModel:
                    epi, tile[0], tile[1], ksplit, addend_slabs, i0,
                    _ptr(p[0]), _ptr(p[1]), _ptr(p[2]), _ptr(p[3]), _ptr(q[0]), _ptr(q[1]), _ptr(q[2]),
                    C.pointer(step_job) if step_job is not None else None,
-                   _ptr(A16), _ptr(B16), _ptr(C16), _ptr(q0_16), _ptr(q2_16), _ptr(B16p),
-                   _ptr(rider_table), rider_first, rider_count if rider_table is not None else 0, _ptr(rider_sq))
+                   _ptr(A16), _ptr(B16), _ptr(C16), _ptr(q0_16), _ptr(q2_16), _ptr(B16p))
         fn = self.lib.air_gemm
         kbuf = C.create_string_buffer(96)
         H.check(self.lib.air_gemm_kernel_name(C.byref(g), kbuf, 96), "air_gemm_kernel_name")
@@ -577,7 +576,7 @@ class AIRModel:
             kernel = "lstm_first_step_kernel<%d>" % (4 if args[1] == 4 else 0)
         if name in ("air_vae_bottleneck_fwd", "air_vae_bottleneck_bwd"):   # instantiated per operand form (bf16 twins or fp32)
             kernel = "bottleneck_%s_kernel<256, %s>" % (name[-3:], "true" if self._twins else "false")
-        if name in ("air_wgrad_grouped", "air_wgrad_grouped_skip"):
+        if name == "air_wgrad_grouped":
             kernel = "wgrad_grouped_bf16_kernel" if self._prec else "wgrad_grouped_kernel"
         if name == "air_adam_clip_step_factored":
             kernel = "adam_factored_bf16_kernel" if self._prec else "adam_factored_kernel"
@@ -704,16 +703,25 @@ class AIRModel:
         fwd.append(self._gemm(x, P["out_w"], self.vrec, NB, d, k, k, d, d, bias=P["out_b"],
                               act=H.ACT_SIGMOID_NOISE, aux=self.eps_x, ldaux=d,
                               aux_scale=float(self.vae_likelihood_std), tag="vae_out", A16=x16, B16=T("out_w"), B16p=TP("out_w")))
-        # compose as FOUR workgroups per image (B x 4 instead of B workgroups; AIR_COMPOSE_BANDS=0: one of 1024 threads):
-        # the per-image sums are completed by the next launch in the one-workgroup order -- bit-identical
-        bands = int(os.environ.get("AIR_COMPOSE_BANDS", "4"))
+        # compose can run as 2 or 4 workgroups per image (AIR_COMPOSE_BANDS=2 / 4: B x bands workgroups instead of B of 1024
+        # threads); the per-image sums are then completed by the next launch in the one-workgroup order -- bit-identical
+        # (measured on MI355X: compose 7.7 us as one workgroup, 8.5 us in 4 bands, ~7.7 in 2 -- every band repeats the set-up
+        # loads, the pixel loop was never the long part; 31 -> 35.5 us at 128 x 128.  Default: one workgroup per image.)
+        bands = int(os.environ.get("AIR_COMPOSE_BANDS", "0"))
         if bands not in (0, 2, 4):
             raise ValueError("AIR_COMPOSE_BANDS must be 0, 2 or 4")
         banded = bands != 0
         self._rec_part = torch.zeros(B, 16, dtype=torch.float32, device=imgs.device) if banded else None
+        # more (image, step) items than CUs: the graph-order write backward takes them longest first (one extra workgroup of
+        # the compose launch sorts them; air_write_fwd_t.wb_order).  AIR_WB_ORDER=0 / 1 forces it off / on.
+        env_o = os.environ.get("AIR_WB_ORDER")
+        want_o = (env_o == "1") if env_o in ("0", "1") else (NB > 256)
+        self._wb_order = (torch.arange(NB, dtype=torch.int32, device=imgs.device)
+                          if (want_o and self.train and self._literal == 2 and NB <= 4096) else None)
         wf = H.WriteFwd(_ptr(self.vrec), _ptr(self.ml), _ptr(imgs), _ptr(self.dyn), _ptr(self.att),
                         _ptr(self._recon), _ptr(self._rec_loss), _ptr(self.d_recon if self.train else None),
-                        _ptr(self.run_loss), _ptr(self.run_digits), _ptr(self._loss_item), B, N, Cc, w, Z, _ptr(self._rec_part), bands)
+                        _ptr(self.run_loss), _ptr(self.run_digits), _ptr(self._loss_item), B, N, Cc, w, Z, _ptr(self._rec_part), bands,
+                        _ptr(self._wb_order))
         keep.append(wf)
         fwd.append(self._call("air_write_fwd", C.byref(wf),
                               nbytes=NB * (d + 2 * Z) * 4 + B * D * 4 * (3 if self.train else 2), tag="compose_fwd"))
@@ -742,102 +750,51 @@ class AIRModel:
             self._bwd, self._opt, self._wgrad_plain = [], [], None
             return
 
-        # ---- the weight-gradient problems (their launch comes last; the table is needed first: RIDERS)
-        # dW = A^T . dY for every variable; weights are shared across the time steps, so every dW contracts over all N*B
-        # rows, the LSTM input weights over sum_t dgates.  Order = tile numbering = order of the global-norm partials:
-        # [Wh, heads' hidden layer, the VAE problems that can RIDE, the other VAE problems, head output units, Wx]
+        # ---- the weight-gradient problems: dW = A^T . dY for every variable; weights are shared across the time steps, so
+        # every dW contracts over all N*B rows, the LSTM input weights over sum_t dgates.  Order = tile numbering = order
+        # of the global-norm partials.
+        # (Round 4 let the VAE tiles RIDE as trailing workgroups of dh_heads and the BPTT steps -- their operands exist once
+        # the data gradient has reached the glimpse.  Bit-identical, and slower: 0.1912 vs 0.1762 ms per step, 0.86 vs 0.70
+        # at 128 x 128 -- a launch lasts as long as its slowest workgroup, a K = 192 tile needs 5.5 us, the carriers 3-4 us.
+        # Removed)
         Gx, Gh = G["lstm_kernel"][:D], G["lstm_kernel"][D:]
         probs = []
 
-        def wgp(A, dY, dW, db, M, Nn, K, A16=None, dY16=None):
-            return H.Wgrad(_ptr(A), _ptr(dY), _ptr(dW), _ptr(db), M, Nn, K, M, Nn, Nn, 0, 0, 0, 0, _ptr(A16), _ptr(dY16))
-        probs.append(wgp(self.h[0], self.dgates, Gh, None, R, 4 * R, NB, o16(self.h16, 0), self.dgates16))
-        probs.append(wgp(self.h[1], self.d_hid, G["whid"], G["bhid"], R, HT, NB, o16(self.h16, 1), self.d_hid16))
-        vae = []
+        def wg(A, dY, dW, db, M, Nn, K, A16=None, dY16=None):
+            probs.append(H.Wgrad(_ptr(A), _ptr(dY), _ptr(dW), _ptr(db), M, Nn, K, M, Nn, Nn, 0, 0, 0, 0, _ptr(A16), _ptr(dY16)))
+        wg(self.h[0], self.dgates, Gh, None, R, 4 * R, NB, o16(self.h16, 0), self.dgates16)
+        wg(self.h[1], self.d_hid, G["whid"], G["bhid"], R, HT, NB, o16(self.h16, 1), self.d_hid16)
         x, x16, k = self.window, self.window16, d
         for i, u in enumerate(rec_u):
-            vae.append(wgp(x, self.d_rec[i], G["rec%d_w" % i], G["rec%d_b" % i], k, u, NB, x16, self.d_rec16[i]))
+            wg(x, self.d_rec[i], G["rec%d_w" % i], G["rec%d_b" % i], k, u, NB, x16, self.d_rec16[i])
             x, x16, k = self.rec_act[i], self.rec_act16[i], u
-        vae.append(wgp(x, self.d_ml, G["ml_w"], G["ml_b"], k, 2 * Z, NB, x16, self.d_ml16))
+        wg(x, self.d_ml, G["ml_w"], G["ml_b"], k, 2 * Z, NB, x16, self.d_ml16)
         x, x16, k = self.zs, self.zs16, Z
         for i, u in enumerate(gen_u):
-            vae.append(wgp(x, self.d_gen[i], G["gen%d_w" % i], G["gen%d_b" % i], k, u, NB, x16, self.d_gen16[i]))
+            wg(x, self.d_gen[i], G["gen%d_w" % i], G["gen%d_b" % i], k, u, NB, x16, self.d_gen16[i])
             x, x16, k = self.gen_act[i], self.gen_act16[i], u
-        vae.append(wgp(x, self.d_genpre, G["out_w"], G["out_b"], k, d, NB, x16, self.d_genpre16))
-        # a problem can ride when its tiles take the bf16-twin route (air_wgrad_tile.h::twin_ok) -- every dY of the VAE
-        # exists once the data gradient has reached the glimpse (dgrad_win), i.e. before attend_bwd / dh_heads / the BPTT steps
-        # (the ORDER only depends on the shapes -- the same with and without twins / riders, so that the global norm adds
-        # its partial sums in one order in every mode)
-        shape_ok = lambda q: q.M % 4 == 0 and q.N % 4 == 0  # noqa: E731
-        # (... and the carrying launches have to be bf16-twin kernels: whole 16-byte pieces of their operands)
-        hosts_ok = tw and HT % 8 == 0 and R % 2 == 0
-        first_ride = len(probs)
-        rideable = [q for q in vae if shape_ok(q)]
-        probs += rideable + [q for q in vae if not shape_ok(q)]
-        # OFF by default -- measured on MI355X (tools/ab.sh, 400 steps): 0.1912 ms per step with the 284 VAE tiles riding in
-        # dh_heads and the two BPTT launches, 0.1762 without (0.86 vs 0.70 ms at 128 x 128, where a tile contracts 1280
-        # rows).  A launch lasts as long as its slowest workgroup: a K = 192 tile needs 5.5 us on its own, the carrying
-        # products 3-4 us, so every carrier is stretched by more than the grouped launch at the end saves.
-        # AIR_WGRAD_RIDERS=1 enables it (tests keep the path bit-identical).
-        riding = rideable if (hosts_ok and all(q.A16 and q.dY16 for q in rideable)
-                              and os.environ.get("AIR_WGRAD_RIDERS", "0") == "1") else []
+        wg(x, self.d_genpre, G["out_w"], G["out_b"], k, d, NB, x16, self.d_genpre16)
         probs.append(H.Wgrad(_ptr(self.d_out7), _ptr(self.hid), _ptr(G["wout"]), _ptr(G["bout"]),
                              H.OUT_STRIDE, HT, NB, H.OUT_STRIDE, HT, Hmax, 1, Hs, Hh, Hz))
         # the input-weight gradient contracts over B rows only (sum_t dgates): its many light
         # workgroups go LAST so that they fill the tail of the launch behind the K = N*B ones
-        probs.append(wgp(imgs, self.dgsum, Gx, G["lstm_bias"], D, 4 * R, B, self.images16, self.dgsum16))
+        wg(imgs, self.dgsum, Gx, G["lstm_bias"], D, 4 * R, B, self.images16, self.dgsum16)
         if len(probs) > 12:
             raise NotImplementedError("more than 12 weight matrices (deeper VAE) need a second grouped launch")
         arr = (H.Wgrad * len(probs))(*probs)
         keep.append(arr)
         self._wgrad_arr = arr
-        # the riders' tile range and the device copy of the table they read
-        self._ride_first, self._ride_count, self._ride_table = 0, 0, None
-        if riding:
-            f0, n0_, f1, n1_ = C.c_int(), C.c_int(), C.c_int(), C.c_int()
-            H.check(self.lib.air_wgrad_problem_blocks(arr, len(probs), first_ride, C.byref(f0), C.byref(n0_)), "air_wgrad_problem_blocks")
-            H.check(self.lib.air_wgrad_problem_blocks(arr, len(probs), first_ride + len(riding) - 1, C.byref(f1), C.byref(n1_)),
-                    "air_wgrad_problem_blocks")
-            self._ride_first, self._ride_count = f0.value, f1.value + n1_.value - f0.value
-            nb_tab = self.lib.air_wgrad_table_bytes()
-            host = C.create_string_buffer(nb_tab)
-            tot = self.lib.air_wgrad_table_fill(arr, len(probs), host)
-            if tot <= 0:
-                H.check(tot, "air_wgrad_table_fill")
-            self._ride_table = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(imgs.device)
-        # tiles per carrying launch: dh_heads (N*B/16 x R/16 workgroups of its own), then the BPTT steps (B/16 x R/16 each):
-        # in proportion to the CUs each leaves idle; AIR_WGRAD_RIDER_SPLIT="a,b,c,..." overrides
-        n_hosts = 1 + max(0, N - 1)
-        own = [max(1, (NB + 15) // 16) * max(1, (R + 15) // 16)] + [max(1, (B + 15) // 16) * max(1, (R + 15) // 16)] * (n_hosts - 1)
-        idle = [max(32, 256 - o_) for o_ in own]
-        split = [self._ride_count * v // sum(idle) for v in idle]
-        split[-1] += self._ride_count - sum(split)
-        if os.environ.get("AIR_WGRAD_RIDER_SPLIT"):
-            want = [int(v) for v in os.environ["AIR_WGRAD_RIDER_SPLIT"].split(",")][:n_hosts]
-            want += [0] * (n_hosts - len(want))
-            want[-1] += self._ride_count - sum(want)
-            if min(want) >= 0:
-                split = want
-        ride_at, pos = [], self._ride_first
-        for c_ in split:
-            ride_at.append((pos, c_))
-            pos += c_
-
-        def riders(hi_):
-            """rider arguments of carrying launch hi_ (0 = dh_heads, then the BPTT steps in launch order)"""
-            if self._ride_table is None or ride_at[hi_][1] <= 0:
-                return {}
-            return dict(rider_table=self._ride_table, rider_first=ride_at[hi_][0], rider_count=ride_at[hi_][1], rider_sq=st.partials)
 
         bwd = []
         lit = self._literal
         wb = H.WriteBwd(_ptr(self.d_recon), _ptr(self.vrec), _ptr(self.att), _ptr(self.d_genpre),
-                        _ptr(self.d_sxyw), B, N, Cc, w, lit, None, None, None, None, _ptr(self.d_genpre16))
+                        _ptr(self.d_sxyw), B, N, Cc, w, lit, None, None, None, None, _ptr(self.d_genpre16),
+                        None, None, None, None, _ptr(self._wb_order))
         wbf = H.WriteBwd(_ptr(self.d_recon), _ptr(self.vrec), _ptr(self.att), _ptr(self.d_genpre),
                          _ptr(self.d_sxyw), B, N, Cc, w, lit, _ptr(self._loss_item), _ptr(self.target_num_digits),
                          _ptr(self.run_digits), _ptr(self.scalars), _ptr(self.d_genpre16),
                          *((_ptr(self._rec_part), _ptr(self.run_loss), _ptr(self._rec_loss), _ptr(self._loss_item))
-                           if self._rec_part is not None else (None, None, None, None)))
+                           if self._rec_part is not None else (None, None, None, None)), _ptr(self._wb_order))
         keep += [wb, wbf]
         kbuf = C.create_string_buffer(96)
         H.check(self.lib.air_write_bwd_kernel_name(C.byref(wb), kbuf, 96), "air_write_bwd_kernel_name")
@@ -894,7 +851,7 @@ class AIRModel:
                               p=(self.acts[tl], self.c[tl], self.c[tl + 1]),
                               q=(self.dgates[tl], self.dc[tl % 2], self.dgsum),
                               extra_bytes=4 * B * R * 15, tag="dh_heads", A16=self.d_hid16, B16=T("whid"),
-                              q0_16=o16(self.dgates16, tl), q2_16=(self.dgsum16 if N == 1 else None), **riders(0)))
+                              q0_16=o16(self.dgates16, tl), q2_16=(self.dgsum16 if N == 1 else None)))
         # back-propagation through time: the only sequential part of the backward
         for t in reversed(range(N)):
             last = (t == N - 1)
@@ -909,17 +866,15 @@ class AIRModel:
                                       q=(self.dgates[t], dc_cur, self.dgsum), i0=1,
                                       extra_bytes=4 * B * R * 15, tag="bptt_lstm_bwd",
                                       A16=o16(self.dgates16, t + 1), B16=Wh16, q0_16=o16(self.dgates16, t),
-                                      q2_16=(self.dgsum16 if t == 0 else None), **riders(N - 1 - t)))
+                                      q2_16=(self.dgsum16 if t == 0 else None)))
         self._bwd = bwd
 
         # weight + bias grads of all variables: ONE grouped launch (weights are shared across the
         # time steps, so every dW contracts over all N*B rows; the LSTM input weights over sum_t dgates)
-        # -- minus the tiles that rode in the launches at the end of the backward chain (riders, above)
         arr, probs = self._wgrad_arr, list(self._wgrad_arr)
         wbytes = sum(4 * q.M * q.N + (2 if (q.A16 and q.dY16) else 4) * q.K * (q.M + q.N) for q in probs)
         wflops = sum(2 * q.M * q.N * q.K for q in probs)
-        skip = (self._ride_first, self._ride_count)
-        self._wgrad_plain = self._call("air_wgrad_grouped_skip", arr, len(probs), self._prec, None, None, *skip,
+        self._wgrad_plain = self._call("air_wgrad_grouped", arr, len(probs), self._prec, None, None,
                                        nbytes=wbytes, flops=wflops, tag="wgrad_grouped")
         # single-GPU train step: the same launch also leaves the global-norm partial sums and counts
         # the step, so no separate pass over the 16 MB gradient is needed before Adam
@@ -936,11 +891,11 @@ class AIRModel:
             arr_f = (H.Wgrad * len(probs_f))(*probs_f)
             self._dwx_factors = (H.Wgrad * 1)(H.Wgrad(fx.A, fx.dY, fx.dW, None, fx.M, fx.N, fx.K, fx.lda, fx.ldb, fx.ldc, 0, 0, 0, 0))
             keep.extend([arr_f, self._dwx_factors])
-            self._wgrad_fused = self._call("air_wgrad_grouped_skip", arr_f, len(probs_f), self._prec, _ptr(st.partials),
-                                           _ptr(st.istate), *skip, nbytes=wbytes - 4 * fx.M * fx.N, flops=wflops, tag="wgrad_grouped")
+            self._wgrad_fused = self._call("air_wgrad_grouped", arr_f, len(probs_f), self._prec, _ptr(st.partials),
+                                           _ptr(st.istate), nbytes=wbytes - 4 * fx.M * fx.N, flops=wflops, tag="wgrad_grouped")
         else:
-            self._wgrad_fused = self._call("air_wgrad_grouped_skip", arr, len(probs), self._prec, _ptr(st.partials),
-                                           _ptr(st.istate), *skip, nbytes=wbytes, flops=wflops, tag="wgrad_grouped")
+            self._wgrad_fused = self._call("air_wgrad_grouped", arr, len(probs), self._prec, _ptr(st.partials),
+                                           _ptr(st.istate), nbytes=wbytes, flops=wflops, tag="wgrad_grouped")
 
         self._sqnorm = self._call("air_grad_sqnorm", _ptr(st.grads), st.n, _ptr(st.partials), _ptr(st.istate),
                                   nbytes=4 * st.n, tag="grad_sqnorm")
@@ -1137,8 +1092,7 @@ class AIRModel:
         cs = (H.Colsum * 1)(H.Colsum(_ptr(self.dgsum), _ptr(G["lstm_bias"]), B, 4 * R, 4 * R, 0))
         self._keep += [local, fac, cs]
         ops = dict(world=world, x_all=x_all, dg_all=dg_all, tail=st.grads[D * 4 * R:],
-                   local=self._call("air_wgrad_grouped_skip", local, n_local, self._prec, None, None, self._ride_first,
-                                    self._ride_count, tag="wgrad_grouped_local"),
+                   local=self._call("air_wgrad_grouped", local, n_local, self._prec, None, None, tag="wgrad_grouped_local"),
                    bias=self._call("air_colsum", cs, 1, tag="lstm_bias_colsum"),
                    dwx=self._call("air_wgrad_grouped", fac, 1, self._prec, None, None, tag="wgrad_dWx_gathered"))
         self._dp_factor_ops = ops

@@ -876,7 +876,6 @@ int launch(const air_gemm_t* g, const Args& a0, hipStream_t s) {
     a.slab_stride = (long)a.M * a.ldc;
     // bf16 twins of the operands supplied and this (tile, epilogue, layout) exists as a twin kernel
     if (g->precision == 1 && !TA && twin_rounds(a, TM, TN, false, TB) > 0) return twin_launch(a, TM, TN, TB, grid, s);
-    if (a.rider_count > 0) return AIR_EINVAL;            // riders exist in the bf16-twin kernels only: never dropped silently
     // the lean kernels are instantiated per epilogue; a fused epilogue exists for its one tile shape
     // (resolve_tile) -- any other combination would be a dispatch bug
     constexpr bool T14 = TM == 1 && TN == 4, T12 = TM == 1 && TN == 2, T11 = TM == 1 && TN == 1;
@@ -983,7 +982,6 @@ extern "C" int air_gemm(const air_gemm_t* g, void* stream) {
     hipStream_t s = air_stream(stream);
     if (g->tile_m == 8 && g->tile_n == 4) {
         // the throughput tiling (fp32 A x bf16 shadow, split-K slabs): air_gemm_bf16.hip::gemm_xw_tp_kernel
-        if (a.rider_count > 0) return AIR_EINVAL;
         const int ks = g->ksplit > 1 ? g->ksplit : 1;
         a.kslab = ((a.K + ks - 1) / ks + 3) & ~3;
         const int ok = xw_tp_ok(a, g->precision, g->transA != 0, g->transB != 0, g->ksplit);
@@ -1015,11 +1013,9 @@ extern "C" int air_gemm_kernel_name(const air_gemm_t* g, char* buf, int n) {
         return 0;
     }
     if (g->precision == 1 && !ta && twin_rounds(a, tm, tn, false, tb) > 0) {
-        if (a.rider_count > 0 && !(tm == 1 && tn == 1 && tb && (g->epi == AIR_EPI_LSTM_BWD || g->epi == AIR_EPI_LSTM_BWD_TAIL))) return AIR_EINVAL;
         twin_kernel_name(a, tm, tn, tb, buf, n);
         return 0;
     }
-    if (a.rider_count > 0) return AIR_EINVAL;              // riders need a bf16-twin kernel (as air_gemm itself answers)
     if (g->precision == 1 && use_bf16_v2(a, ta, tb))
         snprintf(buf, n, "gemm_bf16v2_kernel<%d, %d, %s, %d>", tm, tn, tb ? "true" : "false", g->epi);
     else if (g->precision == 0 && use_bf16_v2(a, ta, tb) && getenv("AIR_GEMM_F32_V1") == nullptr)
@@ -1054,9 +1050,6 @@ static int fill_args(const air_gemm_t* g, Args& a) {
     a.i0 = g->i0; a.i1 = 0;
     a.A16 = g->A16; a.B16 = g->B16; a.C16 = g->C16; a.q0_16 = g->q0_16; a.q2_16 = g->q2_16;
     a.B16p = (g->precision == 1 && !g->transA && !g->transB) ? g->B16p : nullptr;
-    a.rider_tab = g->rider_table; a.rider_first = g->rider_first; a.rider_count = g->rider_table ? g->rider_count : 0;
-    a.rider_planes = 0; a.rider_sq = g->rider_sq;
-    if (a.rider_count < 0 || a.rider_first < 0) return AIR_EINVAL;
     a.job_on = 0;
     if (g->step_job) {
         const air_step_job_t& j = *g->step_job;

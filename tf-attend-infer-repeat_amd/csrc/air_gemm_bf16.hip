@@ -22,7 +22,6 @@
 // the fp32-operand bf16 path (tests/test_gpu_kernels.py::test_gemm_bf16_twins_bit_identical).
 // A may stay fp32 (AF32: the hoisted x.Wx reads the caller's fp32 image batch).
 #include "air_gemm_common.h"
-#include "air_wgrad_tile.h"
 #include <atomic>
 #include <cstdlib>
 #include <cstdio>
@@ -71,19 +70,7 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16tw_kernel(Args a)
         air_step_job_run(a.job, blockIdx.z * plane + (long)blockIdx.y * gridDim.x + blockIdx.x, plane * a.job_on);
         return;
     }
-    // weight-gradient riders: the last planes (dispatched behind the product's own workgroups).  Only the kernels at
-    // the end of the backward chain are instantiated with the code (the launcher refuses riders elsewhere).
-    constexpr bool RIDES = TM == 1 && TN == 1 && TB && (EPI_ == AIR_EPI_LSTM_BWD || EPI_ == AIR_EPI_LSTM_BWD_TAIL);
-    if (RIDES && (int)blockIdx.z >= (int)gridDim.z - a.rider_planes) {
-        const int plane = (int)(gridDim.x * gridDim.y);
-        const int r = ((int)blockIdx.z - ((int)gridDim.z - a.rider_planes)) * plane + (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
-        if (r < a.rider_count)
-            airw::run_tile_bf16(*reinterpret_cast<const airw::Table*>(a.rider_tab), a.rider_first + r,
-                                reinterpret_cast<unsigned short*>(Lds), a.rider_sq, nullptr,
-                                reinterpret_cast<float*>(Lds + sizeof(unsigned short) * 2 * airw::NIMG_W * airw::BT * airw::KB));
-        return;
-    }
-    const int nslab = (int)gridDim.z - a.job_on - (RIDES ? a.rider_planes : 0);
+    const int nslab = (int)gridDim.z - a.job_on;
     const int zslab = (int)blockIdx.z - a.job_on;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int tile_m, tile_n;
@@ -432,24 +419,12 @@ __global__ __launch_bounds__(THREADS) void gemm_xw_tp_kernel(Args a)
 }
 
 template <int TM, int TN, bool TB, int EPI_, bool AF32, int R>
-int launch_one(const Args& a0, dim3 grid, hipStream_t s) {
+int launch_one(const Args& a, dim3 grid, hipStream_t s) {
     using Cfg = TwCfg<TM, TN, R>;
     auto kern = gemm_bf16tw_kernel<TM, TN, TB, EPI_, AF32, R>;
-    Args a = a0;
-    size_t lds = Cfg::BYTES;
-    a.rider_planes = 0;
-    if (a.rider_count > 0) {
-        constexpr bool RIDES = TM == 1 && TN == 1 && TB && (EPI_ == AIR_EPI_LSTM_BWD || EPI_ == AIR_EPI_LSTM_BWD_TAIL);
-        if (!RIDES || !a.rider_tab) return AIR_EINVAL;
-        const int plane = (int)(grid.x * grid.y);
-        a.rider_planes = (a.rider_count + plane - 1) / plane;
-        grid.z += a.rider_planes;
-        const size_t need = sizeof(unsigned short) * 2 * airw::NIMG_W * airw::BT * airw::KB + 16;    // the tile's images / fp32 output tile + the norm reduction
-        if (lds < need) lds = need;
-    }
-    const int rc = air_grant_lds(reinterpret_cast<const void*>(kern), lds);
+    const int rc = air_grant_lds(reinterpret_cast<const void*>(kern), Cfg::BYTES);
     if (rc) return rc;
-    hipLaunchKernelGGL(kern, grid, dim3(THREADS), lds, s, a);
+    hipLaunchKernelGGL(kern, grid, dim3(THREADS), Cfg::BYTES, s, a);
     AIR_CHECK_LAUNCH();
     return 0;
 }

@@ -58,10 +58,6 @@ struct Args {
     // optional step prologue (schedules + Philox noise) carried by the workgroups of an extra grid.z
     // plane: the hoisted x.Wx launch needs neither, so the prologue costs no launch of its own
     int job_on; AirStepJob job;   // job_on = number of grid.z planes given to the prologue (0 = none)
-    // optional weight-gradient RIDERS (air_gemm_t.rider_table): the LAST rider_planes grid.z planes of this launch run
-    // tiles rider_first .. rider_first + rider_count - 1 of a grouped weight-gradient table (air_wgrad_tile.h) -- work
-    // whose operands exist already, on the CUs this narrow launch leaves idle
-    const void* rider_tab; int rider_first, rider_count, rider_planes; float* rider_sq;
 };
 
 // Epilogue operands (bias / addend / aux / LSTM state) are PREFETCHED into registers at kernel

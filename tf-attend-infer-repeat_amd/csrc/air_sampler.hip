@@ -29,8 +29,15 @@ extern "C" int air_debug_stamps_wg(unsigned long long* out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(air_stamps_wg), sizeof(unsigned long long) * (n < 4096 * 8 ? n : 4096 * 8));
 }
 #define AIR_STAMP_WG(i) do { if (threadIdx.x == 0) air_stamps_wg[((blockIdx.y * gridDim.x + blockIdx.x) & 4095) * 8 + (i)] = wall_clock64(); } while (0)
+// accumulating form (large canvases: four passes per workgroup): slot i += now - t0, and plain values
+#define AIR_STAMP_WG_ADD(i, t0) do { if (threadIdx.x == 0) air_stamps_wg[((blockIdx.y * gridDim.x + blockIdx.x) & 4095) * 8 + (i)] += wall_clock64() - (t0); } while (0)
+#define AIR_STAMP_WG_SET(i, v) do { if (threadIdx.x == 0) air_stamps_wg[((blockIdx.y * gridDim.x + blockIdx.x) & 4095) * 8 + (i)] = (unsigned long long)(v); } while (0)
+#define AIR_NOW() wall_clock64()
 #else
 #define AIR_STAMP_WG(i) do { } while (0)
+#define AIR_STAMP_WG_ADD(i, t0) do { } while (0)
+#define AIR_STAMP_WG_SET(i, v) do { } while (0)
+#define AIR_NOW() 0ull
 #endif
 
 namespace {
@@ -635,10 +642,81 @@ __global__ __launch_bounds__(THREADS) void attend_bwd_kernel(air_attend_bwd_t a)
 // also does the per-image bookkeeping (KLs, running loss, digit count).
 constexpr int CF_THREADS = 1024;
 constexpr int CF_BANDS = 4;
+
+// LONGEST-FIRST ORDER of the (image, step) items for the graph-order write backward (air_write_fwd_t.wb_order), computed
+// by ONE extra workgroup of the compose launch.  Why: the backward's workgroups differ by two orders of magnitude in work
+// -- an inactive item returns at once, an item whose glimpse is small pushes up to 4 C^2 corner terms through its CU's
+// LDS atomic pipe -- and with several workgroups per CU (128 x 128: 1280 items on 256 CUs) the hardware hands them out
+// in launch order: per-CU stamps (tools/wb_wg_stamps.py --stress) showed 68 k corner terms per CU on average but 218 k on
+// the busiest, which then IS the launch (282 us against a mean CU busy time of 138).  Greedy dispatch of a list sorted
+// by decreasing cost is the classic 4/3-optimal schedule.  Cost of an item = the corner terms it will accumulate (exact:
+// the out-of-range columns x rows of its write transformer, x 4 taps) + a constant for its fixed phases; 0 when
+// inactive.  The order is a permutation: which workgroup computes an item changes nothing in the results.
+constexpr int WB_ORDER_MAX = 4096;
+constexpr int WB_COST_SHIFT = 10, WB_BUCKETS = 96;          // cost classes of 1024 terms (~2 us of atomic pipe each)
+__device__ __forceinline__ void wb_order_block(const air_write_fwd_t& a, unsigned* lds /* >= 4096 words */) {
+    // A COUNTING sort by cost class (a full bitonic sort of 2048 keys took this one workgroup 40 us -- longer than the
+    // compose launch it rides in): class histogram with LDS atomics, prefix over the classes from the most expensive
+    // down, scatter.  Within a class the order is whatever the atomics deliver -- it only decides which workgroup
+    // computes which item, never a result.
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int NB = a.N * a.B, C = a.C, w = a.w;
+    int* hist = reinterpret_cast<int*>(lds);                // [WB_BUCKETS]
+    int* basep = hist + WB_BUCKETS;                         // [WB_BUCKETS]
+    for (int i = tid; i < 2 * WB_BUCKETS; i += nthreads) hist[i] = 0;
+    __syncthreads();
+    constexpr int PER = (WB_ORDER_MAX + CF_THREADS / CF_BANDS - 1) / (CF_THREADS / CF_BANDS);      // items per thread, at most
+    int cls[PER], pos[PER];
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+        const int it = tid + r * nthreads;
+        cls[r] = -1; pos[r] = 0;
+        if (it < NB) {
+            const float* at = a.att + (size_t)it * AIR_ATT_STRIDE;
+            unsigned cost = 0u;
+            if (at[AIR_ATT_MASK] != 0.0f) {
+                const float s = at[AIR_ATT_S], x = at[AIR_ATT_X], y = at[AIR_ATT_Y];
+                const float ia = 1.0f / s, bx = (-x) / s, by = (-y) / s;
+                // canvas columns / rows whose two taps clip to one index: X < 0 or X >= w - 1 (axis_tap).  X is monotone in
+                // the canvas coordinate (1 / s > 0): both counts are binary searches with axis_tap's own arithmetic
+                auto oob = [&](float bb) {
+                    auto Xof = [&](int j) {
+                        const float step = 2.0f / (float)(C - 1);
+                        const float tt = -1.0f + step * (float)j;
+                        const float xs = ia * tt + bb;
+                        return ((xs + 1.0f) * ((float)w - 1.001f)) / 2.0f;
+                    };
+                    int lo = 0, hi = C;                         // first j with X(j) >= 0
+                    while (lo < hi) { const int m = (lo + hi) >> 1; if (Xof(m) >= 0.0f) hi = m; else lo = m + 1; }
+                    const int below = lo;
+                    lo = 0; hi = C;                             // first j with X(j) >= w - 1
+                    while (lo < hi) { const int m = (lo + hi) >> 1; if (Xof(m) >= (float)(w - 1)) hi = m; else lo = m + 1; }
+                    return below + (C - lo);
+                };
+                cost = 4u * (unsigned)oob(bx) * (unsigned)oob(by) + 12000u;   // + ~25 us of term / chain / set-up phases at 4 cycles per term
+            }
+            // class 0 = the most expensive; inactive items (cost 0) in the last class
+            const int c = cost ? max(0, WB_BUCKETS - 2 - (int)(cost >> WB_COST_SHIFT)) : WB_BUCKETS - 1;
+            cls[r] = c;
+            pos[r] = atomicAdd(&hist[c], 1);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) { int run = 0; for (int c = 0; c < WB_BUCKETS; ++c) { basep[c] = run; run += hist[c]; } }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < PER; ++r)
+        if (cls[r] >= 0) a.wb_order[basep[cls[r]] + pos[r]] = tid + r * nthreads;
+}
+
 template <int NT, bool BANDS>
 __global__ __launch_bounds__(NT) void write_fwd_kernel(air_write_fwd_t a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (a.wb_order && (int)blockIdx.x == a.B) {                  // the one extra workgroup of the launch (block-uniform)
+        if (!BANDS || blockIdx.y == 0) wb_order_block(a, reinterpret_cast<unsigned*>(smem));
+        return;
+    }
     const int b = blockIdx.x, band = BANDS ? (int)blockIdx.y : 0, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int vt = band * NT + tid;                                       // virtual thread of the image, 0 .. 1023
     const int C = a.C, w = a.w, Z = a.Z, N = a.N, B = a.B;
@@ -1089,7 +1167,12 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
     const bool lds_ordered = seq_flags & 1, ring_ok = seq_flags & 2;
     const int mix16 = (seq_flags >> 8) & 0xff;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int b = blockIdx.x, t = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // which (image, step) item this workgroup computes: its grid position, or -- a.order given -- entry `linear block id` of
+    // the longest-first permutation the compose launch left (wb_order_block)
+    const int lin = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+    const int item = a.order ? a.order[lin] : lin;
+    const int b = item % a.B, t = item / a.B;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NW = WB_THREADS / 64;
     const int C = a.C, w = a.w, CC = C * C, CCp = (CC + 3) & ~3;
     const size_t row = (size_t)t * a.B + b;
@@ -1110,7 +1193,7 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
     float* sh_T = ALLPH ? sh_g + CCp : sh_g;               // [4 or 1][C*C] terms, rectangle-blocked per tap (16-byte aligned)
     const float* gsrc = a.d_recon + (size_t)b * CC;
 
-    if (a.fin_scalars && b == 0 && t == 0) {
+    if (a.fin_scalars && lin == (a.order ? (int)(gridDim.x * gridDim.y) - 1 : 0)) {     // (ordered: the lightest item's workgroup)
         float r4[4] = {0.f, 0.f, 0.f, 0.f};
         for (int i = tid; i < a.B; i += WB_THREADS) {
             // (banded compose: the per-image sums are finished here, air_write_fwd_t.rec_part)
@@ -1466,22 +1549,33 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
                 if (j >= C) { j -= C; ++i; }
             }
         };
+        // (debug stamps of every workgroup: [1] terms, [2] chains, [3] corner phase summed over the four passes, [4] hardware
+        // id (XCC / SE / CU), [5] pipe mask, [6] end; tools/wb_wg_stamps.py --stress)
+        AIR_STAMP_WG_SET(1, 0); AIR_STAMP_WG_SET(2, 0); AIR_STAMP_WG_SET(3, 0);
+        AIR_STAMP_WG_SET(4, (__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 16) | __builtin_amdgcn_s_getreg(4 | (0 << 6) | (15 << 11)));
+        AIR_STAMP_WG_SET(5, pipe_mask | (sh_cn[0] + sh_cn[1] + sh_cn[2] + sh_cn[3]) << 4);
         for (int ph = 0; ph < 4; ++ph) {
+            const unsigned long long ta = AIR_NOW();
             if (ph == 0) stage_one(std::integral_constant<int, 0>{});
             else if (ph == 1) stage_one(std::integral_constant<int, 1>{});
             else if (ph == 2) stage_one(std::integral_constant<int, 2>{});
             else stage_one(std::integral_constant<int, 3>{});
             __syncthreads();
             AIR_STAMP(50 + 3 * ph);
+            AIR_STAMP_WG_ADD(1, ta);
+            const unsigned long long tb = AIR_NOW();
             chains(ph, ph + 1);
             __syncthreads();
             AIR_STAMP(51 + 3 * ph);
+            AIR_STAMP_WG_ADD(2, tb);
+            const unsigned long long tc = AIR_NOW();
             if (wave < 4) {
                 if ((pipe_mask >> wave) & 1) feed_corner(wave, ph, ph + 1);
                 else if (ring_ok) ring_corner(wave, ph, ph + 1);
             } else if (ph == 0) theta_loop(TH0, THN);
             __syncthreads();
             AIR_STAMP(52 + 3 * ph);
+            AIR_STAMP_WG_ADD(3, tc);
         }
     }
     if (!ALLPH) { publish(); __syncthreads(); }
@@ -1684,21 +1778,26 @@ extern "C" int air_write_fwd(const air_write_fwd_t* a, void* stream) {
         return AIR_EINVAL;
     if (a->B <= 0 || a->N <= 0 || a->C < 2 || a->w < 2 || a->Z <= 0) return AIR_EINVAL;
     if (a->N > MAX_STEPS) return AIR_ELIMIT;
-    const size_t lds = write_smem(a->N, a->C, a->w);
+    size_t lds = write_smem(a->N, a->C, a->w);
+    const unsigned extra = a->wb_order ? 1u : 0u;                 // + the workgroup that sorts the backward's items
+    if (a->wb_order) {
+        if ((long)a->N * a->B > WB_ORDER_MAX) return AIR_ELIMIT;
+        if (lds < WB_ORDER_MAX * sizeof(unsigned)) lds = WB_ORDER_MAX * sizeof(unsigned);
+    }
     if (a->rec_part && a->bands == 2) {
         int rc = ensure_lds(write_fwd_kernel<CF_THREADS / 2, true>, lds);
         if (rc) return rc;
-        hipLaunchKernelGGL((write_fwd_kernel<CF_THREADS / 2, true>), dim3(a->B, 2), dim3(CF_THREADS / 2), lds, air_stream(stream), *a);
+        hipLaunchKernelGGL((write_fwd_kernel<CF_THREADS / 2, true>), dim3(a->B + extra, 2), dim3(CF_THREADS / 2), lds, air_stream(stream), *a);
     } else if (a->rec_part) {
         if (a->bands != 0 && a->bands != CF_BANDS) return AIR_EINVAL;
         int rc = ensure_lds(write_fwd_kernel<CF_THREADS / CF_BANDS, true>, lds);
         if (rc) return rc;
-        hipLaunchKernelGGL((write_fwd_kernel<CF_THREADS / CF_BANDS, true>), dim3(a->B, CF_BANDS), dim3(CF_THREADS / CF_BANDS), lds,
+        hipLaunchKernelGGL((write_fwd_kernel<CF_THREADS / CF_BANDS, true>), dim3(a->B + extra, CF_BANDS), dim3(CF_THREADS / CF_BANDS), lds,
                            air_stream(stream), *a);
     } else {
         int rc = ensure_lds(write_fwd_kernel<CF_THREADS, false>, lds);
         if (rc) return rc;
-        hipLaunchKernelGGL((write_fwd_kernel<CF_THREADS, false>), dim3(a->B), dim3(CF_THREADS), lds, air_stream(stream), *a);
+        hipLaunchKernelGGL((write_fwd_kernel<CF_THREADS, false>), dim3(a->B + extra), dim3(CF_THREADS), lds, air_stream(stream), *a);
     }
     AIR_CHECK_LAUNCH();
     return 0;
@@ -1717,6 +1816,7 @@ extern "C" int air_write_bwd(const air_write_bwd_t* a, void* stream) {
     if (!a || !a->d_recon || !a->vrec || !a->att || !a->d_gen_pre || !a->d_sxy_write) return AIR_EINVAL;
     if (a->B <= 0 || a->N <= 0 || a->C < 2 || a->w < 2) return AIR_EINVAL;
     if (a->fin_rec_part && (!a->fin_scalars || !a->fin_run_loss || !a->fin_rec_loss || !a->fin_loss_item_out)) return AIR_EINVAL;
+    if (a->order && a->literal != 2) return AIR_EINVAL;           // (the ordered form exists in the graph-order kernel only)
     if (2 * a->w > THREADS) return AIR_ELIMIT;
     if (a->literal == 2) {
         if (a->w * a->w > WB_THREADS) return AIR_ELIMIT;
@@ -1726,11 +1826,13 @@ extern "C" int air_write_bwd(const air_write_bwd_t* a, void* stream) {
         int rc = allph ? ensure_lds(write_bwd_graph_kernel<true>, lds) : ensure_lds(write_bwd_graph_kernel<false>, lds);
         if (rc) return rc;
         int flags = accumulators(air_stream(stream));
-        // pipe / ring mix (write_bwd_graph_kernel::pipe_mask): c in sixteenths.  Large canvases -- several workgroups per
-        // CU share the one atomic pipe -- default to c = 2; one workgroup per CU (all taps resident) keeps the pipe.
-        // AIR_WB_MIX=<float> overrides (0 = pipe only).
+        // pipe / ring mix (write_bwd_graph_kernel::pipe_mask): c in sixteenths; AIR_WB_MIX=<float>, default 0 = pipe only.
+        // Measured at 128 x 128 (tools/ab.sh, tools/wb_wg_stamps.py --stress): 0.715 / 0.712 / 0.721 / 0.831 ms per step at
+        // c = 0 / 1 / 2 / 3 before the items were ordered, 0.635 / 0.637 / 0.642 at c = 0 / 1 / 2 after -- a ring stream
+        // lasts as long as the pipe would have taken for the whole workgroup, and the launch was never bound by the pipe's
+        // RATE but by which CU got the most work (wb_order_block).
         static const int mix_env = [] { const char* e = getenv("AIR_WB_MIX"); return e ? (int)(atof(e) * 16.0 + 0.5) : -1; }();
-        int mix16 = mix_env >= 0 ? mix_env : (allph ? 0 : 32);
+        int mix16 = mix_env >= 0 ? mix_env : 0;
         if (mix16 > 255) mix16 = 255;
         if ((flags & 3) == 3) flags |= mix16 << 8;
         if (allph) hipLaunchKernelGGL(write_bwd_graph_kernel<true>, dim3(a->B, a->N), dim3(WB_THREADS), lds, air_stream(stream), *a, flags);

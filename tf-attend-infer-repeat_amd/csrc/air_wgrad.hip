@@ -155,14 +155,11 @@ __device__ __forceinline__ float tile_f32(const Prob& pr, int m0, int n0, float 
     return bias_sq;
 }
 
-// skip_first / skip_count: a contiguous range of the table's blocks that RIDER workgroups of earlier launches have already
-// computed (air_gemm_t.rider_table): the grid only holds the others, every block keeps its number (= its global-norm slot)
-__global__ __launch_bounds__(THREADS) void wgrad_grouped_kernel(Table tab, float* __restrict__ sq_partials, int32_t* __restrict__ istate,
-                                                                int skip_first, int skip_count)
+__global__ __launch_bounds__(THREADS) void wgrad_grouped_kernel(Table tab, float* __restrict__ sq_partials, int32_t* __restrict__ istate)
 {
     __shared__ __attribute__((aligned(16))) float As[2][KC * LS];
     __shared__ __attribute__((aligned(16))) float Bs[2][KC * LS];
-    const int block = (int)blockIdx.x < skip_first ? (int)blockIdx.x : (int)blockIdx.x + skip_count;
+    const int block = (int)blockIdx.x;
     int m0, n0;
     const Prob& pr = find_tile(tab, block, m0, n0);
     const float bias_sq = tile_f32<6>(pr, m0, n0, As, Bs);      // K = 192 (3 steps x 64 images) in one round trip
@@ -173,13 +170,12 @@ __global__ __launch_bounds__(THREADS) void wgrad_grouped_kernel(Table tab, float
 
 
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void wgrad_grouped_bf16_kernel(
-    Table tab, float* __restrict__ sq_partials, int32_t* __restrict__ istate, int skip_first, int skip_count)
+    Table tab, float* __restrict__ sq_partials, int32_t* __restrict__ istate)
 {
     // [operand][image][column 0..63][k 0..63] bf16 = 2 x 3 x 8 KB; reused as the fp32 output tile
     __shared__ __attribute__((aligned(16))) unsigned short Img[2 * NIMG_W * BT * KB];
-    const int block = (int)blockIdx.x < skip_first ? (int)blockIdx.x : (int)blockIdx.x + skip_count;
     __shared__ float sq_red[4];
-    run_tile_bf16(tab, block, Img, sq_partials, istate, sq_red);
+    run_tile_bf16(tab, (int)blockIdx.x, Img, sq_partials, istate, sq_red);
 }
 
 // ---------------------------------------------------------------------------
@@ -310,46 +306,15 @@ extern "C" int air_wgrad_num_blocks(const air_wgrad_t* probs, int count) {
     return rc ? rc : tab.total_blocks;
 }
 
-extern "C" int air_wgrad_grouped_skip(const air_wgrad_t* probs, int count, int precision,
-                                      float* sq_partials, int32_t* istate, int skip_first, int skip_count, void* stream) {
+extern "C" int air_wgrad_grouped(const air_wgrad_t* probs, int count, int precision,
+                                 float* sq_partials, int32_t* istate, void* stream) {
     Table tab;
     const int rc = fill_table(probs, count, tab, sq_partials != nullptr);
     if (rc) return rc;
     if (precision != 0 && precision != 1) return AIR_EINVAL;
-    if (skip_first < 0 || skip_count < 0 || skip_first + skip_count > tab.total_blocks) return AIR_EINVAL;
-    if (skip_count > 0 && skip_first == 0) return AIR_EINVAL;               // block 0 counts the step: it stays in this launch
-    const int blocks = tab.total_blocks - skip_count;
-    if (blocks <= 0) return AIR_EINVAL;
-    if (precision == 1) hipLaunchKernelGGL(wgrad_grouped_bf16_kernel, dim3(blocks), dim3(THREADS), 0, air_stream(stream), tab, sq_partials, istate, skip_first, skip_count);
-    else hipLaunchKernelGGL(wgrad_grouped_kernel, dim3(blocks), dim3(THREADS), 0, air_stream(stream), tab, sq_partials, istate, skip_first, skip_count);
+    if (precision == 1) hipLaunchKernelGGL(wgrad_grouped_bf16_kernel, dim3(tab.total_blocks), dim3(THREADS), 0, air_stream(stream), tab, sq_partials, istate);
+    else hipLaunchKernelGGL(wgrad_grouped_kernel, dim3(tab.total_blocks), dim3(THREADS), 0, air_stream(stream), tab, sq_partials, istate);
     AIR_CHECK_LAUNCH();
-    return 0;
-}
-
-extern "C" int air_wgrad_grouped(const air_wgrad_t* probs, int count, int precision,
-                                 float* sq_partials, int32_t* istate, void* stream) {
-    return air_wgrad_grouped_skip(probs, count, precision, sq_partials, istate, 0, 0, stream);
-}
-
-/* the descriptor table of a grouped launch as the kernels read it, for RIDERS (air_gemm_t.rider_table): filled into HOST
- * memory here, copied to the device by the caller (the library never allocates) */
-extern "C" int air_wgrad_table_bytes(void) { return (int)sizeof(Table); }
-extern "C" int air_wgrad_table_fill(const air_wgrad_t* probs, int count, void* host_dst) {
-    if (!host_dst) return AIR_EINVAL;
-    Table tab;
-    const int rc = fill_table(probs, count, tab, true);
-    if (rc) return rc;
-    memcpy(host_dst, &tab, sizeof(Table));
-    return tab.total_blocks;
-}
-/* first block and number of blocks of problem `problem` in the table's numbering */
-extern "C" int air_wgrad_problem_blocks(const air_wgrad_t* probs, int count, int problem, int* first, int* nblocks) {
-    if (!first || !nblocks || problem < 0 || problem >= count) return AIR_EINVAL;
-    Table tab;
-    const int rc = fill_table(probs, count, tab, true);
-    if (rc) return rc;
-    *first = tab.p[problem].first_block;
-    *nblocks = (problem + 1 < count ? tab.p[problem + 1].first_block : tab.total_blocks) - tab.p[problem].first_block;
     return 0;
 }
 

@@ -1,6 +1,9 @@
-// Device code of the weight-gradient tiles (dW = A^T . dY, one 64 x 64 output tile per workgroup), shared by the grouped
-// weight-gradient launch (air_wgrad.hip) and by the GEMM kernels that carry tiles as RIDERS (air_gemm_bf16.hip): trailing
-// workgroups of the narrow launches at the end of the backward chain compute weight gradients whose operands already exist.
+// Device code of the weight-gradient tiles (dW = A^T . dY, one 64 x 64 output tile per workgroup) of the grouped
+// weight-gradient launch (air_wgrad.hip).  A header of its own since round 4, when the tiles could also RIDE as trailing
+// workgroups of the narrow GEMM launches at the end of the backward chain (dh_heads, the BPTT steps) -- built, bit-identical,
+// and measured slower (a launch lasts as long as its slowest workgroup, and a K = 192 tile outlasts the carrying products:
+// 0.1912 vs 0.1762 ms per step; the rider code alone cost the carriers 1.4 us through its registers): removed again,
+// DESIGN.md section 8.
 #pragma once
 #include "air_common.h"
 #include <type_traits>
