@@ -1436,14 +1436,25 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
             slot_run(ph, (c & 2) ? w - 1 : 0, (c & 1) ? w - 1 : 0, start, n);
             start = __builtin_amdgcn_readfirstlane(start); n = __builtin_amdgcn_readfirstlane(n);
             if (n <= 0) continue;
-            float r = lane < n ? sh_T[start + lane] : -0.0f;
-            for (int b = 0; b < n; b += 64) {
-                const int nx = b + 64 + lane;
-                const float rn = nx < n ? sh_T[start + nx] : -0.0f;      // the next batch's read under this batch's adds
+            // RD batches of 64 terms are read ahead of the adds: beside a feeding wave the LDS serves a read only after the
+            // atomics queued in front of it (up to 16 instructions of ~255 cycles per feeding wave), i.e. thousands of cycles
+            // late -- with ONE batch in flight (768 cycles of adds) a ring beside the pipe ran at a fraction of its 12
+            // cycles per term
+            constexpr int RD = 8;
+            float r[RD];
 #pragma unroll
-                for (int k = 0; k < 64; ++k)
-                    asm volatile("v_add_f32_dpp %0, %0, %1 wave_ror:1 row_mask:0xf bank_mask:0xf" : "+v"(S) : "v"(r));
-                r = rn;
+            for (int d = 0; d < RD; ++d) { const int ix = d * 64 + lane; r[d] = ix < n ? sh_T[start + ix] : -0.0f; }
+            for (int b = 0; b < n; b += 64 * RD) {
+#pragma unroll
+                for (int d = 0; d < RD; ++d) {
+                    if (b + d * 64 < n) {                                   // (uniform)
+#pragma unroll
+                        for (int k = 0; k < 64; ++k)
+                            asm volatile("v_add_f32_dpp %0, %0, %1 wave_ror:1 row_mask:0xf bank_mask:0xf" : "+v"(S) : "v"(r[d]));
+                    }
+                    const int nx = b + (d + RD) * 64 + lane;
+                    r[d] = nx < n ? sh_T[start + nx] : -0.0f;               // refill this slot: RD batches ahead
+                }
             }
         }
         __builtin_amdgcn_s_setprio(0);
