@@ -673,7 +673,10 @@ __global__ __launch_bounds__(THREADS) void gemm_f32v2_kernel(Args a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int tile_m, tile_n;
     xcd_tile(tile_m, tile_n);
-    const int m0 = tile_m * BM, n0 = EPI_ == AIR_EPI_LSTM_FWD0 ? tile_n * 4 : tile_n * BN / TN * (a.gstride == 16 ? TN : 1);
+    // 16 columns = 4 gates x 4 units: the first-step launch, and (EPI_LSTM_FWD_Q) the later LSTM steps -- 256 workgroups
+    // of 16 columns instead of 64 of 64, the same accumulation per element
+    constexpr bool QUADF = EPI_ == AIR_EPI_LSTM_FWD0 || EPI_ == EPI_LSTM_FWD_Q;
+    const int m0 = tile_m * BM, n0 = QUADF ? tile_n * 4 : tile_n * BN / TN * (a.gstride == 16 ? TN : 1);
     const int kbeg = zslab * a.kslab;
     const int kend = min(a.K, kbeg + a.kslab);
 
@@ -733,8 +736,8 @@ __global__ __launch_bounds__(THREADS) void gemm_f32v2_kernel(Args a)
                 const int c = t / (BN * 2), q = (t / 8) % (BN / 4), g = t & 7;
                 const int col = q * 4, j = col >> 4, cc = col & 15;
                 // (LSTM_FWD0: column quad q = gate q of the four units n0 .. n0+3)
-                const int gn = EPI_ == AIR_EPI_LSTM_FWD0 ? n0 + q * a.gstride : n0 + j * a.gstride + cc;
-                const int cg = EPI_ == AIR_EPI_LSTM_FWD0 ? n0 : n0 + cc + (a.gstride == 16 ? j * 16 : 0);
+                const int gn = QUADF ? n0 + q * a.gstride : n0 + j * a.gstride + cc;
+                const int cg = QUADF ? n0 : n0 + cc + (a.gstride == 16 ? j * 16 : 0);
                 const int gk = kr + c * KB + g * 8;
                 const bool okc = (t < R * BN * 2) && cg < a.gwidth && gn < a.N;
                 const bool okh = okc && cg + 2 < a.gwidth && gn + 2 < a.N;     // upper half of the column quad
@@ -898,6 +901,21 @@ int launch(const air_gemm_t* g, const Args& a0, hipStream_t s) {
             else hipLaunchKernelGGL((KERNEL<1, 1, TB, AIR_EPI_REPARAM_BWD>), grid, dim3(THREADS), LDS, s, a);             \
         }                                                                                                               \
     } while (0)
+    if constexpr (T14 && !TB && !TA) {
+        // exact-fp32 LSTM step on four-unit x four-gate tiles (as the bf16-twin path does): 4 x the workgroups, a quarter of
+        // the operand bytes each; AIR_LSTM_FWD_WIDE keeps the 64-column grouped tiles
+        if (g->precision == 0 && epi == AIR_EPI_LSTM_FWD && (a.gwidth & 3) == 0 && use_bf16_v2(a, TA, TB) &&
+            getenv("AIR_GEMM_F32_V1") == nullptr && getenv("AIR_LSTM_FWD_WIDE") == nullptr && !a.job_on) {
+            using CfgQ = F32V2Cfg<1, 1>;
+            auto kq = gemm_f32v2_kernel<1, 1, false, EPI_LSTM_FWD_Q>;
+            const int rcq = air_grant_lds(reinterpret_cast<const void*>(kq), CfgQ::BYTES);
+            if (rcq) return rcq;
+            dim3 gq((a.gwidth + 3) / 4, grid.y, grid.z);
+            hipLaunchKernelGGL(kq, gq, dim3(THREADS), CfgQ::BYTES, s, a);
+            AIR_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     if (g->precision == 1) {
         const bool v2 = use_bf16_v2(a, TA, TB);
         if (v2) AIR_V2_LAUNCH(gemm_bf16v2_kernel, 0);
@@ -1018,8 +1036,12 @@ extern "C" int air_gemm_kernel_name(const air_gemm_t* g, char* buf, int n) {
     }
     if (g->precision == 1 && use_bf16_v2(a, ta, tb))
         snprintf(buf, n, "gemm_bf16v2_kernel<%d, %d, %s, %d>", tm, tn, tb ? "true" : "false", g->epi);
-    else if (g->precision == 0 && use_bf16_v2(a, ta, tb) && getenv("AIR_GEMM_F32_V1") == nullptr)
-        snprintf(buf, n, "gemm_f32v2_kernel<%d, %d, %s, %d>", tm, tn, tb ? "true" : "false", g->epi);
+    else if (g->precision == 0 && use_bf16_v2(a, ta, tb) && getenv("AIR_GEMM_F32_V1") == nullptr) {
+        if (g->epi == AIR_EPI_LSTM_FWD && !ta && !tb && (a.gwidth & 3) == 0 && getenv("AIR_LSTM_FWD_WIDE") == nullptr && !g->step_job)
+            snprintf(buf, n, "gemm_f32v2_kernel<1, 1, false, %d>", EPI_LSTM_FWD_Q);
+        else
+            snprintf(buf, n, "gemm_f32v2_kernel<%d, %d, %s, %d>", tm, tn, tb ? "true" : "false", g->epi);
+    }
     else
         snprintf(buf, n, "gemm_%s_kernel<%d, %d, %s, %s>", g->precision == 1 ? "bf16" : "f32", tm, tn,
                  ta ? "true" : "false", tb ? "true" : "false");
