@@ -413,6 +413,8 @@ typedef struct {
     const uint16_t* X16; const uint16_t* Wml16; const uint16_t* Wg16;   /* bf16 twins of the three operands (all or none;
                                           * X16 16-byte aligned with ldx % 8 == 0, the weights 8-byte aligned): read instead of
                                           * the fp32 arrays, same results */
+    int32_t exact_fp32;                  /* 1: exact fp32 products (v_mfma_f32_16x16x4_f32) on the fp32 operands -- the fp32
+                                          * path; twins ignored / not written; additionally 2 Z <= 104 */
 } air_bottleneck_fwd_t;
 typedef struct {
     const float* dG; const float* Wg; const float* ml; const float* eps;
@@ -422,6 +424,7 @@ typedef struct {
     int32_t M, K1, Z, H;
     uint16_t* d_ml16; uint16_t* d_x16;   /* bf16 twins of d_ml / d_x written next to them (nullable) */
     const uint16_t* dG16; const uint16_t* Wg16; const uint16_t* Wml16;  /* bf16 twins of the three operands (all or none) */
+    int32_t exact_fp32;                  /* as in air_bottleneck_fwd_t */
 } air_bottleneck_bwd_t;
 int air_vae_bottleneck_fwd(const air_bottleneck_fwd_t* a, void* stream);
 int air_vae_bottleneck_bwd(const air_bottleneck_bwd_t* a, void* stream);

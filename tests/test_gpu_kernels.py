@@ -1556,3 +1556,89 @@ def test_write_bwd_takes_its_items_longest_first_without_changing_results(H, Cc,
     # refused: an order with a backward that is not the graph-order one; too many items to sort
     wb = H.WriteBwd(_p(d_recon), _p(vrec_d), _p(att_d), _p(dgen), _p(dsx), B, N, Cc, w, 0, None, None, None, None, None, None, None, None, None, _p(order))
     assert lib.air_write_bwd(C.byref(wb), _stream()) == -1
+
+
+@pytest.mark.parametrize("M,Hd,Z", [(192, 256, 50), (37, 192, 50), (16, 256, 52), (5, 64, 2)])
+def test_vae_bottleneck_forward_exact_fp32(H, M, Hd, Z):
+    """air_bottleneck_fwd_t.exact_fp32: vae.py:16-30 in one launch with exact fp32 products (the fp32 path's arithmetic):
+    against float64 on the fp32 operands, and against the two exact-fp32 air_gemm launches it replaces."""
+    rng = np.random.RandomState(5)
+    K1 = 256
+    X = rng.uniform(0, 2, (M, K1)).astype(np.float32)
+    Wml = rng.uniform(-0.1, 0.1, (K1, 2 * Z)).astype(np.float32)
+    bml = rng.uniform(-0.1, 0.1, 2 * Z).astype(np.float32)
+    eps = rng.randn(M, Z).astype(np.float32)
+    Wg = rng.uniform(-0.3, 0.3, (Z, Hd)).astype(np.float32)
+    bg = rng.uniform(-0.1, 0.1, Hd).astype(np.float32)
+    t = {k: torch.tensor(v, device="cuda") for k, v in dict(X=X, Wml=Wml, bml=bml, eps=eps, Wg=Wg, bg=bg).items()}
+    ml = torch.full((M, 2 * Z), float("nan"), device="cuda")
+    z = torch.full((M, Z), float("nan"), device="cuda")
+    g = torch.full((M, Hd), float("nan"), device="cuda")
+    a = H.BottleneckFwd(_p(t["X"]), _p(t["Wml"]), _p(t["bml"]), _p(t["eps"]), _p(t["Wg"]), _p(t["bg"]), _p(ml), _p(z), _p(g),
+                        M, K1, Z, Hd, K1, None, None, None, None, None, 1)
+    H.check(H.lib().air_vae_bottleneck_fwd(C.byref(a), _stream()))
+    torch.cuda.synchronize()
+    ml_ref = X.astype(np.float64) @ Wml.astype(np.float64) + bml
+    z_ref = ml_ref[:, :Z] + eps * np.sqrt(np.exp(ml_ref[:, Z:]))
+    assert np.abs(ml.cpu().numpy() - ml_ref).max() < 3e-6
+    # (the sample amplifies the log-variance's last bits by eps * exp(lv / 2) / 2: relative to its own magnitude)
+    assert np.all(np.abs(z.cpu().numpy() - z_ref) <= 4e-6 * np.maximum(1.0, np.abs(z_ref)))
+    g_ref = _softplus_tf(z.cpu().numpy().astype(np.float64) @ Wg.astype(np.float64) + bg)
+    assert np.all(np.abs(g.cpu().numpy() - g_ref) <= 4e-6 * np.maximum(1.0, np.abs(g_ref)))
+    ml2, z2, g2 = torch.empty_like(ml), torch.empty_like(z), torch.empty_like(g)
+    g1 = _gemm_struct(H, t["X"], t["Wml"], ml2, M, 2 * Z, K1, K1, 2 * Z, 2 * Z, 0, bias=t["bml"], epi=H.EPI_REPARAM_FWD,
+                      p0=t["eps"], q0=z2)
+    H.check(H.lib().air_gemm(C.byref(g1), _stream()))
+    g2s = _gemm_struct(H, z2, t["Wg"], g2, M, Hd, Z, Z, Hd, Hd, 0, bias=t["bg"], act=H.ACT_SOFTPLUS)
+    H.check(H.lib().air_gemm(C.byref(g2s), _stream()))
+    torch.cuda.synchronize()
+    # (two fp32 summation orders of a K = 256 contraction: each within 3e-6 of float64)
+    assert (ml - ml2).abs().max() < 6e-6
+    assert bool(((z - z2).abs() <= 1e-5 * z2.abs().clamp(min=1.0)).all()) and bool(((g - g2).abs() <= 2e-5 * g2.abs().clamp(min=1.0)).all())
+    # limit of the exact form: Wml rows of at most 104 floats in LDS
+    a.Z = 54
+    assert H.lib().air_vae_bottleneck_fwd(C.byref(a), _stream()) == -2
+
+
+@pytest.mark.parametrize("M,K1,Z", [(192, 256, 50), (37, 200, 50), (16, 64, 64), (5, 256, 2)])
+def test_vae_bottleneck_backward_exact_fp32(H, M, K1, Z):
+    """air_bottleneck_bwd_t.exact_fp32: d_z = dG.Wg^T, the reparameterisation + KL gradients, d_x = (d_ml.Wml^T) *
+    softplus'(x) with exact fp32 products: against float64 and against the two exact-fp32 launches it replaces."""
+    rng = np.random.RandomState(6)
+    Hd = 256
+    dG = rng.randn(M, Hd).astype(np.float32) * 0.1
+    Wg = rng.uniform(-0.3, 0.3, (Z, Hd)).astype(np.float32)
+    ml = rng.uniform(-1, 1, (M, 2 * Z)).astype(np.float32)
+    eps = rng.randn(M, Z).astype(np.float32)
+    att = np.zeros((M, H.ATT_STRIDE), np.float32)
+    att[:, H.ATT_MASK] = rng.randint(0, 2, M)
+    dyn = np.zeros(32, np.float32)
+    dyn[H.DYN_GRAD_SCALE], dyn[H.DYN_VAE_PV], dyn[H.DYN_VAE_PM] = 1.0 / 64, 0.8, 0.1
+    Wml = rng.uniform(-0.1, 0.1, (K1, 2 * Z)).astype(np.float32)
+    x = rng.uniform(0.01, 2, (M, K1)).astype(np.float32)
+    t = {k: torch.tensor(v, device="cuda") for k, v in dict(dG=dG, Wg=Wg, ml=ml, eps=eps, att=att, dyn=dyn, Wml=Wml, x=x).items()}
+    d_ml = torch.full((M, 2 * Z), float("nan"), device="cuda")
+    d_x = torch.full((M, K1), float("nan"), device="cuda")
+    a = H.BottleneckBwd(_p(t["dG"]), _p(t["Wg"]), _p(t["ml"]), _p(t["eps"]), _p(t["att"]), _p(t["dyn"]), _p(t["Wml"]), _p(t["x"]),
+                        _p(d_ml), _p(d_x), M, K1, Z, Hd, None, None, None, None, None, 1)
+    H.check(H.lib().air_vae_bottleneck_bwd(C.byref(a), _stream()))
+    torch.cuda.synchronize()
+    dz = dG.astype(np.float64) @ Wg.astype(np.float64).T
+    klg = att[:, H.ATT_MASK:H.ATT_MASK + 1].astype(np.float64) * dyn[H.DYN_GRAD_SCALE]
+    var = np.exp(ml[:, Z:].astype(np.float64))
+    dmean = dz + klg * (ml[:, :Z] - dyn[H.DYN_VAE_PM]) / dyn[H.DYN_VAE_PV]
+    dlv = dz * eps * 0.5 * np.sqrt(var) + klg * 0.5 * (var / dyn[H.DYN_VAE_PV] - 1.0)
+    ref = np.concatenate([dmean, dlv], 1)
+    got = d_ml.cpu().numpy()
+    assert np.abs(got - ref).max() < 3e-6
+    dx_ref = (got.astype(np.float64) @ Wml.astype(np.float64).T) * (1.0 - np.exp(-x.astype(np.float64)))
+    assert np.abs(d_x.cpu().numpy() - dx_ref).max() < 3e-6
+    d_ml2, d_x2 = torch.empty_like(d_ml), torch.empty_like(d_x)
+    g1 = _gemm_struct(H, t["dG"], t["Wg"], d_ml2, M, Z, Hd, Hd, Hd, 2 * Z, 0, transB=1, epi=H.EPI_REPARAM_BWD,
+                      p0=t["ml"], p1=t["eps"], p2=t["att"], p3=t["dyn"])
+    H.check(H.lib().air_gemm(C.byref(g1), _stream()))
+    g2 = _gemm_struct(H, d_ml2, t["Wml"], d_x2, M, K1, 2 * Z, 2 * Z, 2 * Z, K1, 0, transB=1, aux=t["x"], ldaux=K1,
+                      actgrad=H.GRAD_SOFTPLUS)
+    H.check(H.lib().air_gemm(C.byref(g2), _stream()))
+    torch.cuda.synchronize()
+    assert (d_ml - d_ml2).abs().max() < 6e-6 and (d_x - d_x2).abs().max() < 6e-6

@@ -575,7 +575,8 @@ class AIRModel:
         if name == "air_lstm_first_step":                    # instantiated per slab count: <4> in the train step, <0> = run-time count
             kernel = "lstm_first_step_kernel<%d>" % (4 if args[1] == 4 else 0)
         if name in ("air_vae_bottleneck_fwd", "air_vae_bottleneck_bwd"):   # instantiated per operand form (bf16 twins or fp32)
-            kernel = "bottleneck_%s_kernel<256, %s>" % (name[-3:], "true" if self._twins else "false")
+            kernel = ("bottleneck_%s_kernel<256, %s>" % (name[-3:], "true" if self._twins else "false") if self._prec == 1
+                      else "bottleneck_%s_f32_kernel<256>" % name[-3:])
         if name == "air_wgrad_grouped":
             kernel = "wgrad_grouped_bf16_kernel" if self._prec else "wgrad_grouped_kernel"
         if name == "air_adam_clip_step_factored":
@@ -677,13 +678,15 @@ class AIRModel:
         # the bottleneck (last recognition product -> reparameterised sample -> first generative layer) is
         # ONE launch where the fused kernel's limits hold (bf16 operands; vae.py:16-30); else two GEMMs
         nofuse = os.environ.get("AIR_NO_BOTTLENECK_FUSION") == "1"
-        fuse_f = (self._prec == 1 and not nofuse and len(gen_u) >= 1 and k == 256 and Z <= 64 and Z % 2 == 0
+        # (fp32 path: the exact-fp32 form of the kernel, 2 Z <= 104)
+        fuse_f = (not nofuse and len(gen_u) >= 1 and k == 256 and Z <= (64 if self._prec == 1 else 52) and Z % 2 == 0
                   and gen_u[0] % 4 == 0)
         first_gen = 0
         if fuse_f:
             bf = H.BottleneckFwd(_ptr(x), _ptr(P["ml_w"]), _ptr(P["ml_b"]), _ptr(self.eps_z), _ptr(P["gen0_w"]),
                                  _ptr(P["gen0_b"]), _ptr(self.ml), _ptr(self.zs), _ptr(self.gen_act[0]), NB, k, Z, gen_u[0], k,
-                                 _ptr(self.zs16), _ptr(self.gen_act16[0]), _ptr(x16), _ptr(T("ml_w")), _ptr(T("gen0_w")))
+                                 _ptr(self.zs16), _ptr(self.gen_act16[0]), _ptr(x16), _ptr(T("ml_w")), _ptr(T("gen0_w")),
+                                 0 if self._prec == 1 else 1)
             keep.append(bf)
             fwd.append(self._call("air_vae_bottleneck_fwd", C.byref(bf),
                                   nbytes=4 * (NB * (k + 4 * Z + gen_u[0]) + k * 2 * Z + Z * gen_u[0]),
@@ -809,7 +812,7 @@ class AIRModel:
                                   aux=self.gen_act[i], ldaux=u, actgrad=H.GRAD_SOFTPLUS, tag="dgrad_gen",
                                   A16=dy16, B16=T(wname), C16=self.d_gen16[i]))
             dy, dy16, n_out, wname = self.d_gen[i], self.d_gen16[i], u, "gen%d_w" % i
-        fuse_b = (self._prec == 1 and not nofuse and len(gen_u) >= 1 and len(rec_u) >= 1 and gen_u[0] == 256
+        fuse_b = (not nofuse and len(gen_u) >= 1 and len(rec_u) >= 1 and gen_u[0] == 256
                   and Z <= 64 and Z % 2 == 0)
         last_rec = len(rec_u)
         if fuse_b:
@@ -817,7 +820,7 @@ class AIRModel:
             bb = H.BottleneckBwd(_ptr(dy), _ptr(P["gen0_w"]), _ptr(self.ml), _ptr(self.eps_z), _ptr(self.att), _ptr(self.dyn),
                                  _ptr(P["ml_w"]), _ptr(self.rec_act[-1]), _ptr(self.d_ml), _ptr(self.d_rec[-1]),
                                  NB, rec_u[-1], Z, gen_u[0], _ptr(self.d_ml16), _ptr(self.d_rec16[-1]),
-                                 _ptr(dy16), _ptr(T("gen0_w")), _ptr(T("ml_w")))
+                                 _ptr(dy16), _ptr(T("gen0_w")), _ptr(T("ml_w")), 0 if self._prec == 1 else 1)
             keep.append(bb)
             bwd.append(self._call("air_vae_bottleneck_bwd", C.byref(bb),
                                   nbytes=4 * (NB * (gen_u[0] + 5 * Z + 2 * rec_u[-1]) + Z * gen_u[0] + rec_u[-1] * 2 * Z),

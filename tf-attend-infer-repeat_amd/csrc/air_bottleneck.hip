@@ -433,6 +433,264 @@ __global__ __launch_bounds__(THREADS) void bottleneck_bwd_kernel(BwdArgs a)
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// EXACT-fp32 forms of the two kernels (air_bottleneck_*_t.exact_fp32; the fp32 path of the model: the reference's own
+// arithmetic).  Same work split and hand-over through LDS as above; operands stay fp32, products run on
+// v_mfma_f32_16x16x4_f32.  One 16-byte LDS read of a k-contiguous operand feeds FOUR MFMAs through the k-permutation
+// gemm_f32v2_kernel uses: lane l supplies k = 16 kb + 4 (l >> 4) + e to the e-th of them, for A and B alike.  A
+// row-major [K, N] weight (Wml and Wg of the forward) is kept AS IT LIES in LDS ([k][N + 4] floats, coalesced copies)
+// and its fragments are read as four scalars per 16 k -- a register transposition into [column][k] images would cost
+// this latency-bound kernel more than the scalar reads do.  Limits: K1 = 256 / H = 256; forward 2 Z <= 104.
+// ---------------------------------------------------------------------------
+constexpr int FPAD = 4;                            // floats: 16-byte row shift of the k-contiguous images
+
+template <int K1>
+__global__ __launch_bounds__(THREADS) void bottleneck_fwd_f32_kernel(FwdArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+    constexpr int L1 = K1 + FPAD, LW = 104 + FPAD, L2 = 64 + FPAD;
+    float* A1 = reinterpret_cast<float*>(smem);   // [16][L1]   X tile, k contiguous
+    float* B1 = A1 + 16 * L1;                     // [K1][LW]   Wml as it lies: column c < 2Z of row k at k * LW + c
+    float* A2 = B1 + K1 * LW;                     // [16][L2]   z tile, k (unit) contiguous, k >= Z zero
+    float* B2 = A2 + 16 * L2;                     // [64][L2]   Wg rows k < Z of this slice as they lie, rows >= Z zero
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * 16, n0 = blockIdx.y * 64;
+    const int M = a.M, Z = a.Z, H = a.H, Z2 = 2 * a.Z;
+
+    // ---- every load of the workgroup, back to back ------------------------------------------------
+    constexpr int NX = 16 * K1 / 4 / THREADS;
+    float4 vx[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        const int t = tid + THREADS * i, row = t / (K1 / 4), c4 = t % (K1 / 4);
+        vx[i] = fetch16(a.X, m0 + row < M, (size_t)(m0 + row) * a.ldx + c4 * 4);
+    }
+    const int NQ = Z2 >> 2;                        // float4 per row of Wml (Z even: whole quads), <= 26
+    const int ntask = NQ * K1;
+    constexpr int NW = (26 * K1 + THREADS - 1) / THREADS;
+    float4 vw[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const int t = tid + THREADS * i;
+        vw[i] = fetch16(a.Wml, t < ntask, (size_t)t * 4);                  // (rows are contiguous: task t = quad t of the matrix)
+    }
+    constexpr int NGQ = 64 * 16 / THREADS;         // Wg slice: 64 rows x 16 quads
+    float4 vg[NGQ];
+#pragma unroll
+    for (int i = 0; i < NGQ; ++i) {
+        const int t = tid + THREADS * i, row = t >> 4, c4 = t & 15;
+        vg[i] = fetch16(a.Wg, row < Z && n0 + c4 * 4 < H, (size_t)row * H + n0 + c4 * 4);
+    }
+    const int u = wave * 16 + (lane & 15);
+    const bool uok = u < Z;
+    float e_eps[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int m = m0 + (lane >> 4) * 4 + q;
+        e_eps[q] = a.eps[(uok && m < M) ? (size_t)m * Z + u : 0];
+    }
+    const float b_mean = a.bml[uok ? u : 0], b_lv = a.bml[uok ? Z + u : 0];
+    const int n = n0 + u;
+    const float b_g = a.bg[n < H ? n : 0];
+
+    // ---- into LDS -------------------------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        const int t = tid + THREADS * i, row = t / (K1 / 4), c4 = t % (K1 / 4);
+        *reinterpret_cast<float4*>(&A1[row * L1 + c4 * 4]) = zero_unless(m0 + row < M, vx[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const int t = tid + THREADS * i;
+        if (t < ntask) {
+            const int row = t / NQ, c4 = t - row * NQ;
+            *reinterpret_cast<float4*>(&B1[row * LW + c4 * 4]) = vw[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NGQ; ++i) {
+        const int t = tid + THREADS * i, row = t >> 4, c4 = t & 15;
+        *reinterpret_cast<float4*>(&B2[row * L2 + c4 * 4]) = zero_unless(row < Z && n0 + c4 * 4 < H, vg[i]);
+    }
+    __syncthreads();
+
+    // ---- first product: wave w owns the units 16w .. 16w+15, mean and log-variance in the same lanes --
+    // (units >= Z read columns that belong to other units or lie in the row padding: finite or not, they only reach
+    // output columns nobody stores; the index is clamped so that every read stays inside the image)
+    f32x4 am = {0.f, 0.f, 0.f, 0.f}, al = {0.f, 0.f, 0.f, 0.f};
+    const int cm = min(u, LW - 1), cl = min(Z + u, LW - 1);
+#pragma unroll 4
+    for (int kb = 0; kb < K1 / 16; ++kb) {
+        const int k0 = kb * 16 + (lane >> 4) * 4;
+        const float4 av = *reinterpret_cast<const float4*>(&A1[(lane & 15) * L1 + k0]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float ae = e == 0 ? av.x : e == 1 ? av.y : e == 2 ? av.z : av.w;
+            am = __builtin_amdgcn_mfma_f32_16x16x4f32(ae, B1[(k0 + e) * LW + cm], am, 0, 0, 0);
+            al = __builtin_amdgcn_mfma_f32_16x16x4f32(ae, B1[(k0 + e) * LW + cl], al, 0, 0, 0);
+        }
+    }
+    // vae.py:16-24: mean | log_var (+bias), sample = mean + eps*sqrt(exp(lv)); the slice-0 workgroups store them
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = (lane >> 4) * 4 + q, m = m0 + row;
+        const float mean = am[q] + b_mean, lv = al[q] + b_lv;
+        const float zz = mean + e_eps[q] * sqrtf(expf(lv));
+        if (blockIdx.y == 0 && uok && m < M) {
+            a.ml[(size_t)m * Z2 + u] = mean;
+            a.ml[(size_t)m * Z2 + Z + u] = lv;
+            a.z[(size_t)m * Z + u] = zz;
+        }
+        A2[row * L2 + u] = (uok && m < M) ? zz : 0.0f;
+    }
+    __syncthreads();
+
+    // ---- second product: wave w owns columns n0 + 16w .. of this slice (K = 64 units, zero beyond Z) --
+    f32x4 ag = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        const int k0 = kb * 16 + (lane >> 4) * 4;
+        const float4 av = *reinterpret_cast<const float4*>(&A2[(lane & 15) * L2 + k0]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float ae = e == 0 ? av.x : e == 1 ? av.y : e == 2 ? av.z : av.w;
+            ag = __builtin_amdgcn_mfma_f32_16x16x4f32(ae, B2[(k0 + e) * L2 + u], ag, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int m = m0 + (lane >> 4) * 4 + q;
+        if (m < M && n < H) a.g[(size_t)m * H + n] = air_softplus(ag[q] + b_g);
+    }
+}
+
+template <int H>
+__global__ __launch_bounds__(THREADS) void bottleneck_bwd_f32_kernel(BwdArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+    constexpr int L1 = H + FPAD, L2 = 128 + FPAD;
+    float* A1 = reinterpret_cast<float*>(smem);   // [16][L1]   dG tile
+    float* B1 = A1 + 16 * L1;                     // [64][L1]   Wg rows (unit z; rows >= Z zero)
+    float* A2 = B1 + 64 * L1;                     // [16][L2]   d_ml tile (d_mean at u, d_lv at Z + u), k >= 2Z zero
+    float* B2 = A2 + 16 * L2;                     // [64][L2]   Wml rows of this slice, k >= 2Z zero
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * 16, j0 = blockIdx.y * 64;
+    const int M = a.M, Z = a.Z, Z2 = 2 * a.Z, K1 = a.K1;
+
+    constexpr int NX = 16 * H / 4 / THREADS;
+    float4 vx[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        const int t = tid + THREADS * i, row = t / (H / 4), c4 = t % (H / 4);
+        vx[i] = fetch16(a.dG, m0 + row < M, (size_t)(m0 + row) * H + c4 * 4);
+    }
+    constexpr int NG = 64 * H / 4 / THREADS;
+    float4 vg[NG];
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+        const int t = tid + THREADS * i, row = t / (H / 4), c4 = t % (H / 4);
+        vg[i] = fetch16(a.Wg, row < Z, (size_t)row * H + c4 * 4);
+    }
+    const int NQ = (Z2 + 3) >> 2;
+    const unsigned inv_nq = ((1u << 20) + NQ - 1) / NQ;
+    constexpr int NM = 8;
+    float4 vm[NM];
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+        const int t = tid + THREADS * i;
+        const int row = (int)(((unsigned)t * inv_nq) >> 20), c4 = t - row * NQ;
+        vm[i] = fetch16(a.Wml, row < 64 && j0 + row < K1, (size_t)(j0 + row) * Z2 + c4 * 4);
+    }
+    const int u = wave * 16 + (lane & 15);
+    const bool uok = u < Z;
+    float e_mean[4], e_lv[4], e_eps[4], e_mask[4], e_x[4];
+    const int jn = j0 + u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int m = m0 + (lane >> 4) * 4 + q;
+        const bool ok = uok && m < M;
+        e_mean[q] = a.ml[ok ? (size_t)m * Z2 + u : 0];
+        e_lv[q] = a.ml[ok ? (size_t)m * Z2 + Z + u : 0];
+        e_eps[q] = a.eps[ok ? (size_t)m * Z + u : 0];
+        e_mask[q] = a.att[m < M ? (size_t)m * AIR_ATT_STRIDE + AIR_ATT_MASK : 0];
+        e_x[q] = a.x[(m < M && jn < K1) ? (size_t)m * K1 + jn : 0];
+    }
+    const float gs = a.dyn[AIR_DYN_GRAD_SCALE], pv = a.dyn[AIR_DYN_VAE_PV], pm = a.dyn[AIR_DYN_VAE_PM];
+
+    // zero the second product's images: their k padding (>= 2Z) must not meet stale LDS contents
+    for (int i = tid; i < (16 + 64) * L2 / 4; i += THREADS)
+        reinterpret_cast<float4*>(A2)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        const int t = tid + THREADS * i, row = t / (H / 4), c4 = t % (H / 4);
+        *reinterpret_cast<float4*>(&A1[row * L1 + c4 * 4]) = zero_unless(m0 + row < M, vx[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+        const int t = tid + THREADS * i, row = t / (H / 4), c4 = t % (H / 4);
+        *reinterpret_cast<float4*>(&B1[row * L1 + c4 * 4]) = zero_unless(row < Z, vg[i]);
+    }
+    __syncthreads();                               // the zero fill is complete before anything lands in A2 / B2
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+        const int t = tid + THREADS * i;
+        const int row = (int)(((unsigned)t * inv_nq) >> 20), c4 = t - row * NQ;
+        if (row >= 64) continue;
+        *reinterpret_cast<float4*>(&B2[row * L2 + c4 * 4]) = zero_unless(j0 + row < K1, vm[i]);   // 2Z % 4 == 0 (Z even): whole quads
+    }
+
+    // ---- first product: d_z for the units of this wave (both operands k-contiguous) ------------------------
+    f32x4 az = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int kb = 0; kb < H / 16; ++kb) {
+        const int k0 = kb * 16 + (lane >> 4) * 4;
+        const float4 av = *reinterpret_cast<const float4*>(&A1[(lane & 15) * L1 + k0]);
+        const float4 bv = *reinterpret_cast<const float4*>(&B1[u * L1 + k0]);
+        az = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, az, 0, 0, 0);
+        az = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, az, 0, 0, 0);
+        az = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, az, 0, 0, 0);
+        az = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, az, 0, 0, 0);
+    }
+    // vae.py:22-24 + the KL of air_model.py:386-392: d loss / d mean, d loss / d log-variance
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = (lane >> 4) * 4 + q, m = m0 + row;
+        const float klg = e_mask[q] * gs;
+        const float var = expf(e_lv[q]);
+        const float sd = sqrtf(var);
+        const float d = az[q];
+        const float dmean = d + klg * (e_mean[q] - pm) / pv;
+        const float dlv = d * e_eps[q] * 0.5f * sd + klg * 0.5f * (var / pv - 1.0f);
+        if (uok && m < M) {
+            if (blockIdx.y == 0) { a.d_ml[(size_t)m * Z2 + u] = dmean; a.d_ml[(size_t)m * Z2 + Z + u] = dlv; }
+            A2[row * L2 + u] = dmean;
+            A2[row * L2 + Z + u] = dlv;
+        }
+    }
+    __syncthreads();
+
+    // ---- second product: d_x = (d_ml . Wml^T) * softplus'(x), columns j0 + 16w .. (K = 128, zero beyond 2Z) ----
+    f32x4 ax = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+        const int k0 = kb * 16 + (lane >> 4) * 4;
+        const float4 av = *reinterpret_cast<const float4*>(&A2[(lane & 15) * L2 + k0]);
+        const float4 bv = *reinterpret_cast<const float4*>(&B2[u * L2 + k0]);
+        ax = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, ax, 0, 0, 0);
+        ax = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, ax, 0, 0, 0);
+        ax = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, ax, 0, 0, 0);
+        ax = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, ax, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int m = m0 + (lane >> 4) * 4 + q;
+        if (m < M && jn < K1) a.d_x[(size_t)m * K1 + jn] = ax[q] * (1.0f - expf(-e_x[q]));
+    }
+}
+
 template <typename K>
 int grant_lds(K kernel, size_t bytes) { return air_grant_lds(reinterpret_cast<const void*>(kernel), bytes); }
 
@@ -447,6 +705,18 @@ extern "C" int air_vae_bottleneck_fwd(const air_bottleneck_fwd_t* a, void* strea
     if (a->K1 != 256 || a->Z > 64) return AIR_ELIMIT;
     if ((a->Z & 1) || (a->H & 3) || (a->ldx & 3) || !al16(a->X) || !al16(a->Wml) || !al16(a->Wg)) return AIR_EALIGN;
     constexpr int K1 = 256;
+    if (a->exact_fp32) {
+        if (2 * a->Z > 104) return AIR_ELIMIT;                      // Wml as it lies: rows of at most 104 + 4 floats of LDS
+        const size_t ldsf = sizeof(float) * (16 * (K1 + FPAD) + K1 * (104 + FPAD) + (16 + 64) * (64 + FPAD));
+        const int rcf = grant_lds(bottleneck_fwd_f32_kernel<K1>, ldsf);
+        if (rcf) return rcf;
+        FwdArgs kf{a->X, a->Wml, a->bml, a->eps, a->Wg, a->bg, a->ml, a->z, a->g, a->M, a->Z, a->H, a->ldx, nullptr, nullptr,
+                   nullptr, nullptr, nullptr};
+        hipLaunchKernelGGL((bottleneck_fwd_f32_kernel<K1>), dim3((a->M + 15) / 16, (a->H + 63) / 64), dim3(THREADS), ldsf,
+                           air_stream(stream), kf);
+        AIR_CHECK_LAUNCH();
+        return 0;
+    }
     const size_t lds = sizeof(unsigned short) * ((16 + 128) * (K1 + PAD) + (16 + 64) * (64 + PAD));
     // twin operands: all three or none; whole 16-byte pieces of X rows, 8-byte pieces of the weight rows
     const bool tw = a->X16 && a->Wml16 && a->Wg16 && al16(a->X16) && (a->ldx & 7) == 0 && al8(a->Wml16) && al8(a->Wg16);
@@ -467,6 +737,17 @@ extern "C" int air_vae_bottleneck_bwd(const air_bottleneck_bwd_t* a, void* strea
     if (a->H != 256 || a->Z > 64) return AIR_ELIMIT;
     if ((a->Z & 1) || !al16(a->dG) || !al16(a->Wg) || !al16(a->Wml)) return AIR_EALIGN;
     constexpr int H = 256;
+    if (a->exact_fp32) {
+        const size_t ldsf = sizeof(float) * ((16 + 64) * (H + FPAD) + (16 + 64) * (128 + FPAD));
+        const int rcf = grant_lds(bottleneck_bwd_f32_kernel<H>, ldsf);
+        if (rcf) return rcf;
+        BwdArgs kf{a->dG, a->Wg, a->ml, a->eps, a->att, a->dyn, a->Wml, a->x, a->d_ml, a->d_x, a->M, a->Z, a->K1, nullptr, nullptr,
+                   nullptr, nullptr, nullptr};
+        hipLaunchKernelGGL((bottleneck_bwd_f32_kernel<H>), dim3((a->M + 15) / 16, (a->K1 + 63) / 64), dim3(THREADS), ldsf,
+                           air_stream(stream), kf);
+        AIR_CHECK_LAUNCH();
+        return 0;
+    }
     const size_t lds = sizeof(unsigned short) * ((16 + 64) * (H + PAD) + (16 + 64) * (128 + PAD));
     const bool tw = a->dG16 && a->Wg16 && a->Wml16 && al16(a->dG16) && al16(a->Wg16) && al8(a->Wml16);
     const int rc = tw ? grant_lds(bottleneck_bwd_kernel<H, true>, lds) : grant_lds(bottleneck_bwd_kernel<H, false>, lds);
