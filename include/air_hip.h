@@ -240,6 +240,12 @@ typedef struct {
  * sq_partials is given: its tiles are computed and squared but not stored (the gradient is rebuilt
  * from its factors by air_adam_clip_step_factored). */
 int air_wgrad_num_blocks(const air_wgrad_t* probs, int count);
+/* Workgroups air_wgrad_grouped(precision) launches for these problems: air_wgrad_num_blocks() unless a problem runs in
+ * STRIPS -- at precision 1 a twin problem of >= 2048 tiles with nothing ragged (K = 128, 192 or 256, M % 64 == 0,
+ * N % 128 == 0, 16-byte rows) gives each workgroup 4 consecutive column tiles of a block-row, its A block staged once
+ * (dWx at 128 x 128: 160 -> 25 MB fetched).  Values, db and the partials (still one per tile, at the same index) are
+ * bit-identical either way.  Diagnostic; AIR_WGRAD_STRIP=<tiles per workgroup, 0 = off> overrides. */
+int air_wgrad_num_workgroups(const air_wgrad_t* probs, int count, int precision);
 int air_wgrad_grouped(const air_wgrad_t* probs /*HOST array, <= 12*/, int count, int precision,
                       float* sq_partials, int32_t* istate, void* stream);
 

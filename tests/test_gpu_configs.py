@@ -161,6 +161,9 @@ def test_stress_config_as_benchmarked_bf16_b256(am, monkeypatch):
     assert any("gemm_xw_tp_kernel" in k for k in names), names
     assert any("write_bwd_graph_kernel<false>" in k for k in names), names
     assert any("wgrad_grouped_bf16_kernel" in k for k in names) and any("gemm_bf16tw_kernel" in k for k in names)
+    # ... and the input-weight gradient (4096 tiles) runs in strips of 4 column tiles: 3072 fewer workgroups than tiles
+    nprob = len(m._wgrad_arr)
+    assert m.lib.air_wgrad_num_blocks(m._wgrad_arr, nprob) - m.lib.air_wgrad_num_workgroups(m._wgrad_arr, nprob, 1) == 3072
     m.forward()
     o = ao.air_forward(params, images[:n], targets[:n], _slice_noise(noise, n), hp, True, -2.0, early_exit=False)
     rec = _np(m.reconstruction)[:n]
@@ -190,6 +193,8 @@ def test_stress_config_as_benchmarked_bf16_b256(am, monkeypatch):
         mm = make(tw)
         assert mm._twins == tw
         assert not any("gemm_xw_tp_kernel" in op.kernel for op in mm.train_step_ops())
+        nprob = len(mm._wgrad_arr)       # strips only with twins: the comparison below is strips vs one tile per workgroup
+        assert (mm.lib.air_wgrad_num_blocks(mm._wgrad_arr, nprob) - mm.lib.air_wgrad_num_workgroups(mm._wgrad_arr, nprob, 1)) == (3072 if tw else 0)
         if tw:
             mm.forward()
             fwd_latency = dict(h=mm.h.clone(), recon=mm.reconstruction.clone(), loss=float(mm.loss))

@@ -399,8 +399,9 @@ WGRAD_CASES = [
 ]
 
 
+# (last case: a problem of >= 2048 tiles -- its column sums db are owned by block-rows 0..15 instead of block-row 0)
 @pytest.mark.parametrize("prec", [0, 1])
-@pytest.mark.parametrize("shapes", WGRAD_CASES)
+@pytest.mark.parametrize("shapes", WGRAD_CASES + [[(256, 320, 64), (4096, 2048, 64)]])
 def test_wgrad_grouped(H, shapes, prec):
     rng = np.random.RandomState(len(shapes) + prec)
     dev = "cuda"
@@ -1110,7 +1111,12 @@ def test_gemm_ragged_shapes_keep_the_fp32_operand_kernels(H):
         assert torch.equal(C16.view(torch.bfloat16), Ct.to(torch.bfloat16))
 
 
-@pytest.mark.parametrize("shapes", WGRAD_CASES + [[(256, 1024, 1280), (2500, 1024, 256)]])
+# (the last two hold a problem of >= 2048 tiles: with twins it runs in STRIPS, run_strip_bf16)
+@pytest.mark.parametrize("shapes", WGRAD_CASES + [[(256, 1024, 1280), (2500, 1024, 256)],
+                                                  [(256, 1024, 192), (8192, 1024, 256), (100, 36, 64)], [(4096, 2048, 128)],
+                                                  # long contractions with 16-byte rows (even / odd / ragged round
+                                                  # counts, ragged M and N)
+                                                  [(784, 512, 1280), (104, 200, 400), (64, 64, 384), (72, 136, 520)]])
 def test_wgrad_grouped_bf16_twins_bit_identical(H, shapes):
     """air_wgrad_grouped(precision=1) with bf16 twins of A and dY (air_wgrad_t.A16 / dY16) against the same
     launch without them: dW, db and the global-norm partials BIT-IDENTICAL.  Covers 16-byte rows (ld % 8 == 0),
@@ -1133,10 +1139,15 @@ def test_wgrad_grouped_bf16_twins_bit_identical(H, shapes):
                                  _p(A16) if twins else None, _p(Y16) if twins else None))
         arr = (H.Wgrad * len(probs))(*probs)
         nblk = H.lib().air_wgrad_num_blocks(arr, len(probs))
+        # strips: only with twins, only for the big problems (4 column tiles per workgroup)
+        big = sum((M // 64) * (N // 64) for (M, N, K) in shapes if (M // 64) * (N // 64) >= 2048)
+        assert H.lib().air_wgrad_num_workgroups(arr, len(probs), 1) == (nblk - big + big // 4 if twins else nblk)
+        assert H.lib().air_wgrad_num_workgroups(arr, len(probs), 0) == nblk
         part = torch.full((nblk,), float("nan"), device=dev)
         ist = torch.zeros(8, dtype=torch.int32, device=dev)
         H.check(H.lib().air_wgrad_grouped(arr, len(probs), 1, _p(part), _p(ist), _stream()), "air_wgrad_grouped")
         torch.cuda.synchronize()
+        assert int(ist[H.IST_GLOBAL_STEP]) == 1
         outs.append(keep + [part])
     for a, b in zip(*outs):
         assert torch.equal(a, b)

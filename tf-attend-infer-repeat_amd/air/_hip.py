@@ -132,6 +132,7 @@ _SIGNATURES = {
                                             C.POINTER(Panel), C.c_int, _p, _p, _p]),
     "air_colsum": (C.c_int, [C.POINTER(Colsum), C.c_int, _p]),
     "air_wgrad_num_blocks": (C.c_int, [C.POINTER(Wgrad), C.c_int]),
+    "air_wgrad_num_workgroups": (C.c_int, [C.POINTER(Wgrad), C.c_int, C.c_int]),
     "air_wgrad_grouped": (C.c_int, [C.POINTER(Wgrad), C.c_int, C.c_int, _p, _p, _p]),
     "air_lstm_gates_fwd": (C.c_int, [_p, _p, _p, _p, _p, C.c_int, C.c_int, _p]),
     "air_lstm_first_step": (C.c_int, [_p, C.c_int, _p, _p, _p, _p, _p, C.c_int, C.c_int, _p]),

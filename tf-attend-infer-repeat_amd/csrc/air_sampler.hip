@@ -278,7 +278,14 @@ __device__ __forceinline__ HeadSeg head_segments(int Hs, int Hh, int Hz) {
     for (int i = 1; i < 5; ++i) h.off[i] = h.off[i - 1] + h.wid[i - 1];
     return h;
 }
-__device__ __constant__ int kOutHead[7] = {0, 1, 2, 2, 3, 3, 4};
+// output unit -> head, head -> (offset, width), as arithmetic: a table in constant memory indexed per lane, then a
+// dynamically indexed HeadSeg (which the compiler keeps in scratch memory) were two dependent memory round trips on
+// attend_fwd's critical path
+__device__ __forceinline__ constexpr int out_head(int o) { return o < 2 ? o : (o < 4 ? 2 : (o < 6 ? 3 : 4)); }
+__device__ __forceinline__ int head_wid(int Hs, int Hh, int Hz, int h) { return h < 2 ? Hs : (h < 4 ? Hh : Hz); }
+__device__ __forceinline__ int head_off(int Hs, int Hh, int h) {
+    return h == 0 ? 0 : h == 1 ? Hs : h == 2 ? 2 * Hs : h == 3 ? 2 * Hs + Hh : 2 * Hs + 2 * Hh;
+}
 
 // air_model.py:443-447 for one element
 __device__ __forceinline__ float gauss_kl_term(float plv, float lv, float var, float pv, float mean, float pm) {
@@ -372,8 +379,9 @@ __global__ __launch_bounds__(THREADS) void attend_fwd_kernel(air_attend_fwd_t a)
         float p = 0.0f;
         const int tp = dot - 7;
         if (dot < 7) {
-            const int h = kOutHead[dot];
-            for (int j = gl; j < hs.wid[h]; j += 16) p += sh_hid[hs.off[h] + j] * sh_wout[dot * a.wout_ld + j];
+            const int h = out_head(dot);
+            const int hw = head_wid(a.Hs, a.Hh, a.Hz, h), ho = head_off(a.Hs, a.Hh, h);
+            for (int j = gl; j < hw; j += 16) p += sh_hid[ho + j] * sh_wout[dot * a.wout_ld + j];
         } else {
             const float* hp = sh_hprev + tp * hs.wid[4];
             for (int j = gl; j < hs.wid[4]; j += 16) p += hp[j] * sh_wout[6 * a.wout_ld + j];
@@ -603,9 +611,8 @@ __global__ __launch_bounds__(THREADS) void attend_bwd_kernel(air_attend_bwd_t a)
     __syncthreads();
     // back through the 7 output units and the hidden ReLU
     for (int j = tid; j < HT; j += THREADS) {
-        int h = 0;
-        while (h < 4 && j >= hs.off[h + 1]) ++h;
-        const int jj = j - hs.off[h];
+        const int h = (j >= a.Hs) + (j >= 2 * a.Hs) + (j >= 2 * a.Hs + a.Hh) + (j >= 2 * a.Hs + 2 * a.Hh);
+        const int jj = j - head_off(a.Hs, a.Hh, h);
         // all seven weights and the activation fetched unconditionally (jj < wout_ld for every unit), the units of other
         // heads masked to an exact +0 term: the conditional form was one load + s_waitcnt per unit, one after the other
         float wv[7];
@@ -616,7 +623,7 @@ __global__ __launch_bounds__(THREADS) void attend_bwd_kernel(air_attend_bwd_t a)
 #pragma unroll
         for (int o = 0; o < 7; ++o) {
             const float term = sh_d[o] * wv[o];
-            v += (kOutHead[o] == h) ? term : 0.0f;
+            v += (out_head(o) == h) ? term : 0.0f;
         }
         const float dv = (hv > 0.0f) ? v : 0.0f;
         a.d_hid[row * HT + j] = dv;

@@ -13,6 +13,7 @@
 // independent: one launch fills the chip instead of ten latency-bound ones.
 #include "air_wgrad_tile.h"
 #include <cstring>
+#include <cstdlib>
 
 using namespace airw;
 
@@ -73,7 +74,7 @@ __device__ __forceinline__ float tile_f32(const Prob& pr, int m0, int n0, float 
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     float colsum = 0.0f;        // wave 0 of block-row 0: column n0 + lane of dY (or of A for the head units)
-    const bool do_bias = (db != nullptr) && (wave == 0) && (head_pack ? (n0 == 0) : (m0 == 0));
+    const bool do_bias = (db != nullptr) && (wave == 0) && (head_pack ? (n0 == 0) : owns_bias(pr, m0, n0));
 
     auto compute = [&](int buf) {
         const float* as = As[buf];
@@ -173,8 +174,10 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
     Table tab, float* __restrict__ sq_partials, int32_t* __restrict__ istate)
 {
     // [operand][image][column 0..63][k 0..63] bf16 = 2 x 3 x 8 KB; reused as the fp32 output tile
-    __shared__ __attribute__((aligned(16))) unsigned short Img[2 * NIMG_W * BT * KB];
-    __shared__ float sq_red[4];
+    // dynamic: 48 KB of operand images (a strip workgroup uses 32), then STRIP_TAIL bytes: 4 floats for the partial's
+    // reduction + the parked bias squares of a strip
+    extern __shared__ __attribute__((aligned(16))) unsigned short Img[];
+    float* sq_red = reinterpret_cast<float*>(Img + 2 * NIMG_W * BT * KB);
     run_tile_bf16(tab, (int)blockIdx.x, Img, sq_partials, istate, sq_red);
 }
 
@@ -276,11 +279,28 @@ __global__ __launch_bounds__(THREADS) void adam_factored_bf16_kernel(Prob pr, Ad
 
 AIR_STAMPS_READER(air_debug_stamps_wgrad)
 
-static int fill_table(const air_wgrad_t* probs, int count, Table& tab, bool allow_null_dw) {
+// Column tiles per strip workgroup for the problems that qualify (0: none).  AIR_WGRAD_STRIP overrides (A/B, tests).
+static int strip_width() {
+    static const int g = [] { const char* e = getenv("AIR_WGRAD_STRIP"); return e ? atoi(e) : 4; }();
+    return g;
+}
+// A problem runs in strips (run_strip_bf16) when its output dwarfs its operands and nothing is ragged.
+static int strip_of(const air_wgrad_t& g, int want) {
+    if (want <= 1 || !g.A16 || !g.dY16 || !g.dW || g.head_pack) return 0;
+    if ((g.K != 128 && g.K != 192 && g.K != 256) || (g.M % BT) != 0) return 0;
+    if ((g.lda & 7) != 0 || (g.ldb & 7) != 0 || ((uintptr_t)g.A16 & 15) != 0 || ((uintptr_t)g.dY16 & 15) != 0) return 0;
+    const long tiles = (long)(g.M / BT) * ((g.N + BT - 1) / BT);
+    if (tiles < 2048) return 0;
+    int w = want > STRIP_MAXG ? STRIP_MAXG : want;
+    while (w > 1 && (g.N % (BT * w)) != 0) w >>= 1;
+    return w > 1 ? w : 0;
+}
+
+static int fill_table(const air_wgrad_t* probs, int count, Table& tab, bool allow_null_dw, int strips = 0) {
     if (!probs || count <= 0) return AIR_EINVAL;
     if (count > MAXP) return AIR_ELIMIT;
     tab.count = count;
-    int blocks = 0;
+    int blocks = 0, parts = 0;
     for (int i = 0; i < count; ++i) {
         const air_wgrad_t& g = probs[i];
         if (!g.A || !g.dY || g.M <= 0 || g.N <= 0 || g.K <= 0) return AIR_EINVAL;
@@ -292,11 +312,18 @@ static int fill_table(const air_wgrad_t* probs, int count, Table& tab, bool allo
         p.head_pack = g.head_pack; p.Hs = g.Hs; p.Hh = g.Hh; p.Hz = g.Hz;
         p.tiles_n = (g.N + BT - 1) / BT;
         p.first_block = blocks;
+        p.first_part = parts;
+        p.strip = strip_of(g, strips);
+        const int tiles_m = (g.M + BT - 1) / BT;
+        p.bias_mod = (!g.head_pack && (long)tiles_m * p.tiles_n >= 2048) ? (tiles_m < 16 ? tiles_m : 16) : 0;
         tab.first[i] = blocks;
-        blocks += p.tiles_n * ((g.M + BT - 1) / BT);
+        const int tiles = p.tiles_n * ((g.M + BT - 1) / BT);
+        parts += tiles;
+        blocks += p.strip ? tiles / p.strip : tiles;
     }
     for (int i = count; i < MAXP; ++i) { tab.p[i] = tab.p[0]; tab.first[i] = 0x7fffffff; }
-    tab.total_blocks = blocks;
+    tab.total_blocks = parts;
+    tab.launch_blocks = blocks;
     return 0;
 }
 
@@ -306,13 +333,26 @@ extern "C" int air_wgrad_num_blocks(const air_wgrad_t* probs, int count) {
     return rc ? rc : tab.total_blocks;
 }
 
+extern "C" int air_wgrad_num_workgroups(const air_wgrad_t* probs, int count, int precision) {
+    if (precision != 0 && precision != 1) return AIR_EINVAL;
+    Table tab;
+    const int rc = fill_table(probs, count, tab, true, precision == 1 ? strip_width() : 0);
+    return rc ? rc : (precision == 1 ? tab.launch_blocks : tab.total_blocks);
+}
+
 extern "C" int air_wgrad_grouped(const air_wgrad_t* probs, int count, int precision,
                                  float* sq_partials, int32_t* istate, void* stream) {
-    Table tab;
-    const int rc = fill_table(probs, count, tab, sq_partials != nullptr);
-    if (rc) return rc;
     if (precision != 0 && precision != 1) return AIR_EINVAL;
-    if (precision == 1) hipLaunchKernelGGL(wgrad_grouped_bf16_kernel, dim3(tab.total_blocks), dim3(THREADS), 0, air_stream(stream), tab, sq_partials, istate);
+    Table tab;
+    const int rc = fill_table(probs, count, tab, sq_partials != nullptr, precision == 1 ? strip_width() : 0);
+    if (rc) return rc;
+    if (precision == 1) {
+        static_assert(STRIP_LDS <= 2 * NIMG_W * BT * KB * 2, "a strip image must fit the one-tile workgroups' LDS");
+        const size_t lds = sizeof(unsigned short) * 2 * NIMG_W * BT * KB + STRIP_TAIL;
+        const int rg = air_grant_lds(reinterpret_cast<const void*>(wgrad_grouped_bf16_kernel), lds);
+        if (rg) return rg;
+        hipLaunchKernelGGL(wgrad_grouped_bf16_kernel, dim3(tab.launch_blocks), dim3(THREADS), lds, air_stream(stream), tab, sq_partials, istate);
+    }
     else hipLaunchKernelGGL(wgrad_grouped_kernel, dim3(tab.total_blocks), dim3(THREADS), 0, air_stream(stream), tab, sq_partials, istate);
     AIR_CHECK_LAUNCH();
     return 0;

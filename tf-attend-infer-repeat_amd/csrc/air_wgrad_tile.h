@@ -23,11 +23,24 @@ struct Prob {
     const unsigned short* A16; const unsigned short* dY16;      // bf16 twins of A / dY (nullable): see tile_bf16_tw
     int M, N, K, lda, ldb, ldc;
     int head_pack, Hs, Hh, Hz;
-    int tiles_n, first_block;
+    int tiles_n, first_block;   // first_block: first WORKGROUP of the problem in the grouped launch
+    int first_part;             // first global-norm partial (= tile number: one partial per 64 x 64 tile, whoever computes it)
+    int strip;                  // > 0: a workgroup owns `strip` consecutive column tiles of one block-row (run_strip_bf16)
+    int bias_mod;               // which block-row sums db of column tile nt: 0 -> block-row 0; else block-row nt % bias_mod
 };
+// db[n0 .. n0 + 63] (and its share of the global norm) belongs to ONE tile of the column.  Block-row 0 for ordinary problems;
+// for the big ones (>= 2048 tiles, by shape alone -- so every precision / operand path of a problem agrees and the partials
+// stay bit-identical between them) the owners are spread over the first block-rows: sixteen column sums in block-row 0
+// were the long pole of a strip launch (a strip workgroup of block-row 0 summed all of its columns: +12 us at 4 tiles).
+__device__ __forceinline__ bool owns_bias(const Prob& pr, int m0, int n0) {
+    const int nt = n0 / BT, mb = m0 / BT;
+    return pr.bias_mod > 0 ? (mb == nt % pr.bias_mod) : (mb == 0);
+}
 // first[i] = first workgroup of problem i (INT_MAX past `count`): kept apart from the descriptors so that
 // ONE wide scalar load fetches all of them and the owner is found without a chain of dependent loads
-struct Table { int count; int total_blocks; int first[MAXP]; Prob p[MAXP]; };
+// (total_blocks = tiles = global-norm partials; launch_blocks = workgroups of the grouped launch: fewer when a problem
+// runs in strips)
+struct Table { int count; int total_blocks; int launch_blocks; int first[MAXP]; Prob p[MAXP]; };
 
 // One float4 of a row-major operand, zero outside [rows x cols], in two branch-free halves: fetch4
 // issues the load(s) with out-of-range accesses redirected to element 0, mask4 zeroes what was out of
@@ -64,11 +77,11 @@ __device__ __forceinline__ float4 mask4(float4 t, int row, int col, int rows, in
 // (apply_gradients(global_step=...), air_model.py:692-694)
 // (sq_red: 4 floats of LDS supplied by the kernel -- a carrying GEMM kernel must not own static LDS: it could no longer
 // be granted the whole 160 KB as dynamic LDS, hipFuncSetAttribute refuses static + dynamic > 160 KB)
-__device__ __forceinline__ void publish_sq(float sq, float* sq_partials, int32_t* istate, int block, float* sq_red) {
+__device__ __forceinline__ void publish_sq(float sq, float* sq_partials, int32_t* istate, int part, float* sq_red) {
     sq = air_block_sum_256(sq, sq_red);
     if (threadIdx.x == 0) {
-        sq_partials[block] = sq;
-        if (block == 0 && istate) istate[AIR_IST_GLOBAL_STEP] += 1;
+        sq_partials[part] = sq;
+        if (part == 0 && istate) istate[AIR_IST_GLOBAL_STEP] += 1;
     }
 }
 
@@ -100,13 +113,14 @@ __device__ __forceinline__ float store_tile(const Prob& pr, int m0, int n0, cons
     } else {
         // head output units (air_model.py:294-316, 376): A = d_out7 [K,8], dY = hid [K,HT];
         // unit o only owns the hidden segment of its head: dW = wout[o][n - off], db = bout[o] = sum_k d_out7[k][o]
-        const int wid[5] = {pr.Hs, pr.Hs, pr.Hh, pr.Hh, pr.Hz};
-        const int head[7] = {0, 1, 2, 2, 3, 3, 4};
+        // (unit -> head -> segment as arithmetic: indexed tables cost a chain of dependent loads per element)
+        const int Hs = pr.Hs, Hh = pr.Hh, Hz = pr.Hz;
         for (int it = tid; it < 7 * BT; it += THREADS) {
             const int o = it / BT, col = it % BT, n = n0 + col;
-            int off = 0;
-            for (int h = 0; h < head[o]; ++h) off += wid[h];
-            if (m0 == 0 && n < N && n >= off && n < off + wid[head[o]]) {
+            const int hd = o < 2 ? o : (o < 4 ? 2 : (o < 6 ? 3 : 4));
+            const int off = hd == 0 ? 0 : hd == 1 ? Hs : hd == 2 ? 2 * Hs : hd == 3 ? 2 * Hs + Hh : 2 * Hs + 2 * Hh;
+            const int wd = hd < 2 ? Hs : (hd < 4 ? Hh : Hz);
+            if (m0 == 0 && n < N && n >= off && n < off + wd) {
                 const float t = Ct[o * LS + col];
                 dW[(size_t)o * ldc + (n - off)] = t;
                 sq += t * t;
@@ -122,6 +136,16 @@ __device__ __forceinline__ const Prob& find_tile(const Table& tab, int block, in
     for (int i = 1; i < MAXP; ++i) pi += (block >= tab.first[i]) ? 1 : 0;
     const Prob& pr = tab.p[pi];
     const int local = block - pr.first_block;
+    if (pr.strip > 0) {
+        // strips: the groups of one block-row share its A block.  Workgroups go round-robin over the 8 XCDs, so block-rows
+        // are dealt per XCD (every group of a block-row on the SAME XCD, back to back: one L2 fetches the A block once)
+        const int groups = pr.tiles_n / pr.strip, tiles_m = (pr.M + BT - 1) / BT;
+        int mb, g;
+        if ((tiles_m & 7) == 0) { const int x = local & 7, s = local >> 3; mb = (s / groups) * 8 + x; g = s % groups; }
+        else { mb = local / groups; g = local % groups; }
+        m0 = mb * BT; n0 = g * pr.strip * BT;
+        return pr;
+    }
     m0 = (local / pr.tiles_n) * BT; n0 = (local % pr.tiles_n) * BT;
     return pr;
 }
@@ -169,7 +193,7 @@ __device__ __forceinline__ float tile_bf16(const Prob& pr, int m0, int n0, unsig
     const int ld = op ? ldb : lda, cols = op ? N : M, c0 = (op ? n0 : m0) + 4 * q;
     const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
     unsigned short* img = Img + (size_t)op * NIMG * BT * KB;
-    const bool bias_block = (db != nullptr) && (head_pack ? (n0 == 0) : (m0 == 0));
+    const bool bias_block = (db != nullptr) && (head_pack ? (n0 == 0) : owns_bias(pr, m0, n0));
     const bool bias_thread = bias_block && (op == (head_pack ? 0 : 1));
     float csum[4] = {0.f, 0.f, 0.f, 0.f};
 
@@ -310,7 +334,7 @@ __device__ __forceinline__ float tile_bf16(const Prob& pr, int m0, int n0, unsig
 // gfx950's transpose read ds_read_b64_tr_b16 (tools/exp/tr_read.hip; the same scheme as the forward GEMM's
 // row-major weights, air_gemm_bf16.hip).  Same bf16 values, same k order per wave as tile_bf16: the tile is
 // bit-identical.  The bias gradient still comes from the fp32 dY (column sums before rounding, in tile_bf16's
-// order) -- only the m0 == 0 tiles pay those loads.
+// order) -- only the tiles that own a column's bias (owns_bias) pay those loads.
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
@@ -318,6 +342,60 @@ __device__ __forceinline__ bool twin_ok(const Prob& pr) {
     auto a8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; };
     return pr.A16 && pr.dY16 && !pr.head_pack && a8(pr.A16) && a8(pr.dY16) && (pr.lda & 3) == 0 && (pr.ldb & 3) == 0 &&
            (pr.M & 3) == 0 && (pr.N & 3) == 0;
+}
+
+// Bias gradient of a twin tile in block-row 0: fp32 column sums of dY[:, n0 .. n0 + 63] in tile_bf16's order -- per k-run g the
+// rows g*8 + r of image c, images in order; the xor-tree over g follows.  Run after the MFMAs (the operand registers are
+// free), the next image's 8 loads in flight while this one is summed.  (Round 4 tried three images in flight, all fetches
+// unconditional: 36.8 -> 31.9 us for a K = 1280 tile that owns a bias, but 9.4 -> 9.8 us at K = 192 and +1.5 us on the
+// 50 x 50 step -- not kept.  A K = 1280 tile is 15.7 us without its bias: the fp32 column sums of 1280 rows by 128 threads
+// remain the long pole of the 128 x 128 launch.)  Threads 128..255 hold dY's staging
+// role of tile_bf16 (g = k-run of 8 rows, q = column quad); returns this thread's share of the squared bias gradient.
+__device__ __forceinline__ float bias_tw(const Prob& pr, int n0)
+{
+    const int tid = threadIdx.x;
+    const int N = pr.N, K = pr.K, ldb = pr.ldb;
+    float* db = pr.db;
+    const int bg = tid & 7, bq = (tid & 127) >> 3;
+    const bool bias_thread = tid >= 128;
+    float csum[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias_thread) {
+        const bool vec = ((ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(pr.dY) & 15) == 0);
+        const int nimg = (K + KB - 1) / KB;
+        float4 cur[8], nxt[8];
+        auto fetch_img = [&](float4 (&v)[8], int c) __attribute__((always_inline)) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                v[r] = vec ? fetch4<true>(pr.dY, ldb, c * KB + bg * 8 + r, n0 + 4 * bq, K, N)
+                           : fetch4<false>(pr.dY, ldb, c * KB + bg * 8 + r, n0 + 4 * bq, K, N);
+        };
+        fetch_img(cur, 0);
+        for (int c = 0; c < nimg; ++c) {
+            if (c + 1 < nimg) fetch_img(nxt, c + 1);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float4 t = mask4(cur[r], c * KB + bg * 8 + r, n0 + 4 * bq, K, N);
+                csum[0] += t.x; csum[1] += t.y; csum[2] += t.z; csum[3] += t.w;
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) cur[r] = nxt[r];
+        }
+    }
+    float sq = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float s = csum[j];
+        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+        csum[j] = s;
+    }
+    if (bias_thread && bg == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = 4 * bq + j;
+            if (n0 + col < N) { db[n0 + col] = csum[j]; sq += csum[j] * csum[j]; }
+        }
+    }
+    return sq;
 }
 
 template <int NIMG>
@@ -334,11 +412,7 @@ __device__ __forceinline__ float tile_bf16_tw(const Prob& pr, int m0, int n0, un
     // 16-byte pieces when rows start 16-byte aligned (ld % 8 == 0), else 8-byte pieces (ld % 4 == 0)
     const bool a16 = (lda & 7) == 0 && (reinterpret_cast<uintptr_t>(pr.A16) & 15) == 0 && (M & 7) == 0;
     const bool b16 = (ldb & 7) == 0 && (reinterpret_cast<uintptr_t>(pr.dY16) & 15) == 0 && (N & 7) == 0;
-    const bool bias_block = (db != nullptr) && (m0 == 0);
-    // the bias threads' fp32 view of dY: g = k-run (8 rows), q = column quad -- tile_bf16's staging role of operand dY
-    const int bg = tid & 7, bq = (tid & 127) >> 3;
-    const bool bias_thread = bias_block && tid >= 128;
-    float csum[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool bias_block = (db != nullptr) && owns_bias(pr, m0, n0);
 
     f32x4 acc[2][2];
 #pragma unroll
@@ -447,49 +521,7 @@ __device__ __forceinline__ float tile_bf16_tw(const Prob& pr, int m0, int n0, un
             }
     }
     AIR_STAMP(5);
-    if (bias_thread) {
-        // fp32 column sums of dY (m0 == 0 tiles only) in tile_bf16's order: per k-run g the rows g*8 + r of image c, images
-        // in order; the xor-tree over g follows.  After the MFMAs (the operand registers are free), the next image's 8 loads
-        // in flight while this one is summed: ONE exposed round trip per tile (three sequential ones per round made the
-        // bias tiles the long pole of the launch: 41 us at K = 1280).
-        const bool vec = ((ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(pr.dY) & 15) == 0);
-        const int nimg = (K + KB - 1) / KB;
-        float4 cur[8], nxt[8];
-        auto fetch_img = [&](float4 (&v)[8], int c) __attribute__((always_inline)) {
-#pragma unroll
-            for (int r = 0; r < 8; ++r)
-                v[r] = vec ? fetch4<true>(pr.dY, ldb, c * KB + bg * 8 + r, n0 + 4 * bq, K, N)
-                           : fetch4<false>(pr.dY, ldb, c * KB + bg * 8 + r, n0 + 4 * bq, K, N);
-        };
-        fetch_img(cur, 0);
-        for (int c = 0; c < nimg; ++c) {
-            if (c + 1 < nimg) fetch_img(nxt, c + 1);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const float4 t = mask4(cur[r], c * KB + bg * 8 + r, n0 + 4 * bq, K, N);
-                csum[0] += t.x; csum[1] += t.y; csum[2] += t.z; csum[3] += t.w;
-            }
-#pragma unroll
-            for (int r = 0; r < 8; ++r) cur[r] = nxt[r];
-        }
-    }
-
-    float sq = 0.0f;
-    if (bias_block) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float s = csum[j];
-            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
-            csum[j] = s;
-        }
-        if (bias_thread && bg == 0) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int col = 4 * bq + j;
-                if (n0 + col < N) { db[n0 + col] = csum[j]; sq += csum[j] * csum[j]; }
-            }
-        }
-    }
+    const float sq = bias_block ? bias_tw(pr, n0) : 0.0f;
     __syncthreads();
     float* Ct = reinterpret_cast<float*>(Img);
 #pragma unroll
@@ -504,20 +536,188 @@ __device__ __forceinline__ float tile_bf16_tw(const Prob& pr, int m0, int n0, un
 }
 
 
-// One rider / grouped-launch workgroup of the bf16 path: tile `block` of the table; Img = 48 KB of LDS (16-byte aligned),
-// sq_red = 4 more floats.  sq_partials == NULL: no global-norm partial is published.
+// STRIP workgroup (round 4): the 64 x 64 tiles (m0, n0), (m0, n0 + 64), ... of `pr.strip` consecutive column tiles of one
+// block-row, for a problem whose output is far larger than its operands -- dWx = X^T . (sum_t dgates) at 128 x 128 is
+// 16 384 x 1 024 = 4 096 tiles over K = 256 rows.  One tile per workgroup made every tile fetch its own 32 KB block of the
+// image twin (the 16 tiles of a block-row start together on 8 different XCDs) and pay the whole load - stage - multiply -
+// store chain (8.9 us a tile with three resident per CU: 48 us for the launch on its own).  Here the A block is fetched ONCE
+// and its MFMA fragments stay in registers; the dY tiles stream through one 32 KB image with the next tile's loads in flight
+// under this tile's MFMAs, epilogue and stores (3 us a tile); the output tile passes through the same LDS.  Same bf16 values,
+// same k order per accumulator, one global-norm partial per TILE at its old index: bit-identical to the per-tile kernel.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int STRIP_KMAX = 256;
+#ifdef AIR_STAMPS
+#ifndef STRIP_STAMP_BLOCK
+#define STRIP_STAMP_BLOCK 600
+#endif
+#define STRIP_STAMP(i) do { if (blockIdx.x == STRIP_STAMP_BLOCK && threadIdx.x == 0) air_stamps_dev[i] = wall_clock64(); } while (0)
+#else
+#define STRIP_STAMP(i) do { } while (0)
+#endif
+constexpr int STRIP_LDS = STRIP_KMAX * BT * 2;              // bytes: one [K][64] image (32 KB <= the 48 KB of the one-tile workgroups)
+constexpr int STRIP_MAXG = 16;                               // column tiles per strip workgroup, at most
+constexpr int STRIP_TAIL = (4 + STRIP_MAXG * 16) * 4;       // bytes behind the images: reduction scratch + parked bias squares
+template <int NPER>     // 16-byte pieces per thread per operand = K / 32 (a template argument: the operand registers must be
+                        // statically indexed -- with a run-time count the compiler kept them in scratch memory and waited for
+                        // every load on the spot: 12 us to stage the first images)
+__device__ __forceinline__ void run_strip_bf16(const Prob& pr, int m0, int n0, unsigned short* Img, float* __restrict__ sq_partials,
+                                               int32_t* __restrict__ istate, float* sq_red)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int G = pr.strip;
+    const unsigned lda = (unsigned)pr.lda, ldb = (unsigned)pr.ldb;
+    const char* Ab = reinterpret_cast<const char*>(pr.A16);
+    const char* Yb = reinterpret_cast<const char*>(pr.dY16);
+    unsigned short* ImgB = Img;                               // [K][64 n] (first the A block, [K][64 m]); then the fp32 output tile
+    const bool has_bias = pr.db != nullptr;
+    constexpr int PMAX = NPER;
+
+    // Bias gradient of the column tiles this block-row owns (owns_bias: at most one of the strip for the big problems),
+    // BEFORE the tile loop: the 16 threads that hold a share of its square park it in LDS.
+    float* bias_park = sq_red + 4;                            // [strip][16] floats behind the reduction scratch
+    if (has_bias) {
+        for (int j = 0; j < G; ++j) {
+            if (!owns_bias(pr, m0, n0 + j * BT)) continue;    // block-uniform
+            const float b = bias_tw(pr, n0 + j * BT);
+            if (tid >= 128 && (tid & 7) == 0) bias_park[j * 16 + ((tid & 127) >> 3)] = b;
+        }
+        __syncthreads();
+    }
+
+    STRIP_STAMP(0);
+    // piece t = tid + 256 i: row t >> 3, 8 columns from (t & 7) * 8 -- lane-linear rows of 128 bytes
+    const unsigned k0 = (unsigned)(tid >> 3), c8 = (unsigned)(tid & 7) * 8u;
+    // (the register images are declared per use, never carried around the tile loop: an array that lives across the
+    // loop's back edge stayed in scratch memory, every load waited for on the spot)
+    auto issue_b = [&](u32x4 (&rb)[PMAX], int nn) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PMAX; ++i)
+            rb[i] = *reinterpret_cast<const u32x4*>(Yb + ((k0 + 32u * i) * ldb + (unsigned)nn + c8) * 2u);
+    };
+    auto stage_b = [&](const u32x4 (&rb)[PMAX]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PMAX; ++i)
+            *reinterpret_cast<u32x4*>(&ImgB[(tid + THREADS * i) * 8]) = rb[i];
+    };
+    // The strip is walked from a start that depends on the block-row: the 256 rows of a dY tile lie 2 KB (N * 2 bytes)
+    // apart, i.e. in ONE L2 channel, and workgroups that start together stay in step -- all of them on the same tile would
+    // queue on that channel (measured: 10 us per tile, the launch twice as slow as one tile per workgroup).
+    const int mb = m0 / BT;
+    const int rot = (mb + (mb >> 3)) % G;
+    auto tile_at = [&](int j) { int t = j + rot; if (t >= G) t -= G; return t; };
+    // The A block passes through the image ONCE: each wave keeps the fragments of its 32 columns (all K rows: NPER k-steps
+    // x 2 column groups x 4 registers = 64 registers at K = 256) for the whole strip, so a tile reads only dY fragments from
+    // LDS (the fragment reads, not the MFMAs, bounded a tile: 128 KB per tile per workgroup at 128 bytes per clock) and the
+    // workgroup needs ONE 32 KB image -- three workgroups per CU, like the one-tile workgroups of the same launch.
+    const int il = lane & 15;
+    bf16x8 av[NPER][2];
+    {
+        u32x4 ra[PMAX], rb[PMAX];
+#pragma unroll
+        for (int i = 0; i < PMAX; ++i)
+            ra[i] = *reinterpret_cast<const u32x4*>(Ab + ((k0 + 32u * i) * lda + (unsigned)m0 + c8) * 2u);
+        issue_b(rb, n0 + tile_at(0) * BT);
+#pragma unroll
+        for (int i = 0; i < PMAX; ++i)
+            *reinterpret_cast<u32x4*>(&ImgB[(tid + THREADS * i) * 8]) = ra[i];
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < NPER; ++kk) {
+            const int krow = kk * 32 + (lane >> 4) * 8 + (il >> 2);
+            const unsigned short* pa = &ImgB[krow * BT + wm + (il & 3) * 4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pa + i * 16));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pa + i * 16 + 4 * BT));
+                av[kk][i] = bf16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            }
+        }
+        __syncthreads();
+        stage_b(rb);
+    }
+    STRIP_STAMP(1);
+
+    const int part0 = pr.first_part + mb * pr.tiles_n + n0 / BT;
+    for (int j = 0; j < G; ++j) {
+        const int tj = tile_at(j);
+        const int nj = n0 + tj * BT;
+        __syncthreads();                                      // the images are staged
+        STRIP_STAMP(2 + 6 * j);
+        // next dY tile: in flight until this tile is stored.  UNCONDITIONAL (the last round re-reads its own tile): behind
+        // a branch the loaded registers merge with their old values, and the compiler waits for the loads right here
+        u32x4 rb[PMAX];
+        issue_b(rb, n0 + tile_at(j + 1 < G ? j + 1 : j) * BT);
+        __builtin_amdgcn_sched_barrier(0);                    // (the scheduler would sink the loads below the MFMAs)
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < NPER; ++kk) {                   // k-steps of 32 rows, in tile_bf16_tw's order
+            const int krow = kk * 32 + (lane >> 4) * 8 + (il >> 2);
+            const unsigned short* pb = &ImgB[krow * BT + wn + (il & 3) * 4];
+            bf16x8 bv[2];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pb + jj * 16));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pb + jj * 16 + 4 * BT));
+                bv[jj] = bf16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+                    acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[kk][i], bv[jj], acc[i][jj], 0, 0, 0);
+        }
+        STRIP_STAMP(3 + 6 * j);
+        const float bias_sq = (has_bias && owns_bias(pr, m0, nj) && tid >= 128 && (tid & 7) == 0) ? bias_park[tj * 16 + ((tid & 127) >> 3)] : 0.0f;
+        __syncthreads();                                      // every wave is done reading the dY image
+        float* Ct = reinterpret_cast<float*>(ImgB);           // 64 x LS floats = 20 KB <= 32 KB
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq)
+                    Ct[(wm + i * 16 + (lane >> 4) * 4 + qq) * LS + wn + jj * 16 + (lane & 15)] = acc[i][jj][qq];
+        __syncthreads();
+        STRIP_STAMP(4 + 6 * j);
+        const float sq = store_tile(pr, m0, nj, Ct, bias_sq);
+        STRIP_STAMP(5 + 6 * j);
+        if (sq_partials) publish_sq(sq, sq_partials, istate, part0 + tj, sq_red);
+        STRIP_STAMP(6 + 6 * j);
+        if (j + 1 < G) {
+            __syncthreads();                                  // the output tile has left LDS
+            stage_b(rb);
+        }
+        STRIP_STAMP(7 + 6 * j);
+    }
+}
+
+// One rider / grouped-launch workgroup of the bf16 path: tile `block` of the table; Img = 48 KB of LDS (16-byte aligned;
+// STRIP_LDS when the table holds a strip problem), sq_red = 4 more floats.  sq_partials == NULL: no global-norm partial is
+// published.
 __device__ __forceinline__ void run_tile_bf16(const Table& tab, int block, unsigned short* Img, float* __restrict__ sq_partials,
                                               int32_t* __restrict__ istate, float* sq_red)
 {
     int m0, n0;
     const Prob& pr = find_tile(tab, block, m0, n0);
     AIR_STAMP(0);
+    if (pr.strip > 0) {                      // K = 128 / 192 / 256 (strip_of)
+        if (pr.K == 256) run_strip_bf16<8>(pr, m0, n0, Img, sq_partials, istate, sq_red);
+        else if (pr.K == 192) run_strip_bf16<6>(pr, m0, n0, Img, sq_partials, istate, sq_red);
+        else run_strip_bf16<4>(pr, m0, n0, Img, sq_partials, istate, sq_red);
+        return;
+    }
     // block-uniform: operands from their bf16 twins where the problem supplies usable ones
     const float bias_sq = twin_ok(pr) ? tile_bf16_tw<NIMG_W>(pr, m0, n0, Img) : tile_bf16<NIMG_W>(pr, m0, n0, Img);
     AIR_STAMP(6);
     const float sq = store_tile(pr, m0, n0, reinterpret_cast<const float*>(Img), bias_sq);
     AIR_STAMP(7);
-    if (sq_partials) publish_sq(sq, sq_partials, istate, block, sq_red);
+    if (sq_partials) publish_sq(sq, sq_partials, istate, pr.first_part + (block - pr.first_block), sq_red);
     AIR_STAMP(8);
 }
 
