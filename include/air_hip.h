@@ -241,10 +241,11 @@ typedef struct {
  * from its factors by air_adam_clip_step_factored). */
 int air_wgrad_num_blocks(const air_wgrad_t* probs, int count);
 /* Workgroups air_wgrad_grouped(precision) launches for these problems: air_wgrad_num_blocks() unless a problem runs in
- * STRIPS -- at precision 1 a twin problem of >= 2048 tiles with nothing ragged (K = 128, 192 or 256, M % 64 == 0,
- * N % 128 == 0, 16-byte rows) gives each workgroup 4 consecutive column tiles of a block-row, its A block staged once
- * (dWx at 128 x 128: 160 -> 25 MB fetched).  Values, db and the partials (still one per tile, at the same index) are
- * bit-identical either way.  Diagnostic; AIR_WGRAD_STRIP=<tiles per workgroup, 0 = off> overrides. */
+ * STRIPS -- at precision 1 a twin problem of >= 512 tiles (K = 64, 128, 192 or 256; 16-byte dY rows; M % 4 == 0) gives each
+ * workgroup 2 (from 2048 tiles: 4) consecutive column tiles of a block-row, its A block fetched once and its MFMA fragments
+ * kept in registers.  Values, db and the partials (still one per tile, at the same index) are bit-identical either way.
+ * For a problem of >= 512 tiles (any precision) the tile that sums db of column tile nt is the one in block-row nt % 16,
+ * not block-row 0.  Diagnostic; AIR_WGRAD_STRIP=<tiles per workgroup, 0 = off> overrides. */
 int air_wgrad_num_workgroups(const air_wgrad_t* probs, int count, int precision);
 int air_wgrad_grouped(const air_wgrad_t* probs /*HOST array, <= 12*/, int count, int precision,
                       float* sq_partials, int32_t* istate, void* stream);

@@ -162,6 +162,7 @@ def test_stress_config_as_benchmarked_bf16_b256(am, monkeypatch):
     assert any("write_bwd_graph_kernel<false>" in k for k in names), names
     assert any("wgrad_grouped_bf16_kernel" in k for k in names) and any("gemm_bf16tw_kernel" in k for k in names)
     # ... and the input-weight gradient (4096 tiles) runs in strips of 4 column tiles: 3072 fewer workgroups than tiles
+    # (no other problem of the step reaches 512 tiles)
     nprob = len(m._wgrad_arr)
     assert m.lib.air_wgrad_num_blocks(m._wgrad_arr, nprob) - m.lib.air_wgrad_num_workgroups(m._wgrad_arr, nprob, 1) == 3072
     m.forward()

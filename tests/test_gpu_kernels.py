@@ -399,7 +399,8 @@ WGRAD_CASES = [
 ]
 
 
-# (last case: a problem of >= 2048 tiles -- its column sums db are owned by block-rows 0..15 instead of block-row 0)
+# (problems of >= 512 tiles -- the first case's 2500 x 1024, the last case -- have their column sums db owned by
+# block-rows 0..15 instead of block-row 0)
 @pytest.mark.parametrize("prec", [0, 1])
 @pytest.mark.parametrize("shapes", WGRAD_CASES + [[(256, 320, 64), (4096, 2048, 64)]])
 def test_wgrad_grouped(H, shapes, prec):
@@ -1111,7 +1112,8 @@ def test_gemm_ragged_shapes_keep_the_fp32_operand_kernels(H):
         assert torch.equal(C16.view(torch.bfloat16), Ct.to(torch.bfloat16))
 
 
-# (the last two hold a problem of >= 2048 tiles: with twins it runs in STRIPS, run_strip_bf16)
+# (problems of >= 512 tiles run in STRIPS with twins, run_strip_bf16: the first case's 2500 x 1024 over K = 64 in masked
+# 8-byte pieces, the 8192 x 1024 / 4096 x 2048 ones in 16-byte pieces)
 @pytest.mark.parametrize("shapes", WGRAD_CASES + [[(256, 1024, 1280), (2500, 1024, 256)],
                                                   [(256, 1024, 192), (8192, 1024, 256), (100, 36, 64)], [(4096, 2048, 128)],
                                                   # long contractions with 16-byte rows (even / odd / ragged round
@@ -1139,9 +1141,13 @@ def test_wgrad_grouped_bf16_twins_bit_identical(H, shapes):
                                  _p(A16) if twins else None, _p(Y16) if twins else None))
         arr = (H.Wgrad * len(probs))(*probs)
         nblk = H.lib().air_wgrad_num_blocks(arr, len(probs))
-        # strips: only with twins, only for the big problems (4 column tiles per workgroup)
-        big = sum((M // 64) * (N // 64) for (M, N, K) in shapes if (M // 64) * (N // 64) >= 2048)
-        assert H.lib().air_wgrad_num_workgroups(arr, len(probs), 1) == (nblk - big + big // 4 if twins else nblk)
+        # strips: only with twins, only for the big problems (>= 512 tiles: 2 column tiles per workgroup, >= 2048: 4)
+        saved = 0
+        for (M, N, K) in shapes:
+            tiles = -(-M // 64) * -(-N // 64)
+            if tiles >= 512 and K in (64, 128, 192, 256) and M % 4 == 0 and N % 256 == 0:
+                saved += tiles - tiles // (4 if tiles >= 2048 else 2)
+        assert H.lib().air_wgrad_num_workgroups(arr, len(probs), 1) == (nblk - saved if twins else nblk)
         assert H.lib().air_wgrad_num_workgroups(arr, len(probs), 0) == nblk
         part = torch.full((nblk,), float("nan"), device=dev)
         ist = torch.zeros(8, dtype=torch.int32, device=dev)

@@ -279,24 +279,31 @@ __global__ __launch_bounds__(THREADS) void adam_factored_bf16_kernel(Prob pr, Ad
 
 AIR_STAMPS_READER(air_debug_stamps_wgrad)
 
-// Column tiles per strip workgroup for the problems that qualify (0: none).  AIR_WGRAD_STRIP overrides (A/B, tests).
-static int strip_width() {
-    static const int g = [] { const char* e = getenv("AIR_WGRAD_STRIP"); return e ? atoi(e) : 4; }();
+// AIR_WGRAD_STRIP=<column tiles per strip workgroup> overrides the width strip_of picks (0: no strips; A/B, tests).
+static int strip_override() {
+    static const int g = [] { const char* e = getenv("AIR_WGRAD_STRIP"); return e ? atoi(e) : -1; }();
     return g;
 }
-// A problem runs in strips (run_strip_bf16) when its output dwarfs its operands and nothing is ragged.
-static int strip_of(const air_wgrad_t& g, int want) {
-    if (want <= 1 || !g.A16 || !g.dY16 || !g.dW || g.head_pack) return 0;
-    if ((g.K != 128 && g.K != 192 && g.K != 256) || (g.M % BT) != 0) return 0;
-    if ((g.lda & 7) != 0 || (g.ldb & 7) != 0 || ((uintptr_t)g.A16 & 15) != 0 || ((uintptr_t)g.dY16 & 15) != 0) return 0;
-    const long tiles = (long)(g.M / BT) * ((g.N + BT - 1) / BT);
-    if (tiles < 2048) return 0;
-    int w = want > STRIP_MAXG ? STRIP_MAXG : want;
+// Tiles from which a problem counts as BIG (shape alone): it runs in strips when it has twins, and the owners of its bias
+// columns are spread over block-rows in every precision.
+constexpr long BIG_TILES = 512;
+// A problem runs in strips (run_strip_bf16) when its output dwarfs its operands: 4 column tiles per workgroup from 2048
+// tiles (dWx at 128 x 128: 4096 tiles over K = 256), 2 from 512 (dWx at 50 x 50: 640 light K = 64 tiles that, one per
+// workgroup, pushed the launch past the 768 resident workgroups into a second round).
+static int strip_of(const air_wgrad_t& g, bool allow) {
+    if (!allow || !g.A16 || !g.dY16 || !g.dW || g.head_pack) return 0;
+    if (g.K != 64 && g.K != 128 && g.K != 192 && g.K != 256) return 0;
+    if ((g.lda & 3) != 0 || (g.M & 3) != 0 || ((uintptr_t)g.A16 & 7) != 0) return 0;
+    if ((g.ldb & 7) != 0 || ((uintptr_t)g.dY16 & 15) != 0) return 0;
+    const long tiles = (long)((g.M + BT - 1) / BT) * ((g.N + BT - 1) / BT);
+    if (tiles < BIG_TILES) return 0;
+    int w = strip_override() >= 0 ? strip_override() : (tiles >= 2048 ? 4 : 2);
+    if (w > STRIP_MAXG) w = STRIP_MAXG;
     while (w > 1 && (g.N % (BT * w)) != 0) w >>= 1;
     return w > 1 ? w : 0;
 }
 
-static int fill_table(const air_wgrad_t* probs, int count, Table& tab, bool allow_null_dw, int strips = 0) {
+static int fill_table(const air_wgrad_t* probs, int count, Table& tab, bool allow_null_dw, bool strips = false) {
     if (!probs || count <= 0) return AIR_EINVAL;
     if (count > MAXP) return AIR_ELIMIT;
     tab.count = count;
@@ -315,7 +322,7 @@ static int fill_table(const air_wgrad_t* probs, int count, Table& tab, bool allo
         p.first_part = parts;
         p.strip = strip_of(g, strips);
         const int tiles_m = (g.M + BT - 1) / BT;
-        p.bias_mod = (!g.head_pack && (long)tiles_m * p.tiles_n >= 2048) ? (tiles_m < 16 ? tiles_m : 16) : 0;
+        p.bias_mod = (!g.head_pack && (long)tiles_m * p.tiles_n >= BIG_TILES) ? (tiles_m < 16 ? tiles_m : 16) : 0;
         tab.first[i] = blocks;
         const int tiles = p.tiles_n * ((g.M + BT - 1) / BT);
         parts += tiles;
@@ -336,7 +343,7 @@ extern "C" int air_wgrad_num_blocks(const air_wgrad_t* probs, int count) {
 extern "C" int air_wgrad_num_workgroups(const air_wgrad_t* probs, int count, int precision) {
     if (precision != 0 && precision != 1) return AIR_EINVAL;
     Table tab;
-    const int rc = fill_table(probs, count, tab, true, precision == 1 ? strip_width() : 0);
+    const int rc = fill_table(probs, count, tab, true, precision == 1);
     return rc ? rc : (precision == 1 ? tab.launch_blocks : tab.total_blocks);
 }
 
@@ -344,7 +351,7 @@ extern "C" int air_wgrad_grouped(const air_wgrad_t* probs, int count, int precis
                                  float* sq_partials, int32_t* istate, void* stream) {
     if (precision != 0 && precision != 1) return AIR_EINVAL;
     Table tab;
-    const int rc = fill_table(probs, count, tab, sq_partials != nullptr, precision == 1 ? strip_width() : 0);
+    const int rc = fill_table(probs, count, tab, sq_partials != nullptr, precision == 1);
     if (rc) return rc;
     if (precision == 1) {
         static_assert(STRIP_LDS <= 2 * NIMG_W * BT * KB * 2, "a strip image must fit the one-tile workgroups' LDS");

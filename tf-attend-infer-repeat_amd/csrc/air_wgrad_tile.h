@@ -558,9 +558,12 @@ constexpr int STRIP_KMAX = 256;
 constexpr int STRIP_LDS = STRIP_KMAX * BT * 2;              // bytes: one [K][64] image (32 KB <= the 48 KB of the one-tile workgroups)
 constexpr int STRIP_MAXG = 16;                               // column tiles per strip workgroup, at most
 constexpr int STRIP_TAIL = (4 + STRIP_MAXG * 16) * 4;       // bytes behind the images: reduction scratch + parked bias squares
-template <int NPER>     // 16-byte pieces per thread per operand = K / 32 (a template argument: the operand registers must be
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+template <int NPER,     // 16-byte pieces per thread per operand = K / 32 (a template argument: the operand registers must be
                         // statically indexed -- with a run-time count the compiler kept them in scratch memory and waited for
                         // every load on the spot: 12 us to stage the first images)
+          bool A8>      // the A block in 8-byte pieces, masked at M: rows of the A twin are only 8-byte aligned and the last
+                        // block-row is ragged (the 50 x 50 canvas: M = lda = 2500)
 __device__ __forceinline__ void run_strip_bf16(const Prob& pr, int m0, int n0, unsigned short* Img, float* __restrict__ sq_partials,
                                                int32_t* __restrict__ istate, float* sq_red)
 {
@@ -614,14 +617,31 @@ __device__ __forceinline__ void run_strip_bf16(const Prob& pr, int m0, int n0, u
     const int il = lane & 15;
     bf16x8 av[NPER][2];
     {
-        u32x4 ra[PMAX], rb[PMAX];
+        u32x4 rb[PMAX];
+        if constexpr (!A8) {
+            u32x4 ra[PMAX];
 #pragma unroll
-        for (int i = 0; i < PMAX; ++i)
-            ra[i] = *reinterpret_cast<const u32x4*>(Ab + ((k0 + 32u * i) * lda + (unsigned)m0 + c8) * 2u);
-        issue_b(rb, n0 + tile_at(0) * BT);
+            for (int i = 0; i < PMAX; ++i)
+                ra[i] = *reinterpret_cast<const u32x4*>(Ab + ((k0 + 32u * i) * lda + (unsigned)m0 + c8) * 2u);
+            issue_b(rb, n0 + tile_at(0) * BT);
 #pragma unroll
-        for (int i = 0; i < PMAX; ++i)
-            *reinterpret_cast<u32x4*>(&ImgB[(tid + THREADS * i) * 8]) = ra[i];
+            for (int i = 0; i < PMAX; ++i)
+                *reinterpret_cast<u32x4*>(&ImgB[(tid + THREADS * i) * 8]) = ra[i];
+        } else {
+            // piece t = tid + 256 i: row t >> 4, 4 columns from (t & 15) * 4; a piece at or past column M reads element 0
+            // and is staged as zeros (M % 4 == 0: pieces are whole)
+            u32x2 ra[2 * PMAX];
+            const unsigned kq = (unsigned)(tid >> 4), c4 = (unsigned)(tid & 15) * 4u;
+            const bool okm = m0 + (int)c4 < pr.M;
+#pragma unroll
+            for (int i = 0; i < 2 * PMAX; ++i)
+                ra[i] = *reinterpret_cast<const u32x2*>(Ab + (okm ? ((kq + 16u * i) * lda + (unsigned)m0 + c4) * 2u : 0u));
+            issue_b(rb, n0 + tile_at(0) * BT);
+            const u32x2 zero = {0u, 0u};
+#pragma unroll
+            for (int i = 0; i < 2 * PMAX; ++i)
+                *reinterpret_cast<u32x2*>(&ImgB[(tid + THREADS * i) * 4]) = okm ? ra[i] : zero;
+        }
         __syncthreads();
 #pragma unroll
         for (int kk = 0; kk < NPER; ++kk) {
@@ -706,10 +726,19 @@ __device__ __forceinline__ void run_tile_bf16(const Table& tab, int block, unsig
     int m0, n0;
     const Prob& pr = find_tile(tab, block, m0, n0);
     AIR_STAMP(0);
-    if (pr.strip > 0) {                      // K = 128 / 192 / 256 (strip_of)
-        if (pr.K == 256) run_strip_bf16<8>(pr, m0, n0, Img, sq_partials, istate, sq_red);
-        else if (pr.K == 192) run_strip_bf16<6>(pr, m0, n0, Img, sq_partials, istate, sq_red);
-        else run_strip_bf16<4>(pr, m0, n0, Img, sq_partials, istate, sq_red);
+    if (pr.strip > 0) {                      // K = 64 / 128 / 192 / 256 (strip_of)
+        const bool a16 = (pr.lda & 7) == 0 && (reinterpret_cast<uintptr_t>(pr.A16) & 15) == 0 && (pr.M % BT) == 0;
+        if (a16) {
+            if (pr.K == 256) run_strip_bf16<8, false>(pr, m0, n0, Img, sq_partials, istate, sq_red);
+            else if (pr.K == 192) run_strip_bf16<6, false>(pr, m0, n0, Img, sq_partials, istate, sq_red);
+            else if (pr.K == 128) run_strip_bf16<4, false>(pr, m0, n0, Img, sq_partials, istate, sq_red);
+            else run_strip_bf16<2, false>(pr, m0, n0, Img, sq_partials, istate, sq_red);
+        } else {
+            if (pr.K == 256) run_strip_bf16<8, true>(pr, m0, n0, Img, sq_partials, istate, sq_red);
+            else if (pr.K == 192) run_strip_bf16<6, true>(pr, m0, n0, Img, sq_partials, istate, sq_red);
+            else if (pr.K == 128) run_strip_bf16<4, true>(pr, m0, n0, Img, sq_partials, istate, sq_red);
+            else run_strip_bf16<2, true>(pr, m0, n0, Img, sq_partials, istate, sq_red);
+        }
         return;
     }
     // block-uniform: operands from their bf16 twins where the problem supplies usable ones
