@@ -294,10 +294,17 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16tw_kernel(Args a)
 // loads of FOUR stages in flight per thread and two workgroups per CU; the row panel of a (row tile, slab) pair is kept in
 // one XCD's L2 for its 16 column tiles.  Interior tiles only (M % 64, N % 64, K slab % 64 == 0: the dispatcher checks).
 // ---------------------------------------------------------------------------
+// BN = 128 (round 4): the launch is bound by what ONE CU can pull through its L1 (~45 GB/s when every line misses it):
+// with 64 x 64 tiles a CU's two workgroups read 2 x (512 KB of fp32 rows + 256 KB of bf16 columns) per slab = 1.5 MB ->
+// 37 us.  A 64 x 128 tile (each wave 32 x 64) reads 512 + 512 KB for twice the outputs: 256 workgroups, one per CU, 1 MB
+// each.  Same k order per accumulator: bit-identical.
+template <int BN>
 __global__ __launch_bounds__(THREADS) void gemm_xw_tp_kernel(Args a)
 {
-    constexpr int BM = 64, BN = 64, KB = 64, D = 4;      // D: stages of global loads in flight per thread (a memory round
+    constexpr int BM = 64, KB = 64, D = 4;               // D: stages of global loads in flight per thread (a memory round
                                                          // trip is ~1 us, a stage's MFMAs ~0.15 us: one stage ahead is not enough)
+    constexpr int NJ = BN / 32;                          // 16-column MFMA tiles per wave (its half of the tile's columns)
+    constexpr int PPR = BN / 8, RPP = THREADS / PPR, NBP = KB / RPP;    // B: 16-byte pieces per k row, rows per pass, passes
     __shared__ __attribute__((aligned(16))) unsigned short ImgA[2][BM * KB];   // [row][64 k], 16-byte slots swizzled by row
     __shared__ __attribute__((aligned(16))) unsigned short ImgB[2][KB * BN];   // [k][64 n] as it lies (transpose read)
     // the step prologue's planes of workgroups come LAST in dispatch order here: the product's 512 workgroups take their
@@ -333,23 +340,23 @@ __global__ __launch_bounds__(THREADS) void gemm_xw_tp_kernel(Args a)
     }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int kbeg = zslab * a.kslab, kend = min(a.K, kbeg + a.kslab);
-    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;      // this wave's 32 x 32 quadrant, over the whole K slab
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * (BN / 2);   // this wave's 32 x BN/2 part, over the whole K slab
 
-    f32x4 acc[2][2];
+    f32x4 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // staging maps: A piece = float4 (4 k) of row (tid >> 4) + 16 i; B piece = 16 bytes (8 columns) of k row (tid >> 3) + 32 i
-    const int ar = tid >> 4, ah = tid & 15, bk = tid >> 3, bh = tid & 7;
+    // staging maps: A piece = float4 (4 k) of row (tid >> 4) + 16 i; B piece = 16 bytes (8 columns) of k row tid / PPR + RPP i
+    const int ar = tid >> 4, ah = tid & 15, bk = tid / PPR, bh = tid % PPR;
     const float* pa = a.A + (size_t)(m0 + ar) * a.lda + ah * 4;
     const unsigned short* pb = a.B16 + (size_t)bk * a.ldb + n0 + bh * 8;
     const unsigned la = ar * KB + (((ah >> 1) ^ (ar & 7)) << 3) + (ah & 1) * 4;      // (row + 16 i) & 7 == ar & 7
     typedef float f32v4 __attribute__((ext_vector_type(4)));
     typedef unsigned u32v4 __attribute__((ext_vector_type(4)));
     f32v4 va[D][4];                                       // (native vector types: the HIP structs kept this ring in scratch)
-    u32v4 vb[D][2];
+    u32v4 vb[D][NBP];
     // (the ring slot is a compile-time constant everywhere -- std::integral_constant -- so that the ring lives in
     // registers: with a run-time slot index the arrays went to scratch memory, 39.8 -> 54.6 us)
     auto load_stage = [&](auto dc, int k0) __attribute__((always_inline)) {
@@ -357,7 +364,7 @@ __global__ __launch_bounds__(THREADS) void gemm_xw_tp_kernel(Args a)
 #pragma unroll
         for (int i = 0; i < 4; ++i) va[d][i] = *reinterpret_cast<const f32v4*>(pa + (size_t)(16 * i) * a.lda + k0);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) vb[d][i] = *reinterpret_cast<const u32v4*>(pb + (size_t)(k0 + 32 * i) * a.ldb);
+        for (int i = 0; i < NBP; ++i) vb[d][i] = *reinterpret_cast<const u32v4*>(pb + (size_t)(k0 + RPP * i) * a.ldb);
     };
     int buf = 0;
     auto stage = [&](auto dc, int k0) __attribute__((always_inline)) {
@@ -370,13 +377,13 @@ __global__ __launch_bounds__(THREADS) void gemm_xw_tp_kernel(Args a)
             *reinterpret_cast<uint2*>(&ImgA[buf][la + 16 * i * KB]) = w;
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) *reinterpret_cast<u32v4*>(&ImgB[buf][(bk + 32 * i) * BN + bh * 8]) = vb[d][i];
+        for (int i = 0; i < NBP; ++i) *reinterpret_cast<u32v4*>(&ImgB[buf][(bk + RPP * i) * BN + bh * 8]) = vb[d][i];
         if (k0 + D * KB < kend) load_stage(dc, k0 + D * KB);        // refill this ring slot: D stages ahead
         __syncthreads();                                  // (also: everyone is past the MFMAs of the stage that used the other buffer)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int slot = ks * 4 + (lane >> 4), il = lane & 15;
-            bf16x8 av[2], bv[2];
+            bf16x8 av[2], bv[NJ];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int row = wm + i * 16 + il;
@@ -384,7 +391,7 @@ __global__ __launch_bounds__(THREADS) void gemm_xw_tp_kernel(Args a)
             }
             const unsigned short* blk = &ImgB[buf][(ks * 32 + (lane >> 4) * 8 + (il >> 2)) * BN + wn + (il & 3) * 4];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
                 const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(blk + j * 16));
                 const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(blk + j * 16 + 4 * BN));
@@ -393,7 +400,7 @@ __global__ __launch_bounds__(THREADS) void gemm_xw_tp_kernel(Args a)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < NJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
         buf ^= 1;
@@ -412,7 +419,7 @@ __global__ __launch_bounds__(THREADS) void gemm_xw_tp_kernel(Args a)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 Cz[(size_t)(m0 + wm + i * 16 + (lane >> 4) * 4 + q) * a.ldc + n0 + wn + j * 16 + (lane & 15)] = acc[i][j][q];
@@ -528,7 +535,11 @@ int xw_tp_ok(const Args& a, int precision, bool ta, bool tb, int ksplit) {
 
 int xw_tp_launch(const Args& a0, int job_planes_hint, hipStream_t s) {
     Args a = a0;
-    dim3 grid(a.N / 64, a.M / 64, 1);
+    // 64 x 128 tiles when they still give every CU a workgroup (AIR_XW_TP_BN=64 keeps the square tiles: A/B)
+    static const int bn_env = [] { const char* e = getenv("AIR_XW_TP_BN"); return e ? atoi(e) : 0; }();
+    const long slabs = (a.K + a.kslab - 1) / a.kslab;
+    const bool wide = bn_env != 64 && (a.N % 128) == 0 && (bn_env == 128 || (long)(a.N / 128) * (a.M / 64) * slabs >= 256);
+    dim3 grid(a.N / (wide ? 128 : 64), a.M / 64, 1);
     if (a.job_on) {
         const long quads = (a.job.n_normal + 3) / 4 + (a.job.n_uniform + 3) / 4 + (a.job.twin_n + 3) / 4 + a.job.ad_n / 4;
         const long plane = (long)grid.x * grid.y * THREADS;
@@ -539,7 +550,8 @@ int xw_tp_launch(const Args& a0, int job_planes_hint, hipStream_t s) {
     grid.z = (a.K + a.kslab - 1) / a.kslab + a.job_on;
     a.slab_stride = (long)a.M * a.ldc;
     { const char* e = getenv("AIR_XW_TP_MAP"); a.i1 = (e && e[0] == 'p') ? 1 : 0; }      // (i1: unused by this kernel otherwise)
-    hipLaunchKernelGGL(gemm_xw_tp_kernel, grid, dim3(THREADS), 0, s, a);
+    if (wide) hipLaunchKernelGGL(gemm_xw_tp_kernel<128>, grid, dim3(THREADS), 0, s, a);
+    else hipLaunchKernelGGL(gemm_xw_tp_kernel<64>, grid, dim3(THREADS), 0, s, a);
     AIR_CHECK_LAUNCH();
     return 0;
 }
