@@ -38,6 +38,7 @@ int twin_launch(const Args& a, int tm, int tn, bool tb, dim3 grid, hipStream_t s
 void twin_kernel_name(const Args& a, int tm, int tn, bool tb, char* buf, int n);
 int xw_tp_ok(const Args& a, int precision, bool ta, bool tb, int ksplit);
 int xw_tp_launch(const Args& a, int job_planes_hint, hipStream_t s);
+int xw_tp_columns(const Args& a);
 }
 
 namespace {
@@ -961,6 +962,10 @@ void resolve_tile(const air_gemm_t* g, int& tm, int& tn) {
         if (t11 <= 1024) { tm = 1; tn = 1; }
         else if (t11 <= 4096) { tm = 2; tn = 2; }
         else { tm = 2; tn = 4; }
+        // AIR_GEMM_BIG_TILE="tm,tn": the tile of the products beyond 1024 16x16 tiles (M = N*B = 1280 rows at 128 x 128), A/B
+        static const int big = [] { const char* e = getenv("AIR_GEMM_BIG_TILE"); int a = 0, b = 0;
+                                    return (e && sscanf(e, "%d,%d", &a, &b) == 2) ? a * 16 + b : 0; }();
+        if (big && t11 > 1024) { tm = big / 16; tn = big % 16; }
     }
 }
 
@@ -1027,7 +1032,7 @@ extern "C" int air_gemm_kernel_name(const air_gemm_t* g, char* buf, int n) {
     if (g->tile_m == 8 && g->tile_n == 4) {
         const int ok = xw_tp_ok(a, g->precision, ta, tb, g->ksplit);
         if (ok) return ok;
-        snprintf(buf, n, "gemm_xw_tp_kernel");
+        snprintf(buf, n, "gemm_xw_tp_kernel<%d>", xw_tp_columns(a));
         return 0;
     }
     if (g->precision == 1 && !ta && twin_rounds(a, tm, tn, false, tb) > 0) {

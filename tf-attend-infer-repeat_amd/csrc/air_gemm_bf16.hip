@@ -533,12 +533,17 @@ int xw_tp_ok(const Args& a, int precision, bool ta, bool tb, int ksplit) {
     return 0;
 }
 
-int xw_tp_launch(const Args& a0, int job_planes_hint, hipStream_t s) {
-    Args a = a0;
-    // 64 x 128 tiles when they still give every CU a workgroup (AIR_XW_TP_BN=64 keeps the square tiles: A/B)
+// 64 x 128 tiles when they still give every CU a workgroup (AIR_XW_TP_BN=64 keeps the square tiles: A/B)
+int xw_tp_columns(const Args& a) {
     static const int bn_env = [] { const char* e = getenv("AIR_XW_TP_BN"); return e ? atoi(e) : 0; }();
     const long slabs = (a.K + a.kslab - 1) / a.kslab;
     const bool wide = bn_env != 64 && (a.N % 128) == 0 && (bn_env == 128 || (long)(a.N / 128) * (a.M / 64) * slabs >= 256);
+    return wide ? 128 : 64;
+}
+
+int xw_tp_launch(const Args& a0, int job_planes_hint, hipStream_t s) {
+    Args a = a0;
+    const bool wide = xw_tp_columns(a0) == 128;
     dim3 grid(a.N / (wide ? 128 : 64), a.M / 64, 1);
     if (a.job_on) {
         const long quads = (a.job.n_normal + 3) / 4 + (a.job.n_uniform + 3) / 4 + (a.job.twin_n + 3) / 4 + a.job.ad_n / 4;
