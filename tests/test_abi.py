@@ -103,6 +103,18 @@ def test_argument_errors_without_gpu(H):
     nul = (H.Wgrad * 1)(H.Wgrad(A, A, None, None, 2, 4, 2, 2, 4, 4, 0, 0, 0, 0))
     assert lib.air_wgrad_grouped(nul, 1, 1, None, None, None) == -1
     assert lib.air_wgrad_num_blocks(nul, 1) == 1
+    assert lib.air_wgrad_num_workgroups(nul, 1, 1) == 1 and lib.air_wgrad_num_workgroups(nul, 1, 0) == 1
+    assert lib.air_wgrad_num_workgroups(nul, 1, 2) == -1 and lib.air_wgrad_num_workgroups(None, 1, 1) == -1
+    # strips are a property of the problem table: >= 512 tiles with twins at precision 1 (2 column tiles per workgroup,
+    # 4 from 2048 tiles), never at precision 0 or without twins
+    T = C.c_void_p(64)
+    big = (H.Wgrad * 1)(H.Wgrad(A, A, A, None, 2048, 1024, 128, 2048, 1024, 1024, 0, 0, 0, 0, T, T))
+    assert lib.air_wgrad_num_blocks(big, 1) == 512 and lib.air_wgrad_num_workgroups(big, 1, 1) == 256
+    assert lib.air_wgrad_num_workgroups(big, 1, 0) == 512
+    big4 = (H.Wgrad * 1)(H.Wgrad(A, A, A, None, 16384, 1024, 256, 16384, 1024, 1024, 0, 0, 0, 0, T, T))
+    assert lib.air_wgrad_num_workgroups(big4, 1, 1) == 1024
+    notw = (H.Wgrad * 1)(H.Wgrad(A, A, A, None, 2048, 1024, 128, 2048, 1024, 1024, 0, 0, 0, 0))
+    assert lib.air_wgrad_num_workgroups(notw, 1, 1) == 512
     assert lib.air_optim_num_partials(1000) > 0
     # panel-blocked twins: null buffers, bad descriptors
     one = (H.Panel * 1)(H.Panel(0, 0, 4, 8, 0, 0))

@@ -1162,6 +1162,34 @@ def test_wgrad_grouped_bf16_twins_bit_identical(H, shapes):
         assert np.abs(Wt.cpu().numpy() - ref).max() <= 1e-5 * np.sqrt(K) * 4 * np.abs(ref).max()
 
 
+def test_wgrad_strips_without_partials_or_bias(H):
+    """A strip problem (>= 512 tiles, twins) launched without sq_partials and without db: same dW as with both, nothing
+    else written (the strip's partial / bias bookkeeping is optional like the one-tile kernel's)."""
+    dev = "cuda"
+    rng = np.random.RandomState(3)
+    M, N, K = 2048, 1024, 128
+    At = torch.tensor(rng.randn(K, M).astype(np.float32), device=dev)
+    Yt = torch.tensor(rng.randn(K, N).astype(np.float32), device=dev)
+    A16, Y16 = _bf16_twin(H, At), _bf16_twin(H, Yt)
+    outs = []
+    for full in (True, False):
+        Wt = torch.full((M, N), float("nan"), device=dev)
+        bt = torch.full((N,), float("nan"), device=dev)
+        arr = (H.Wgrad * 1)(H.Wgrad(_p(At), _p(Yt), _p(Wt), _p(bt) if full else None, M, N, K, M, N, N, 0, 0, 0, 0, _p(A16), _p(Y16)))
+        nblk = H.lib().air_wgrad_num_blocks(arr, 1)
+        assert H.lib().air_wgrad_num_workgroups(arr, 1, 1) == nblk // 2
+        part = torch.full((nblk,), float("nan"), device=dev)
+        ist = torch.zeros(8, dtype=torch.int32, device=dev)
+        H.check(H.lib().air_wgrad_grouped(arr, 1, 1, _p(part) if full else None, _p(ist) if full else None, _stream()))
+        torch.cuda.synchronize()
+        outs.append((Wt, bt, part, ist))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert bool(torch.isnan(outs[1][1]).all()) and bool(torch.isnan(outs[1][2]).all()) and int(outs[1][3][H.IST_GLOBAL_STEP]) == 0
+    ref = Yt.double().sum(0)
+    assert float((outs[0][1].double() - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) and int(outs[0][3][H.IST_GLOBAL_STEP]) == 1
+    assert abs(float(outs[0][2].double().sum()) - float((outs[0][0].double() ** 2).sum() + (outs[0][1].double() ** 2).sum())) <= 1e-5 * float((outs[0][0].double() ** 2).sum())
+
+
 _LDS_ORDER_SCRIPT = r'''
 import ctypes as C, os, sys
 import numpy as np, torch
