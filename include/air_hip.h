@@ -239,6 +239,8 @@ typedef struct {
  * istate[GLOBAL_STEP] += 1, as air_grad_sqnorm does.  A plain problem may have dW == NULL when
  * sq_partials is given: its tiles are computed and squared but not stored (the gradient is rebuilt
  * from its factors by air_adam_clip_step_factored). */
+/* air_wgrad_num_blocks(): the number of global-norm partials = 64 x 64 tiles of all problems + one per bias column tile of
+ * the problems with K >= 384 (their db is summed by workgroups of their own, the launch's first, instead of by a tile). */
 int air_wgrad_num_blocks(const air_wgrad_t* probs, int count);
 /* Workgroups air_wgrad_grouped(precision) launches for these problems: air_wgrad_num_blocks() unless a problem runs in
  * STRIPS -- at precision 1 a twin problem of >= 512 tiles (K = 64, 128, 192 or 256; 16-byte dY rows; M % 4 == 0) gives each

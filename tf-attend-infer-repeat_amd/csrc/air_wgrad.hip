@@ -161,12 +161,13 @@ __global__ __launch_bounds__(THREADS) void wgrad_grouped_kernel(Table tab, float
     __shared__ __attribute__((aligned(16))) float As[2][KC * LS];
     __shared__ __attribute__((aligned(16))) float Bs[2][KC * LS];
     const int block = (int)blockIdx.x;
+    __shared__ float sq_red[4 + 64];                            // (+ 64: a bias workgroup parks half of its column sums)
+    if (block < tab.nbias) { run_bias_block(tab, block, sq_partials, sq_red); return; }
     int m0, n0;
     const Prob& pr = find_tile(tab, block, m0, n0);
     const float bias_sq = tile_f32<6>(pr, m0, n0, As, Bs);      // K = 192 (3 steps x 64 images) in one round trip
     const float sq = store_tile(pr, m0, n0, &As[0][0], 0.0f) + bias_sq;
-    __shared__ float sq_red[4];
-    if (sq_partials) publish_sq(sq, sq_partials, istate, block, sq_red);
+    if (sq_partials) publish_sq(sq, sq_partials, istate, pr.first_part + (block - pr.first_block), sq_red);
 }
 
 
@@ -307,7 +308,15 @@ static int fill_table(const air_wgrad_t* probs, int count, Table& tab, bool allo
     if (!probs || count <= 0) return AIR_EINVAL;
     if (count > MAXP) return AIR_ELIMIT;
     tab.count = count;
-    int blocks = 0, parts = 0;
+    // bias columns of the long contractions (K >= 384, shape alone: every precision and operand path agrees) are summed by
+    // workgroups of their own, the launch's first (run_bias_wg); their partials follow the tiles'
+    int nbias = 0;
+    for (int i = 0; i < count; ++i) {
+        const air_wgrad_t& g = probs[i];
+        if (g.db && !g.head_pack && g.K >= 384 && g.N > 0) nbias += (g.N + BT - 1) / BT;
+    }
+    tab.nbias = nbias;
+    int blocks = nbias, parts = 0, bias_blocks = 0;
     for (int i = 0; i < count; ++i) {
         const air_wgrad_t& g = probs[i];
         if (!g.A || !g.dY || g.M <= 0 || g.N <= 0 || g.K <= 0) return AIR_EINVAL;
@@ -320,6 +329,8 @@ static int fill_table(const air_wgrad_t* probs, int count, Table& tab, bool allo
         p.tiles_n = (g.N + BT - 1) / BT;
         p.first_block = blocks;
         p.first_part = parts;
+        p.bias_first = -1; p.bias_part = -1;
+        if (g.db && !g.head_pack && g.K >= 384) { p.bias_first = bias_blocks; p.bias_part = bias_blocks; bias_blocks += p.tiles_n; }
         p.strip = strip_of(g, strips);
         const int tiles_m = (g.M + BT - 1) / BT;
         p.bias_mod = (!g.head_pack && (long)tiles_m * p.tiles_n >= BIG_TILES) ? (tiles_m < 16 ? tiles_m : 16) : 0;
@@ -329,7 +340,9 @@ static int fill_table(const air_wgrad_t* probs, int count, Table& tab, bool allo
         blocks += p.strip ? tiles / p.strip : tiles;
     }
     for (int i = count; i < MAXP; ++i) { tab.p[i] = tab.p[0]; tab.first[i] = 0x7fffffff; }
-    tab.total_blocks = parts;
+    for (int i = 0; i < count; ++i)
+        if (tab.p[i].bias_part >= 0) tab.p[i].bias_part += parts;       // the bias partials follow the tiles'
+    tab.total_blocks = parts + nbias;
     tab.launch_blocks = blocks;
     return 0;
 }
@@ -344,7 +357,7 @@ extern "C" int air_wgrad_num_workgroups(const air_wgrad_t* probs, int count, int
     if (precision != 0 && precision != 1) return AIR_EINVAL;
     Table tab;
     const int rc = fill_table(probs, count, tab, true, precision == 1);
-    return rc ? rc : (precision == 1 ? tab.launch_blocks : tab.total_blocks);
+    return rc ? rc : tab.launch_blocks;
 }
 
 extern "C" int air_wgrad_grouped(const air_wgrad_t* probs, int count, int precision,
@@ -360,7 +373,7 @@ extern "C" int air_wgrad_grouped(const air_wgrad_t* probs, int count, int precis
         if (rg) return rg;
         hipLaunchKernelGGL(wgrad_grouped_bf16_kernel, dim3(tab.launch_blocks), dim3(THREADS), lds, air_stream(stream), tab, sq_partials, istate);
     }
-    else hipLaunchKernelGGL(wgrad_grouped_kernel, dim3(tab.total_blocks), dim3(THREADS), 0, air_stream(stream), tab, sq_partials, istate);
+    else hipLaunchKernelGGL(wgrad_grouped_kernel, dim3(tab.launch_blocks), dim3(THREADS), 0, air_stream(stream), tab, sq_partials, istate);
     AIR_CHECK_LAUNCH();
     return 0;
 }

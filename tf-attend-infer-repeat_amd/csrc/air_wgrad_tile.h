@@ -27,12 +27,15 @@ struct Prob {
     int first_part;             // first global-norm partial (= tile number: one partial per 64 x 64 tile, whoever computes it)
     int strip;                  // > 0: a workgroup owns `strip` consecutive column tiles of one block-row (run_strip_bf16)
     int bias_mod;               // which block-row sums db of column tile nt: 0 -> block-row 0; else block-row nt % bias_mod
+    int bias_first, bias_part;  // >= 0: db is summed by workgroups OF ITS OWN (run_bias_wg), one per column tile -- their first
+                                // workgroup in the launch and their first global-norm partial; -1: by the tiles (owns_bias)
 };
 // db[n0 .. n0 + 63] (and its share of the global norm) belongs to ONE tile of the column.  Block-row 0 for ordinary problems;
 // for the big ones (>= 2048 tiles, by shape alone -- so every precision / operand path of a problem agrees and the partials
 // stay bit-identical between them) the owners are spread over the first block-rows: sixteen column sums in block-row 0
 // were the long pole of a strip launch (a strip workgroup of block-row 0 summed all of its columns: +12 us at 4 tiles).
 __device__ __forceinline__ bool owns_bias(const Prob& pr, int m0, int n0) {
+    if (pr.bias_first >= 0) return false;
     const int nt = n0 / BT, mb = m0 / BT;
     return pr.bias_mod > 0 ? (mb == nt % pr.bias_mod) : (mb == 0);
 }
@@ -40,7 +43,8 @@ __device__ __forceinline__ bool owns_bias(const Prob& pr, int m0, int n0) {
 // ONE wide scalar load fetches all of them and the owner is found without a chain of dependent loads
 // (total_blocks = tiles = global-norm partials; launch_blocks = workgroups of the grouped launch: fewer when a problem
 // runs in strips)
-struct Table { int count; int total_blocks; int launch_blocks; int first[MAXP]; Prob p[MAXP]; };
+// nbias: the launch's first workgroups, which sum bias columns of the long-contraction problems (run_bias_wg)
+struct Table { int count; int total_blocks; int launch_blocks; int nbias; int first[MAXP]; Prob p[MAXP]; };
 
 // One float4 of a row-major operand, zero outside [rows x cols], in two branch-free halves: fetch4
 // issues the load(s) with out-of-range accesses redirected to element 0, mask4 zeroes what was out of
@@ -717,12 +721,104 @@ __device__ __forceinline__ void run_strip_bf16(const Prob& pr, int m0, int n0, u
     }
 }
 
+// BIAS workgroup (round 4): db[n0 .. n0 + 63] = column sums of the fp32 dY over all K rows, and its squares as one
+// global-norm partial of its own.  For the long contractions (K >= 384: the 128 x 128 configuration's N*B = 1280 rows) the
+// column sums were the long pole of the launch when a tile did them on the side -- 128 threads, one 64-row image at a
+// time: 21 us on top of the tile's 15.7.  Here they have the launch's FIRST workgroups to themselves (they start at once
+// and finish under the tiles), all 256 threads (the two halves take alternate images) and two images in flight per
+// thread.  Order of summation (the definition for every operand path and precision of such a problem): thread (h, g, q)
+// adds rows 8g .. 8g+7 of its images c = h, h+2, ... in order; xor-tree over g; half 0 + half 1.
+__device__ __forceinline__ void run_bias_wg(const Prob& pr, int n0, int part, float* __restrict__ sq_partials, float* sq_red)
+{
+    const int tid = threadIdx.x;
+    const int N = pr.N, K = pr.K;
+    const unsigned ldb = (unsigned)pr.ldb;
+    const float* __restrict__ Y = pr.dY;
+    const int g = tid & 7, q = (tid >> 3) & 15, h = tid >> 7;
+    const int col = n0 + 4 * q;
+    const bool vec = ((ldb & 3u) == 0u) && ((reinterpret_cast<uintptr_t>(Y) & 15) == 0);
+    const int nimg = (K + KB - 1) / KB;
+    float csum[4] = {0.f, 0.f, 0.f, 0.f};
+    auto fetch_img = [&](f32x4 (&v)[8], int c) __attribute__((always_inline)) {
+        if (c >= nimg) c = nimg - 1;                          // (past the end: a valid image again, never summed)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int row = c * KB + g * 8 + r;
+            const bool okr = row < K;
+            const unsigned at = (unsigned)row * ldb + (unsigned)col;
+            if (vec) v[r] = *reinterpret_cast<const f32x4*>(Y + ((okr && col < N) ? at : 0u));
+            else {
+                v[r].x = Y[(okr && col < N) ? at : 0u];
+                v[r].y = Y[(okr && col + 1 < N) ? at + 1u : 0u];
+                v[r].z = Y[(okr && col + 2 < N) ? at + 2u : 0u];
+                v[r].w = Y[(okr && col + 3 < N) ? at + 3u : 0u];
+            }
+        }
+    };
+    auto sum_img = [&](const f32x4 (&v)[8], int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const bool okr = c * KB + g * 8 + r < K;
+            csum[0] += (okr && col < N) ? v[r].x : 0.f;
+            csum[1] += (okr && col + 1 < N) ? v[r].y : 0.f;
+            csum[2] += (okr && col + 2 < N) ? v[r].z : 0.f;
+            csum[3] += (okr && col + 3 < N) ? v[r].w : 0.f;
+        }
+    };
+    f32x4 v0[8], v1[8];
+    fetch_img(v0, h);
+    for (int c = h; c < nimg; c += 4) {
+        fetch_img(v1, c + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        sum_img(v0, c);
+        fetch_img(v0, c + 4);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 2 < nimg) sum_img(v1, c + 2);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float t = csum[j];
+        t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4);
+        csum[j] = t;
+    }
+    float* park = sq_red + 4;                                 // 64 floats: half 1's column sums
+    if (h == 1 && g == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) park[4 * q + j] = csum[j];
+    }
+    __syncthreads();
+    float sq = 0.0f;
+    if (h == 0 && g == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float t = csum[j] + park[4 * q + j];
+            if (col + j < N) { pr.db[col + j] = t; sq += t * t; }
+        }
+    }
+    if (sq_partials) {
+        sq = air_block_sum_256(sq, sq_red);
+        if (tid == 0) sq_partials[part] = sq;
+    }
+}
+
+// the launch's first tab.nbias workgroups: bias columns of the long-contraction problems (either precision)
+__device__ __forceinline__ void run_bias_block(const Table& tab, int block, float* __restrict__ sq_partials, float* sq_red) {
+    int k = 0;                               // the last problem whose bias workgroups start at or before this one
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i)
+        if (i < tab.count && tab.p[i].bias_first >= 0 && block >= tab.p[i].bias_first) k = i;
+    const Prob& pb = tab.p[k];
+    const int idx = block - pb.bias_first;
+    run_bias_wg(pb, idx * BT, pb.bias_part + idx, sq_partials, sq_red);
+}
+
 // One rider / grouped-launch workgroup of the bf16 path: tile `block` of the table; Img = 48 KB of LDS (16-byte aligned;
 // STRIP_LDS when the table holds a strip problem), sq_red = 4 more floats.  sq_partials == NULL: no global-norm partial is
 // published.
 __device__ __forceinline__ void run_tile_bf16(const Table& tab, int block, unsigned short* Img, float* __restrict__ sq_partials,
                                               int32_t* __restrict__ istate, float* sq_red)
 {
+    if (block < tab.nbias) { run_bias_block(tab, block, sq_partials, sq_red); return; }
     int m0, n0;
     const Prob& pr = find_tile(tab, block, m0, n0);
     AIR_STAMP(0);

@@ -17,7 +17,12 @@ if flags:
     print("built with", flags)
 from bench import HP, ANNEAL, synthetic_canvases
 from air import air_model as am
-images, targets = synthetic_canvases(64, 50, 2, 1)
+STRESS = os.environ.get("STRESS") == "1"       # configs[3]: 128x128 canvas, 5 steps, batch 256
+hp = dict(HP)
+if STRESS:
+    hp.update(canvas_size=128, max_steps=5, max_digits=4)
+HP = hp
+images, targets = synthetic_canvases(256 if STRESS else 64, hp["canvas_size"], hp["max_digits"], 1)
 m = am.AIRModel(torch.tensor(images, device="cuda"), torch.tensor(targets, device="cuda"), cnn=False, train=True,
                 annealing_schedules=ANNEAL, gemm_precision="bf16", input_weight_gradient="stored", **HP)
 for _ in range(3):
@@ -41,15 +46,16 @@ def sub(idx, null_dw=False):
     ps = []
     for i in idx:
         q = arr[i]
-        ps.append(H.Wgrad(q.A, q.dY, None if null_dw else q.dW, q.db, q.M, q.N, q.K, q.lda, q.ldb, q.ldc, q.head_pack, q.Hs, q.Hh, q.Hz))
+        ps.append(H.Wgrad(q.A, q.dY, None if null_dw else q.dW, q.db, q.M, q.N, q.K, q.lda, q.ldb, q.ldc, q.head_pack, q.Hs, q.Hh, q.Hz,
+                          q.A16, q.dY16))
     a = (H.Wgrad * len(ps))(*ps)
     return a, len(ps)
 ist = torch.zeros(8, dtype=torch.int32, device="cuda")
-for prec in (1, 0):
+for prec in ((1,) if STRESS else (1, 0)):
     for name, (a, k) in (("all", sub(range(n))), ("all but dWx", sub(range(n - 1))), ("dWx stored", sub([n - 1])),
                          ("dWx norm-only", sub([n - 1], True))):
         us = t(lambda: H.check(lib.air_wgrad_grouped(a, k, prec, P(part), P(ist), s), "wgrad"))
-        print("prec %d  %-14s %4d workgroups  %.2f us" % (prec, name, lib.air_wgrad_num_blocks(a, k), us))
+        print("prec %d  %-14s %4d workgroups  %.2f us" % (prec, name, lib.air_wgrad_num_workgroups(a, k, prec), us))
     for i in range(n):
         a, k = sub([i])
         q = arr[i]
