@@ -249,7 +249,7 @@ int air_wgrad_num_blocks(const air_wgrad_t* probs, int count);
  * For a problem of >= 512 tiles (any precision) the tile that sums db of column tile nt is the one in block-row nt % 16,
  * not block-row 0.  Diagnostic; AIR_WGRAD_STRIP=<tiles per workgroup, 0 = off> overrides. */
 int air_wgrad_num_workgroups(const air_wgrad_t* probs, int count, int precision);
-int air_wgrad_grouped(const air_wgrad_t* probs /*HOST array, <= 12*/, int count, int precision,
+int air_wgrad_grouped(const air_wgrad_t* probs /*HOST array, <= 16*/, int count, int precision,
                       float* sq_partials, int32_t* istate, void* stream);
 
 /* column sums db[n] = sum_r dY[r*ld + n]  (BiasAdd_grad nodes) for `count` problems */

@@ -286,6 +286,10 @@ RAGGED = [
     (37, dict(max_steps=4, max_digits=3, canvas_size=33, windows_size=17, vae_latent_dimensions=7, rnn_units=80,
               vae_recognition_units=(50,), vae_generative_units=(30,), scale_hidden_units=24,
               shift_hidden_units=24, z_pres_hidden_units=40)),
+    # a deeper VAE (4 + 4 layers): 14 weight-gradient problems in the one grouped launch (up to 16)
+    (6, dict(max_steps=2, canvas_size=40, windows_size=20, vae_latent_dimensions=12, rnn_units=64,
+             vae_recognition_units=(96, 64, 48, 32), vae_generative_units=(32, 48, 64, 96),
+             scale_hidden_units=32, shift_hidden_units=32, z_pres_hidden_units=16)),
 ]
 
 

@@ -782,8 +782,8 @@ class AIRModel:
         # the input-weight gradient contracts over B rows only (sum_t dgates): its many light
         # workgroups go LAST so that they fill the tail of the launch behind the K = N*B ones
         wg(imgs, self.dgsum, Gx, G["lstm_bias"], D, 4 * R, B, self.images16, self.dgsum16)
-        if len(probs) > 12:
-            raise NotImplementedError("more than 12 weight matrices (deeper VAE) need a second grouped launch")
+        if len(probs) > 16:
+            raise NotImplementedError("more than 16 weight matrices (a VAE of more than 10 layers) need a second grouped launch")
         arr = (H.Wgrad * len(probs))(*probs)
         keep.append(arr)
         self._wgrad_arr = arr

@@ -16,7 +16,7 @@ constexpr int THREADS = 256;
 constexpr int BT = 64;          // output tile (both dims)
 constexpr int KC = 32;          // rows per staged chunk
 constexpr int LS = BT + 16;     // LDS row stride: = 16 (mod 32) dwords -> conflict-free fragment reads, 16-B aligned
-constexpr int MAXP = 12;
+constexpr int MAXP = 16;
 
 struct Prob {
     const float* A; const float* dY; float* dW; float* db;
