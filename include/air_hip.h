@@ -227,7 +227,8 @@ typedef struct {
     int32_t M, N, K, lda, ldb, ldc;
     int32_t head_pack, Hs, Hh, Hz;
     /* bf16 twins of A / dY (precision 1, nullable, same leading dimensions; see air_gemm_t): a problem that has both
-     * (8-byte aligned, lda/ldb/M/N multiples of 4, not head_pack) reads its operands as bf16 -- bit-identical dW.
+     * (8-byte aligned, lda/ldb/N multiples of 4, M a multiple of 4 or lda >= M rounded up to 4 -- padded rows --, not
+     * head_pack) reads its operands as bf16 -- bit-identical dW.
      * db is always summed from the fp32 dY. */
     const uint16_t* A16; const uint16_t* dY16;
 } air_wgrad_t;
@@ -424,6 +425,9 @@ typedef struct {
                                           * the fp32 arrays, same results */
     int32_t exact_fp32;                  /* 1: exact fp32 products (v_mfma_f32_16x16x4_f32) on the fp32 operands -- the fp32
                                           * path; twins ignored / not written; additionally 2 Z <= 104 */
+    int32_t ldz;                         /* row stride of z and z16 in elements; 0 = Z.  A stride that is a multiple of 4
+                                          * (Z = 50 -> 52) lets the weight gradient of the first generative layer read z's
+                                          * twin in 8-byte pieces (air_wgrad_t: lda % 4 == 0, lda >= M rounded up to 4) */
 } air_bottleneck_fwd_t;
 typedef struct {
     const float* dG; const float* Wg; const float* ml; const float* eps;

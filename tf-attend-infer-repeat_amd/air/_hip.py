@@ -111,7 +111,7 @@ class WriteBwd(C.Structure):
 class BottleneckFwd(C.Structure):
     _fields_ = [("X", _p), ("Wml", _p), ("bml", _p), ("eps", _p), ("Wg", _p), ("bg", _p), ("ml", _p), ("z", _p), ("g", _p),
                 ("M", _i), ("K1", _i), ("Z", _i), ("H", _i), ("ldx", _i), ("z16", _p), ("g16", _p),
-                ("X16", _p), ("Wml16", _p), ("Wg16", _p), ("exact_fp32", _i)]
+                ("X16", _p), ("Wml16", _p), ("Wg16", _p), ("exact_fp32", _i), ("ldz", _i)]
 
 
 class BottleneckBwd(C.Structure):

@@ -492,6 +492,11 @@ class AIRModel:
         self.window = f(N, B, d)
         self.rec_act = [f(N, B, u) for u in self.vae_recognition_units]
         self.ml = f(N, B, 2 * Z)
+        # z rows are padded to a multiple of 4 (Z = 50 -> 52) where the fused bottleneck writes them (air_bottleneck_fwd_t.ldz):
+        # the weight gradient of the first generative layer then reads z's twin in 8-byte pieces instead of taking the
+        # fp32-operand tiles (35 -> 15 us for that problem at 128 x 128).  self.zs is the [N, B, Z] view either way.
+        self._zs_ld = (Z + 3) & ~3
+        self._zs_pad = f(N, B, self._zs_ld)
         self.zs = f(N, B, Z)
         self.gen_act = [f(N, B, u) for u in self.vae_generative_units]
         self.vrec = f(N, B, d)
@@ -507,6 +512,7 @@ class AIRModel:
         self.window16 = h16(N, B, d)
         self.rec_act16 = [h16(N, B, u) for u in self.vae_recognition_units]
         self.zs16 = h16(N, B, Z)
+        self._zs16_pad = h16(N, B, self._zs_ld)
         self.gen_act16 = [h16(N, B, u) for u in self.vae_generative_units]
         self.images16 = None
         if self.train:
@@ -682,11 +688,13 @@ class AIRModel:
         fuse_f = (not nofuse and len(gen_u) >= 1 and k == 256 and Z <= (64 if self._prec == 1 else 52) and Z % 2 == 0
                   and gen_u[0] % 4 == 0)
         first_gen = 0
+        self._zs_fused = fuse_f
         if fuse_f:
+            self.zs = self._zs_pad[:, :, :Z]                 # (the sample lives in the padded rows)
             bf = H.BottleneckFwd(_ptr(x), _ptr(P["ml_w"]), _ptr(P["ml_b"]), _ptr(self.eps_z), _ptr(P["gen0_w"]),
-                                 _ptr(P["gen0_b"]), _ptr(self.ml), _ptr(self.zs), _ptr(self.gen_act[0]), NB, k, Z, gen_u[0], k,
-                                 _ptr(self.zs16), _ptr(self.gen_act16[0]), _ptr(x16), _ptr(T("ml_w")), _ptr(T("gen0_w")),
-                                 0 if self._prec == 1 else 1)
+                                 _ptr(P["gen0_b"]), _ptr(self.ml), _ptr(self._zs_pad), _ptr(self.gen_act[0]), NB, k, Z, gen_u[0], k,
+                                 _ptr(self._zs16_pad), _ptr(self.gen_act16[0]), _ptr(x16), _ptr(T("ml_w")), _ptr(T("gen0_w")),
+                                 0 if self._prec == 1 else 1, self._zs_ld)
             keep.append(bf)
             fwd.append(self._call("air_vae_bottleneck_fwd", C.byref(bf),
                                   nbytes=4 * (NB * (k + 4 * Z + gen_u[0]) + k * 2 * Z + Z * gen_u[0]),
@@ -763,8 +771,8 @@ class AIRModel:
         Gx, Gh = G["lstm_kernel"][:D], G["lstm_kernel"][D:]
         probs = []
 
-        def wg(A, dY, dW, db, M, Nn, K, A16=None, dY16=None):
-            probs.append(H.Wgrad(_ptr(A), _ptr(dY), _ptr(dW), _ptr(db), M, Nn, K, M, Nn, Nn, 0, 0, 0, 0, _ptr(A16), _ptr(dY16)))
+        def wg(A, dY, dW, db, M, Nn, K, A16=None, dY16=None, lda=None):
+            probs.append(H.Wgrad(_ptr(A), _ptr(dY), _ptr(dW), _ptr(db), M, Nn, K, lda or M, Nn, Nn, 0, 0, 0, 0, _ptr(A16), _ptr(dY16)))
         wg(self.h[0], self.dgates, Gh, None, R, 4 * R, NB, o16(self.h16, 0), self.dgates16)
         wg(self.h[1], self.d_hid, G["whid"], G["bhid"], R, HT, NB, o16(self.h16, 1), self.d_hid16)
         x, x16, k = self.window, self.window16, d
@@ -773,8 +781,11 @@ class AIRModel:
             x, x16, k = self.rec_act[i], self.rec_act16[i], u
         wg(x, self.d_ml, G["ml_w"], G["ml_b"], k, 2 * Z, NB, x16, self.d_ml16)
         x, x16, k = self.zs, self.zs16, Z
+        zl = None
+        if self._zs_fused:
+            x, x16, zl = self._zs_pad, self._zs16_pad, self._zs_ld
         for i, u in enumerate(gen_u):
-            wg(x, self.d_gen[i], G["gen%d_w" % i], G["gen%d_b" % i], k, u, NB, x16, self.d_gen16[i])
+            wg(x, self.d_gen[i], G["gen%d_w" % i], G["gen%d_b" % i], k, u, NB, x16, self.d_gen16[i], lda=(zl if i == 0 else None))
             x, x16, k = self.gen_act[i], self.gen_act16[i], u
         wg(x, self.d_genpre, G["out_w"], G["out_b"], k, d, NB, x16, self.d_genpre16)
         probs.append(H.Wgrad(_ptr(self.d_out7), _ptr(self.hid), _ptr(G["wout"]), _ptr(G["bout"]),

@@ -68,6 +68,7 @@ struct FwdArgs {
     int M, Z, H, ldx;
     unsigned short* z16; unsigned short* g16;      // bf16 twins of z / g (nullable)
     const unsigned short* X16; const unsigned short* Wml16; const unsigned short* Wg16;   // bf16 twins of the operands (TW)
+    int ldz;                                       // row stride of z / z16 (>= Z)
 };
 
 // K1 = width of X (the last recognition layer), compile-time
@@ -231,8 +232,8 @@ __global__ __launch_bounds__(THREADS) void bottleneck_fwd_kernel(FwdArgs a)
         if (blockIdx.y == 0 && uok && m < M) {
             a.ml[(size_t)m * Z2 + u] = mean;
             a.ml[(size_t)m * Z2 + Z + u] = lv;
-            a.z[(size_t)m * Z + u] = zz;
-            if (a.z16) a.z16[(size_t)m * Z + u] = bf16_of(zz);
+            a.z[(size_t)m * a.ldz + u] = zz;
+            if (a.z16) a.z16[(size_t)m * a.ldz + u] = bf16_of(zz);
         }
         A2[row * L2 + u] = (uok && m < M) ? bf16_of(zz) : (unsigned short)0;
     }
@@ -541,7 +542,7 @@ __global__ __launch_bounds__(THREADS) void bottleneck_fwd_f32_kernel(FwdArgs a)
         if (blockIdx.y == 0 && uok && m < M) {
             a.ml[(size_t)m * Z2 + u] = mean;
             a.ml[(size_t)m * Z2 + Z + u] = lv;
-            a.z[(size_t)m * Z + u] = zz;
+            a.z[(size_t)m * a.ldz + u] = zz;
         }
         A2[row * L2 + u] = (uok && m < M) ? zz : 0.0f;
     }
@@ -704,6 +705,8 @@ extern "C" int air_vae_bottleneck_fwd(const air_bottleneck_fwd_t* a, void* strea
     if (a->M <= 0 || a->K1 <= 0 || a->Z <= 0 || a->H <= 0 || a->ldx < a->K1) return AIR_EINVAL;
     if (a->K1 != 256 || a->Z > 64) return AIR_ELIMIT;
     if ((a->Z & 1) || (a->H & 3) || (a->ldx & 3) || !al16(a->X) || !al16(a->Wml) || !al16(a->Wg)) return AIR_EALIGN;
+    if (a->ldz != 0 && a->ldz < a->Z) return AIR_EINVAL;
+    const int ldz = a->ldz > 0 ? a->ldz : a->Z;
     constexpr int K1 = 256;
     if (a->exact_fp32) {
         if (2 * a->Z > 104) return AIR_ELIMIT;                      // Wml as it lies: rows of at most 104 + 4 floats of LDS
@@ -711,7 +714,7 @@ extern "C" int air_vae_bottleneck_fwd(const air_bottleneck_fwd_t* a, void* strea
         const int rcf = grant_lds(bottleneck_fwd_f32_kernel<K1>, ldsf);
         if (rcf) return rcf;
         FwdArgs kf{a->X, a->Wml, a->bml, a->eps, a->Wg, a->bg, a->ml, a->z, a->g, a->M, a->Z, a->H, a->ldx, nullptr, nullptr,
-                   nullptr, nullptr, nullptr};
+                   nullptr, nullptr, nullptr, ldz};
         hipLaunchKernelGGL((bottleneck_fwd_f32_kernel<K1>), dim3((a->M + 15) / 16, (a->H + 63) / 64), dim3(THREADS), ldsf,
                            air_stream(stream), kf);
         AIR_CHECK_LAUNCH();
@@ -723,7 +726,7 @@ extern "C" int air_vae_bottleneck_fwd(const air_bottleneck_fwd_t* a, void* strea
     const int rc = tw ? grant_lds(bottleneck_fwd_kernel<K1, true>, lds) : grant_lds(bottleneck_fwd_kernel<K1, false>, lds);
     if (rc) return rc;
     FwdArgs k{a->X, a->Wml, a->bml, a->eps, a->Wg, a->bg, a->ml, a->z, a->g, a->M, a->Z, a->H, a->ldx, a->z16, a->g16,
-              a->X16, a->Wml16, a->Wg16};
+              a->X16, a->Wml16, a->Wg16, ldz};
     const dim3 grid((a->M + 15) / 16, (a->H + 63) / 64);
     if (tw) hipLaunchKernelGGL((bottleneck_fwd_kernel<K1, true>), grid, dim3(THREADS), lds, air_stream(stream), k);
     else hipLaunchKernelGGL((bottleneck_fwd_kernel<K1, false>), grid, dim3(THREADS), lds, air_stream(stream), k);

@@ -344,8 +344,10 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 __device__ __forceinline__ bool twin_ok(const Prob& pr) {
     auto a8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; };
+    // (M % 4 != 0 is fine when the A rows are padded to a multiple of 4: a piece that straddles M stays inside its row, and
+    // the output rows it feeds are beyond M -- never stored)
     return pr.A16 && pr.dY16 && !pr.head_pack && a8(pr.A16) && a8(pr.dY16) && (pr.lda & 3) == 0 && (pr.ldb & 3) == 0 &&
-           (pr.M & 3) == 0 && (pr.N & 3) == 0;
+           ((pr.M & 3) == 0 || pr.lda >= ((pr.M + 3) & ~3)) && (pr.N & 3) == 0;
 }
 
 // Bias gradient of a twin tile in block-row 0: fp32 column sums of dY[:, n0 .. n0 + 63] in tile_bf16's order -- per k-run g the
