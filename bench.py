@@ -266,7 +266,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary blocks (fp32 step, stress config, inference)")
-    ap.add_argument("--backward", default="reference", choices=["reference", "taps", "exact"])
+    ap.add_argument("--backward", default="reference", choices=["reference", "reference_blocked", "taps", "exact"])
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

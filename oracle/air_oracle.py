@@ -264,13 +264,50 @@ def transformer(U, theta, out_size, return_aux=False):
     return out
 
 
-def transformer_backward(U, theta, out_size, d_out):
+BLOCKED_CHUNKS = 16     # at most this many chunks per (input pixel, tap) term stream of order="blocked16" ...
+BLOCKED_CHUNK_MIN = 64  # ... none of them shorter than this (a stream of up to 64 terms is one chunk)
+
+
+def blocked_segment_sum(ids, vals, num, chunks=BLOCKED_CHUNKS, chunk_min=BLOCKED_CHUNK_MIN):
+    """The accumulation order of backward="reference_blocked" for ONE tap's Gather gradient: the terms that go
+    to one input pixel ("slot"), n of them in output-pixel order, are cut into contiguous pieces of
+    cs = max(ceil(n / chunks), chunk_min) terms (the last one shorter); each piece is summed sequentially from
+    +0.0 in fp32.  Returns (slot, chunk_sum) pairs ordered by slot, then by chunk -- the caller adds them onto
+    one accumulator per slot, tap after tap (a, b, c, d), chunk after chunk.  The in-range window pixels of the
+    AIR write (a handful of terms per tap) therefore keep per-tap sequential sums; only the border pixels that
+    collect the out-of-range canvas -- thousands of terms, the reference's 10 000-term chain
+    (transformer.py:108-116 under tf.gradients) -- are cut."""
+    order = np.argsort(ids, kind="stable")
+    si, sv = ids[order], vals[order]
+    if si.size == 0:
+        return si, sv
+    first = np.concatenate([[True], si[1:] != si[:-1]])
+    start = np.flatnonzero(first)                                  # first term of every slot
+    n = np.diff(np.concatenate([start, [si.size]]))
+    cs = np.maximum(-(-n // chunks), chunk_min)
+    rank = np.arange(si.size) - np.repeat(start, n)                # position within the slot's stream
+    chunk = rank // np.repeat(cs, n)
+    nch = -(-n // cs)
+    cbase = np.concatenate([[0], np.cumsum(nch)[:-1]])
+    gchunk = np.repeat(cbase, n) + chunk
+    sums = np.zeros(int(nch.sum()), vals.dtype)
+    np.add.at(sums, gchunk, sv)                                    # sequential within every chunk, from +0.0
+    return np.repeat(si[start], nch), sums
+
+
+def transformer_backward(U, theta, out_size, d_out, order="sequential"):
     """What tf.gradients builds for transformer(U, theta, out_size) (transformer.py:56-171), in the op
     order of the reference's saved graph (model/air-model.meta, `.../st_backward/...` gradient nodes;
     executed by oracle/graphdef_exec.py, pinned to this function by tests/test_graph_exec.py):
 
       * d U: the four Gather gradients are concatenated (a, b, c, d) and reduced by ONE
-        UnsortedSegmentSum -- np.add.at visits the terms in that order, like the TF CPU kernel;
+        UnsortedSegmentSum -- np.add.at visits the terms in that order, like the TF CPU kernel
+        (order="sequential", the default).  order="blocked16" (AIRModel(backward="reference_blocked")) keeps the
+        same concatenated a, b, c, d stream per input pixel but cuts every tap's piece of it into up to 16
+        contiguous chunks (of at least 64 terms) that are summed independently and then added left to right
+        (blocked_segment_sum): the same terms,
+        the same left-to-right structure, a sum tree a GPU can evaluate in parallel -- the realisation a
+        parallel UnsortedSegmentSum (TF's GPU kernel uses unordered atomics) stands for, made deterministic;
       * coordinate gradients: mul_10..13_grad / mul_6..9_grad products, Sub negations, then AddN_10
         (x) and AddN_11 (y) over the legs of wa, wb, wc, wd left to right; truediv_grad, mul_grad;
       * d theta: MatMul_grad -- contraction of (d x_s, d y_s) with the grid rows (x_t, y_t, 1).
@@ -288,11 +325,13 @@ def transformer_backward(U, theta, out_size, d_out):
     Ia, Ib, Ic, Id = U[bidx, y0, x0], U[bidx, y1, x0], U[bidx, y0, x1], U[bidx, y1, x1]
     # d U: [a-terms of every output pixel, then b, c, d] into one accumulator per input pixel
     d_U = np.zeros((B, Hi * Wi), dtype)
+    assert order in ("sequential", "blocked16"), order
     for b in range(B):
-        idx = np.concatenate([y0[b] * Wi + x0[b], y1[b] * Wi + x0[b], y0[b] * Wi + x1[b], y1[b] * Wi + x1[b]])
-        val = np.concatenate([(wx0[b] * wy0[b]) * g[b], (wx0[b] * wy1[b]) * g[b],
-                              (wx1[b] * wy0[b]) * g[b], (wx1[b] * wy1[b]) * g[b]])
-        np.add.at(d_U[b], idx, val)
+        idx = [y0[b] * Wi + x0[b], y1[b] * Wi + x0[b], y0[b] * Wi + x1[b], y1[b] * Wi + x1[b]]
+        val = [(wx0[b] * wy0[b]) * g[b], (wx0[b] * wy1[b]) * g[b], (wx1[b] * wy0[b]) * g[b], (wx1[b] * wy1[b]) * g[b]]
+        if order == "blocked16":
+            idx, val = zip(*(blocked_segment_sum(i, v, Hi * Wi) for i, v in zip(idx, val)))
+        np.add.at(d_U[b], np.concatenate(idx), np.concatenate(val))
     ga, gb, gc, gd = g * Ia, g * Ib, g * Ic, g * Id
     dX = ((-(ga * wy0) + -(gb * wy1)) + gc * wy0) + gd * wy1
     dY = ((-(wx0 * ga) + wx0 * gb) + -(wx1 * gc)) + wx1 * gd

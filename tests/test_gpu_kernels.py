@@ -811,11 +811,14 @@ def _write_theta(s, x, y):
     return th
 
 
-@pytest.mark.parametrize("Cc,w,N,B", [(50, 28, 3, 6), (71, 28, 2, 5), (128, 28, 5, 4), (128, 20, 2, 3)])
-def test_write_bwd_graph_order_matches_oracle_all_canvas_sizes(H, Cc, w, N, B):
-    """air_write_bwd(literal=2) -- the default backward="reference" -- against oracle.transformer_backward
-    (pinned to the reference's executed graph, transformer.py:56-117 under tf.gradients) on random inputs.
-    C = 50 takes write_bwd_graph_kernel<true> (all four taps' terms resident), C >= 63 the per-tap staged
+@pytest.mark.parametrize("literal,order", [(2, "sequential"), (3, "blocked16")])
+@pytest.mark.parametrize("Cc,w,N,B", [(50, 28, 3, 6), (71, 28, 2, 5), (128, 28, 5, 4), (128, 20, 2, 3), (50, 32, 2, 3), (40, 9, 2, 4)])
+def test_write_bwd_graph_order_matches_oracle_all_canvas_sizes(H, Cc, w, N, B, literal, order):
+    """air_write_bwd(literal=2) -- backward="reference" -- against oracle.transformer_backward
+    (pinned to the reference's executed graph, transformer.py:56-117 under tf.gradients) on random inputs, and
+    air_write_bwd(literal=3) -- backward="reference_blocked" -- against the same function with order="blocked16"
+    (every tap's piece of a window pixel's term stream in 16 chunks, oracle.blocked_segment_sum).
+    C = 50 takes write_bwd_{graph,blocked}_kernel<true> (all four taps' terms resident), C >= 63 the per-tap staged
     <false> variant that every large canvas (BASELINE configs[3]: 128x128, N = 5) runs.  d_gen_pre (the
     UnsortedSegmentSum result times SigmoidGrad) BIT FOR BIT, residue included; theta / z legs <= 2e-5."""
     name = C.create_string_buffer(96)
@@ -824,6 +827,7 @@ def test_write_bwd_graph_order_matches_oracle_all_canvas_sizes(H, Cc, w, N, B):
     x = rng.uniform(-0.8, 0.8, (N, B)).astype(np.float32)
     y = rng.uniform(-0.8, 0.8, (N, B)).astype(np.float32)
     s[0, 0], x[0, 0], y[0, 0] = 0.3, -0.95, 0.9            # glimpse in a canvas corner: one corner slot owns most pixels
+    s[0, 1], x[0, 1], y[0, 1] = 0.97, 0.02, -0.01          # the glimpse covers the canvas: no out-of-range pixels, long interior streams
     z = rng.uniform(0.05, 1.0, (N, B)).astype(np.float32)
     mask = np.ones((N, B), np.float32)
     mask[N - 1, B - 1] = 0.0                              # a stopped item: Select(active, ., 0)
@@ -836,9 +840,9 @@ def test_write_bwd_graph_order_matches_oracle_all_canvas_sizes(H, Cc, w, N, B):
     att_d, g_d, v_d = (torch.tensor(v, device="cuda") for v in (att, g, vrec))
     dgen = torch.full((N, B, w * w), 7.0, device="cuda")
     dsx = torch.full((N, B, 4), 7.0, device="cuda")
-    wb = H.WriteBwd(_p(g_d), _p(v_d), _p(att_d), _p(dgen), _p(dsx), B, N, Cc, w, 2, None, None, None, None)
+    wb = H.WriteBwd(_p(g_d), _p(v_d), _p(att_d), _p(dgen), _p(dsx), B, N, Cc, w, literal, None, None, None, None)
     H.check(H.lib().air_write_bwd_kernel_name(C.byref(wb), name, 96))
-    assert name.value.decode() == "write_bwd_graph_kernel<%s>" % ("true" if Cc <= 62 else "false")
+    assert name.value.decode() == "write_bwd_%s_kernel<%s>" % ("graph" if literal == 2 else "blocked", "true" if Cc <= 62 else "false")
     H.check(H.lib().air_write_bwd(C.byref(wb), _stream()), "air_write_bwd")
     torch.cuda.synchronize()
     dgen, dsx = dgen.cpu().numpy(), dsx.cpu().numpy()
@@ -847,7 +851,7 @@ def test_write_bwd_graph_order_matches_oracle_all_canvas_sizes(H, Cc, w, N, B):
         th = _write_theta(s[t], x[t], y[t])
         U = vrec[t].reshape(B, w, w)
         d_out = (z[t][:, None] * g).reshape(B, Cc, Cc)                        # canvas/mul_grad: z * Select_grad
-        dU, dth = ao.transformer_backward(U, th, (Cc, Cc), d_out)
+        dU, dth = ao.transformer_backward(U, th, (Cc, Cc), d_out, order=order)
         ref = ((dU.reshape(B, -1) * vrec[t]) * (np.float32(1.0) - vrec[t])).astype(np.float32)   # SigmoidGrad
         patch = ao.transformer(U, th, (Cc, Cc)).reshape(B, -1).astype(np.float64)
         for b in range(B):

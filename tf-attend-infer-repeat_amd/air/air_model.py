@@ -329,10 +329,13 @@ class AIRModel:
         #   reference's training signal carries; bit-identical to the graph at kernel level.
         # "taps": per-tap sums added ((d+c)+b)+a (the order torch-CPU autograd happens to use; the
         #   residue is ~400x smaller than the reference graph's).  "exact": the mathematical adjoint.
-        if backward not in ("reference", "taps", "exact"):
-            raise ValueError("backward must be 'reference', 'taps' or 'exact'")
+        # "reference_blocked": the reference graph's term streams (a, b, c, d per window pixel, canvas-pixel order) with
+        #   every tap's piece cut into 16 chunks that are summed side by side and added left to right
+        #   (oracle.transformer_backward(order="blocked16")): the same residue mechanism without the 10 000-term chain.
+        if backward not in ("reference", "reference_blocked", "taps", "exact"):
+            raise ValueError("backward must be 'reference', 'reference_blocked', 'taps' or 'exact'")
         self.backward = backward
-        self._literal = {"reference": 2, "taps": 1, "exact": 0}[backward]
+        self._literal = {"reference_blocked": 3, "reference": 2, "taps": 1, "exact": 0}[backward]
         self._prec = 1 if prec == "bf16" else 0
         # bf16 path: every GEMM operand also exists as a bf16 twin in memory (written by the producing kernel /
         # by Adam), so the GEMMs read 2-byte operands and convert nothing -- bit-identical results (the twin IS
@@ -728,7 +731,7 @@ class AIRModel:
         env_o = os.environ.get("AIR_WB_ORDER")
         want_o = (env_o == "1") if env_o in ("0", "1") else (NB > 256)
         self._wb_order = (torch.arange(NB, dtype=torch.int32, device=imgs.device)
-                          if (want_o and self.train and self._literal == 2 and NB <= 4096) else None)
+                          if (want_o and self.train and self._literal >= 2 and NB <= 4096) else None)
         wf = H.WriteFwd(_ptr(self.vrec), _ptr(self.ml), _ptr(imgs), _ptr(self.dyn), _ptr(self.att),
                         _ptr(self._recon), _ptr(self._rec_loss), _ptr(self.d_recon if self.train else None),
                         _ptr(self.run_loss), _ptr(self.run_digits), _ptr(self._loss_item), B, N, Cc, w, Z, _ptr(self._rec_part), bands,
@@ -854,7 +857,7 @@ class AIRModel:
         ab = H.AttendBwd(_ptr(self.hid), _ptr(P["wout"]), _ptr(imgs), _ptr(self.eps_scale),
                          _ptr(self.eps_shift), _ptr(self.dyn), _ptr(self.out7), _ptr(self.att),
                          _ptr(self.d_window), _ptr(self.d_sxyw), _ptr(self.d_hid), _ptr(self.d_out7),
-                         B, N, Cc, w, Hs, Hh, Hz, Hmax, lit, _ptr(self.d_hid16))
+                         B, N, Cc, w, Hs, Hh, Hz, Hmax, min(lit, 2), _ptr(self.d_hid16))
         keep.append(ab)
         bwd.append(self._call("air_attend_bwd", C.byref(ab), nbytes=NB * ((D + d + 2 * HT) * 4 + 64), tag="attend_bwd"))
         # heads' contribution to d loss / d h'[t] for every step

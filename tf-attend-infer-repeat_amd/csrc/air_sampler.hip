@@ -29,12 +29,14 @@ extern "C" int air_debug_stamps_wg(unsigned long long* out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(air_stamps_wg), sizeof(unsigned long long) * (n < 4096 * 8 ? n : 4096 * 8));
 }
 #define AIR_STAMP_WG(i) do { if (threadIdx.x == 0) air_stamps_wg[((blockIdx.y * gridDim.x + blockIdx.x) & 4095) * 8 + (i)] = wall_clock64(); } while (0)
+#define AIR_STAMP_WG_T(i, t) do { if (threadIdx.x == (t)) air_stamps_wg[((blockIdx.y * gridDim.x + blockIdx.x) & 4095) * 8 + (i)] = wall_clock64(); } while (0)
 // accumulating form (large canvases: four passes per workgroup): slot i += now - t0, and plain values
 #define AIR_STAMP_WG_ADD(i, t0) do { if (threadIdx.x == 0) air_stamps_wg[((blockIdx.y * gridDim.x + blockIdx.x) & 4095) * 8 + (i)] += wall_clock64() - (t0); } while (0)
 #define AIR_STAMP_WG_SET(i, v) do { if (threadIdx.x == 0) air_stamps_wg[((blockIdx.y * gridDim.x + blockIdx.x) & 4095) * 8 + (i)] = (unsigned long long)(v); } while (0)
 #define AIR_NOW() wall_clock64()
 #else
 #define AIR_STAMP_WG(i) do { } while (0)
+#define AIR_STAMP_WG_T(i, t) do { } while (0)
 #define AIR_STAMP_WG_ADD(i, t0) do { } while (0)
 #define AIR_STAMP_WG_SET(i, v) do { } while (0)
 #define AIR_NOW() 0ull
@@ -1165,8 +1167,17 @@ __device__ __forceinline__ float stream_add(float acc, const float* T, int start
 
 // ALLPH: the terms of all four taps are resident (4*C*C floats of LDS, no barrier between taps);
 // otherwise one tap at a time through one buffer (large canvases)
-template <bool ALLPH>
-__global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_bwd_t a, int seq_flags)
+// BLOCKED (literal == 3, backward="reference_blocked"): the same term streams -- per window pixel the a-, b-, c-, d-tap
+// terms in canvas-pixel order -- but every (slot, tap) stream of n terms is cut into at most WB_CHUNKS contiguous chunks
+// of max(ceil(n / WB_CHUNKS), WB_CHUNK_MIN) terms, each summed from +0.0 by a lane of its own (register chain), and the
+// chunk sums are added onto the slot's accumulator left to right, tap after tap (oracle.blocked_segment_sum,
+// order="blocked16"): a sum tree of depth n/16 + 64 instead of one chain of 4n adds.  A stream of up to 64 terms is ONE
+// chunk (its tap's sum), so only the border slots that collect the out-of-range pixels are cut at all.
+// No LDS atomics, no lane-order property, no probe; the coordinate / z gradients are taken in the term pass.
+constexpr int WB_CHUNKS = 16, WB_CHUNK_MIN = 64;
+__device__ __forceinline__ int wb_chunk_len(int n) { return max((n + WB_CHUNKS - 1) / WB_CHUNKS, WB_CHUNK_MIN); }
+template <bool ALLPH, bool BLOCKED>
+__device__ __forceinline__ void write_bwd_graph_body(const air_write_bwd_t& a, int seq_flags)
 {
     // seq_flags (accumulators(), below): bit 0 the LDS atomic pipe applies lanes in order, bit 1 the lane-ring accumulator
     // is exact on this part (used when the pipe is not); bits 8..15: pipe / ring MIX factor c in sixteenths (0 = every
@@ -1320,11 +1331,30 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
 
     // tap ph = a, b, c, d <-> (y0,x0), (y1,x0), (y0,x1), (y1,x1)
     const int di = WB_THREADS / C, dj = WB_THREADS % C;
+    float d00 = 0.f, d02 = 0.f, d11 = 0.f, d12 = 0.f, dz = 0.f;
+    // BLOCKED: theta / z gradients of one canvas pixel, taken where its terms are computed (taps from the tables, the
+    // window from LDS -- nothing starves the LDS in this mode); per-thread sums over a fixed pixel set, combined over the
+    // waves in a fixed order at the end
+    auto theta_px = [&](const Tap& tx, const Tap& ty, float g, float gp, int i, int j) {
+        const float Ia = sh_win[ty.i0 * w + tx.i0], Ib = sh_win[ty.i1 * w + tx.i0];
+        const float Ic = sh_win[ty.i0 * w + tx.i1], Id = sh_win[ty.i1 * w + tx.i1];
+        dz += g * bilinear4(tx, ty, Ia, Ib, Ic, Id);                                // canvas/mul_grad: Select_grad * window_recon
+        float gX, gY;
+        graph_dxy(gp, Ia, Ib, Ic, Id, tx, ty, (float)w - 1.001f, gX, gY);
+        d00 += gX * sh_t[j]; d02 += gX;                                             // MatMul_grad: rows of theta x (x_t, y_t, 1)
+        d11 += gY * sh_t[i]; d12 += gY;
+    };
+    auto theta_publish = [&]() {
+        d00 = air_wave_sum(d00); d02 = air_wave_sum(d02); d11 = air_wave_sum(d11); d12 = air_wave_sum(d12); dz = air_wave_sum(dz);
+        if (lane == 0) { float* r = sh_red + wave * 8; r[0] = d00; r[1] = d02; r[2] = d11; r[3] = d12; r[4] = dz; }
+    };
     auto stage_T = [&](int ph0, int ph1) {
         int i = tid / C, j = tid % C;
         for (int p = tid; p < CC; p += WB_THREADS) {
             const Tap tx = sh_tx[j], ty = sh_ty[i];
-            const float gp = z * (ALLPH ? sh_g[p] : gsrc[p]);                       // canvas/mul_grad: z * Select_grad
+            const float g0 = ALLPH ? sh_g[p] : gsrc[p];
+            const float gp = z * g0;                                                // canvas/mul_grad: z * Select_grad
+            if (BLOCKED) theta_px(tx, ty, g0, gp, i, j);
             const int4 ci = sh_ci[j], ri = sh_ri[i];
             const int cl0 = ci.x, cn0 = ci.y, cl1 = ci.z, cn1 = ci.w;               // runs of this column's x0 / x1 key
             const int rl0 = ri.x, rn0 = ri.y, rl1 = ri.z, rn1 = ri.w;               // runs of this row's y0 / y1 key
@@ -1346,13 +1376,15 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
         start = (ALLPH ? ph * CCp : 0) + rlo * C + nrows * clo;
         n = nrows * ncols;
     };
-    const int sp = tid / w, sq = tid % w;
-    const bool is_slot = tid < w * w;
+    // which window pixel ("slot") this thread accumulates.  BLOCKED: waves 0..3 take the corner slots' chunks, so the slots
+    // start at thread 256 and the last w*w - 768 of them fall to the first threads (after their corner work)
+    const int sl = BLOCKED ? (tid >= 4 * 64 ? tid - 4 * 64 : tid + (WB_THREADS - 4 * 64)) : tid;
+    const int sp = sl / w, sq = sl % w;
+    const bool is_slot = sl < w * w;
     // (a part whose LDS atomics are not lane-ordered -- lds_order_probe -- has no "corner" slots: their four long runs go
     // through the register chains like every other slot's; slow, but the same sequential order by construction)
-    const bool corner = (lds_ordered || ring_ok) && is_slot && (sp == 0 || sp == w - 1) && (sq == 0 || sq == w - 1);
+    const bool corner = (BLOCKED || lds_ordered || ring_ok) && is_slot && (sp == 0 || sp == w - 1) && (sq == 0 || sq == w - 1);
     float acc = 0.0f;
-    float d00 = 0.f, d02 = 0.f, d11 = 0.f, d12 = 0.f, dz = 0.f;
     // The corner slots' streams -> ds_add_f32 on one LDS word per corner: wave c feeds corner c, 64
     // consecutive terms per instruction, tap after tap (an instruction costs ~140 + 1.8 cycles per active
     // lane, tools/exp/lds_atomic_cost.hip).  16 instructions per batch; reads, adds and waits are inline asm
@@ -1513,21 +1545,123 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
             for (int ph = ph0; ph < ph1; ++ph) {
                 int start, n;
                 slot_run(ph, sp, sq, start, n);
-                acc = stream_add(acc, sh_T, start, n);
+                if (!BLOCKED) acc = stream_add(acc, sh_T, start, n);
+                else {
+                    const int cs = wb_chunk_len(n);
+                    for (int k0 = 0; k0 < n; k0 += cs) acc += stream_add(0.0f, sh_T, start + k0, min(cs, n - k0));
+                }
             }
     };
     // the non-corner slots' outputs
     auto publish = [&]() {
         if (is_slot && !corner) {
-            const float r = sh_win[tid];
+            const float r = sh_win[sl];
             const float dgv = (acc * r) * (1.0f - r);        // SigmoidGrad of vae.py:39-41: dy * y * (1 - y)
-            dgen[tid] = dgv;
-            if (dgen16) dgen16[tid] = air_bf16_of(dgv);
+            dgen[sl] = dgv;
+            if (dgen16) dgen16[sl] = air_bf16_of(dgv);
+        }
+    };
+    // BLOCKED: chunk k of corner (cp, cq)'s stream of tap ph, summed from +0.0 (empty chunks: +0.0, the identity)
+    auto corner_chunk = [&](int ph, int cp, int cq, int k) -> float {
+        int start, n;
+        slot_run(ph, cp, cq, start, n);
+        n = max(n, 0);
+        const int cs = wb_chunk_len(n), off = k * cs;
+        return stream_add(0.0f, sh_T, start + off, min(max(n - off, 0), cs));
+    };
+    auto publish_corner = [&](int c, float du) {
+        const int it = ((c & 2) ? w - 1 : 0) * w + ((c & 1) ? w - 1 : 0);
+        const float r = sh_win[it];
+        const float dgv = (du * r) * (1.0f - r);
+        dgen[it] = dgv;
+        if (dgen16) dgen16[it] = air_bf16_of(dgv);
+    };
+    // theta_recon = [[1/s, 0, -x/s], [0, 1/s, -y/s]] (air_model.py:353-356): truediv_grad .. truediv_3_grad,
+    // summed in AddN_24's order; Neg_grad / Neg_1_grad for x, y.  One wave: lanes 0..4 each combine one quantity over
+    // the waves' partials in wave order; lane 0 collects them by shuffle
+    auto finish_theta = [&]() {
+        float u = 0.0f;
+        if (lane < 5) { u = sh_red[lane]; for (int wv = 1; wv < NW; ++wv) u += sh_red[wv * 8 + lane]; }
+        float t5[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) t5[k] = __shfl(u, k, 64);
+        if (lane == 0) {
+            const float n1 = (-1.0f / s) / s;
+            dsx[0] = ((t5[0] * n1 + t5[1] * ((x / s) / s)) + t5[2] * n1) + t5[3] * ((y / s) / s);
+            dsx[1] = -(t5[1] / s);
+            dsx[2] = -(t5[3] / s);
+            dsx[3] = t5[4];
         }
     };
     // waves 0..3 feed one corner each to the atomic pipe; the pixel loop runs beside them on the other twelve
     constexpr int TH0 = 4 * 64, THN = WB_THREADS - TH0;
-    if (ALLPH) {
+    if (BLOCKED && ALLPH) {
+        // [terms of all taps + coordinate gradients] | [waves 0..3: corner c's 4 x 16 chunks, one per lane, then their 64
+        // sums added in stream order || the other slots' streams, one lane each || wave 15: the theta / z outputs]
+        AIR_STAMP_WG(1);
+        stage_T(0, 4);
+        theta_publish();
+        __syncthreads();
+        AIR_STAMP(43);
+        AIR_STAMP_WG(2);
+        if (wave < 4) {
+            const float sk = corner_chunk(lane >> 4, (wave & 2) ? w - 1 : 0, (wave & 1) ? w - 1 : 0, lane & 15);
+            float du = 0.0f;
+#pragma unroll
+            for (int l = 0; l < 64; ++l) du += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sk), l));
+            if (lane == 0) publish_corner(wave, du);
+        }
+        AIR_STAMP(44);
+        AIR_STAMP_WG(3);
+        chains(0, 4);
+        AIR_STAMP_WG(4);
+        AIR_STAMP_WG_T(5, 8 * 64);
+        publish();
+        if (wave == NW - 1) finish_theta();
+        AIR_STAMP(47);
+        AIR_STAMP_WG(6);
+        AIR_STAMP_WG_T(7, 15 * 64);
+        return;
+    } else if (BLOCKED) {
+        // one tap per pass (large canvases).  Wave 1 holds the four corners' chunks of the pass (lane = corner * 16 + chunk)
+        // and carries the corner accumulators from pass to pass; the coordinate gradients ride in pass 0
+        float cacc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int ph = 0; ph < 4; ++ph) {
+            int i = tid / C, j = tid % C;
+            const bool x1 = ph >> 1, y1 = ph & 1;
+            for (int p = tid; p < CC; p += WB_THREADS) {
+                const Tap tx = sh_tx[j], ty = sh_ty[i];
+                const float g0 = gsrc[p];
+                const float gp = z * g0;
+                if (ph == 0) theta_px(tx, ty, g0, gp, i, j);
+                const int4 ci = sh_ci[j], ri = sh_ri[i];
+                const float wgt = (x1 ? tx.w1 : tx.w0) * (y1 ? ty.w1 : ty.w0);
+                const int clo = x1 ? ci.z : ci.x, ncols = x1 ? ci.w : ci.y, rlo = y1 ? ri.z : ri.x, nrows = y1 ? ri.w : ri.y;
+                sh_T[rlo * C + nrows * clo + (i - rlo) * ncols + (j - clo)] = wgt * gp;
+                i += di; j += dj;
+                if (j >= C) { j -= C; ++i; }
+            }
+            if (ph == 0) theta_publish();
+            __syncthreads();
+            if (wave == 1) {
+                const int c = lane >> 4;
+                const float sk = corner_chunk(ph, (c & 2) ? w - 1 : 0, (c & 1) ? w - 1 : 0, lane & 15);
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                    for (int k = 0; k < 16; ++k)
+                        cacc[cc] += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sk), cc * 16 + k));
+            }
+            chains(ph, ph + 1);
+            if (ph == 0 && wave == NW - 1) finish_theta();
+            if (ph < 3) __syncthreads();
+        }
+        publish();
+        if (wave == 1 && lane < 4) publish_corner(lane, lane == 0 ? cacc[0] : lane == 1 ? cacc[1] : lane == 2 ? cacc[2] : cacc[3]);
+        AIR_STAMP(47);
+        AIR_STAMP_WG(6);
+        return;
+    } else if (ALLPH) {
         // [terms of all taps] | [short chains + slot outputs on all waves: no LDS atomics in flight, every dependent LDS
         // read returns at full speed] | [corner accumulation on the LDS || pixel loop on VALU / memory]
         AIR_STAMP_WG(1);
@@ -1604,25 +1738,20 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_b
         dgen[tid] = dgv;
         if (dgen16) dgen16[tid] = air_bf16_of(dgv);
     }
-    if (tid < 64) {
-        // lanes 0..4 each combine one quantity over the waves; lane 0 collects them by shuffle
-        float u = 0.0f;
-        if (lane < 5) { u = sh_red[lane]; for (int wv = 1; wv < NW; ++wv) u += sh_red[wv * 8 + lane]; }
-        float t5[5];
-#pragma unroll
-        for (int k = 0; k < 5; ++k) t5[k] = __shfl(u, k, 64);
-        if (tid == 0) {
-        // theta_recon = [[1/s, 0, -x/s], [0, 1/s, -y/s]] (air_model.py:353-356): truediv_grad .. truediv_3_grad,
-        // summed in AddN_24's order; Neg_grad / Neg_1_grad for x, y
-        const float n1 = (-1.0f / s) / s;
-        dsx[0] = ((t5[0] * n1 + t5[1] * ((x / s) / s)) + t5[2] * n1) + t5[3] * ((y / s) / s);
-        dsx[1] = -(t5[1] / s);
-        dsx[2] = -(t5[3] / s);
-        dsx[3] = t5[4];
-        }
-    }
+    if (tid < 64) finish_theta();
     AIR_STAMP(47);
     AIR_STAMP_WG(6);
+}
+
+template <bool ALLPH>
+__global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_bwd_t a, int seq_flags)
+{
+    write_bwd_graph_body<ALLPH, false>(a, seq_flags);
+}
+template <bool ALLPH>
+__global__ __launch_bounds__(WB_THREADS) void write_bwd_blocked_kernel(air_write_bwd_t a)
+{
+    write_bwd_graph_body<ALLPH, true>(a, 0);
 }
 
 // the canvas is staged in LDS only when one prefetch pass covers it (PF * THREADS floats, see the kernels)
@@ -1824,8 +1953,9 @@ extern "C" int air_write_fwd(const air_write_fwd_t* a, void* stream) {
 /* name of the kernel function air_write_bwd dispatches this descriptor to, as rocprofv3 prints it */
 extern "C" int air_write_bwd_kernel_name(const air_write_bwd_t* a, char* buf, int n) {
     if (!a || !buf || n <= 0 || a->C < 2 || a->w < 2) return AIR_EINVAL;
-    if (a->literal == 2)
-        snprintf(buf, n, "write_bwd_graph_kernel<%s>", write_bwd_graph_smem(a->C, a->w, true) <= 80 * 1024 ? "true" : "false");
+    if (a->literal == 2 || a->literal == 3)
+        snprintf(buf, n, "write_bwd_%s_kernel<%s>", a->literal == 3 ? "blocked" : "graph",
+                 write_bwd_graph_smem(a->C, a->w, true) <= 80 * 1024 ? "true" : "false");
     else snprintf(buf, n, "write_bwd_kernel");
     return 0;
 }
@@ -1834,8 +1964,21 @@ extern "C" int air_write_bwd(const air_write_bwd_t* a, void* stream) {
     if (!a || !a->d_recon || !a->vrec || !a->att || !a->d_gen_pre || !a->d_sxy_write) return AIR_EINVAL;
     if (a->B <= 0 || a->N <= 0 || a->C < 2 || a->w < 2) return AIR_EINVAL;
     if (a->fin_rec_part && (!a->fin_scalars || !a->fin_run_loss || !a->fin_rec_loss || !a->fin_loss_item_out)) return AIR_EINVAL;
-    if (a->order && a->literal != 2) return AIR_EINVAL;           // (the ordered form exists in the graph-order kernel only)
+    if (a->literal < 0 || a->literal > 3) return AIR_EINVAL;
+    if (a->order && a->literal < 2) return AIR_EINVAL;            // (the ordered form exists in the graph-order kernels only)
     if (2 * a->w > THREADS) return AIR_ELIMIT;
+    if (a->literal == 3) {
+        // the blocked graph order: register chains only -- no LDS-atomic lane order to probe, capture-safe from the first call
+        if (a->w * a->w > WB_THREADS) return AIR_ELIMIT;
+        const bool allph = write_bwd_graph_smem(a->C, a->w, true) <= 80 * 1024;
+        const size_t lds = write_bwd_graph_smem(a->C, a->w, allph);
+        int rc = allph ? ensure_lds(write_bwd_blocked_kernel<true>, lds) : ensure_lds(write_bwd_blocked_kernel<false>, lds);
+        if (rc) return rc;
+        if (allph) hipLaunchKernelGGL(write_bwd_blocked_kernel<true>, dim3(a->B, a->N), dim3(WB_THREADS), lds, air_stream(stream), *a);
+        else hipLaunchKernelGGL(write_bwd_blocked_kernel<false>, dim3(a->B, a->N), dim3(WB_THREADS), lds, air_stream(stream), *a);
+        AIR_CHECK_LAUNCH();
+        return 0;
+    }
     if (a->literal == 2) {
         if (a->w * a->w > WB_THREADS) return AIR_ELIMIT;
         // all four taps' terms resident when they fit next to a second workgroup's share of the LDS

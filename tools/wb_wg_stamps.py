@@ -25,10 +25,13 @@ from air import air_model as am
 STRESS = "--stress" in sys.argv                      # configs[3]: 128x128 canvas, 5 steps, batch 256
 if STRESS:
     sys.argv.remove("--stress")
+BLOCKED = "--blocked" in sys.argv                    # backward="reference_blocked" (write_bwd_blocked_kernel)
+if BLOCKED:
+    sys.argv.remove("--blocked")
 hp = dict(HP, canvas_size=128, max_steps=5, max_digits=4) if STRESS else dict(HP)
 images, targets = synthetic_canvases(256 if STRESS else 64, hp["canvas_size"], hp["max_digits"], 1)
 m = am.AIRModel(torch.tensor(images, device="cuda"), torch.tensor(targets, device="cuda"), cnn=False, train=True,
-                annealing_schedules=ANNEAL, gemm_precision="bf16", **hp)
+                annealing_schedules=ANNEAL, gemm_precision="bf16", backward="reference_blocked" if BLOCKED else "reference", **hp)
 for _ in range(5):
     m.training()
 torch.cuda.synchronize()
@@ -72,6 +75,25 @@ if STRESS:
               "max %.1f us; sum of term + chain time per CU mean %.1f us; corner terms per CU mean %.0f max %.0f -> pipe-only bound %.1f us at 4.06 cycles" % (
                   len(cus), per[:, 0].mean(), per[:, 0].max(), per[:, 1].mean(), per[:, 1].max(), per[:, 2].mean(), per[:, 2].max(),
                   per[:, 3].mean(), per[:, 4].mean(), per[:, 4].max(), per[:, 4].max() * 4.06 / 2100.0))
+    sys.exit(0)
+if BLOCKED and not STRESS:
+    # stamps of the blocked kernel: [0] start, [1] set-up done, [2] terms + coordinate gradients + barrier, wave 0: [3] corner
+    # chunks + combine, [4] its slots' streams, [6] end; [5] wave 8 after its slots' streams, [7] wave 15 at its end
+    for rep in range(3):
+        op(s)
+        torch.cuda.synchronize()
+        n = 192
+        buf = (C.c_ulonglong * (n * 8))()
+        H._LIB.air_debug_stamps_wg(buf, n * 8)
+        v = np.array(list(buf), dtype=np.int64).reshape(n, 8) / 100.0
+        v = v[v[:, 1] > 0]
+        t0 = v[:, 0].min()
+        r = v - v[:, :1]
+        print("launch %d: %d live workgroups; first start -> last end %.2f us; start skew %.2f us" % (
+            rep, len(v), max(v[:, 6].max(), v[:, 7].max()) - t0, v[:, 0].max() - t0))
+        for k, nm in ((1, "set-up done"), (2, "terms + theta + barrier"), (3, "wave 0: corner chunks + combine"), (4, "wave 0: slot streams"),
+                      (5, "wave 8: slot streams"), (6, "wave 0: end"), (7, "wave 15: end")):
+            print("  %-34s mean %6.2f  max %6.2f" % (nm, r[:, k].mean(), r[:, k].max()))
     sys.exit(0)
 for rep in range(3):
     op(s)
