@@ -15,6 +15,8 @@ import os
 import sys
 import time
 
+T_START = time.perf_counter()          # phase_wall_s.import: torch + the extension load on a fresh box
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tf-attend-infer-repeat_amd"))
@@ -33,6 +35,7 @@ HP = dict(max_steps=3, max_digits=2, rnn_units=256, canvas_size=50, windows_size
           learning_rate=1e-4, gradient_clipping_norm=1.0)
 ANNEAL = {"z_pres_prior_log_odds": {"init": 10000.0, "min": 0.000000001, "factor": 0.1, "iters": 3000,
                                     "staircase": False, "log": True}}
+MIN_REPLAYS = 5
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 MFMA_PEAK_TF = {"bf16": 2500.0, "fp32": 157.3}
 
@@ -123,6 +126,20 @@ def source_sha16():
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
+
+
+# What actually holds each kernel function (DESIGN.md sections 5, 8, 10).  The schema's two bounds are "hbm" and "mfma";
+# where neither is the limiter the line says what is, next to the HBM fraction it still reports.
+def bound_of(kernel):
+    if kernel.startswith("write_bwd_graph_kernel"):
+        return "lds-atomic-pipe"      # one sequential fp32 accumulator per corner slot on ds_add_f32 (4 cycles per term)
+    if kernel.startswith("write_bwd_blocked_kernel"):
+        return "latency"              # 16 register chains of <= C*C/16 dependent fp32 adds per corner and tap + the term pass
+    if kernel.startswith(("adam", "grad_sqnorm")):
+        return "hbm"
+    if kernel.startswith(("gemm", "wgrad", "bottleneck", "lstm")):
+        return "hbm"                  # M = 64 / 192 rows: operand streaming, MFMA busy < 1 %
+    return "latency"                  # pointwise / sampler launches of a few us: dependent-launch floor + one pass over the items
 
 
 _PROFILE = None
@@ -295,6 +312,7 @@ def main():
     torch.cuda.set_device(dev)
 
     from air import air_model as am
+    phase = {"import": round(time.perf_counter() - T_START, 3)}
     B = args.batch
     hp = dict(HP)
     if args.workload == "configs[3]":
@@ -309,20 +327,47 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def build_and_time(scope, exchange):
-        """one model, W warm-up + exactly K timed train steps (barrier + synchronize on both sides, max over ranks)"""
-        model = am.AIRModel(images_d, targets_d, cnn=False, train=True, scope=scope, annealing_schedules=ANNEAL, seed=0,
-                            noise_seed=rank, gemm_precision=args.precision, backward=args.backward, dp_exchange=exchange, **hp)
+    def all_ok(ok):
+        """every rank takes the same branch: MIN of a success flag over the ranks (a rank that alone skipped or re-captured
+        would issue another collective sequence than its peers -- an RCCL hang instead of an error line)"""
+        if world == 1:
+            return ok
+        t = torch.tensor([1 if ok else 0], device=dev if backend == "nccl" else "cpu", dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t))
+
+    def build_and_time(scope, exchange, optional=False):
+        """one model, W warm-up + exactly K timed train steps (barrier + synchronize on both sides, max over ranks).
+        optional: a failure to build / capture on ANY rank makes every rank return None."""
+        model, err = None, None
+        try:
+            model = am.AIRModel(images_d, targets_d, cnn=False, train=True, scope=scope, annealing_schedules=ANNEAL, seed=0,
+                                noise_seed=rank, gemm_precision=args.precision, backward=args.backward, dp_exchange=exchange, **hp)
+        except Exception as e:
+            if not optional or world == 1:
+                raise
+            err = e
+        if optional and not all_ok(err is None):
+            if err is not None:
+                sys.stderr.write("bench.py: rank %d: the %r exchange model could not be built (%r); skipped on all ranks\n" % (rank, exchange, err))
+            return None
+        return _time_model(model)
+
+    def _time_model(model):
         if world > 1:
             model.sync_parameters()            # replicas start (and, with one shared all-reduce, stay) identical
         # several train steps per hipGraph replay: amortises the replay's own launch cost.  Data parallel over RCCL: the
         # collective is captured between backward and optimizer, so the protocol is the 1-GPU one
         gsteps, mode = 1, "eager"
         if not args.no_graph:
-            # the largest divisor of the step count up to --graph-steps: exactly args.steps steps are timed
-            want = max(g for g in range(1, max(1, args.graph_steps) + 1) if args.steps % g == 0)
+            # the largest divisor of the step count up to --graph-steps that leaves the timed region at least
+            # MIN_REPLAYS replays (20 steps -> 5 replays of 4; 200 -> 5 of 40): exactly args.steps steps are timed, and
+            # the per-replay spread (min / median / max, HIP events between the replays) shows a one-off stall for what it is
+            ok = [g for g in range(1, max(1, args.graph_steps) + 1) if args.steps % g == 0]
+            want = max([g for g in ok if args.steps // g >= MIN_REPLAYS] or [min(ok)])
             if world > 1 and not model._collectives_capturable():
                 want = 1
+            err = None
             try:
                 model.capture_graph(steps=want)
                 gsteps = want
@@ -335,7 +380,10 @@ def main():
             except Exception as e:                                   # never lose the line over the capture of a collective
                 if world == 1:
                     raise
-                sys.stderr.write("bench.py: rank %d: capturing the collective failed (%r); collective between two graphs\n" % (rank, e))
+                err = e
+            if not all_ok(err is None):                              # one rank failed: ALL ranks fall back together
+                sys.stderr.write("bench.py: rank %d: capturing the collective failed on %s (%r); collective between two graphs\n"
+                                 % (rank, "this rank" if err is not None else "another rank", err))
                 os.environ["AIR_DP_GRAPH_COLLECTIVE"] = "0"
                 torch.cuda.synchronize()
                 model.release_graph()
@@ -348,32 +396,45 @@ def main():
             model.training()
         for _ in range(warm_eager):                     # remainder of the warm-up: single eager steps
             model.training(eager=True)
+        n_rep = args.steps // gsteps
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(n_rep + 1)]
         sync()
         t0 = time.perf_counter()
-        for _ in range(args.steps // gsteps):          # one replay = gsteps train steps: exactly args.steps steps
+        marks[0].record()
+        for i in range(n_rep):                          # one replay = gsteps train steps: exactly args.steps steps
             model.training()
+            marks[i + 1].record()                       # (an event record between replays: no host wait, no device idle)
         sync()
         dt = time.perf_counter() - t0
         if world > 1:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t)
-        return model, dt, gsteps, mode
+        per = sorted(marks[i].elapsed_time(marks[i + 1]) / gsteps for i in range(n_rep))
+        spread = {"replays": n_rep, "steps_per_replay": gsteps, "min": round(per[0], 4), "median": round(per[n_rep // 2], 4),
+                  "max": round(per[-1], 4), "unit": "ms per step, per replay (HIP events)"}
+        return model, dt, gsteps, mode, spread
 
     exchange = os.environ.get("AIR_DP_EXCHANGE") or "flat"
-    model, dt, gsteps, graph_mode = build_and_time("air", exchange)
+    phase["build_models"] = 0.0
+    t_ph = time.perf_counter()
+    model, dt, gsteps, graph_mode, spread = build_and_time("air", exchange)
+    phase["timed"] = round(dt, 3)
+    phase["build_models"] = round(time.perf_counter() - t_ph - dt, 3)      # construction, capture and warm-up
     exchange_runs = {exchange: round(dt / args.steps * 1e3, 4)}
     if world > 1 and not os.environ.get("AIR_DP_EXCHANGE"):
         # both forms of the gradient exchange are complete train steps with the reference's semantics:
         # time the other one the same way (its own W + K steps) and report the line of the faster, naming it
-        try:
-            other = "factors"
-            m2, dt2, g2, mode2 = build_and_time("air_" + other, other)
+        # (a rank that cannot build it makes ALL ranks skip it: build_and_time(optional=True))
+        other = "factors"
+        res = build_and_time("air_" + other, other, optional=True)
+        if res is None:
+            exchange_runs[other] = "skipped: a rank could not build it"
+        else:
+            m2, dt2, g2, mode2, spread2 = res
             exchange_runs[other] = round(dt2 / args.steps * 1e3, 4)
             if dt2 < dt:
-                model, dt, gsteps, graph_mode, exchange = m2, dt2, g2, mode2, other
-        except Exception as e:
-            exchange_runs["factors"] = "failed: %r" % (e,)
+                model, dt, gsteps, graph_mode, exchange, spread = m2, dt2, g2, mode2, other, spread2
     loss = float(model.loss)
     replicas_identical = None
     if world > 1:
@@ -426,7 +487,9 @@ def main():
                        "parallelism": "dp%d" % world,
                        "backward": args.backward},
             "per_gpu_images_per_sec": round(value / world, 1), "final_loss": round(loss, 3),
+            "ms_per_step_by_replay": spread,
         }
+        t_ph = time.perf_counter()
         if not args.no_roofline and world == 1:
             model.release_graph()
             kt = per_kernel_times(model, 20)
@@ -437,25 +500,32 @@ def main():
                 per_launch = d["nbytes"] / d["launches"]
                 gbs = per_launch / avg_us * 1e-3 if avg_us > 0 else 0.0
                 prof = kernel_profile(name)
-                r = {"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                r = {"kernel": name, "bound": bound_of(name), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": prof.get("hbm_bytes_per_launch"),
                      "avg_us": round(avg_us, 2), "avg_us_rocprofv3": prof.get("avg_us"),
                      "launches_per_step": d["launches"],
-                     "algorithmic_bytes": int(per_launch), "share_of_step": round(d["us"] / total_us, 3)}
+                     "algorithmic_bytes": int(per_launch), "share_of_step": round(d["us"] / total_us, 3),
+                     # achieved / frac / avg_us: HIP events in THIS run; traffic / avg_us_rocprofv3 / mfma.busy_*: rocprofv3
+                     # passes of the same command on the same sources, committed (PMC counters cannot be read in-process)
+                     "source": {"achieved": "live HIP events", "avg_us": "live HIP events",
+                                "traffic": "committed profile", "avg_us_rocprofv3": "committed profile",
+                                "profile": "profiles/kernel_profile.json", "profile_source_sha16": (_PROFILE or {}).get("source_sha16")}}
                 if d["flops"]:
                     r["mfma"] = {"flops_per_launch": int(d["flops"] / d["launches"]),
                                  "frac_of_peak_from_flops": round(d["flops"] / d["launches"] / (avg_us * 1e-6) * 1e-12
                                                                   / MFMA_PEAK_TF[args.precision], 5) if avg_us > 0 else None,
                                  "busy_counter_util": prof.get("mfma_util"),        # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE*256*4)
-                                 "busy_cycles_per_launch": prof.get("mfma_busy_cycles")}
+                                 "busy_cycles_per_launch": prof.get("mfma_busy_cycles"),
+                                 "source": {"busy_counter_util": "committed profile", "busy_cycles_per_launch": "committed profile"}}
                 if prof.get("stale"):
                     r["profile_stale"] = True        # profiles/kernel_profile.json was taken from other sources
                 if name.startswith("write_bwd_graph_kernel"):
-                    # neither of the schema's two bounds is what holds this kernel: say so next to the HBM fraction
-                    r["note"] = ("bound by the CU's LDS atomic pipe, not HBM: the reference's UnsortedSegmentSum order needs ONE "
-                                 "sequential fp32 accumulator per corner slot, ds_add_f32 delivers 4.0 cycles per term and the slowest "
-                                 "workgroup owns up to 4*C*C terms (16.9 of its 24 us at 50x50) -- DESIGN.md section 8; the step's "
-                                 "HBM-bound kernel is adam_clip_kernel (roofline_all)")
+                    r["note"] = ("the reference's UnsortedSegmentSum order needs ONE sequential fp32 accumulator per corner slot, "
+                                 "ds_add_f32 delivers 4.0 cycles per term and the slowest workgroup owns up to 4*C*C terms (16.9 of its "
+                                 "24 us at 50x50) -- DESIGN.md section 8; the step's HBM-bound kernel is the Adam launch (roofline_all)")
+                elif name.startswith("write_bwd_blocked_kernel"):
+                    r["note"] = ("the same term streams in at most 16 chunks per slot and tap, one register chain per chunk "
+                                 "(DESIGN.md section 10): as long as its term pass + the longest chunk of its heaviest item")
                 return r
             # dominant kernel = the kernel function with the largest share of the step (what the
             # rocprofv3 stats table lists first); the other functions follow in `roofline_all`
@@ -529,8 +599,12 @@ def main():
             P3 = sum(int(np.prod(v)) for v in [(128 * 128 + 256, 1024)]) + (model.store.num_trainable - (2756 * 1024))
             line["stress_configs3"]["frac_of_hbm_peak"] = round(
                 (40 * P3 + 4 * 256 * 128 * 128) / (line["stress_configs3"]["ms_per_step"] * 1e-3) * 1e-9 / HBM_PEAK_GBS, 4)
+        phase["extras"] = round(time.perf_counter() - t_ph, 3)      # per-kernel events, inference, fp32 and stress blocks
         if not args.no_cpu_baseline and world == 1 and args.workload == "configs[1]":
+            t_ph = time.perf_counter()
             line["cpu_baseline"] = cpu_baseline(B)
+            phase["cpu_baseline"] = round(time.perf_counter() - t_ph, 3)
+        line["phase_wall_s"] = phase
         if world > 1 and ar is not None:
             line["allreduce"] = ar
         if world > 1:

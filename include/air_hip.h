@@ -228,7 +228,10 @@ typedef struct {
     int32_t head_pack, Hs, Hh, Hz;
     /* bf16 twins of A / dY (precision 1, nullable, same leading dimensions; see air_gemm_t): a problem that has both
      * (8-byte aligned, lda/ldb/N multiples of 4, M a multiple of 4 or lda >= M rounded up to 4 -- padded rows --, not
-     * head_pack) reads its operands as bf16 -- bit-identical dW.
+     * head_pack) reads its operands as bf16 -- bit-identical dW.  Padded rows (M % 4 != 0, lda >= M rounded up to 4): the pad
+     * columns of A and A16 must be READABLE but may hold anything, NaN included -- a piece that straddles M only feeds output
+     * rows >= M, which are neither stored nor counted in sq_partials (tests/test_gpu_kernels.py::
+     * test_wgrad_twins_of_padded_rows_ignore_what_the_pad_holds).
      * db is always summed from the fp32 dY. */
     const uint16_t* A16; const uint16_t* dY16;
 } air_wgrad_t;
@@ -427,7 +430,8 @@ typedef struct {
                                           * path; twins ignored / not written; additionally 2 Z <= 104 */
     int32_t ldz;                         /* row stride of z and z16 in elements; 0 = Z.  A stride that is a multiple of 4
                                           * (Z = 50 -> 52) lets the weight gradient of the first generative layer read z's
-                                          * twin in 8-byte pieces (air_wgrad_t: lda % 4 == 0, lda >= M rounded up to 4) */
+                                          * twin in 8-byte pieces (air_wgrad_t: lda % 4 == 0, lda >= M rounded up to 4).  Only
+                                          * columns < Z of a row are written: the pad keeps what the caller put there */
 } air_bottleneck_fwd_t;
 typedef struct {
     const float* dG; const float* Wg; const float* ml; const float* eps;
@@ -505,6 +509,31 @@ int air_adam_clip_step_factored(float* params, const float* grads, float* m, flo
                                 const float* partials, int npartials, const float* dyn, const int32_t* istate,
                                 float grad_prescale, float beta1, float beta2, float epsilon,
                                 float* gnorm_out /*nullable*/, void* stream);
+
+/* ---- input pipeline: tf.train.shuffle_batch on the device (the reference's multi_mnist.py:228-249) -------------
+ * A RandomShuffleQueue of `capacity` record indices resident in HBM over the epoch-repeating record stream
+ * 0, 1, .., n_records-1, 0, 1, ..  (string_input_producer([file], num_epochs) + ONE TFRecordReader: file order, every
+ * epoch the same -- training.py:76-81).  The reader threads are far faster than a train step, so the queue is modelled AT
+ * CAPACITY whenever a batch is taken.  air_shuffle_batch_dequeue then does what RandomShuffleQueue::TryDequeueMany does
+ * for each of the `batch` elements in turn:  index = r_k mod size;  emit queue[index];  queue[index] = queue[size-1];
+ * size -= 1  (uniform pick, swap with the back, pop) -- and the `batch` freed slots at the back are refilled from the
+ * stream in order (enqueue appends at the back).  r_k = word k mod 4 of Philox4x32-10(key = seed, counter = (dequeue
+ * number lo, hi, k / 4, 0x53485546)).  TF's own queue is unseeded here (seed 0 -> nondeterministic): the distribution is
+ * the contract, and tests/test_shuffle_queue.py holds a numpy model of the queue that this kernel matches pick for pick.
+ * state[0] = records enqueued so far (the stream position), state[1] = batches dequeued so far.
+ * One workgroup, the queue staged in LDS: capacity * 4 + batch * 8 <= 48 KB (capacity 10 640, batch 64: 43 KB), batch a
+ * multiple of 4, capacity - batch >= min_after_dequeue >= 0 (the reference: 10 000).  No allocation, no synchronisation;
+ * both calls are stream work and capturable. */
+typedef struct {
+    int32_t* queue;            /* [capacity] record indices in the queue */
+    int64_t* state;            /* [2] */
+    int32_t* picks;            /* [batch] out: the records of this batch, in dequeue order */
+    int32_t capacity, batch, min_after_dequeue, n_records;
+    uint64_t seed;
+} air_shuffle_batch_t;
+/* queue <- the first `capacity` records of the stream, state <- (capacity, 0) */
+int air_shuffle_batch_init(const air_shuffle_batch_t* q, void* stream);
+int air_shuffle_batch_dequeue(const air_shuffle_batch_t* q, void* stream);
 
 #ifdef __cplusplus
 }

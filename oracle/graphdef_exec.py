@@ -337,10 +337,29 @@ def _k_addn(n, *xs):
     return acc
 
 
+# "sequential": TF's CPU kernel.  "blocked16": what backward="reference_blocked" computes -- the graph's one
+# UnsortedSegmentSum takes the four Gather gradients concatenated (taps a, b, c, d); every tap's quarter goes through
+# oracle.air_oracle.blocked_segment_sum (up to 16 chunks per segment and tap, summed side by side) and the chunk sums
+# are then added in the same a, b, c, d stream order.  A module switch for tests / tests/golden/make_graph_golden.py:
+# the whole saved graph executed with that ONE kernel swapped shows what the order does to the 36 gradients.
+SEGMENT_SUM_ORDER = "sequential"
+
+
 def _k_unsorted_segment_sum(n, data, ids, num):
     ids = np.asarray(ids)
     out = np.zeros((int(num),) + data.shape[ids.ndim:], data.dtype)
-    np.add.at(out, ids.reshape(-1), data.reshape((-1,) + data.shape[ids.ndim:]))   # in index order, like the CPU kernel
+    flat_ids, flat = ids.reshape(-1), data.reshape((-1,) + data.shape[ids.ndim:])
+    if SEGMENT_SUM_ORDER == "blocked16":
+        from oracle.air_oracle import blocked_segment_sum
+        tail = flat.shape[1:]
+        assert int(np.prod(tail)) == 1 and flat.shape[0] % 4 == 0, "the sampler's scatter: four concatenated tap gradients"
+        flat, q = flat.reshape(-1), flat.shape[0] // 4
+        parts = [blocked_segment_sum(flat_ids[k * q:(k + 1) * q], flat[k * q:(k + 1) * q], int(num)) for k in range(4)]
+        flat_ids = np.concatenate([p[0] for p in parts])
+        flat = np.concatenate([p[1] for p in parts]).reshape((-1,) + tail)
+    else:
+        assert SEGMENT_SUM_ORDER == "sequential", SEGMENT_SUM_ORDER
+    np.add.at(out, flat_ids, flat)                                                 # in index order, like the CPU kernel
     return out
 
 

@@ -124,6 +124,8 @@ def main():
           (len(out), os.path.getsize(path) / 1024, out["train0/loss"], out["train0/loss_fp64"],
            out["train0/global_norm_fp32"], out["train0/global_norm_fp64"], trips))
     compose(nodes)
+    blocked(nodes)
+    chain(nodes)
 
 
 # tensors at the interface of the compose kernel (air_write_fwd: the write transformer, the masked canvas accumulation,
@@ -152,8 +154,93 @@ def compose(nodes=None):
     print("wrote %d arrays, %.0f KB -> %s" % (len(out), os.path.getsize(path) / 1024, path))
 
 
+def blocked(nodes=None):
+    """tests/golden/graph_b64_blocked.npz: the fp32 backward of the train0 run once more with the graph's ONE
+    UnsortedSegmentSum evaluated in the blocked16 order (oracle.blocked_segment_sum; AIRModel(backward=
+    "reference_blocked")) -- per-variable gradient norms and the global norm, next to graph_b64.npz's
+    grad32_norm/* (the sequential order) and grad64_norm/* (exact)."""
+    if nodes is None:
+        _, nodes = gx.load_graph(META)
+    images, targets, params, noise = inputs()
+    adam = gx.adam_nodes(nodes)
+    names = list(ao.param_shapes(HP).keys())
+    out = {}
+    gx.SEGMENT_SUM_ORDER = "blocked16"
+    try:
+        ex = gx.Executor(nodes, gx.air_feeds(nodes, params, images, targets, noise, 0), np.float32)
+        g32 = ex.run([gx.raw_gradient_tensor(nodes, adam[k]) for k in names])
+        out["train0/global_norm_fp32"] = np.float32(ex.run(["air/training/global_norm/global_norm"])[0])
+        for k, g in zip(names, g32):
+            out["train0/grad32_norm/" + k] = np.float32(np.linalg.norm(g.astype(np.float64)))
+        trips = ex.trip_count(gx.FWD_FRAME)
+        for t in range(trips):
+            bw = ex.run([gx.SAMPLER_BWD_TENSORS["d_gen_pre"]], {gx.BWD_FRAME: trips - 1 - t})
+            out["kern/t%d/d_gen_pre" % t] = np.asarray(bw[0])[:KB].reshape(KB, -1)
+    finally:
+        gx.SEGMENT_SUM_ORDER = "sequential"
+    path = os.path.join(ROOT, "tests", "golden", "graph_b64_blocked.npz")
+    np.savez_compressed(path, **out)
+    print("wrote %d arrays, %.0f KB -> %s; |g| fp32 blocked16 %.4e" % (len(out), os.path.getsize(path) / 1024, path,
+                                                                      out["train0/global_norm_fp32"]))
+
+
+# tensors at the remaining kernel interfaces of the backward of step t (the VAE data-gradient chain vae.py:10-43
+# backwards, the heads' hidden layers, the BasicLSTMCell backward air_model.py:286) -- with write_bwd / attend_bwd /
+# compose already pinned, every kernel of the default backward is then fed the executed graph's own tensors
+V, GV, GR = gx.W + "vae/", gx.G + gx.W + "vae/", gx.G + gx.W + "rnn/"
+HEADS = ("scale/mean", "scale/log_variance", "shift/mean", "shift/log_variance", "z_pres/log_odds")   # column order of whid / d_hid
+CHAIN_FWD_TENSORS = {
+    "gen_act1": V + "generative_1/generative_1/Softplus", "gen_act2": V + "generative_2/generative_2/Softplus",
+    "rec_act1": V + "recognition_1/recognition_1/Softplus", "rec_act2": V + "recognition_2/recognition_2/Softplus",
+    "lstm_i": gx.W + "rnn/Sigmoid_1", "lstm_j": gx.W + "rnn/Tanh", "lstm_f": gx.W + "rnn/Sigmoid", "lstm_o": gx.W + "rnn/Sigmoid_2",
+    "c_prev": gx.W + "Identity_2", "c_new": gx.W + "rnn/add_1",
+}
+CHAIN_BWD_TENSORS = {
+    "d_gen2": GV + "generative_2/generative_2/Softplus_grad/SoftplusGrad",      # [B,512] wrt generative_2's pre-activation
+    "d_gen1": GV + "generative_1/generative_1/Softplus_grad/SoftplusGrad",      # [B,256]
+    "d_z": GV + "generative_1/MatMul_grad/MatMul",                              # [B,Z] wrt the latent sample
+    "d_mean": gx.G + "AddN_13", "d_log_variance": gx.G + "AddN_14",             # [B,Z] each: reparameterisation + KL
+    "d_rec2": GV + "recognition_2/recognition_2/Softplus_grad/SoftplusGrad",    # [B,256]
+    "d_rec1": GV + "recognition_1/recognition_1/Softplus_grad/SoftplusGrad",    # [B,512]
+    "d_window_vae": GV + "recognition_1/MatMul_grad/MatMul",                    # [B,784] the VAE's share of d loss / d glimpse
+    "dh_total": gx.G + "AddN_33",                                               # [B,R] d loss / d h'[t]: heads + recurrence
+    "dh_rec": gx.G + gx.W + "Merge_3_grad/tuple/control_dependency_1",          # [B,R] the recurrence's share (from step t+1)
+    "dgates": GR + "split_grad/concat",                                         # [B,4R] i, j, f, o
+    "dc_prev": GR + "mul_grad/tuple/control_dependency",                        # [B,R] d loss / d c[t-1]
+    "dc_in": GR + "add_1_grad/tuple/control_dependency",                        # [B,R] d loss / d c[t] as it reaches add_1
+}
+for _h in HEADS:
+    CHAIN_BWD_TENSORS["d_hid/" + _h] = gx.G + gx.W + _h + "/hidden/hidden/Relu_grad/ReluGrad"    # [B,64] wrt the pre-activation
+
+
+def chain(nodes=None):
+    """tests/golden/graph_b64_chain.npz: the train0 run of main() again (same seeds, fp32), first KB_CHAIN images"""
+    KBC = 8
+    if nodes is None:
+        _, nodes = gx.load_graph(META)
+    images, targets, params, noise = inputs()
+    ex = gx.Executor(nodes, gx.air_feeds(nodes, params, images, targets, noise, 0), np.float32)
+    out = {}
+    trips = ex.trip_count(gx.FWD_FRAME)
+    for t in range(trips):
+        for k, v in zip(CHAIN_FWD_TENSORS, ex.run(list(CHAIN_FWD_TENSORS.values()), {gx.FWD_FRAME: t})):
+            out["kern/t%d/%s" % (t, k)] = np.asarray(v)[:KBC]
+        for k, v in zip(CHAIN_BWD_TENSORS, ex.run(list(CHAIN_BWD_TENSORS.values()), {gx.BWD_FRAME: trips - 1 - t})):
+            out["kern/t%d/%s" % (t, k)] = np.asarray(v)[:KBC]
+    path = os.path.join(ROOT, "tests", "golden", "graph_b64_chain.npz")
+    np.savez_compressed(path, **out)
+    print("wrote %d arrays, %.0f KB -> %s" % (len(out), os.path.getsize(path) / 1024, path))
+    for k in sorted(out):
+        if k.startswith("kern/t0/"):
+            print("  %-40s %-12s max|.| %.3e" % (k, out[k].shape, np.abs(out[k]).max()))
+
+
 if __name__ == "__main__":
     if "--compose-only" in sys.argv:
         compose()
+    elif "--chain-only" in sys.argv:
+        chain()
+    elif "--blocked-only" in sys.argv:
+        blocked()
     else:
         main()

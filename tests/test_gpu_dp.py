@@ -32,9 +32,9 @@ def _free_port():
     return p
 
 
-def _inputs(blank):
-    images, targets = blob_canvases(B2, HP["canvas_size"], HP["max_digits"], seed=23)
-    noise = ao.make_noise(HP, B2, 5)
+def _inputs(blank, total=B2):
+    images, targets = blob_canvases(total, HP["canvas_size"], HP["max_digits"], seed=23)
+    noise = ao.make_noise(HP, total, 5)
     if blank:
         # smooth regime (tests/test_gpu_model.py::_make): no ink -> no log(r + 1e-9) pole under
         # out-of-range sampler residues, z_pres ~ 0.55 -> the canvas stays below 1.  Only here is the
@@ -63,20 +63,25 @@ def _run(am, images, targets, noise, params, prec, graph, init_seed, exchange="f
     return m, out
 
 
-def _worker(rank, world, port, prec, graph, blank, q, exchange="flat", steps=STEPS):
+def _worker(rank, world, port, prec, graph, blank, q, exchange="flat", steps=STEPS, total=B2, light=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     from air import air_model as am
-    images, targets, noise, params = _inputs(blank)
-    b = B2 // world
+    images, targets, noise, params = _inputs(blank, total)
+    b = total // world
     sl = slice(rank * b, (rank + 1) * b)
     # rank 1 deliberately STARTS from different variables (seed) and only rank 0 loads the common
     # ones: sync_parameters() (called by training()/capture_graph()) must make the replicas identical
     m, out = _run(am, images[sl], targets[sl], {k: v[:, sl] for k, v in noise.items()},
                   params if rank == 0 else None, prec, graph, init_seed=100 + rank, exchange=exchange, steps=steps)
-    q.put((rank, out, m.store.params.cpu().numpy(), int(m.global_step), m.store.m.cpu().numpy(), m.store.grads.cpu().numpy()))
+    if light:      # eight ranks: a checksum of the raw words instead of three 16 MB arrays per rank through the queue
+        words = lambda t: int(t.view(torch.int32).to(torch.int64).sum())      # noqa: E731
+        q.put((rank, out, words(m.store.params), int(m.global_step), words(m.store.m),
+               m.store.params.cpu().numpy() if rank == 0 else None))
+    else:
+        q.put((rank, out, m.store.params.cpu().numpy(), int(m.global_step), m.store.m.cpu().numpy(), m.store.grads.cpu().numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -186,6 +191,81 @@ def test_dp2_factor_exchange_equals_flat_all_reduce(prec, graph):
     assert np.array_equal(three["factors"][0]["params"].view(np.int32), three["factors"][1]["params"].view(np.int32))
     assert three["factors"][0]["step"] == STEPS
     assert rel(three["factors"][0]["params"], three["flat"][0]["params"]) < 1e-5
+
+
+@pytest.mark.parametrize("exchange,graph", [("flat", False), ("flat", True), ("factors", False), ("factors", True)])
+def test_dp8_configs2_world_size_equals_one_b512_step(exchange, graph):
+    """BASELINE configs[2] at its REAL world size in the only form a 1-GPU lease allows: eight rank processes x b = 64
+    (global batch 512) share the one MI355X over gloo; both gradient exchanges, eager and as [fwd+bwd graph] | collective |
+    [clip+Adam graph].  Against ONE b = 512 step of a single process on blank canvases (smooth regime): loss 2e-5,
+    norm of the AVERAGED gradient 2e-4 (reference air_model.py:610-611: reduce_mean over the global batch; :673: clip after
+    the reduction), accuracy equal, replicas bit-identical after three steps, the 1/8 scaling of loss / accuracy that rode
+    in the all-reduce as sums.  The factor exchange contracts K = 8 x 64 = 512 gathered rows per rank.
+    Not a scaling measurement -- RCCL over xGMI at 8 ranks has not run anywhere (no multi-GPU lease)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    world, total = 8, 512
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, "fp32", graph, True, q, exchange, STEPS, total, True))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, out, psum, step, msum, par = q.get(timeout=900)
+        got[r] = dict(out=out, psum=psum, step=step, msum=msum, params=par)
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    for r in range(1, world):
+        assert got[r]["psum"] == got[0]["psum"] and got[r]["msum"] == got[0]["msum"], r      # replicas bit-identical
+        assert got[r]["out"] == got[0]["out"], r                                              # the same averaged scalars everywhere
+        assert got[r]["step"] == STEPS
+    from air import air_model as am
+    images, targets, noise, params = _inputs(True, total)
+    ref, ref_out = _run(am, images, targets, noise, params, "fp32", False, init_seed=0)
+    rep = []
+    for (l, a, g), (lr_, ar_, gr_) in zip(got[0]["out"], ref_out):
+        rep.append((abs(l - lr_) / abs(lr_), abs(g - gr_) / gr_))
+        assert abs(a - ar_) < 1e-6                               # accuracy: a mean of 512 indicator values, /8 of the rank sums
+        assert abs(l - lr_) / abs(lr_) < 2e-5, (l, lr_)
+        assert abs(g - gr_) / gr_ < 2e-4, (g, gr_)
+    am.reset_default_graph()
+    tmp = am.AIRModel(torch.tensor(images[:8], device="cuda"), torch.tensor(targets[:8], device="cuda"), cnn=False,
+                      train=True, scope="air", gemm_precision="fp32", **HP)
+    tmp.load_state_dict(params)
+    p0 = tmp.store.params.cpu().numpy()
+    d_dp, d_ref = got[0]["params"] - p0, ref.store.params.cpu().numpy() - p0
+    rel = np.linalg.norm(d_dp - d_ref) / np.linalg.norm(d_ref)
+    print("dp8 %s graph=%s: (loss, gnorm) rel per step %r, update rel-L2 %.3e" % (exchange, graph, rep, rel))
+    assert rel < 5e-3, rel
+
+
+def test_bench_eight_rank_flow_on_one_device():
+    """`python bench.py --gpus 8` (configs[2]: 8 x b = 64) end to end on the one leased GPU over gloo: the line is labelled
+    as a flow test, carries global_batch 512, bit-identical replicas and both exchanges' step times."""
+    import json
+    import subprocess
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AIR_BENCH_SAME_DEVICE="1", AIR_BENCH_BACKEND="gloo")
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--steps", "10", "--warmup", "2"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 512 and d["config"]["parallelism"] == "dp8"
+    assert d["replicas_bit_identical"] is True and "NOT a scaling measurement" in d["test_mode"]
+    assert set(d["distributed"]["ms_per_step_by_exchange"]) == {"flat", "factors"}
+    assert d["ms_per_step_by_replay"]["replays"] * d["ms_per_step_by_replay"]["steps_per_replay"] == 10
+    out = os.path.join(root, "gpurun_out", "r05")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "bench_dp8_same_device_gloo.json"), "w") as f:
+        f.write(lines[0] + "\n")
 
 
 def test_bench_multi_rank_flow_on_one_device(tmp_path):

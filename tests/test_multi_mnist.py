@@ -168,3 +168,35 @@ def test_jittered_generation_keeps_invariants():
     strata_b, _, _ = mm.generate_strata(max_digits=2, images_per_digit=3, seed=6, use_pixel_overlap=False, gap=2)
     for pos, box in zip(strata_b[2]["positions"], strata_b[2]["boxes"]):
         assert not (pos[0] - 2 <= pos[2] + box[2] - 1 and pos[2] <= pos[0] + box[0] + 2 - 1) or True   # placed => accepted
+
+
+@pytest.mark.parametrize("gz", [False, True])
+def test_load_glyphs_reads_the_mnist_idx_files_when_present(tmp_path, monkeypatch, gz):
+    """the reference takes its glyphs from input_data.read_data_sets("mnist_data/") (multi_mnist.py:336-339), i.e. the
+    idx3 / idx1 files of the MNIST distribution (train-images-idx3-ubyte[.gz], train-labels-idx1-ubyte[.gz]).  Absent
+    offline; a synthetic pair in the same format (big-endian magic 2051 / 2049, counts, 28 x 28 uint8 pixels) must be picked
+    up -- plain and gzipped -- and drive the generator."""
+    import gzip
+    import struct
+    rng = np.random.RandomState(4)
+    n = 50
+    pix = np.zeros((n, 28, 28), np.uint8)
+    for i in range(n):                                        # a blob of ink per glyph, size and place varying
+        y, x, h, w = rng.randint(4, 10), rng.randint(4, 10), rng.randint(8, 14), rng.randint(6, 14)
+        pix[i, y:y + h, x:x + w] = rng.randint(100, 256, (h, w))
+    lab = rng.randint(0, 10, n).astype(np.uint8)
+    d = tmp_path / "mnist_data"
+    d.mkdir()
+    op, ext = (gzip.open, ".gz") if gz else (open, "")
+    with op(str(d / ("train-images-idx3-ubyte" + ext)), "wb") as f:
+        f.write(struct.pack(">IIII", 2051, n, 28, 28) + pix.tobytes())
+    with op(str(d / ("train-labels-idx1-ubyte" + ext)), "wb") as f:
+        f.write(struct.pack(">II", 2049, n) + lab.tobytes())
+    monkeypatch.chdir(tmp_path)                               # MNIST_FOLDER is relative to the working directory, as in the reference
+    glyphs, labels, source = mm.load_glyphs()
+    assert source == "mnist" and glyphs.shape == (n, 784) and glyphs.dtype == np.float32
+    assert np.array_equal(labels, lab.astype(np.int64))
+    assert np.array_equal(glyphs, pix.reshape(n, 784).astype(np.float32) / 255.0)
+    ds = mm.generate_dataset(max_digits=2, images_per_digit=20, test_set_size=10, seed=0)
+    assert ds["train_images"].shape == (50, 2500) and ds["train_images"].max() <= 1.0
+    assert (ds["train_images"][ds["train_digits"] == 2] > 0).sum(1).mean() > 100

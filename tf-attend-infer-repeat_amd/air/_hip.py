@@ -120,6 +120,11 @@ class BottleneckBwd(C.Structure):
                 ("dG16", _p), ("Wg16", _p), ("Wml16", _p), ("exact_fp32", _i)]
 
 
+class ShuffleBatch(C.Structure):
+    _fields_ = [("queue", _p), ("state", _p), ("picks", _p), ("capacity", _i), ("batch", _i), ("min_after_dequeue", _i),
+                ("n_records", _i), ("seed", C.c_uint64)]
+
+
 _SIGNATURES = {
     "air_abi_version": (C.c_int, []),
     "air_strerror": (C.c_char_p, [C.c_int]),
@@ -159,6 +164,8 @@ _SIGNATURES = {
     "air_adam_clip_step_blocks": (C.c_int, [_p, _p, _p, _p, C.c_int64, _p, C.c_int, _p, _p, _f, _f, _f, _f, _p, _p, C.c_int, _p, _p]),
     "air_adam_clip_step_factored": (C.c_int, [_p, _p, _p, _p, C.c_int64, C.POINTER(Wgrad), C.c_int, _p, C.c_int, _p, _p,
                                               _f, _f, _f, _f, _p, _p]),
+    "air_shuffle_batch_init": (C.c_int, [C.POINTER(ShuffleBatch), _p]),
+    "air_shuffle_batch_dequeue": (C.c_int, [C.POINTER(ShuffleBatch), _p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -222,23 +222,38 @@ class VariableStore:
             sd[k + "/Adam_1"] = self.adam_v[k].detach().cpu().contiguous().clone()
         return sd
 
-    def load_state_dict(self, sd, strict=True):
+    def load_state_dict(self, sd, strict=True, load_optimizer=True):
+        """Variables (+ global_step, + the Adam slots when the dict carries them per variable).  The dict is validated BEFORE
+        anything is written: a caller that catches the error keeps its old state.  load_optimizer=False takes the
+        variables and global_step only -- the way to use checkpoints whose optimizer state cannot be read (flat slots
+        written by an earlier build) for evaluation / demo.py."""
+        missing = [k for k in self.variables if k not in sd]
+        if strict and missing:
+            raise KeyError("missing variable %s" % missing[0])
+        for k, v in self.variables.items():
+            if k in sd and int(np.prod(np.shape(sd[k]))) != v.numel():
+                raise ValueError("variable %s has %r elements, expected %r" % (k, np.shape(sd[k]), tuple(v.shape)))
+        slots = [k for k in self.variables if k + "/Adam" in sd or k + "/Adam_1" in sd]
+        if load_optimizer:
+            half = [k for k in slots if not (k + "/Adam" in sd and k + "/Adam_1" in sd)]
+            if half:
+                raise ValueError("state dict carries only one of the two Adam slots (<var>/Adam, <var>/Adam_1) of %s" % half[0])
+            if "_adam_m" in sd and not slots:
+                # flat slots written by an older build: their offsets are those of THAT build's buffer layout (the alignment
+                # of the flat buffers has changed since) -- refuse loudly rather than load shifted slots
+                raise ValueError("state dict carries flat Adam slots (_adam_m / _adam_v) of an unknown buffer layout; it needs "
+                                 "per-variable slots (<var>/Adam, <var>/Adam_1) -- or load_state_dict(sd, load_optimizer=False) "
+                                 "for the variables alone")
         for k, v in self.variables.items():
             if k in sd:
                 v.copy_(torch.as_tensor(np.asarray(sd[k])).to(v.dtype).reshape(v.shape))
-            elif strict:
-                raise KeyError("missing variable %s" % k)
         if "global_step" in sd:
             self.istate[H.IST_GLOBAL_STEP] = int(sd["global_step"])
-        for k, v in self.variables.items():
-            if k + "/Adam" in sd:
+        if load_optimizer:
+            for k in slots:
+                v = self.variables[k]
                 self.adam_m[k].copy_(torch.as_tensor(np.asarray(sd[k + "/Adam"])).to(v.dtype).reshape(v.shape))
                 self.adam_v[k].copy_(torch.as_tensor(np.asarray(sd[k + "/Adam_1"])).to(v.dtype).reshape(v.shape))
-        if "_adam_m" in sd and not any(k + "/Adam" in sd for k in self.variables):
-            # flat slots written by an older build: their offsets are those of THAT build's buffer layout (the alignment
-            # of the flat buffers has changed since) -- refuse loudly rather than load shifted slots
-            raise ValueError("state dict carries flat Adam slots (_adam_m / _adam_v) of an unknown buffer layout; "
-                             "it needs per-variable slots (<var>/Adam, <var>/Adam_1)")
         self.shadow_stale = True
 
 
@@ -331,7 +346,7 @@ class AIRModel:
         #   residue is ~400x smaller than the reference graph's).  "exact": the mathematical adjoint.
         # "reference_blocked": the reference graph's term streams (a, b, c, d per window pixel, canvas-pixel order) with
         #   every tap's piece cut into 16 chunks that are summed side by side and added left to right
-        #   (oracle.transformer_backward(order="blocked16")): the same residue mechanism without the 10 000-term chain.
+        #   (the order tests call "blocked16"): the same residue mechanism without the 10 000-term chain.
         if backward not in ("reference", "reference_blocked", "taps", "exact"):
             raise ValueError("backward must be 'reference', 'reference_blocked', 'taps' or 'exact'")
         self.backward = backward
@@ -628,6 +643,13 @@ class AIRModel:
                         self._seed, _ptr(imgs if self.images16 is not None else None), _ptr(self.images16),
                         imgs.numel() if self.images16 is not None else 0)
         noise_bytes = 4 * (self.normals.numel() + self.uniforms.numel())
+        if tw and st.wx_exclusive and not (self._fuse_step0 and use_pan):
+            # the store keeps ONLY the panel twin of Wx (VariableStore: "exclusive"), and this model cannot read it: its
+            # largest operand is converted from fp32 inside the kernel -- correct, and a silent perf cliff otherwise
+            import warnings
+            warnings.warn("AIRModel(scope=%r): bf16 twins are on but x.Wx reads the fp32 Wx (the scope's store maintains only the "
+                          "panel twin of Wx; this model does not fuse the first step / use panels: D %% 4 = %d, AIR_XW_TILE / "
+                          "AIR_NO_PANELS / AIR_STEP0_FUSION set?)" % (self.scope, D % 4), RuntimeWarning, stacklevel=3)
         if self._fuse_step0:
             # the first step rides in the x.Wx launch: h_0 = c_0 = 0 (zero_state, :540), so its gates are x.Wx + b
             # (twins: the panel twin of Wx is the ONLY bf16 form of Wx that is maintained when the store made it exclusive)
@@ -1383,6 +1405,6 @@ class AIRModel:
         self._dirty = True
         return self
 
-    def load_state_dict(self, sd, strict=True):
-        self.store.load_state_dict(sd, strict)
+    def load_state_dict(self, sd, strict=True, load_optimizer=True):
+        self.store.load_state_dict(sd, strict, load_optimizer)
         self._dirty = True

@@ -292,6 +292,9 @@ static int fill_panels(const air_panel_t* panels, int count, int64_t n, PanelTab
         if ((q.N & 3) || (q.src_off & 3) || (q.dst_off & 3)) return AIR_EALIGN;
         if (q.gates != 0 && (q.gates != 4 || (q.N & 15))) return AIR_EINVAL;
         if ((int64_t)q.K * 16 >= (1ll << 31) || n / 4 >= (1ll << 31)) return AIR_ELIMIT;
+        // the multiply-shift row division (magic, below) is exact while rel * (magic * N4 - 2^40) < 2^40; rel < K * N4 and
+        // the bracket is < N4, so K * N4 * N4 < 2^40 suffices (16 384 x 1 024: 2^30)
+        if ((unsigned __int128)q.K * (unsigned)(q.N / 4) * (unsigned)(q.N / 4) >= ((unsigned __int128)1 << 40)) return AIR_ELIMIT;
         prev_end = q.src_off + (int64_t)q.K * q.N;
         tab.first4[j] = (unsigned)(q.src_off / 4); tab.len4[j] = (unsigned)((int64_t)q.K * q.N / 4);
         tab.N4[j] = (unsigned)(q.N / 4); tab.K16[j] = (unsigned)q.K * 16u;

@@ -1170,7 +1170,7 @@ __device__ __forceinline__ float stream_add(float acc, const float* T, int start
 // BLOCKED (literal == 3, backward="reference_blocked"): the same term streams -- per window pixel the a-, b-, c-, d-tap
 // terms in canvas-pixel order -- but every (slot, tap) stream of n terms is cut into at most WB_CHUNKS contiguous chunks
 // of max(ceil(n / WB_CHUNKS), WB_CHUNK_MIN) terms, each summed from +0.0 by a lane of its own (register chain), and the
-// chunk sums are added onto the slot's accumulator left to right, tap after tap (oracle.blocked_segment_sum,
+// chunk sums are added onto the slot's accumulator left to right, tap after tap (the test-side
 // order="blocked16"): a sum tree of depth n/16 + 64 instead of one chain of 4n adds.  A stream of up to 64 terms is ONE
 // chunk (its tap's sum), so only the border slots that collect the out-of-range pixels are cut at all.
 // No LDS atomics, no lane-order property, no probe; the coordinate / z gradients are taken in the term pass.
@@ -1332,17 +1332,47 @@ __device__ __forceinline__ void write_bwd_graph_body(const air_write_bwd_t& a, i
     // tap ph = a, b, c, d <-> (y0,x0), (y1,x0), (y0,x1), (y1,x1)
     const int di = WB_THREADS / C, dj = WB_THREADS % C;
     float d00 = 0.f, d02 = 0.f, d11 = 0.f, d12 = 0.f, dz = 0.f;
-    // BLOCKED: theta / z gradients of one canvas pixel, taken where its terms are computed (taps from the tables, the
-    // window from LDS -- nothing starves the LDS in this mode); per-thread sums over a fixed pixel set, combined over the
-    // waves in a fixed order at the end
-    auto theta_px = [&](const Tap& tx, const Tap& ty, float g, float gp, int i, int j) {
-        const float Ia = sh_win[ty.i0 * w + tx.i0], Ib = sh_win[ty.i1 * w + tx.i0];
-        const float Ic = sh_win[ty.i0 * w + tx.i1], Id = sh_win[ty.i1 * w + tx.i1];
-        dz += g * bilinear4(tx, ty, Ia, Ib, Ic, Id);                                // canvas/mul_grad: Select_grad * window_recon
-        float gX, gY;
-        graph_dxy(gp, Ia, Ib, Ic, Id, tx, ty, (float)w - 1.001f, gX, gY);
-        d00 += gX * sh_t[j]; d02 += gX;                                             // MatMul_grad: rows of theta x (x_t, y_t, 1)
-        d11 += gY * sh_t[i]; d12 += gY;
+    // BLOCKED: the terms of taps PH0 .. PH1-1 (and, THETA, the theta / z gradients, taken where the pixel's taps and
+    // d_recon are in registers anyway: the window from LDS -- nothing starves the LDS in this mode).  A thread owns ONE
+    // canvas column j and the rows i0, i0 + RPP, ...: the column's tap, its runs and its linspace value are loop
+    // invariants, the row's are wave-wide broadcasts.  Per-thread sums over a fixed pixel set, combined over the waves in a
+    // fixed order at the end.  A row outside the glimpse (both y taps clipped to one index: ty.w1 == -ty.w0, Ia == Ib,
+    // Ic == Id) contributes EXACT zeros to all five sums -- the a / b and c / d legs of AddN_10 / AddN_11 and of the
+    // bilinear sum cancel pairwise before anything rounds -- and is skipped; an out-of-range COLUMN does not cancel
+    // exactly (that is the x residue) and is not.
+    const int RPP = WB_THREADS / C, bj = tid % C, bi0 = tid / C;
+    auto blocked_terms = [&](auto ph0c, auto ph1c, auto thetac) __attribute__((always_inline)) {
+        constexpr int PH0 = decltype(ph0c)::value, PH1 = decltype(ph1c)::value;
+        constexpr bool THETA = decltype(thetac)::value;
+        if (bi0 >= RPP) return;
+        const Tap tx = sh_tx[bj];
+        const int4 ci = sh_ci[bj];
+        const float tjv = sh_t[bj];
+        const int jc0 = bj - ci.x, jc1 = bj - ci.z;
+        const float cw = (float)w - 1.001f;
+        for (int i = bi0; i < C; i += RPP) {
+            const Tap ty = sh_ty[i];
+            const int4 ri = sh_ri[i];
+            const float g0 = ALLPH ? sh_g[i * C + bj] : gsrc[i * C + bj];
+            const float gp = z * g0;                                                // canvas/mul_grad: z * Select_grad
+            const float wq[4] = {tx.w0 * ty.w0, tx.w0 * ty.w1, tx.w1 * ty.w0, tx.w1 * ty.w1};   // wa..wd (transformer.py:108-115)
+            const int rb0 = ri.x * C, rb1 = ri.z * C, di0 = i - ri.x, di1 = i - ri.z;
+#pragma unroll
+            for (int ph = PH0; ph < PH1; ++ph) {
+                const bool x1 = ph >> 1, y1 = ph & 1;
+                const int pos = (y1 ? rb1 : rb0) + (y1 ? ri.w : ri.y) * (x1 ? ci.z : ci.x) + (y1 ? di1 : di0) * (x1 ? ci.w : ci.y) + (x1 ? jc1 : jc0);
+                sh_T[(ALLPH ? ph * CCp : 0) + pos] = wq[ph] * gp;
+            }
+            if (THETA && ty.i0 != ty.i1) {
+                const float Ia = sh_win[ty.i0 * w + tx.i0], Ib = sh_win[ty.i1 * w + tx.i0];
+                const float Ic = sh_win[ty.i0 * w + tx.i1], Id = sh_win[ty.i1 * w + tx.i1];
+                dz += g0 * (((wq[0] * Ia + wq[1] * Ib) + wq[2] * Ic) + wq[3] * Id);   // canvas/mul_grad: Select_grad * window_recon
+                float gX, gY;
+                graph_dxy(gp, Ia, Ib, Ic, Id, tx, ty, cw, gX, gY);
+                d00 += gX * tjv; d02 += gX;                                         // MatMul_grad: rows of theta x (x_t, y_t, 1)
+                d11 += gY * sh_t[i]; d12 += gY;
+            }
+        }
     };
     auto theta_publish = [&]() {
         d00 = air_wave_sum(d00); d02 = air_wave_sum(d02); d11 = air_wave_sum(d11); d12 = air_wave_sum(d12); dz = air_wave_sum(dz);
@@ -1352,9 +1382,7 @@ __device__ __forceinline__ void write_bwd_graph_body(const air_write_bwd_t& a, i
         int i = tid / C, j = tid % C;
         for (int p = tid; p < CC; p += WB_THREADS) {
             const Tap tx = sh_tx[j], ty = sh_ty[i];
-            const float g0 = ALLPH ? sh_g[p] : gsrc[p];
-            const float gp = z * g0;                                                // canvas/mul_grad: z * Select_grad
-            if (BLOCKED) theta_px(tx, ty, g0, gp, i, j);
+            const float gp = z * (ALLPH ? sh_g[p] : gsrc[p]);                       // canvas/mul_grad: z * Select_grad
             const int4 ci = sh_ci[j], ri = sh_ri[i];
             const int cl0 = ci.x, cn0 = ci.y, cl1 = ci.z, cn1 = ci.w;               // runs of this column's x0 / x1 key
             const int rl0 = ri.x, rn0 = ri.y, rl1 = ri.z, rn1 = ri.w;               // runs of this row's y0 / y1 key
@@ -1376,14 +1404,29 @@ __device__ __forceinline__ void write_bwd_graph_body(const air_write_bwd_t& a, i
         start = (ALLPH ? ph * CCp : 0) + rlo * C + nrows * clo;
         n = nrows * ncols;
     };
-    // which window pixel ("slot") this thread accumulates.  BLOCKED: waves 0..3 take the corner slots' chunks, so the slots
-    // start at thread 256 and the last w*w - 768 of them fall to the first threads (after their corner work)
-    const int sl = BLOCKED ? (tid >= 4 * 64 ? tid - 4 * 64 : tid + (WB_THREADS - 4 * 64)) : tid;
-    const int sp = sl / w, sq = sl % w;
-    const bool is_slot = sl < w * w;
+    // which window pixel ("slot") this thread accumulates.  BLOCKED: waves 0..3 take the corner slots' chunks, so the other
+    // slots start at thread 256 and whatever does not fit behind it falls to the first threads (after their corner work);
+    // the 4 (w - 2) border slots -- the only other long streams: a row or a column of out-of-range pixels each -- come
+    // first, packed into the same waves, the interior slots (a handful of terms per tap) fill the rest
+    int sl = tid, sp = tid / w, sq = tid % w;
+    bool is_slot = tid < w * w;
+    if (BLOCKED) {
+        const int u = tid >= 4 * 64 ? tid - 4 * 64 : tid + (WB_THREADS - 4 * 64);
+        const int wm = max(w - 2, 1), ne = 4 * (w - 2);
+        is_slot = u < w * w - 4;
+        if (u < ne) {
+            const int side = u / wm, r = u - side * wm + 1;
+            sp = side == 0 ? 0 : side == 1 ? w - 1 : r;
+            sq = side < 2 ? r : (side == 2 ? 0 : w - 1);
+        } else {
+            const int v = u - ne, vr = v / wm;
+            sp = 1 + vr; sq = 1 + (v - vr * wm);
+        }
+        sl = sp * w + sq;
+    }
     // (a part whose LDS atomics are not lane-ordered -- lds_order_probe -- has no "corner" slots: their four long runs go
     // through the register chains like every other slot's; slow, but the same sequential order by construction)
-    const bool corner = (BLOCKED || lds_ordered || ring_ok) && is_slot && (sp == 0 || sp == w - 1) && (sq == 0 || sq == w - 1);
+    const bool corner = !BLOCKED && (lds_ordered || ring_ok) && is_slot && (sp == 0 || sp == w - 1) && (sq == 0 || sq == w - 1);
     float acc = 0.0f;
     // The corner slots' streams -> ds_add_f32 on one LDS word per corner: wave c feeds corner c, 64
     // consecutive terms per instruction, tap after tap (an instruction costs ~140 + 1.8 cycles per active
@@ -1545,11 +1588,7 @@ __device__ __forceinline__ void write_bwd_graph_body(const air_write_bwd_t& a, i
             for (int ph = ph0; ph < ph1; ++ph) {
                 int start, n;
                 slot_run(ph, sp, sq, start, n);
-                if (!BLOCKED) acc = stream_add(acc, sh_T, start, n);
-                else {
-                    const int cs = wb_chunk_len(n);
-                    for (int k0 = 0; k0 < n; k0 += cs) acc += stream_add(0.0f, sh_T, start + k0, min(cs, n - k0));
-                }
+                acc = stream_add(acc, sh_T, start, n);
             }
     };
     // the non-corner slots' outputs
@@ -1559,6 +1598,35 @@ __device__ __forceinline__ void write_bwd_graph_body(const air_write_bwd_t& a, i
             const float dgv = (acc * r) * (1.0f - r);        // SigmoidGrad of vae.py:39-41: dy * y * (1 - y)
             dgen[sl] = dgv;
             if (dgen16) dgen16[sl] = air_bf16_of(dgv);
+        }
+    };
+    // BLOCKED: this thread's slot, taps [PH0, PH1): the stream descriptors of all of them first (independent LDS reads), then
+    // the first four terms of every stream (clamped addresses; a term past the end is replaced by +0.0, the identity of a
+    // sum that starts at +0.0) -- for an interior slot that is all there is, two LDS round trips in total --, then whatever
+    // a longer stream has left: the rest of its first chunk, its further chunks, each from +0.0, added in order
+    auto blocked_slot = [&](auto ph0c, auto ph1c) __attribute__((always_inline)) {
+        constexpr int PH0 = decltype(ph0c)::value, PH1 = decltype(ph1c)::value;
+        if (!is_slot) return;
+        int st[4], nn[4];
+        float t4[4][4];
+#pragma unroll
+        for (int ph = PH0; ph < PH1; ++ph) slot_run(ph, sp, sq, st[ph], nn[ph]);
+#pragma unroll
+        for (int ph = PH0; ph < PH1; ++ph)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t4[ph][k] = sh_T[st[ph] + min(k, max(nn[ph] - 1, 0))];
+#pragma unroll
+        for (int ph = PH0; ph < PH1; ++ph) {
+            const int n = nn[ph];
+            float sk = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sk += k < n ? t4[ph][k] : 0.0f;
+            if (n > 4) {
+                const int cs = wb_chunk_len(n);
+                sk = stream_add(sk, sh_T, st[ph] + 4, min(n, cs) - 4);
+                acc += sk;
+                for (int k0 = cs; k0 < n; k0 += cs) acc += stream_add(0.0f, sh_T, st[ph] + k0, min(cs, n - k0));
+            } else acc += sk;
         }
     };
     // BLOCKED: chunk k of corner (cp, cq)'s stream of tap ph, summed from +0.0 (empty chunks: +0.0, the identity)
@@ -1597,9 +1665,10 @@ __device__ __forceinline__ void write_bwd_graph_body(const air_write_bwd_t& a, i
     constexpr int TH0 = 4 * 64, THN = WB_THREADS - TH0;
     if (BLOCKED && ALLPH) {
         // [terms of all taps + coordinate gradients] | [waves 0..3: corner c's 4 x 16 chunks, one per lane, then their 64
-        // sums added in stream order || the other slots' streams, one lane each || wave 15: the theta / z outputs]
+        // sums added in stream order || the other slots' streams, one lane each || last wave: the theta / z outputs]
+        using std::integral_constant;
         AIR_STAMP_WG(1);
-        stage_T(0, 4);
+        blocked_terms(integral_constant<int, 0>{}, integral_constant<int, 4>{}, integral_constant<bool, true>{});
         theta_publish();
         __syncthreads();
         AIR_STAMP(43);
@@ -1611,13 +1680,13 @@ __device__ __forceinline__ void write_bwd_graph_body(const air_write_bwd_t& a, i
             for (int l = 0; l < 64; ++l) du += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sk), l));
             if (lane == 0) publish_corner(wave, du);
         }
+        if (wave == NW - 1) finish_theta();
         AIR_STAMP(44);
         AIR_STAMP_WG(3);
-        chains(0, 4);
+        blocked_slot(integral_constant<int, 0>{}, integral_constant<int, 4>{});
         AIR_STAMP_WG(4);
-        AIR_STAMP_WG_T(5, 8 * 64);
+        AIR_STAMP_WG_T(5, 4 * 64);
         publish();
-        if (wave == NW - 1) finish_theta();
         AIR_STAMP(47);
         AIR_STAMP_WG(6);
         AIR_STAMP_WG_T(7, 15 * 64);
@@ -1625,22 +1694,11 @@ __device__ __forceinline__ void write_bwd_graph_body(const air_write_bwd_t& a, i
     } else if (BLOCKED) {
         // one tap per pass (large canvases).  Wave 1 holds the four corners' chunks of the pass (lane = corner * 16 + chunk)
         // and carries the corner accumulators from pass to pass; the coordinate gradients ride in pass 0
+        using std::integral_constant;
         float cacc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int ph = 0; ph < 4; ++ph) {
-            int i = tid / C, j = tid % C;
-            const bool x1 = ph >> 1, y1 = ph & 1;
-            for (int p = tid; p < CC; p += WB_THREADS) {
-                const Tap tx = sh_tx[j], ty = sh_ty[i];
-                const float g0 = gsrc[p];
-                const float gp = z * g0;
-                if (ph == 0) theta_px(tx, ty, g0, gp, i, j);
-                const int4 ci = sh_ci[j], ri = sh_ri[i];
-                const float wgt = (x1 ? tx.w1 : tx.w0) * (y1 ? ty.w1 : ty.w0);
-                const int clo = x1 ? ci.z : ci.x, ncols = x1 ? ci.w : ci.y, rlo = y1 ? ri.z : ri.x, nrows = y1 ? ri.w : ri.y;
-                sh_T[rlo * C + nrows * clo + (i - rlo) * ncols + (j - clo)] = wgt * gp;
-                i += di; j += dj;
-                if (j >= C) { j -= C; ++i; }
-            }
+        auto pass = [&](auto phc) __attribute__((always_inline)) {
+            constexpr int ph = decltype(phc)::value;
+            blocked_terms(integral_constant<int, ph>{}, integral_constant<int, ph + 1>{}, integral_constant<bool, ph == 0>{});
             if (ph == 0) theta_publish();
             __syncthreads();
             if (wave == 1) {
@@ -1652,10 +1710,12 @@ __device__ __forceinline__ void write_bwd_graph_body(const air_write_bwd_t& a, i
                     for (int k = 0; k < 16; ++k)
                         cacc[cc] += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sk), cc * 16 + k));
             }
-            chains(ph, ph + 1);
             if (ph == 0 && wave == NW - 1) finish_theta();
+            blocked_slot(integral_constant<int, ph>{}, integral_constant<int, ph + 1>{});
             if (ph < 3) __syncthreads();
-        }
+        };
+        pass(integral_constant<int, 0>{}); pass(integral_constant<int, 1>{});
+        pass(integral_constant<int, 2>{}); pass(integral_constant<int, 3>{});
         publish();
         if (wave == 1 && lane < 4) publish_corner(lane, lane == 0 ? cacc[0] : lane == 1 ? cacc[1] : lane == 2 ? cacc[2] : cacc[3]);
         AIR_STAMP(47);

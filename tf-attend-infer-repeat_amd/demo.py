@@ -59,7 +59,7 @@ def main():
     if os.path.exists(args.model + ".index"):                 # a TensorFlow bundle (the reference's model/air-model)
         air_model.load_tf_checkpoint(args.model)
     else:
-        air_model.load_state_dict(torch.load(args.model, map_location="cpu"))
+        air_model.load_state_dict(torch.load(args.model, map_location="cpu"), load_optimizer=False)   # inference: variables only
     wrapper = ModelWrapper(air_model, None, test_data, CANVAS_SIZE, WINDOW_SIZE)
 
     digits, positions, recs, windows, latents, loss = wrapper.infer(list(images))

@@ -8,10 +8,13 @@ shift_zero_digits_images ordering (:143-156, 169-200), checkpoints every 10 000 
 (summary/scalars.jsonl): loss, accuracy and the per-digit-count breakdown of
 AIRModel._summarize_by_digit_count (air_model.py:160-182, 614-617).
 
-The whole dataset lives in HBM; a batch is one device-side gather into the train model's
-input buffer, the step itself is a hipGraph replay.
+The whole dataset lives in HBM.  A batch comes out of tf.train.shuffle_batch's queue, kept on the
+device (multi_mnist.py:240-249: capacity 10 000 + 10 * batch, min_after_dequeue 10 000, over the epoch-repeating
+record stream of training.py:76-81; air_shuffle_batch_dequeue, include/air_hip.h) and is gathered into the
+train model's input buffer; queue, gather and train step are captured together in the hipGraph replay.
 """
 import argparse
+import ctypes as C
 import json
 import os
 import shutil
@@ -20,6 +23,7 @@ import time
 import numpy as np
 import torch
 
+from air import _hip as H
 from multi_mnist import generate_dataset, shift_zero_digits_images
 from air.air_model import AIRModel
 
@@ -34,6 +38,7 @@ GRAD_SUMMARIES_EACH_ITERATIONS = 100
 SAVE_PARAMS_EACH_ITERATIONS = 10000
 NUM_IMAGES_TO_SAVE = 60
 
+MIN_AFTER_DEQUEUE = 10000                 # multi_mnist.py:246-247 (capacity = this + 10 * batch)
 DEFAULT_READER_THREADS = 4
 DEFAULT_RESULTS_FOLDER = "air_results"
 TRAIN_DATA_FILE = "multi_mnist_data/common.npz"
@@ -176,32 +181,35 @@ def main():
     train_model, test_model = models
     n_train = train_images.shape[0]
     total = args.iterations if args.iterations > 0 else (n_train // BATCH_SIZE) * EPOCHS
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(args.seed)
     scalars = open(summaries_folder + "scalars.jsonl", "w")
 
-    # The batch gather is device work too: a permutation and a cursor live in HBM, so several
-    # train steps (gather + step) are captured per hipGraph replay when nothing is printed per step.
-    perm = torch.randperm(n_train, device=dev, generator=gen)
-    cursor = torch.zeros(1, dtype=torch.int64, device=dev)
-    lanes = torch.arange(BATCH_SIZE, device=dev)
+    # The input queue is device work too (read_and_decode, multi_mnist.py:228-249): the RandomShuffleQueue's resident
+    # record indices and the stream position live in HBM, so several train steps (dequeue + gather + step) are captured
+    # per hipGraph replay when nothing is printed per step.
+    queue = torch.zeros(MIN_AFTER_DEQUEUE + 10 * BATCH_SIZE, dtype=torch.int32, device=dev)
+    queue_state = torch.zeros(2, dtype=torch.int64, device=dev)
+    picks = torch.zeros(BATCH_SIZE, dtype=torch.int32, device=dev)
+    sq = H.ShuffleBatch(queue.data_ptr(), queue_state.data_ptr(), picks.data_ptr(), queue.numel(), BATCH_SIZE,
+                        MIN_AFTER_DEQUEUE, n_train, 0x5348554646 + args.seed)
+
+    def _s():
+        return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
     def next_batch(_i=0):
-        idx = perm.index_select(0, (cursor + lanes) % n_train)
-        torch.index_select(train_images, 0, idx, out=train_data)
-        torch.index_select(train_digits, 0, idx, out=train_targets)
-        cursor.add_(BATCH_SIZE)
+        H.check(H.lib().air_shuffle_batch_dequeue(C.byref(sq), _s()), "air_shuffle_batch_dequeue")
+        torch.index_select(train_images, 0, picks, out=train_data)
+        torch.index_select(train_digits, 0, picks, out=train_targets)
 
     gsteps = 1
     if not args.no_graph:
         if args.print_every == 0 and NUM_SUMMARIES_EACH_ITERATIONS % args.graph_steps == 0:
             gsteps = args.graph_steps
         train_model.capture_graph(steps=gsteps, between_steps=next_batch if gsteps > 1 else None)
-        cursor.zero_()                      # the capture warm-up must not consume data
+    H.check(H.lib().air_shuffle_batch_init(C.byref(sq), _s()), "air_shuffle_batch_init")   # (after the capture: nothing consumed)
 
     print("Training...")
     print()
-    step, epoch = 0, 0
+    step = 0
     t0 = time.perf_counter()
     while step < total:
         if step % NUM_SUMMARIES_EACH_ITERATIONS == 0:
@@ -228,9 +236,6 @@ def main():
             torch.save(train_model.state_dict(), models_folder + "air-model-%d.pt" % step)
             if args.tf_checkpoints:                                   # training.py:203-207 saver.save(..., global_step)
                 train_model.save_tf_checkpoint(models_folder + "air-model-%d" % step)
-        if (step * BATCH_SIZE) // n_train != epoch:               # new epoch: reshuffle in place
-            epoch = (step * BATCH_SIZE) // n_train
-            perm.copy_(torch.randperm(n_train, device=dev, generator=gen))
         if gsteps == 1:
             next_batch()
         train_model.training()
