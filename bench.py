@@ -133,7 +133,7 @@ def source_sha16():
 def bound_of(kernel):
     if kernel.startswith("write_bwd_graph_kernel"):
         return "lds-atomic-pipe"      # one sequential fp32 accumulator per corner slot on ds_add_f32 (4 cycles per term)
-    if kernel.startswith("write_bwd_blocked_kernel"):
+    if kernel.startswith(("write_bwd_blocked_kernel", "write_bwd_carried_kernel")):
         return "latency"              # 16 register chains of <= C*C/16 dependent fp32 adds per corner and tap + the term pass
     if kernel.startswith(("adam", "grad_sqnorm")):
         return "hbm"
@@ -283,7 +283,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary blocks (fp32 step, stress config, inference)")
-    ap.add_argument("--backward", default="reference", choices=["reference", "reference_blocked", "taps", "exact"])
+    ap.add_argument("--backward", default="reference", choices=["reference", "reference_carried", "reference_blocked", "taps", "exact"])
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -523,7 +523,7 @@ def main():
                     r["note"] = ("the reference's UnsortedSegmentSum order needs ONE sequential fp32 accumulator per corner slot, "
                                  "ds_add_f32 delivers 4.0 cycles per term and the slowest workgroup owns up to 4*C*C terms (16.9 of its "
                                  "24 us at 50x50) -- DESIGN.md section 8; the step's HBM-bound kernel is the Adam launch (roofline_all)")
-                elif name.startswith("write_bwd_blocked_kernel"):
+                elif name.startswith(("write_bwd_blocked_kernel", "write_bwd_carried_kernel")):
                     r["note"] = ("the same term streams in at most 16 chunks per slot and tap, one register chain per chunk "
                                  "(DESIGN.md section 10): as long as its term pass + the longest chunk of its heaviest item")
                 return r

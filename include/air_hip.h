@@ -386,7 +386,15 @@ typedef struct {
     float* d_gen_pre;                    /* [N,B,w*w] grad wrt gen_mean pre-sigmoid input */
     float* d_sxy_write;                  /* [N,B,4]: ds,dx,dy (via theta_recon), dz */
     int32_t B, N, C, w;
-    int32_t literal;                     /* see air_attend_bwd_t            */
+    int32_t literal;                     /* 0, 1, 2: see air_attend_bwd_t.  air_write_bwd only:
+                                            3: the graph's term streams (2), every (window pixel, tap) stream cut into at most
+                                               16 chunks of at least 64 terms that are summed from +0.0 side by side and added
+                                               left to right (backward="reference_blocked"; no LDS atomics, no probe);
+                                            4: as 2 for every window pixel whose four streams have at most 64 terms each; a
+                                               pixel with a longer stream walks the chunks of 3 TWICE -- C from +0.0, Q from P =
+                                               the running sum of the earlier C's -- and sums Q - P left to right, so that every
+                                               add rounds at the magnitude it has in the one long chain of 2
+                                               (backward="reference_carried")                                                */
     /* optional: workgroup (0,0) also does air_finalize's batch means (train step: saves a launch).
      * fin_scalars == NULL disables; loss_item is the [B] output of air_write_fwd */
     const float* fin_loss_item; const int32_t* fin_targets; const int32_t* fin_digits;

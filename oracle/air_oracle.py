@@ -295,6 +295,65 @@ def blocked_segment_sum(ids, vals, num, chunks=BLOCKED_CHUNKS, chunk_min=BLOCKED
     return np.repeat(si[start], nch), sums
 
 
+def _seq_sum(start, terms):
+    """fl(...fl(fl(start + t0) + t1)... ) in the dtype of `terms` (np.add.accumulate adds left to right)"""
+    if len(terms) == 0:
+        return terms.dtype.type(start)
+    return np.add.accumulate(np.concatenate([[start], terms]).astype(terms.dtype))[-1]
+
+
+def carried_segment_sum(ids4, vals4, num, chunks=BLOCKED_CHUNKS, chunk_min=BLOCKED_CHUNK_MIN):
+    """The accumulation order of backward="reference_carried" (order="carried16"): the four Gather gradients ids4 / vals4
+    (taps a, b, c, d) into `num` accumulators.
+
+    A slot (input pixel) whose four term streams all have at most `chunk_min` terms is summed exactly as the reference's
+    UnsortedSegmentSum sums it: one accumulator through its a-, b-, c-, d-terms.  That is every slot but the ones that collect
+    the out-of-range canvas (the four window corners; at canvases above 64 pixels the border rows / columns as well).
+    A slot with a longer stream keeps the reference's left-to-right structure AND the magnitude of its roundings, on chunks
+    that can be walked side by side.  Every tap's stream of n terms is cut into contiguous chunks of
+    cs = max(ceil(n / chunks), chunk_min) terms; with P = R = +0.0, for every chunk in stream order (a, b, c, d):
+        C = the chunk summed sequentially from +0.0                  (what order="blocked16" adds up)
+        Q = the chunk summed sequentially from P                     (the chain the reference runs there: P stands for
+                                                                      the reference's accumulator at the chunk's start,
+                                                                      so every add rounds at the magnitude it rounds at
+                                                                      in the sequential order)
+        R = R + (Q - P);  P = P + C
+    and R is the slot's sum.  All C of a slot are independent, P is their running sum, all Q are independent given P: two
+    chains of n / chunks adds instead of one of 4 n.  The out-of-range terms cancel pairwise in exact arithmetic (a against
+    c, b against d); what is left of them is rounding residue, and its size is set by the magnitude of the accumulator
+    the terms are added to -- which `blocked16` (every chunk from +0.0) shrinks by an order of magnitude and this
+    order keeps."""
+    dtype = vals4[0].dtype
+    f = dtype.type
+    per_tap = []
+    counts = np.zeros((4, num), np.int64)
+    for k in range(4):
+        order = np.argsort(ids4[k], kind="stable")
+        si, sv = ids4[k][order], vals4[k][order]
+        counts[k] = np.bincount(si, minlength=num)
+        per_tap.append((si, sv, np.concatenate([[0], np.cumsum(counts[k])])))
+    long_slot = (counts > chunk_min).any(0)
+    out = np.zeros(num, dtype)
+    keep = [~long_slot[i] for i in ids4]
+    np.add.at(out, np.concatenate([i[m] for i, m in zip(ids4, keep)]), np.concatenate([v[m] for v, m in zip(vals4, keep)]))
+    for slot in np.flatnonzero(long_slot):
+        P = R = f(0)
+        for k in range(4):
+            si, sv, off = per_tap[k]
+            t = sv[off[slot]:off[slot + 1]]
+            n = len(t)
+            if n == 0:
+                continue
+            cs = max(-(-n // chunks), chunk_min)
+            for k0 in range(0, n, cs):
+                ch = t[k0:k0 + cs]
+                C, Q = _seq_sum(f(0), ch), _seq_sum(P, ch)
+                R = f(R + f(Q - P))
+                P = f(P + C)
+        out[slot] = R
+    return out
+
+
 def transformer_backward(U, theta, out_size, d_out, order="sequential"):
     """What tf.gradients builds for transformer(U, theta, out_size) (transformer.py:56-171), in the op
     order of the reference's saved graph (model/air-model.meta, `.../st_backward/...` gradient nodes;
@@ -308,6 +367,8 @@ def transformer_backward(U, theta, out_size, d_out, order="sequential"):
         (blocked_segment_sum): the same terms,
         the same left-to-right structure, a sum tree a GPU can evaluate in parallel -- the realisation a
         parallel UnsortedSegmentSum (TF's GPU kernel uses unordered atomics) stands for, made deterministic;
+        order="carried16" (AIRModel(backward="reference_carried")): the reference's order for every slot with short streams,
+        chunks walked from a carried estimate of the reference's accumulator for the long ones (carried_segment_sum);
       * coordinate gradients: mul_10..13_grad / mul_6..9_grad products, Sub negations, then AddN_10
         (x) and AddN_11 (y) over the legs of wa, wb, wc, wd left to right; truediv_grad, mul_grad;
       * d theta: MatMul_grad -- contraction of (d x_s, d y_s) with the grid rows (x_t, y_t, 1).
@@ -325,10 +386,13 @@ def transformer_backward(U, theta, out_size, d_out, order="sequential"):
     Ia, Ib, Ic, Id = U[bidx, y0, x0], U[bidx, y1, x0], U[bidx, y0, x1], U[bidx, y1, x1]
     # d U: [a-terms of every output pixel, then b, c, d] into one accumulator per input pixel
     d_U = np.zeros((B, Hi * Wi), dtype)
-    assert order in ("sequential", "blocked16"), order
+    assert order in ("sequential", "blocked16", "carried16"), order
     for b in range(B):
         idx = [y0[b] * Wi + x0[b], y1[b] * Wi + x0[b], y0[b] * Wi + x1[b], y1[b] * Wi + x1[b]]
         val = [(wx0[b] * wy0[b]) * g[b], (wx0[b] * wy1[b]) * g[b], (wx1[b] * wy0[b]) * g[b], (wx1[b] * wy1[b]) * g[b]]
+        if order == "carried16":
+            d_U[b] = carried_segment_sum(idx, val, Hi * Wi)
+            continue
         if order == "blocked16":
             idx, val = zip(*(blocked_segment_sum(i, v, Hi * Wi) for i, v in zip(idx, val)))
         np.add.at(d_U[b], np.concatenate(idx), np.concatenate(val))

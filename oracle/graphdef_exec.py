@@ -340,7 +340,8 @@ def _k_addn(n, *xs):
 # "sequential": TF's CPU kernel.  "blocked16": what backward="reference_blocked" computes -- the graph's one
 # UnsortedSegmentSum takes the four Gather gradients concatenated (taps a, b, c, d); every tap's quarter goes through
 # oracle.air_oracle.blocked_segment_sum (up to 16 chunks per segment and tap, summed side by side) and the chunk sums
-# are then added in the same a, b, c, d stream order.  A module switch for tests / tests/golden/make_graph_golden.py:
+# are then added in the same a, b, c, d stream order.  "carried16": backward="reference_carried" (carried_segment_sum).
+# A module switch for tests / tests/golden/make_graph_golden.py:
 # the whole saved graph executed with that ONE kernel swapped shows what the order does to the 36 gradients.
 SEGMENT_SUM_ORDER = "sequential"
 
@@ -357,6 +358,13 @@ def _k_unsorted_segment_sum(n, data, ids, num):
         parts = [blocked_segment_sum(flat_ids[k * q:(k + 1) * q], flat[k * q:(k + 1) * q], int(num)) for k in range(4)]
         flat_ids = np.concatenate([p[0] for p in parts])
         flat = np.concatenate([p[1] for p in parts]).reshape((-1,) + tail)
+    elif SEGMENT_SUM_ORDER == "carried16":
+        # backward="reference_carried": short streams as the CPU kernel, long ones through oracle.air_oracle.carried_segment_sum
+        from oracle.air_oracle import carried_segment_sum
+        assert int(np.prod(flat.shape[1:])) == 1 and flat.shape[0] % 4 == 0, "the sampler's scatter: four concatenated tap gradients"
+        flat, q = flat.reshape(-1), flat.shape[0] // 4
+        return carried_segment_sum([flat_ids[k * q:(k + 1) * q] for k in range(4)], [flat[k * q:(k + 1) * q] for k in range(4)],
+                                   int(num)).reshape(out.shape)
     else:
         assert SEGMENT_SUM_ORDER == "sequential", SEGMENT_SUM_ORDER
     np.add.at(out, flat_ids, flat)                                                 # in index order, like the CPU kernel

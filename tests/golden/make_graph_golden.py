@@ -125,6 +125,7 @@ def main():
            out["train0/global_norm_fp32"], out["train0/global_norm_fp64"], trips))
     compose(nodes)
     blocked(nodes)
+    blocked(nodes, "carried16")
     chain(nodes)
 
 
@@ -154,18 +155,18 @@ def compose(nodes=None):
     print("wrote %d arrays, %.0f KB -> %s" % (len(out), os.path.getsize(path) / 1024, path))
 
 
-def blocked(nodes=None):
-    """tests/golden/graph_b64_blocked.npz: the fp32 backward of the train0 run once more with the graph's ONE
-    UnsortedSegmentSum evaluated in the blocked16 order (oracle.blocked_segment_sum; AIRModel(backward=
-    "reference_blocked")) -- per-variable gradient norms and the global norm, next to graph_b64.npz's
-    grad32_norm/* (the sequential order) and grad64_norm/* (exact)."""
+def blocked(nodes=None, order="blocked16"):
+    """tests/golden/graph_b64_blocked.npz (graph_b64_carried.npz): the fp32 backward of the train0 run once more with the
+    graph's ONE UnsortedSegmentSum evaluated in the blocked16 (carried16) order (oracle.blocked_segment_sum /
+    carried_segment_sum; AIRModel(backward="reference_blocked" / "reference_carried")) -- per-variable gradient norms and the
+    global norm, next to graph_b64.npz's grad32_norm/* (the sequential order) and grad64_norm/* (exact)."""
     if nodes is None:
         _, nodes = gx.load_graph(META)
     images, targets, params, noise = inputs()
     adam = gx.adam_nodes(nodes)
     names = list(ao.param_shapes(HP).keys())
     out = {}
-    gx.SEGMENT_SUM_ORDER = "blocked16"
+    gx.SEGMENT_SUM_ORDER = order
     try:
         ex = gx.Executor(nodes, gx.air_feeds(nodes, params, images, targets, noise, 0), np.float32)
         g32 = ex.run([gx.raw_gradient_tensor(nodes, adam[k]) for k in names])
@@ -178,10 +179,10 @@ def blocked(nodes=None):
             out["kern/t%d/d_gen_pre" % t] = np.asarray(bw[0])[:KB].reshape(KB, -1)
     finally:
         gx.SEGMENT_SUM_ORDER = "sequential"
-    path = os.path.join(ROOT, "tests", "golden", "graph_b64_blocked.npz")
+    path = os.path.join(ROOT, "tests", "golden", "graph_b64_%s.npz" % order[:-2])
     np.savez_compressed(path, **out)
-    print("wrote %d arrays, %.0f KB -> %s; |g| fp32 blocked16 %.4e" % (len(out), os.path.getsize(path) / 1024, path,
-                                                                      out["train0/global_norm_fp32"]))
+    print("wrote %d arrays, %.0f KB -> %s; |g| fp32 %s %.4e" % (len(out), os.path.getsize(path) / 1024, path, order,
+                                                               out["train0/global_norm_fp32"]))
 
 
 # tensors at the remaining kernel interfaces of the backward of step t (the VAE data-gradient chain vae.py:10-43
@@ -242,5 +243,7 @@ if __name__ == "__main__":
         chain()
     elif "--blocked-only" in sys.argv:
         blocked()
+    elif "--carried-only" in sys.argv:
+        blocked(order="carried16")
     else:
         main()

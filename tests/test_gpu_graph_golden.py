@@ -208,12 +208,14 @@ def _att(H, gold, N):
     return att
 
 
-@pytest.mark.parametrize("literal", [2, 3])
+@pytest.mark.parametrize("literal", [2, 3, 4])
 def test_write_bwd_reproduces_the_graphs_scatter_bit_for_bit(H, gold, golden_dir, literal):
     """literal 2 (backward="reference") against the executed graph's UnsortedSegmentSum; literal 3
-    (backward="reference_blocked") against the SAME graph executed with that one kernel in the blocked16 order
-    (tests/golden/graph_b64_blocked.npz, make_graph_golden.py --blocked-only) -- both bit for bit."""
-    blk = np.load(os.path.join(golden_dir, "graph_b64_blocked.npz"))
+    (backward="reference_blocked") / 4 ("reference_carried") against the SAME graph executed with that one kernel in the
+    blocked16 / carried16 order (tests/golden/graph_b64_{blocked,carried}.npz, make_graph_golden.py --blocked-only /
+    --carried-only) -- all bit for bit.  literal 4 additionally equals literal 2's fixture on every window pixel whose four
+    streams are short (the reference's own chain there)."""
+    blk = np.load(os.path.join(golden_dir, "graph_b64_%s.npz" % ("carried" if literal == 4 else "blocked")))
     N, Cc, w = int(gold["train0/steps_executed"]), HP["canvas_size"], HP["windows_size"]
     att = _cuda(_att(H, gold, N))
     # d loss / d running_recon is the same tensor at every step (the canvas is a running sum)
@@ -241,6 +243,12 @@ def test_write_bwd_reproduces_the_graphs_scatter_bit_for_bit(H, gold, golden_dir
         # active items: the UnsortedSegmentSum accumulation order, bit for bit (residue included)
         assert np.array_equal(dgen[t][act], ref[act]), (t, float(np.abs(dgen[t][act] - ref[act]).max()))
         assert np.abs(ref[act]).max() > 1.0          # the residue is there: the exact gradient is ~1e-2
+        if literal == 4:
+            seq = gold[k + "d_gen_pre"].reshape(KB, -1)[act]
+            same = (dgen[t][act] == seq).mean(0)                                     # per window pixel, over the active items
+            interior = np.ones((w, w), bool)
+            interior[0, :] = interior[-1, :] = interior[:, 0] = interior[:, -1] = False
+            assert (same.reshape(w, w)[interior] == 1.0).all()                       # interior pixels: the reference's chain
         # theta_recon legs: reductions over 2500 pixels (order differs from numpy's matmul) -> 1e-5
         ds_ref = ((gold[k + "d_s_write_0"] + gold[k + "d_s_write_1"]) + gold[k + "d_s_write_2"]) + gold[k + "d_s_write_3"]
         for got, ref1, nm in ((dsx[t, :, 0], ds_ref, "ds"), (dsx[t, :, 1], gold[k + "d_x_write"], "dx"),

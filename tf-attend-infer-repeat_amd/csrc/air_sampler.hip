@@ -1176,9 +1176,38 @@ __device__ __forceinline__ float stream_add(float acc, const float* T, int start
 // No LDS atomics, no lane-order property, no probe; the coordinate / z gradients are taken in the term pass.
 constexpr int WB_CHUNKS = 16, WB_CHUNK_MIN = 64;
 __device__ __forceinline__ int wb_chunk_len(int n) { return max((n + WB_CHUNKS - 1) / WB_CHUNKS, WB_CHUNK_MIN); }
-template <bool ALLPH, bool BLOCKED>
+// CARRIED (ORD == 2, literal == 4, backward="reference_carried"): the layout, the term pass and the chunks of BLOCKED, but
+//   * a slot whose four streams all fit one chunk (<= 64 terms each: every slot but the corners and a few long borders) is
+//     summed exactly as the reference sums it -- one accumulator through its a-, b-, c-, d-terms;
+//   * a slot with a longer stream walks every chunk TWICE: C = the chunk from +0.0, Q = the chunk from P, with P the running
+//     sum of the C's before it (a deterministic stand-in for the reference's accumulator at the chunk's start);
+//     R += Q - P; P += C in stream order; R is the slot's sum.  Every add of the Q chains rounds at the magnitude it rounds
+//     at in the reference's one long chain, so the cancellation residue the out-of-range terms leave keeps its size --
+//     BLOCKED shrinks it 10x..300x on the border / corner slots, and training notices.
+//   Two chains of n / 16 adds per corner instead of one of 4 n; no LDS atomics, no probe.
+constexpr int WB_ORD_GRAPH = 0, WB_ORD_BLOCKED = 1, WB_ORD_CARRIED = 2;
+// c += every term, q += every term: the two chains of one chunk in ONE pass over its terms (independent: they overlap)
+__device__ __forceinline__ void stream_add2(float& c, float& q, const float* T, int start, int n) {
+    int k = start;
+    const int end = start + n;
+    while (k < end && (k & 3)) { const float t = T[k]; c += t; q += t; ++k; }
+    const int nb = (end - k) >> 2;
+    if (nb > 0) {
+        const float4* p4 = reinterpret_cast<const float4*>(T + k);
+        float4 c0 = p4[0], c1 = p4[min(1, nb - 1)];
+        for (int b = 0; b < nb; ++b) {
+            const float4 nx = p4[min(b + 2, nb - 1)];
+            c += c0.x; q += c0.x; c += c0.y; q += c0.y; c += c0.z; q += c0.z; c += c0.w; q += c0.w;
+            c0 = c1; c1 = nx;
+        }
+        k += nb * 4;
+    }
+    while (k < end) { const float t = T[k]; c += t; q += t; ++k; }
+}
+template <bool ALLPH, int ORD>
 __device__ __forceinline__ void write_bwd_graph_body(const air_write_bwd_t& a, int seq_flags)
 {
+    constexpr bool BLOCKED = ORD != WB_ORD_GRAPH, CARRIED = ORD == WB_ORD_CARRIED;
     // seq_flags (accumulators(), below): bit 0 the LDS atomic pipe applies lanes in order, bit 1 the lane-ring accumulator
     // is exact on this part (used when the pipe is not); bits 8..15: pipe / ring MIX factor c in sixteenths (0 = every
     // corner on the pipe), see pipe_mask below
@@ -1629,6 +1658,33 @@ __device__ __forceinline__ void write_bwd_graph_body(const air_write_bwd_t& a, i
             } else acc += sk;
         }
     };
+    // CARRIED: this thread's slot, taps [PH0, PH1).  short_s: all four of its streams are single chunks -> the reference's
+    // chain (acc); otherwise P_s / R_s carry the scheme above from tap to tap (and from pass to pass on large canvases)
+    float P_s = 0.0f, R_s = 0.0f;
+    bool short_s = true;
+    if (CARRIED && is_slot) {
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) { int st, n; slot_run(ph, sp, sq, st, n); short_s = short_s && n <= WB_CHUNK_MIN; }
+    }
+    auto carried_slot = [&](auto ph0c, auto ph1c) __attribute__((always_inline)) {
+        constexpr int PH0 = decltype(ph0c)::value, PH1 = decltype(ph1c)::value;
+        if (!is_slot) return;
+#pragma unroll
+        for (int ph = PH0; ph < PH1; ++ph) {
+            int start, n;
+            slot_run(ph, sp, sq, start, n);
+            n = max(n, 0);
+            if (short_s) { acc = stream_add(acc, sh_T, start, n); continue; }
+            const int cs = wb_chunk_len(n);
+            for (int k0 = 0; k0 < n; k0 += cs) {
+                float c = 0.0f, q = P_s;
+                stream_add2(c, q, sh_T, start + k0, min(cs, n - k0));
+                R_s += q - P_s;
+                P_s += c;
+            }
+            acc = R_s;
+        }
+    };
     // BLOCKED: chunk k of corner (cp, cq)'s stream of tap ph, summed from +0.0 (empty chunks: +0.0, the identity)
     auto corner_chunk = [&](int ph, int cp, int cq, int k) -> float {
         int start, n;
@@ -1673,17 +1729,51 @@ __device__ __forceinline__ void write_bwd_graph_body(const air_write_bwd_t& a, i
         __syncthreads();
         AIR_STAMP(43);
         AIR_STAMP_WG(2);
-        if (wave < 4) {
+        if (wave < 4 && !CARRIED) {
             const float sk = corner_chunk(lane >> 4, (wave & 2) ? w - 1 : 0, (wave & 1) ? w - 1 : 0, lane & 15);
             float du = 0.0f;
 #pragma unroll
             for (int l = 0; l < 64; ++l) du += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sk), l));
             if (lane == 0) publish_corner(wave, du);
         }
+        if (wave < 4 && CARRIED) {
+            // corner `wave`: lane = tap * 16 + chunk.  [C of every chunk] -> [P: their exclusive running sum in stream order]
+            // -> [Q of every chunk from its P] -> [R: the running sum of Q - P in stream order]
+            const int cp = (wave & 2) ? w - 1 : 0, cq = (wave & 1) ? w - 1 : 0;
+            int start, n;
+            slot_run(lane >> 4, cp, cq, start, n);
+            n = max(n, 0);
+            int nmax = n;
+#pragma unroll
+            for (int m = 16; m < 64; m <<= 1) nmax = max(nmax, __shfl_xor(nmax, m, 64));
+            if (nmax <= WB_CHUNK_MIN) {
+                // all four streams are single chunks: the reference's chain (lanes 0, 16, 32, 48 hold the taps' runs)
+                float du = 0.0f;
+#pragma unroll
+                for (int ph = 0; ph < 4; ++ph)
+                    du = stream_add(du, sh_T, __builtin_amdgcn_readlane(start, ph * 16), __builtin_amdgcn_readlane(n, ph * 16));
+                if (lane == 0) publish_corner(wave, du);
+            } else {
+                const int cs = wb_chunk_len(n), off = (lane & 15) * cs, len = min(max(n - off, 0), cs);
+                const float ck = stream_add(0.0f, sh_T, start + off, len);
+                float run = 0.0f, pk = 0.0f;
+#pragma unroll
+                for (int l = 0; l < 64; ++l) {
+                    pk = lane == l ? run : pk;
+                    run += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ck), l));
+                }
+                const float dk = stream_add(pk, sh_T, start + off, len) - pk;
+                float du = 0.0f;
+#pragma unroll
+                for (int l = 0; l < 64; ++l) du += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dk), l));
+                if (lane == 0) publish_corner(wave, du);
+            }
+        }
         if (wave == NW - 1) finish_theta();
         AIR_STAMP(44);
         AIR_STAMP_WG(3);
-        blocked_slot(integral_constant<int, 0>{}, integral_constant<int, 4>{});
+        if (CARRIED) carried_slot(integral_constant<int, 0>{}, integral_constant<int, 4>{});
+        else blocked_slot(integral_constant<int, 0>{}, integral_constant<int, 4>{});
         AIR_STAMP_WG(4);
         AIR_STAMP_WG_T(5, 4 * 64);
         publish();
@@ -1696,12 +1786,25 @@ __device__ __forceinline__ void write_bwd_graph_body(const air_write_bwd_t& a, i
         // and carries the corner accumulators from pass to pass; the coordinate gradients ride in pass 0
         using std::integral_constant;
         float cacc[4] = {0.f, 0.f, 0.f, 0.f};
+        // CARRIED: cacc = R of the four corners, cP = their P; cshort: all four streams of the corner are single chunks
+        float cP[4] = {0.f, 0.f, 0.f, 0.f};
+        bool cshort[4] = {true, true, true, true};
+        if (CARRIED && wave == 1) {
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                for (int ph = 0; ph < 4; ++ph) {
+                    int st, n;
+                    slot_run(ph, (cc & 2) ? w - 1 : 0, (cc & 1) ? w - 1 : 0, st, n);
+                    cshort[cc] = cshort[cc] && n <= WB_CHUNK_MIN;
+                }
+        }
         auto pass = [&](auto phc) __attribute__((always_inline)) {
             constexpr int ph = decltype(phc)::value;
             blocked_terms(integral_constant<int, ph>{}, integral_constant<int, ph + 1>{}, integral_constant<bool, ph == 0>{});
             if (ph == 0) theta_publish();
             __syncthreads();
-            if (wave == 1) {
+            if (wave == 1 && !CARRIED) {
                 const int c = lane >> 4;
                 const float sk = corner_chunk(ph, (c & 2) ? w - 1 : 0, (c & 1) ? w - 1 : 0, lane & 15);
 #pragma unroll
@@ -1710,8 +1813,39 @@ __device__ __forceinline__ void write_bwd_graph_body(const air_write_bwd_t& a, i
                     for (int k = 0; k < 16; ++k)
                         cacc[cc] += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sk), cc * 16 + k));
             }
+            if (wave == 1 && CARRIED) {
+                // lane = corner * 16 + chunk of this pass's tap
+                const int c = lane >> 4;
+                int start, n;
+                slot_run(ph, (c & 2) ? w - 1 : 0, (c & 1) ? w - 1 : 0, start, n);
+                n = max(n, 0);
+                const int cs = wb_chunk_len(n), off = (lane & 15) * cs, len = min(max(n - off, 0), cs);
+                const float ck = stream_add(0.0f, sh_T, start + off, len);
+                float pk = 0.0f;
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    float run = cshort[cc] ? cacc[cc] : cP[cc];          // (a short corner continues the reference's chain)
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        pk = lane == cc * 16 + k ? run : pk;
+                        run += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ck), cc * 16 + k));
+                    }
+                    cP[cc] = run;
+                }
+                const float qk = stream_add(pk, sh_T, start + off, len);
+                const float dk = qk - pk;
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    if (cshort[cc]) cacc[cc] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qk), cc * 16));
+                    else
+#pragma unroll
+                        for (int k = 0; k < 16; ++k)
+                            cacc[cc] += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dk), cc * 16 + k));
+                }
+            }
             if (ph == 0 && wave == NW - 1) finish_theta();
-            blocked_slot(integral_constant<int, ph>{}, integral_constant<int, ph + 1>{});
+            if (CARRIED) carried_slot(integral_constant<int, ph>{}, integral_constant<int, ph + 1>{});
+            else blocked_slot(integral_constant<int, ph>{}, integral_constant<int, ph + 1>{});
             if (ph < 3) __syncthreads();
         };
         pass(integral_constant<int, 0>{}); pass(integral_constant<int, 1>{});
@@ -1806,12 +1940,17 @@ __device__ __forceinline__ void write_bwd_graph_body(const air_write_bwd_t& a, i
 template <bool ALLPH>
 __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_bwd_t a, int seq_flags)
 {
-    write_bwd_graph_body<ALLPH, false>(a, seq_flags);
+    write_bwd_graph_body<ALLPH, WB_ORD_GRAPH>(a, seq_flags);
 }
 template <bool ALLPH>
 __global__ __launch_bounds__(WB_THREADS) void write_bwd_blocked_kernel(air_write_bwd_t a)
 {
-    write_bwd_graph_body<ALLPH, true>(a, 0);
+    write_bwd_graph_body<ALLPH, WB_ORD_BLOCKED>(a, 0);
+}
+template <bool ALLPH>
+__global__ __launch_bounds__(WB_THREADS) void write_bwd_carried_kernel(air_write_bwd_t a)
+{
+    write_bwd_graph_body<ALLPH, WB_ORD_CARRIED>(a, 0);
 }
 
 // the canvas is staged in LDS only when one prefetch pass covers it (PF * THREADS floats, see the kernels)
@@ -2013,8 +2152,8 @@ extern "C" int air_write_fwd(const air_write_fwd_t* a, void* stream) {
 /* name of the kernel function air_write_bwd dispatches this descriptor to, as rocprofv3 prints it */
 extern "C" int air_write_bwd_kernel_name(const air_write_bwd_t* a, char* buf, int n) {
     if (!a || !buf || n <= 0 || a->C < 2 || a->w < 2) return AIR_EINVAL;
-    if (a->literal == 2 || a->literal == 3)
-        snprintf(buf, n, "write_bwd_%s_kernel<%s>", a->literal == 3 ? "blocked" : "graph",
+    if (a->literal >= 2 && a->literal <= 4)
+        snprintf(buf, n, "write_bwd_%s_kernel<%s>", a->literal == 4 ? "carried" : a->literal == 3 ? "blocked" : "graph",
                  write_bwd_graph_smem(a->C, a->w, true) <= 80 * 1024 ? "true" : "false");
     else snprintf(buf, n, "write_bwd_kernel");
     return 0;
@@ -2024,7 +2163,7 @@ extern "C" int air_write_bwd(const air_write_bwd_t* a, void* stream) {
     if (!a || !a->d_recon || !a->vrec || !a->att || !a->d_gen_pre || !a->d_sxy_write) return AIR_EINVAL;
     if (a->B <= 0 || a->N <= 0 || a->C < 2 || a->w < 2) return AIR_EINVAL;
     if (a->fin_rec_part && (!a->fin_scalars || !a->fin_run_loss || !a->fin_rec_loss || !a->fin_loss_item_out)) return AIR_EINVAL;
-    if (a->literal < 0 || a->literal > 3) return AIR_EINVAL;
+    if (a->literal < 0 || a->literal > 4) return AIR_EINVAL;
     if (a->order && a->literal < 2) return AIR_EINVAL;            // (the ordered form exists in the graph-order kernels only)
     if (2 * a->w > THREADS) return AIR_ELIMIT;
     if (a->literal == 3) {
@@ -2036,6 +2175,18 @@ extern "C" int air_write_bwd(const air_write_bwd_t* a, void* stream) {
         if (rc) return rc;
         if (allph) hipLaunchKernelGGL(write_bwd_blocked_kernel<true>, dim3(a->B, a->N), dim3(WB_THREADS), lds, air_stream(stream), *a);
         else hipLaunchKernelGGL(write_bwd_blocked_kernel<false>, dim3(a->B, a->N), dim3(WB_THREADS), lds, air_stream(stream), *a);
+        AIR_CHECK_LAUNCH();
+        return 0;
+    }
+    if (a->literal == 4) {
+        // the carried graph order: as above -- register chains only, capture-safe from the first call
+        if (a->w * a->w > WB_THREADS) return AIR_ELIMIT;
+        const bool allph = write_bwd_graph_smem(a->C, a->w, true) <= 80 * 1024;
+        const size_t lds = write_bwd_graph_smem(a->C, a->w, allph);
+        int rc = allph ? ensure_lds(write_bwd_carried_kernel<true>, lds) : ensure_lds(write_bwd_carried_kernel<false>, lds);
+        if (rc) return rc;
+        if (allph) hipLaunchKernelGGL(write_bwd_carried_kernel<true>, dim3(a->B, a->N), dim3(WB_THREADS), lds, air_stream(stream), *a);
+        else hipLaunchKernelGGL(write_bwd_carried_kernel<false>, dim3(a->B, a->N), dim3(WB_THREADS), lds, air_stream(stream), *a);
         AIR_CHECK_LAUNCH();
         return 0;
     }

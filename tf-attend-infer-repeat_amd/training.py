@@ -122,7 +122,7 @@ def main():
     parser.add_argument("--bg-max-intensity", type=float, default=1.0)
     parser.add_argument("--graph-steps", type=int, default=10, help="train steps per hipGraph replay when --print-every 0")
     parser.add_argument("--seed", type=int, default=0)
-    parser.add_argument("--backward", default="reference", choices=["reference", "reference_blocked", "taps", "exact"],
+    parser.add_argument("--backward", default="reference", choices=["reference", "reference_carried", "reference_blocked", "taps", "exact"],
                         help="sampler backward: the reference graph's op order (default), the same streams in 16 chunks per tap, "
                              "per-tap sums, or the exact adjoint")
     args = parser.parse_args()
