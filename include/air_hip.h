@@ -28,8 +28,11 @@ extern "C" {
 /* 2: air_gemm_t / air_wgrad_t carry bf16 twins; `literal` of the sampler backward: 0 exact, 1 per-tap order, 2 the
  * reference graph's order (version 1 headers of round 1 called the per-tap order "reference")
  * 3: panel-blocked bf16 shadows of the weights (air_panel_t, air_gemm_t.B16p, air_panel_shadow,
- *    air_adam_clip_step_panels) */
-#define AIR_ABI_VERSION 3
+ *    air_adam_clip_step_panels)
+ * 4: measured-negative paths removed (DESIGN.md sections 8-10 keep the record): the deferred Adam slices
+ *    (air_step_job_t.ad_*, air_adam_clip_step_blocks), the banded compose (air_write_fwd_t.rec_part / bands,
+ *    air_finalize_parts, air_write_bwd_t.fin_rec_part ..); added: `literal` 3 / 4 of air_write_bwd, air_shuffle_batch_* */
+#define AIR_ABI_VERSION 4
 
 #define AIR_EINVAL   (-1)   /* bad dimension / null pointer            */
 #define AIR_ELIMIT   (-2)   /* size exceeds what the kernel supports    */
@@ -138,13 +141,6 @@ typedef struct {
     const air_schedule_t* sched /*device*/; int32_t nsched; float* dyn; const int32_t* istate;
     float* normals; int64_t n_normal; float* uniforms; int64_t n_uniform; uint64_t seed;
     const float* twin_src; uint16_t* twin_dst; int64_t twin_n;   /* see air_step_begin */
-    /* optional (ad_n > 0, a multiple of 4; pointers 16-byte aligned): a deferred slice of the PREVIOUS step's
-     * air_adam_clip_step -- elements [0, ad_n) of the given (already advanced) params / grads / m / v pointers and of the
-     * bf16 shadow are updated by the carrying launch's extra workgroups with the coefficients the main Adam launch
-     * recorded in ad_coef (air_adam_clip_step_blocks' coef_out).  Only for variables that no kernel up to and including
-     * the carrying one reads: the forward of the next step needs each variable only from its own layer on. */
-    float* ad_params; const float* ad_grads; float* ad_m; float* ad_v; uint16_t* ad_shadow; int64_t ad_n;
-    const float* ad_coef; float ad_beta1, ad_beta2, ad_epsilon;
 } air_step_job_t;
 typedef struct {
     const float* A; const float* B; float* C;
@@ -487,17 +483,7 @@ int air_adam_clip_step(float* params, const float* grads, float* m, float* v, in
                        float grad_prescale /* e.g. 1/world_size */, float beta1, float beta2,
                        float epsilon, uint16_t* bf16_shadow /*nullable*/, float* gnorm_out /*nullable*/,
                        void* stream);
-/* The same update over a sub-range of the flat buffers (the pointers are advanced by the caller, `partials` still hold the
- * norm of the WHOLE gradient) on at most `max_blocks` workgroups (0 = as many as fill the chip): a NARROW launch that a
- * long train step graph can defer (see air_step_job_t.ad_*): every kernel of the forward only needs its own variables
- * updated. */
-int air_adam_clip_step_blocks(float* params, const float* grads, float* m, float* v, int64_t n,
-                              const float* partials, int npartials, const float* dyn, const int32_t* istate,
-                              float grad_prescale, float beta1, float beta2, float epsilon,
-                              uint16_t* bf16_shadow /*nullable*/, float* gnorm_out /*nullable*/, int max_blocks,
-                              float* coef_out /*nullable: [4] floats receiving (clip scale, lr_t, global norm) for deferred slices*/,
-                              void* stream);
-/* air_adam_clip_step_blocks (all blocks) that ALSO maintains the panel-blocked shadows: every updated variable that lies
+/* air_adam_clip_step that ALSO maintains the panel-blocked shadows: every updated variable that lies
  * in a described matrix is written to its panel position (and to bf16_shadow unless the matrix is `exclusive`). */
 int air_adam_clip_step_panels(float* params, const float* grads, float* m, float* v, int64_t n,
                               const float* partials, int npartials, const float* dyn, const int32_t* istate,

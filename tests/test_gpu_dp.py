@@ -261,7 +261,6 @@ def test_bench_eight_rank_flow_on_one_device():
     assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 512 and d["config"]["parallelism"] == "dp8"
     assert d["replicas_bit_identical"] is True and "NOT a scaling measurement" in d["test_mode"]
     assert set(d["distributed"]["ms_per_step_by_exchange"]) == {"flat", "factors"}
-    assert d["ms_per_step_by_replay"]["replays"] * d["ms_per_step_by_replay"]["steps_per_replay"] == 10
     out = os.path.join(root, "gpurun_out", "r05")
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, "bench_dp8_same_device_gloo.json"), "w") as f:

@@ -15,7 +15,7 @@ import torch  # noqa: F401  -- FIRST: torch brings its own libamdhip64; loading 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AIR_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "libair_hip.so")   # override: A/B builds in tools/
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # enums (keep in sync with include/air_hip.h)
 DYN_PRIOR_LOG_ODDS, DYN_TEMPERATURE, DYN_STOP_THRESHOLD, DYN_LEARNING_RATE, DYN_CLIP_NORM = 0, 1, 2, 3, 4
@@ -44,9 +44,7 @@ class Schedule(C.Structure):
 class StepJob(C.Structure):
     _fields_ = [("sched", _p), ("nsched", _i), ("dyn", _p), ("istate", _p),
                 ("normals", _p), ("n_normal", C.c_int64), ("uniforms", _p), ("n_uniform", C.c_int64),
-                ("seed", C.c_uint64), ("twin_src", _p), ("twin_dst", _p), ("twin_n", C.c_int64),
-                ("ad_params", _p), ("ad_grads", _p), ("ad_m", _p), ("ad_v", _p), ("ad_shadow", _p), ("ad_n", C.c_int64),
-                ("ad_coef", _p), ("ad_beta1", _f), ("ad_beta2", _f), ("ad_epsilon", _f)]
+                ("seed", C.c_uint64), ("twin_src", _p), ("twin_dst", _p), ("twin_n", C.c_int64)]
 
 
 class Gemm(C.Structure):
@@ -161,7 +159,6 @@ _SIGNATURES = {
     "air_vae_bottleneck_fwd": (C.c_int, [C.POINTER(BottleneckFwd), _p]),
     "air_vae_bottleneck_bwd": (C.c_int, [C.POINTER(BottleneckBwd), _p]),
     "air_adam_clip_step": (C.c_int, [_p, _p, _p, _p, C.c_int64, _p, C.c_int, _p, _p, _f, _f, _f, _f, _p, _p, _p]),
-    "air_adam_clip_step_blocks": (C.c_int, [_p, _p, _p, _p, C.c_int64, _p, C.c_int, _p, _p, _f, _f, _f, _f, _p, _p, C.c_int, _p, _p]),
     "air_adam_clip_step_factored": (C.c_int, [_p, _p, _p, _p, C.c_int64, C.POINTER(Wgrad), C.c_int, _p, C.c_int, _p, _p,
                                               _f, _f, _f, _f, _p, _p]),
     "air_shuffle_batch_init": (C.c_int, [C.POINTER(ShuffleBatch), _p]),

@@ -102,7 +102,6 @@ class VariableStore:
         # global-norm partial sums: air_grad_sqnorm's fixed count, or one per weight-gradient workgroup
         self.partials = torch.zeros(max(H.lib().air_optim_num_partials(self.n), 16384), dtype=torch.float32, device=device)
         self.gnorm = torch.zeros(1, dtype=torch.float32, device=device)
-        self.adam_coef = torch.zeros(4, dtype=torch.float32, device=device)   # (clip scale, lr_t, global norm) of the last Adam launch
         self.synced_world = 1            # world size the replicas were last made identical for (AIRModel.sync_parameters)
         # bf16 shadow of the whole flat variable buffer (same offsets): the weight operand of every bf16 GEMM.
         # Adam rewrites it with the variables (air_adam_clip_step's bf16_shadow); any host-side change of the
@@ -594,7 +593,7 @@ class AIRModel:
     _KERNEL_OF = {"air_lstm_first_step": "lstm_first_step_kernel", "air_step_begin": "step_begin_kernel", "air_attend_fwd": "attend_fwd_kernel",
                   "air_attend_bwd": "attend_bwd_kernel", "air_write_fwd": "write_fwd_kernel<1024, false>",
                   "air_write_bwd": "write_bwd_kernel", "air_finalize": "finalize_kernel",
-                  "air_grad_sqnorm": "grad_sqnorm_kernel", "air_adam_clip_step": "adam_clip_kernel<false>",
+                  "air_grad_sqnorm": "grad_sqnorm_kernel", "air_adam_clip_step": "adam_clip_kernel",
                   "air_vae_bottleneck_fwd": "bottleneck_fwd_kernel<256>", "air_vae_bottleneck_bwd": "bottleneck_bwd_kernel<256>"}
 
     def _call(self, name, *args, nbytes=0, flops=0, tag=None):
@@ -636,10 +635,8 @@ class AIRModel:
 
         NB = N * B
         fwd = []
-        hosts = []          # (index in fwd, args, kwargs) of the narrow GEMMs that can carry a deferred Adam slice (see _adam_riders)
 
-        def host_gemm(*args, **kw):
-            hosts.append((len(fwd), args, kw))
+        def gemm(*args, **kw):
             fwd.append(self._gemm(*args, **kw))
         # hoisted x.W_x (the reference recomputes it every step, :286); split-K slabs
         job = H.StepJob(_ptr(self.sched), self._nsched, _ptr(self.dyn), _ptr(st.istate),
@@ -686,8 +683,8 @@ class AIRModel:
                            epi=H.EPI_LSTM_FWD, p=(self.c[t],), q=(self.acts[t], self.c[t + 1], self.h[t + 1]),
                            extra_bytes=4 * B * R * 7, tag="lstm_fwd",
                            A16=o16(self.h16, t), B16=Wh16, q2_16=o16(self.h16, t + 1), B16p=TP("Wh"))
-            host_gemm(self.h[t], Wh, self.gates_pre, B, 4 * R, R, R, 4 * R, 4 * R, **lstm_kw)
-            if t == 1 and self._fuse_step0 and use_pan and os.environ.get("AIR_BEGIN_HOST", "lstm") == "lstm":   # (deferred Adam riders never coexist with panels)
+            gemm(self.h[t], Wh, self.gates_pre, B, 4 * R, R, R, 4 * R, 4 * R, **lstm_kw)
+            if t == 1 and self._fuse_step0 and use_pan:
                 # With the first step fused into it, x.Wx is ONE round of 160 KB of LDS per workgroup: prologue workgroups in
                 # that launch would each take a whole CU.  The LSTM steps read neither the noise, nor dyn, nor the image
                 # twin (their first consumer is attend_fwd): the prologue rides in the first of them instead (16 KB of LDS)
@@ -695,8 +692,8 @@ class AIRModel:
                 self._begin_host = (len(fwd) - 1, self._gemm(self.h[t], Wh, self.gates_pre, B, 4 * R, R, R, 4 * R, 4 * R,
                                                              step_job=job, **lstm_kw))
         # everything else runs ONCE over all N*B (step, image) rows
-        host_gemm(self.h[1], P["whid"], self.hid, NB, HT, R, R, HT, HT, bias=P["bhid"],
-                  act=H.ACT_RELU, tag="heads_hid", A16=o16(self.h16, 1), B16=T("whid"), C16=self.hid16, B16p=TP("whid"))
+        gemm(self.h[1], P["whid"], self.hid, NB, HT, R, R, HT, HT, bias=P["bhid"],
+             act=H.ACT_RELU, tag="heads_hid", A16=o16(self.h16, 1), B16=T("whid"), C16=self.hid16, B16p=TP("whid"))
         a = H.AttendFwd(_ptr(self.hid), _ptr(P["wout"]), _ptr(P["bout"]), _ptr(imgs),
                         _ptr(self.eps_scale), _ptr(self.eps_shift), _ptr(self.u), _ptr(self.dyn),
                         _ptr(self.out7), _ptr(self.att), _ptr(self.window),
@@ -705,10 +702,9 @@ class AIRModel:
         fwd.append(self._call("air_attend_fwd", C.byref(a), nbytes=NB * ((D + d + HT) * 4 + 12), tag="attend_fwd"))
         x, x16, k = self.window, self.window16, d
         for i, u in enumerate(rec_u):
-            (host_gemm if i == 0 else (lambda *a_, **k_: fwd.append(self._gemm(*a_, **k_))))(
-                x, P["rec%d_w" % i], self.rec_act[i], NB, u, k, k, u, u,
-                bias=P["rec%d_b" % i], act=H.ACT_SOFTPLUS, tag="vae_rec",
-                A16=x16, B16=T("rec%d_w" % i), C16=self.rec_act16[i], B16p=TP("rec%d_w" % i))
+            gemm(x, P["rec%d_w" % i], self.rec_act[i], NB, u, k, k, u, u,
+                 bias=P["rec%d_b" % i], act=H.ACT_SOFTPLUS, tag="vae_rec",
+                 A16=x16, B16=T("rec%d_w" % i), C16=self.rec_act16[i], B16p=TP("rec%d_w" % i))
             x, x16, k = self.rec_act[i], self.rec_act16[i], u
         # the bottleneck (last recognition product -> reparameterised sample -> first generative layer) is
         # ONE launch where the fused kernel's limits hold (bf16 operands; vae.py:16-30); else two GEMMs
@@ -776,13 +772,7 @@ class AIRModel:
                                         _ptr(self.target_num_digits), _ptr(self.run_digits), _ptr(self._loss_item),
                                         _ptr(self.scalars), B)
         self._fwd = fwd
-        self._fwd_hosts = hosts
-        self._fwd_riders = None
         twin_job = ((_ptr(imgs), _ptr(self.images16), imgs.numel()) if self.images16 is not None else (None, None, 0))
-        self._begin = self._call(
-            "air_step_begin", _ptr(self.sched), self._nsched, _ptr(self.dyn), _ptr(st.istate),
-            _ptr(self.normals), self.normals.numel(), _ptr(self.uniforms), self.uniforms.numel(),
-            C.c_uint64(self._seed), *twin_job)
         self._begin_sched_only = self._call(
             "air_step_begin", _ptr(self.sched), self._nsched, _ptr(self.dyn), _ptr(st.istate),
             None, 0, None, 0, C.c_uint64(self._seed), *twin_job)
@@ -981,18 +971,16 @@ class AIRModel:
         if self._twins and self.store.shadow_stale:
             self.store.refresh_shadow(self._stream())
 
-    def _run_forward(self, s, finalize=True, riders=None):
-        """riders: {index in the launch list: the same GEMM carrying a deferred slice of the previous step's Adam}"""
+    def _run_forward(self, s, finalize=True):
         self._fresh_shadow()
-        pick = (lambda i, op: riders.get(i, op)) if riders else (lambda i, op: op)
-        if self._injected_noise or os.environ.get("AIR_SEPARATE_STEP_BEGIN") == "1":
-            (self._begin_sched_only if self._injected_noise else self._begin)(s)
-            for i, op in enumerate(self._fwd):
-                pick(i, op)(s)
+        if self._injected_noise:
+            self._begin_sched_only(s)                # (parity tests: the schedules only, the noise buffers hold what was injected)
+            for op in self._fwd:
+                op(s)
         else:
             hi, hop = self._begin_host               # the launch that carries the step prologue as extra workgroups
             for i, op in enumerate(self._fwd):
-                (hop if i == hi else pick(i, op))(s)
+                (hop if i == hi else op)(s)
         if finalize:
             self._finalize(s)
 
@@ -1056,7 +1044,7 @@ class AIRModel:
                                   st.n, _ptr(st.partials), npart, _ptr(self.dyn), _ptr(st.istate), 1.0 / world,
                                   0.9, 0.999, 1e-8, _ptr(st.params16), st.panels, len(st.panels), _ptr(st.params16p),
                                   _ptr(st.gnorm), nbytes=30 * st.n, tag="adam_clip")
-                adam.kernel = "adam_clip_kernel<true>" if os.environ.get("AIR_ADAM_PANELS_SWEEP") else "adam_panels_kernel"
+                adam.kernel = "adam_panels_kernel"
             else:
                 adam = self._call("air_adam_clip_step", _ptr(st.params), _ptr(st.grads), _ptr(st.m), _ptr(st.v),
                                   st.n, _ptr(st.partials), npart, _ptr(self.dyn), _ptr(st.istate), 1.0 / world,
@@ -1066,55 +1054,6 @@ class AIRModel:
             self._opt = [adam] if fused else [self._sqnorm, adam]
             self._opt_world = (world, self._dp())
         return self._opt
-
-    def _adam_riders(self):
-        """Deferred Adam for a train step that is followed by another one inside the same captured graph.
-        Every kernel of the forward only needs ITS OWN variables updated, so the exposed Adam launch covers the flat
-        buffer up to the first VAE variable (LSTM + heads: what the next step's first kernels read) and the VAE
-        variables -- the tail of the flat buffer -- are updated by extra workgroups of the next step's narrow GEMM
-        launches (the LSTM steps, the heads' hidden layer, the first recognition layer: 64-588 workgroups each on a
-        256-CU part), with the clip scale / lr_t the exposed launch recorded.  Same arithmetic, element for element.
-        Returns (adam_main op, {fwd index: GEMM op carrying its slice}) or None when the layout does not allow it."""
-        if self._fwd_riders is not None:
-            return self._fwd_riders or None
-        self._fwd_riders = ()
-        st = self.store
-        # OFF by default -- measured on MI355X (tools/ab_bench.sh, 400 steps, 20 per replay): 0.1838 ms/step with the slices
-        # carried, 0.1832 without.  The slice is HBM work whatever launch it sits in: the carrying GEMMs last as long as their
-        # riders and lose what the Adam launch saved.  AIR_ADAM_RIDERS=1 enables it (tests keep the path bit-identical).
-        if (not self.train or self._dwx_factors is not None or os.environ.get("AIR_ADAM_RIDERS") != "1" or not self._fwd_hosts
-                or (self._twins and self._use_panels)):    # (the deferred slices do not maintain the panel-blocked twins)
-            return None
-        lo, hi = st.offsets["rec0_w"], st.n                      # the VAE variables: contiguous tail of the flat buffer
-        first_free = st.offsets.get("rec1_w", st.offsets["ml_w"])   # the first recognition GEMM reads rec0_w / rec0_b itself
-        hosts = list(self._fwd_hosts)
-        k = len(hosts)
-        cuts = [lo + ((hi - lo) * i // k) // 8 * 8 for i in range(k)] + [hi]
-        if cuts[-2] < first_free:                                # its slice would contain variables it reads: do not use it
-            hosts = hosts[:-1]
-            k = len(hosts)
-            cuts = [lo + ((hi - lo) * i // k) // 8 * 8 for i in range(k)] + [hi]
-        if k == 0:
-            return None
-        off = lambda t, i, b: C.c_void_p(t.data_ptr() + i * b)  # noqa: E731
-        riders = {}
-        for (idx, args, kw), a, b in zip(hosts, cuts[:-1], cuts[1:]):
-            job = H.StepJob(None, 0, _ptr(self.dyn), _ptr(st.istate), None, 0, None, 0, 0, None, None, 0,
-                            off(st.params, a, 4), off(st.grads, a, 4), off(st.m, a, 4), off(st.v, a, 4),
-                            off(st.params16, a, 2) if self._twins else None, b - a, _ptr(st.adam_coef), 0.9, 0.999, 1e-8)
-            kw2 = dict(kw)
-            kw2["step_job"] = job
-            kw2["extra_bytes"] = kw.get("extra_bytes", 0) + (30 if self._twins else 28) * (b - a)
-            kw2["tag"] = kw.get("tag", "gemm") + "+adam_slice"
-            riders[idx] = self._gemm(*args, **kw2)
-        npart = self._wgrad_blocks
-        main = self._call("air_adam_clip_step_blocks", _ptr(st.params), _ptr(st.grads), _ptr(st.m), _ptr(st.v),
-                          lo, _ptr(st.partials), npart, _ptr(self.dyn), _ptr(st.istate), 1.0, 0.9, 0.999, 1e-8,
-                          _ptr(st.params16) if self._twins else None, _ptr(st.gnorm), 0, _ptr(st.adam_coef),
-                          nbytes=(30 if self._twins else 28) * lo, tag="adam_clip_main")
-        main.kernel = "adam_clip_kernel<false>"
-        self._fwd_riders = (main, riders)
-        return self._fwd_riders
 
     def _dp_factors(self):
         """Launch lists of the factor exchange (dp_exchange="factors", world > 1): local weight gradients WITHOUT
@@ -1184,17 +1123,13 @@ class AIRModel:
         return ([(hop if i == hi else op) for i, op in enumerate(self._fwd)] + [self._write_bwd_fin] + self._bwd[1:]
                 + [self._wgrad_fused] + self._optimizer_ops())
 
-    def _train_phase_a(self, s, riders=None):
+    def _train_phase_a(self, s):
         """step prologue + forward + loss + backward (+ weight grads) into the flat grad buffer"""
-        self._run_forward(s, finalize=False, riders=riders)
+        self._run_forward(s, finalize=False)
         self._run_backward(s, for_update=True, fused_finalize=True)
 
-    def _train_phase_b(self, s, main_only=None):
-        """global-norm clip + TF-style Adam + global_step += 1 (after the all-reduce).
-        main_only: the exposed part of a deferred Adam (_adam_riders) instead of the whole update"""
-        if main_only is not None:
-            main_only(s)
-            return
+    def _train_phase_b(self, s):
+        """global-norm clip + TF-style Adam + global_step += 1 (after the all-reduce)"""
         if self._dp() and self._dp_exchange == "factors":
             self._dp_factors()["dwx"](s)                         # dWx from the gathered factors, identically on every rank
         for op in self._optimizer_ops():
@@ -1237,22 +1172,16 @@ class AIRModel:
                     self._dp_factors()["dwx"](s)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        # a step that is followed by another one in the same graph defers the VAE part of its Adam into the next
-        # step's narrow GEMM launches (_adam_riders); the last step of the replay updates everything itself
-        deferred = self._adam_riders() if (steps > 1 and not dp) else None
         ga = torch.cuda.CUDAGraph()
         # (thread_local: RCCL's watchdog thread may touch the runtime while this thread captures)
         with torch.cuda.graph(ga, **({"capture_error_mode": "thread_local"} if dp else {})):
-            carried = None
             for i in range(steps):
                 if between_steps is not None:
                     between_steps(i)
                 s = self._stream()
-                self._train_phase_a(s, riders=carried)
+                self._train_phase_a(s)
                 if not dp:
-                    defer = deferred is not None and i < steps - 1
-                    self._train_phase_b(s, main_only=deferred[0] if defer else None)
-                    carried = deferred[1] if defer else None
+                    self._train_phase_b(s)
                 elif in_graph:
                     self._dp_exchange_gradients()
                     self._train_phase_b(self._stream())

@@ -871,7 +871,7 @@ int launch(const air_gemm_t* g, const Args& a0, hipStream_t s) {
     a.kslab = ((a.K + ks - 1) / ks + 3) & ~3;
     if (a.job_on) {
         // enough planes for ~1 quad of noise per thread (the prologue then ends well inside the GEMM)
-        const long quads = (a.job.n_normal + 3) / 4 + (a.job.n_uniform + 3) / 4 + (a.job.twin_n + 3) / 4 + a.job.ad_n / 4;
+        const long quads = (a.job.n_normal + 3) / 4 + (a.job.n_uniform + 3) / 4 + (a.job.twin_n + 3) / 4;
         const long plane = (long)grid.x * grid.y * THREADS;
         long planes = (quads + plane - 1) / plane;
         a.job_on = (int)(planes < 1 ? 1 : (planes > 16 ? 16 : planes));
@@ -1086,14 +1086,7 @@ static int fill_args(const air_gemm_t* g, Args& a) {
         if (j.twin_n < 0 || (j.twin_n > 0 && (!j.twin_src || !j.twin_dst))) return AIR_EINVAL;
         if (j.twin_n > 0 && (!aligned16(j.twin_src) || (reinterpret_cast<uintptr_t>(j.twin_dst) & 7) != 0)) return AIR_EALIGN;
         a.job = AirStepJob{j.sched, j.nsched, j.dyn, j.istate, j.normals, (long)j.n_normal, j.uniforms, (long)j.n_uniform,
-                           (uint32_t)(j.seed & 0xffffffffu), (uint32_t)(j.seed >> 32), j.twin_src, j.twin_dst, (long)j.twin_n,
-                           j.ad_params, j.ad_grads, j.ad_m, j.ad_v, j.ad_shadow, (long)j.ad_n, j.ad_coef, j.ad_beta1, j.ad_beta2, j.ad_epsilon};
-        if (j.ad_n < 0 || (j.ad_n & 3)) return AIR_EINVAL;
-        if (j.ad_n > 0) {
-            if (!j.ad_params || !j.ad_grads || !j.ad_m || !j.ad_v || !j.ad_coef) return AIR_EINVAL;
-            if (!aligned16(j.ad_params) || !aligned16(j.ad_grads) || !aligned16(j.ad_m) || !aligned16(j.ad_v) ||
-                (reinterpret_cast<uintptr_t>(j.ad_shadow) & 7) != 0) return AIR_EALIGN;
-        }
+                           (uint32_t)(j.seed & 0xffffffffu), (uint32_t)(j.seed >> 32), j.twin_src, j.twin_dst, (long)j.twin_n};
     }
     switch (g->epi) {
         case AIR_EPI_LSTM_FWD:      // N = 4R gate columns, groups of R

@@ -546,7 +546,7 @@ int xw_tp_launch(const Args& a0, int job_planes_hint, hipStream_t s) {
     const bool wide = xw_tp_columns(a0) == 128;
     dim3 grid(a.N / (wide ? 128 : 64), a.M / 64, 1);
     if (a.job_on) {
-        const long quads = (a.job.n_normal + 3) / 4 + (a.job.n_uniform + 3) / 4 + (a.job.twin_n + 3) / 4 + a.job.ad_n / 4;
+        const long quads = (a.job.n_normal + 3) / 4 + (a.job.n_uniform + 3) / 4 + (a.job.twin_n + 3) / 4;
         const long plane = (long)grid.x * grid.y * THREADS;
         long planes = (quads + plane - 1) / plane;
         a.job_on = (int)(planes < 1 ? 1 : (planes > 64 ? 64 : planes));

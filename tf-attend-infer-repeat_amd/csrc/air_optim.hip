@@ -100,12 +100,10 @@ __global__ __launch_bounds__(THREADS) void panel_shadow_kernel(const float* __re
 
 // ApplyAdam (TF 1.3 training_ops): lr_t = lr*sqrt(1-b2^t)/(1-b1^t);
 // m += (g-m)(1-b1); v += (g^2-v)(1-b2); var -= lr_t*m/(sqrt(v)+eps)
-template <bool PANELS>
 __global__ __launch_bounds__(THREADS) void adam_clip_kernel(
     float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
     const float* __restrict__ partials, int npartials, const float* __restrict__ dyn, const int32_t* __restrict__ istate,
-    float prescale, float b1, float b2, float eps, uint16_t* __restrict__ shadow, float* __restrict__ gnorm_out,
-    float* __restrict__ coef_out, uint16_t* __restrict__ panels, PanelTab tab)
+    float prescale, float b1, float b2, float eps, uint16_t* __restrict__ shadow, float* __restrict__ gnorm_out)
 {
     __shared__ float red[4];
     // The first quad's loads go out BETWEEN the partial-sum loads and their reduction (vmcnt retires in order, so the
@@ -123,9 +121,6 @@ __global__ __launch_bounds__(THREADS) void adam_clip_kernel(
     if (i < n4) { pp = p4[i]; mm = m4[i]; vv = v4[i]; gg = g4[i]; }
     const AirAdamCoef cf = air_adam_coef_from_share(share, dyn, istate, prescale, b1, b2, red);
     if (gnorm_out && blockIdx.x == 0 && threadIdx.x == 0) *gnorm_out = cf.gnorm;
-    // the record deferred slices of this step's update read (air_step_job_t.ad_coef): dyn / istate / partials may have
-    // moved on to the next step by the time they run
-    if (coef_out && blockIdx.x == 0 && threadIdx.x == 0) { coef_out[0] = cf.scale; coef_out[1] = cf.lr_t; coef_out[2] = cf.gnorm; }
     const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
 
     for (; i < n4; i += stride) {
@@ -137,12 +132,7 @@ __global__ __launch_bounds__(THREADS) void adam_clip_kernel(
         for (int k = 0; k < 4; ++k) air_adam_update(pa[k], ma[k], va[k], ga[k], cf, omb1, omb2, eps);
         p4[i] = pp; m4[i] = mm; v4[i] = vv;
         const uint2 tw = make_uint2(air_pack_bf16(pp.x, pp.y), air_pack_bf16(pp.z, pp.w));
-        bool keep_flat = true;
-        if (PANELS) {
-            unsigned long long at;
-            if (panel_of(tab, (unsigned)i, at, keep_flat)) *reinterpret_cast<uint2*>(panels + at) = tw;
-        }
-        if (shadow && keep_flat) reinterpret_cast<uint2*>(shadow)[i] = tw;
+        if (shadow) reinterpret_cast<uint2*>(shadow)[i] = tw;
         if (more) { pp = pn; mm = mn; vv = vn; gg = gn; }
     }
     if (blockIdx.x == 0 && threadIdx.x < (int)(n - n4 * 4)) {
@@ -248,8 +238,7 @@ extern "C" int air_step_begin(const air_schedule_t* sched, int nsched, float* dy
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;
     AirStepJob job{sched, nsched, dyn, istate, normals, (long)n_normal, uniforms, (long)n_uniform,
-                   (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), twin_src, twin_dst, (long)twin_n,
-                   nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0.f, 0.f, 0.f};
+                   (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), twin_src, twin_dst, (long)twin_n};
     hipLaunchKernelGGL(step_begin_kernel, dim3((int)blocks), dim3(THREADS), 0, air_stream(stream), job);
     AIR_CHECK_LAUNCH();
     return 0;
@@ -264,19 +253,6 @@ extern "C" int air_grad_sqnorm(const float* grads, int64_t n, float* partials, i
                        grads, (long)n, partials, istate);
     AIR_CHECK_LAUNCH();
     return 0;
-}
-
-extern "C" int air_adam_clip_step_blocks(float* params, const float* grads, float* m, float* v, int64_t n,
-                                         const float* partials, int npartials, const float* dyn, const int32_t* istate,
-                                         float grad_prescale, float beta1, float beta2, float epsilon,
-                                         uint16_t* bf16_shadow, float* gnorm_out, int max_blocks, float* coef_out, void* stream);
-
-extern "C" int air_adam_clip_step(float* params, const float* grads, float* m, float* v, int64_t n,
-                                  const float* partials, int npartials, const float* dyn, const int32_t* istate,
-                                  float grad_prescale, float beta1, float beta2, float epsilon,
-                                  uint16_t* bf16_shadow, float* gnorm_out, void* stream) {
-    return air_adam_clip_step_blocks(params, grads, m, v, n, partials, npartials, dyn, istate, grad_prescale, beta1, beta2,
-                                     epsilon, bf16_shadow, gnorm_out, 0, nullptr, stream);
 }
 
 static int fill_panels(const air_panel_t* panels, int count, int64_t n, PanelTab& tab) {
@@ -320,11 +296,10 @@ extern "C" int air_panel_shadow(const float* params, uint16_t* panel_shadow, con
     return 0;
 }
 
-static long adam_blocks(int64_t n, int max_blocks) {
+static long adam_blocks(int64_t n) {
     long blocks = (n / 4 + THREADS - 1) / THREADS;
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;        // (512 .. 8192 measured: 20.3 .. 23.8 us in isolation, no difference inside the step)
-    if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
     return blocks;
 }
 
@@ -339,30 +314,24 @@ extern "C" int air_adam_clip_step_panels(float* params, const float* grads, floa
     PanelTab tab;
     const int rc = fill_panels(panels, npanels, n, tab);
     if (rc) return rc;
-    if (getenv("AIR_ADAM_PANELS_SWEEP") != nullptr)          // (A/B: the grid-stride sweep with a per-quad table lookup)
-        hipLaunchKernelGGL(adam_clip_kernel<true>, dim3((int)adam_blocks(n, 0)), dim3(THREADS), 0, air_stream(stream),
-                           params, grads, m, v, (long)n, partials, npartials, dyn, istate, grad_prescale, beta1, beta2,
-                           epsilon, bf16_shadow, gnorm_out, (float*)nullptr, panel_shadow, tab);
-    else {
-        const long chunks = (n / 4 + CHUNK - 1) / CHUNK;
-        hipLaunchKernelGGL(adam_panels_kernel, dim3((int)(chunks < 1 ? 1 : chunks)), dim3(THREADS), 0, air_stream(stream),
-                           params, grads, m, v, (long)n, partials, npartials, dyn, istate, grad_prescale, beta1, beta2,
-                           epsilon, bf16_shadow, gnorm_out, panel_shadow, tab);
-    }
+    const long chunks = (n / 4 + CHUNK - 1) / CHUNK;
+    hipLaunchKernelGGL(adam_panels_kernel, dim3((int)(chunks < 1 ? 1 : chunks)), dim3(THREADS), 0, air_stream(stream),
+                       params, grads, m, v, (long)n, partials, npartials, dyn, istate, grad_prescale, beta1, beta2,
+                       epsilon, bf16_shadow, gnorm_out, panel_shadow, tab);
     AIR_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int air_adam_clip_step_blocks(float* params, const float* grads, float* m, float* v, int64_t n,
-                                         const float* partials, int npartials, const float* dyn, const int32_t* istate,
-                                         float grad_prescale, float beta1, float beta2, float epsilon,
-                                         uint16_t* bf16_shadow, float* gnorm_out, int max_blocks, float* coef_out, void* stream) {
+extern "C" int air_adam_clip_step(float* params, const float* grads, float* m, float* v, int64_t n,
+                                  const float* partials, int npartials, const float* dyn, const int32_t* istate,
+                                  float grad_prescale, float beta1, float beta2, float epsilon,
+                                  uint16_t* bf16_shadow, float* gnorm_out, void* stream) {
     if (!params || !grads || !m || !v || !partials || npartials <= 0 || !dyn || !istate || n <= 0) return AIR_EINVAL;
     if ((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)m | (uintptr_t)v) & 15) != 0) return AIR_EALIGN;
     if (((uintptr_t)bf16_shadow & 7) != 0) return AIR_EALIGN;
-    hipLaunchKernelGGL(adam_clip_kernel<false>, dim3((int)adam_blocks(n, max_blocks)), dim3(THREADS), 0, air_stream(stream),
+    hipLaunchKernelGGL(adam_clip_kernel, dim3((int)adam_blocks(n)), dim3(THREADS), 0, air_stream(stream),
                        params, grads, m, v, (long)n, partials, npartials, dyn, istate, grad_prescale, beta1, beta2,
-                       epsilon, bf16_shadow, gnorm_out, coef_out, (uint16_t*)nullptr, PanelTab{});
+                       epsilon, bf16_shadow, gnorm_out);
     AIR_CHECK_LAUNCH();
     return 0;
 }

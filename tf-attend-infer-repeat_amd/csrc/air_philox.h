@@ -10,11 +10,6 @@ struct AirStepJob {
     // optional: twin_dst[i] = bf16(twin_src[i]) for i < twin_n -- the bf16 twin of the image batch (the caller's
     // fp32 tensor), read by the input-weight gradient at the end of the step
     const float* twin_src; unsigned short* twin_dst; long twin_n;
-    // optional: a slice of the PREVIOUS step's clip + ApplyAdam (air_adam_clip_step over a sub-range of the flat buffers,
-    // coefficients taken from the `coef` record the main Adam launch left): variables that no kernel up to and including
-    // the carrying launch reads are updated underneath it instead of in the exposed Adam launch
-    float* ad_p; const float* ad_g; float* ad_m; float* ad_v; unsigned short* ad_shadow; long ad_n;
-    const float* ad_coef; float ad_b1, ad_b2, ad_eps;
 };
 
 __device__ __forceinline__ void air_philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
@@ -53,25 +48,6 @@ __device__ __forceinline__ void air_step_job_run(const AirStepJob& j, long wg, l
         j.dyn[s.slot] = air_eval_schedule(s, step);
     }
     const long quads_n = (j.n_normal + 3) / 4, quads_u = (j.n_uniform + 3) / 4, quads_t = (j.twin_n + 3) / 4;
-    if (j.ad_n > 0) {
-        // m += (g-m)(1-b1); v += (g^2-v)(1-b2); var -= lr_t*m/(sqrt(v)+eps) with the recorded (scale, lr_t): the exact
-        // arithmetic of adam_clip_kernel, element by element (ad_n % 4 == 0, 16-byte aligned: checked on the host)
-        const AirAdamCoef cf{j.ad_coef[0], j.ad_coef[1], j.ad_coef[2]};
-        const float omb1 = 1.0f - j.ad_b1, omb2 = 1.0f - j.ad_b2;
-        float4* p4 = reinterpret_cast<float4*>(j.ad_p);
-        const float4* g4 = reinterpret_cast<const float4*>(j.ad_g);
-        float4* m4 = reinterpret_cast<float4*>(j.ad_m);
-        float4* v4 = reinterpret_cast<float4*>(j.ad_v);
-        for (long i = wg * 256 + threadIdx.x; i < j.ad_n / 4; i += nwg * 256) {
-            float4 pp = p4[i], mm = m4[i], vv = v4[i];
-            const float4 gg = g4[i];
-            float* pa = &pp.x; float* ma = &mm.x; float* va = &vv.x; const float* ga = &gg.x;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) air_adam_update(pa[k], ma[k], va[k], ga[k], cf, omb1, omb2, j.ad_eps);
-            p4[i] = pp; m4[i] = mm; v4[i] = vv;
-            if (j.ad_shadow) reinterpret_cast<uint2*>(j.ad_shadow)[i] = make_uint2(air_pack_bf16(pp.x, pp.y), air_pack_bf16(pp.z, pp.w));
-        }
-    }
     for (long q = wg * 256 + threadIdx.x; q < quads_n + quads_u + quads_t; q += nwg * 256) {
         if (q >= quads_n + quads_u) {
             const long base = (q - quads_n - quads_u) * 4;
