@@ -362,12 +362,6 @@ typedef struct {
     int32_t* run_digits;                 /* [B] rec_num_digits              */
     float* loss_item;                    /* [B] run_loss + rec_loss         */
     int32_t B, N, C, w, Z;
-    /* nullable.  Given: the image's 1024 virtual threads run as FOUR workgroups of 256 (grid B x 4: one per CU at
-     * B = 64) and the 16 wave partial sums of its Bernoulli cross-entropy go to rec_part[B][16]; rec_loss / loss_item
-     * are then NOT written here but by the next launch, which adds the partials in the one-workgroup order --
-     * air_write_bwd (fin_rec_part ...) in a train step, air_finalize_parts after a plain forward.  Bit-identical. */
-    float* rec_part;
-    int32_t bands;                       /* with rec_part: 4 (0 = 4) workgroups of 256 threads, or 2 of 512, per image */
     /* nullable, [N*B] (N*B <= 4096): one extra workgroup of this launch sorts the (image, step) items by the work the
      * graph-order write backward will have with them (its corner terms; inactive items last) and leaves the permutation
      * here -- air_write_bwd_t.order.  Worth it when there are more items than CUs (128 x 128, b = 256: 1280 items). */
@@ -396,10 +390,6 @@ typedef struct {
     const float* fin_loss_item; const int32_t* fin_targets; const int32_t* fin_digits;
     float* fin_scalars;
     uint16_t* d_gen_pre16;               /* bf16 twin of d_gen_pre (nullable) */
-    /* after a BANDED compose launch (air_write_fwd_t.rec_part; needs fin_scalars): the finisher first completes the
-     * per-image sums -- rec_loss[i] = -(sum of the 16 partials), loss_item[i] = run_loss[i] + rec_loss[i] -- and writes
-     * them (fin_loss_item is then not read).  All four nullable together. */
-    const float* fin_rec_part; const float* fin_run_loss; float* fin_rec_loss; float* fin_loss_item_out;
     /* nullable (literal 2 only): workgroup i of the launch computes item order[i] = t * B + b instead of item i -- the
      * longest-first permutation of air_write_fwd_t.wb_order (the hardware hands workgroups out in launch order).  Results
      * do not depend on it.  With `order` the batch-mean finisher is the LAST workgroup of the launch. */
@@ -458,9 +448,6 @@ int air_bce_fwd_bwd(const float* images, const float* run_recon, const float* dy
  * scalars[0] = loss, scalars[1] = accuracy */
 int air_finalize(const float* run_loss, const float* rec_loss, const int32_t* targets,
                  const int32_t* digits, float* loss_per_item, float* scalars, int B, void* stream);
-/* the same after a BANDED compose launch (air_write_fwd_t.rec_part [B,16]): rec_loss / loss_per_item are completed here */
-int air_finalize_parts(const float* run_loss, const float* rec_part, float* rec_loss, const int32_t* targets,
-                       const int32_t* digits, float* loss_per_item, float* scalars, int B, void* stream);
 
 /* ---- step prologue: annealing schedules + Philox noise ------------------------
  * Evaluates `nsched` schedules at istate[GLOBAL_STEP] into dyn, and fills

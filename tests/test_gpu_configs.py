@@ -137,10 +137,10 @@ def test_stress_config_as_benchmarked_bf16_b256(am, monkeypatch):
     images, targets = blob_canvases(B, hp["canvas_size"], hp["max_digits"], seed=6)
     params, noise = ao.init_params(hp, 0), ao.make_noise(hp, B, 3)
 
-    def make(twins):
+    def make(twins, **kw):
         am.reset_default_graph()
         m = am.AIRModel(torch.tensor(images, device="cuda"), torch.tensor(targets, device="cuda"), cnn=False, train=True,
-                        scope="air", gemm_precision="bf16", backward="reference", bf16_twins=twins, **hp)
+                        scope="air", gemm_precision="bf16", backward="reference", bf16_twins=twins, **kw, **hp)
         m.load_state_dict(params)
         m.set_noise(noise)
         m.set_dynamic(z_pres_prior_log_odds=-2.0)
@@ -154,7 +154,6 @@ def test_stress_config_as_benchmarked_bf16_b256(am, monkeypatch):
         return dict(params=st.params.clone(), m=st.m.clone(), v=st.v.clone(), grads=st.grads.clone(), gnorm=st.gnorm.clone(),
                     recon=m.reconstruction.clone(), att=m.att.clone(), vrec=m.vrec.clone(), h=m.h.clone())
 
-    monkeypatch.delenv("AIR_XW_TILE", raising=False)
     m = make(True)
     assert m._twins
     names = [op.kernel for op in m.train_step_ops()]
@@ -188,10 +187,9 @@ def test_stress_config_as_benchmarked_bf16_b256(am, monkeypatch):
     three_steps(m)
 
     # the same x.Wx tiling on both sides (latency tiles, 4 slabs): twins on == twins off, bit for bit
-    monkeypatch.setenv("AIR_XW_TILE", "4,2,4")
     res = {}
     for tw in (False, True):
-        mm = make(tw)
+        mm = make(tw, xw_tile=(4, 2, 4))
         assert mm._twins == tw
         assert not any("gemm_xw_tp_kernel" in op.kernel for op in mm.train_step_ops())
         nprob = len(mm._wgrad_arr)       # strips only with twins: the comparison below is strips vs one tile per workgroup
@@ -205,7 +203,6 @@ def test_stress_config_as_benchmarked_bf16_b256(am, monkeypatch):
     # ... and the throughput-tiled default differs from it only by the summation order of x.Wx: same forward up to fp32
     # rounding of a K = 16384 sum (then bf16 rounding of h).  After an update the two runs are not comparable element
     # by element: the gradient carries the reference's chaotic rounding residue.
-    monkeypatch.delenv("AIR_XW_TILE", raising=False)
     dh = float((fwd_default["h"] - fwd_latency["h"]).abs().max())
     dr = float((fwd_default["recon"] - fwd_latency["recon"]).abs().mean())
     print("throughput vs latency tiling of x.Wx: |dh| %.2e, mean |d recon| %.2e, loss %.6f vs %.6f" %

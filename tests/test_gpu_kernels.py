@@ -1493,63 +1493,6 @@ def test_gemm_lstm_tiles_read_gate_interleaved_panels_bit_identically(H):
         np.testing.assert_allclose(res2[0][1].cpu().numpy(), cn, atol=5e-5)
 
 
-@pytest.mark.parametrize("Cc,w,N,B,Z", [(50, 28, 3, 6, 50), (128, 28, 5, 4, 50), (33, 17, 4, 5, 7)])
-def test_compose_in_bands_is_bit_identical_to_one_workgroup_per_image(H, Cc, w, N, B, Z):
-    """air_write_fwd with rec_part (an image's 1024 virtual threads as four workgroups of 256, grid B x 4) + the sums
-    completed by the next launch (air_finalize_parts after a plain forward; air_write_bwd's finisher in a train step)
-    == the one-workgroup launch + air_finalize, BIT FOR BIT: reconstruction, its gradient, KLs, running loss, digit
-    counts, reconstruction_loss, per-item ELBO and the batch means (air_model.py:351-366, 429-439, 580-611)."""
-    rng = np.random.RandomState(Cc + N)
-    lib = H.lib()
-    att = np.zeros((N, B, H.ATT_STRIDE), np.float32)
-    att[:, :, H.ATT_S] = rng.uniform(0.2, 0.7, (N, B)); att[:, :, H.ATT_X] = rng.uniform(-0.7, 0.7, (N, B))
-    att[:, :, H.ATT_Y] = rng.uniform(-0.7, 0.7, (N, B)); att[:, :, H.ATT_Z] = rng.uniform(0.2, 1.0, (N, B))
-    alive = np.cumprod(rng.uniform(0, 1, (N, B)) < 0.8, axis=0).astype(np.float32)
-    att[:, :, H.ATT_MASK] = alive
-    att[1:, :, H.ATT_MASK_PREV] = alive[:-1]; att[0, :, H.ATT_MASK_PREV] = 1.0
-    for k in (H.ATT_KL_Z, H.ATT_KL_SCALE, H.ATT_KL_SHIFT):
-        att[:, :, k] = rng.uniform(0, 3, (N, B))
-    vrec = rng.uniform(0, 1, (N, B, w * w)).astype(np.float32)
-    ml = rng.uniform(-1, 1, (N, B, 2 * Z)).astype(np.float32)
-    images = (rng.uniform(0, 1, (B, Cc * Cc)) * (rng.uniform(0, 1, (B, Cc * Cc)) < 0.2)).astype(np.float32)
-    targets = rng.randint(0, N + 1, B).astype(np.int32)
-    dyn = np.zeros(H.DYN_COUNT, np.float32)
-    dyn[H.DYN_VAE_PM], dyn[H.DYN_VAE_PV], dyn[H.DYN_VAE_PLV], dyn[H.DYN_GRAD_SCALE] = 0.0, 1.0, 0.0, 1.0 / B
-    t = lambda a_, dt=torch.float32: torch.tensor(a_, dtype=dt, device="cuda")  # noqa: E731
-    vrec_d, ml_d, img_d, dyn_d, tg_d = t(vrec), t(ml), t(images), t(dyn), t(targets, torch.int32)
-    res = {}
-    for mode in ("one", "bands", "bands2", "bands_train"):
-        att_d = t(att)
-        recon, d_recon = torch.full((B, Cc * Cc), 7.0, device="cuda"), torch.full((B, Cc * Cc), 7.0, device="cuda")
-        rec_loss, run_loss, loss_item, scal = (torch.full((n_,), 7.0, device="cuda") for n_ in (B, B, B, 4))
-        digits = torch.full((B,), 7, dtype=torch.int32, device="cuda")
-        part = torch.full((B, 16), 7.0, device="cuda") if mode != "one" else None
-        wf = H.WriteFwd(_p(vrec_d), _p(ml_d), _p(img_d), _p(dyn_d), _p(att_d), _p(recon), _p(rec_loss), _p(d_recon),
-                        _p(run_loss), _p(digits), _p(loss_item), B, N, Cc, w, Z, _p(part), 2 if mode == "bands2" else 0)
-        H.check(lib.air_write_fwd(C.byref(wf), _stream()), "air_write_fwd")
-        if mode == "one":
-            H.check(lib.air_finalize(_p(run_loss), _p(rec_loss), _p(tg_d), _p(digits), _p(loss_item), _p(scal), B, _stream()))
-        elif mode in ("bands", "bands2"):
-            torch.cuda.synchronize()
-            assert float(rec_loss[0]) == 7.0 and float(loss_item[0]) == 7.0        # not written by the banded launch itself
-            H.check(lib.air_finalize_parts(_p(run_loss), _p(part), _p(rec_loss), _p(tg_d), _p(digits), _p(loss_item), _p(scal), B, _stream()))
-        else:
-            dgen, dsx = torch.zeros(N, B, w * w, device="cuda"), torch.zeros(N, B, 4, device="cuda")
-            wb = H.WriteBwd(_p(d_recon), _p(vrec_d), _p(att_d), _p(dgen), _p(dsx), B, N, Cc, w, 2, None, _p(tg_d), _p(digits), _p(scal),
-                            None, _p(part), _p(run_loss), _p(rec_loss), _p(loss_item))
-            H.check(lib.air_write_bwd(C.byref(wb), _stream()), "air_write_bwd")
-        torch.cuda.synchronize()
-        res[mode] = [recon, d_recon, rec_loss, run_loss, loss_item, digits, scal[:2].clone(), att_d]
-    for mode in ("bands", "bands2", "bands_train"):
-        for a0, a1 in zip(res["one"], res[mode]):
-            assert torch.equal(a0, a1), mode
-    assert float(res["one"][2].abs().min()) > 0 and bool(torch.isfinite(res["one"][6]).all())
-    # a finisher that is given the partials but not the buffers to complete is refused
-    wb = H.WriteBwd(_p(d_recon), _p(vrec_d), _p(att_d), _p(dgen), _p(dsx), B, N, Cc, w, 2, None, _p(tg_d), _p(digits), _p(scal),
-                    None, _p(part), None, None, None)
-    assert lib.air_write_bwd(C.byref(wb), _stream()) == -1
-
-
 @pytest.mark.parametrize("Cc,w,N,B", [(128, 28, 5, 64), (50, 28, 3, 16)])
 def test_write_bwd_takes_its_items_longest_first_without_changing_results(H, Cc, w, N, B):
     """air_write_fwd_t.wb_order: one extra workgroup of the compose launch sorts the (image, step) items by the corner
@@ -1582,11 +1525,11 @@ def test_write_bwd_takes_its_items_longest_first_without_changing_results(H, Cc,
         digits = torch.zeros(B, dtype=torch.int32, device="cuda")
         order = torch.full((NB,), -1, dtype=torch.int32, device="cuda") if ordered else None
         wf = H.WriteFwd(_p(vrec_d), _p(ml_d), _p(img_d), _p(dyn_d), _p(att_d), _p(recon), _p(rec_loss), _p(d_recon),
-                        _p(run_loss), _p(digits), _p(loss_item), B, N, Cc, w, Z, None, 0, _p(order))
+                        _p(run_loss), _p(digits), _p(loss_item), B, N, Cc, w, Z, _p(order))
         H.check(lib.air_write_fwd(C.byref(wf), _stream()), "air_write_fwd")
         dgen, dsx = torch.full((N, B, w * w), 7.0, device="cuda"), torch.full((N, B, 4), 7.0, device="cuda")
         wb = H.WriteBwd(_p(d_recon), _p(vrec_d), _p(att_d), _p(dgen), _p(dsx), B, N, Cc, w, 2, _p(loss_item), _p(tg_d), _p(digits), _p(scal),
-                        None, None, None, None, None, _p(order))
+                        None, _p(order))
         H.check(lib.air_write_bwd(C.byref(wb), _stream()), "air_write_bwd")
         torch.cuda.synchronize()
         res[ordered] = (recon, d_recon, rec_loss, loss_item, dgen, dsx, scal[:2].clone())
@@ -1614,7 +1557,7 @@ def test_write_bwd_takes_its_items_longest_first_without_changing_results(H, Cc,
         assert torch.equal(a0, a1)
     assert float(res[True][4].abs().max()) > 0 and not bool((res[True][5] == 7.0).any())
     # refused: an order with a backward that is not the graph-order one; too many items to sort
-    wb = H.WriteBwd(_p(d_recon), _p(vrec_d), _p(att_d), _p(dgen), _p(dsx), B, N, Cc, w, 0, None, None, None, None, None, None, None, None, None, _p(order))
+    wb = H.WriteBwd(_p(d_recon), _p(vrec_d), _p(att_d), _p(dgen), _p(dsx), B, N, Cc, w, 0, None, None, None, None, None, _p(order))
     assert lib.air_write_bwd(C.byref(wb), _stream()) == -1
 
 

@@ -96,14 +96,14 @@ class AttendBwd(C.Structure):
 class WriteFwd(C.Structure):
     _fields_ = [("vrec", _p), ("ml", _p), ("images", _p), ("dyn", _p), ("att", _p), ("recon", _p),
                 ("rec_loss", _p), ("d_recon", _p), ("run_loss", _p), ("run_digits", _p), ("loss_item", _p),
-                ("B", _i), ("N", _i), ("C", _i), ("w", _i), ("Z", _i), ("rec_part", _p), ("bands", _i), ("wb_order", _p)]
+                ("B", _i), ("N", _i), ("C", _i), ("w", _i), ("Z", _i), ("wb_order", _p)]
 
 
 class WriteBwd(C.Structure):
     _fields_ = [("d_recon", _p), ("vrec", _p), ("att", _p), ("d_gen_pre", _p), ("d_sxy_write", _p),
                 ("B", _i), ("N", _i), ("C", _i), ("w", _i), ("literal", _i),
                 ("fin_loss_item", _p), ("fin_targets", _p), ("fin_digits", _p), ("fin_scalars", _p), ("d_gen_pre16", _p),
-                ("fin_rec_part", _p), ("fin_run_loss", _p), ("fin_rec_loss", _p), ("fin_loss_item_out", _p), ("order", _p)]
+                ("order", _p)]
 
 
 class BottleneckFwd(C.Structure):
@@ -151,7 +151,6 @@ _SIGNATURES = {
     "air_write_bwd": (C.c_int, [C.POINTER(WriteBwd), _p]),
     "air_bce_fwd_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, C.c_int, C.c_int, _p]),
     "air_finalize": (C.c_int, [_p, _p, _p, _p, _p, _p, C.c_int, _p]),
-    "air_finalize_parts": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, C.c_int, _p]),
     "air_step_begin": (C.c_int, [_p, C.c_int, _p, _p, _p, C.c_int64, _p, C.c_int64, C.c_uint64, _p, _p, C.c_int64, _p]),
     "air_optim_num_partials": (C.c_int, [C.c_int64]),
     "air_grad_sqnorm": (C.c_int, [_p, C.c_int64, _p, _p, _p]),

@@ -290,7 +290,7 @@ class AIRModel:
                  learning_rate=1e-3, gradient_clipping_norm=100.0, cnn=True, cnn_filters=8,
                  num_summary_images=60, train=False, reuse=False, scope="air",
                  annealing_schedules=None, seed=0, gemm_precision=None, backward="reference", noise_seed=None,
-                 input_weight_gradient="stored", bf16_twins=None, dp_exchange=None):
+                 input_weight_gradient="stored", bf16_twins=None, dp_exchange=None, xw_tile=None):
         if cnn:
             # reference :510-533; every caller passes cnn=False (training.py:108, demo.py:24)
             raise NotImplementedError("cnn=True front-end is outside the accelerated hot path; pass cnn=False")
@@ -358,9 +358,7 @@ class AIRModel:
         # bf16 path: every GEMM operand also exists as a bf16 twin in memory (written by the producing kernel /
         # by Adam), so the GEMMs read 2-byte operands and convert nothing -- bit-identical results (the twin IS
         # the rounding the fp32-operand kernels apply on the way into LDS).  bf16_twins=False keeps fp32 operands.
-        if bf16_twins is None:
-            bf16_twins = os.environ.get("AIR_BF16_TWINS", "1") != "0"
-        self._twins = bool(bf16_twins) and self._prec == 1
+        self._twins = (True if bf16_twins is None else bool(bf16_twins)) and self._prec == 1
 
         dev = input_images.device
         if tuple(input_images.shape) != (self.batch_size, canvas_size * canvas_size) or \
@@ -489,8 +487,8 @@ class AIRModel:
         if self._twins and D > 4096 and B % 64 == 0 and R % 16 == 0 and D % 512 == 0:
             # full batches of a large canvas: the throughput tiling (64 x 64 per workgroup, 8 K-slabs), gemm_xw_tp_kernel
             self._xw_ksplit, self._xw_tile = 8, (8, 4)
-        if os.environ.get("AIR_XW_TILE"):                    # tuning hook: "tm,tn,ksplit" (ksplit <= 8 slabs)
-            tm_, tn_, ks_ = (int(v) for v in os.environ["AIR_XW_TILE"].split(","))
+        if xw_tile is not None:                              # (tile_m, tile_n, ksplit <= 8) in 16-row / 16-column units: the split-K
+            tm_, tn_, ks_ = (int(v) for v in xw_tile)        # product on THAT tiling (tests: a common tiling for bit-identity)
             self._xw_ksplit, self._xw_tile = ks_, (tm_, tn_)
         # ONE launch computes x.Wx (no split-K) and, in its epilogue, the first LSTM step (zero state: no h.Wh) --
         # AIR_EPI_LSTM_FWD0 on four-unit x four-gate tiles.  On the row-major shadow of Wx such a tile reads 8-byte pieces
@@ -501,8 +499,7 @@ class AIRModel:
         # AIR_STEP0_FUSION=0 / 1 forces it off / on.
         env0 = os.environ.get("AIR_STEP0_FUSION")
         want0 = (env0 == "1") if env0 in ("0", "1") else (self._prec == 1 and D <= 4096)
-        self._fuse_step0 = (want0 and self.store.fuse_step0 and R % 4 == 0 and D % 4 == 0
-                            and not os.environ.get("AIR_XW_TILE"))
+        self._fuse_step0 = want0 and self.store.fuse_step0 and R % 4 == 0 and D % 4 == 0 and xw_tile is None
         self._xw_slabs = 1 if self._fuse_step0 else self.lib.air_gemm_slabs(D, self._xw_ksplit)
         self.xw = f(self._xw_slabs, B, 4 * R)            # x.Wx (split-K slabs when not fused)
         self.gates_pre = f(B, 4 * R)
@@ -569,11 +566,6 @@ class AIRModel:
               A16=None, B16=None, C16=None, q0_16=None, q2_16=None, B16p=None):
         p = list(p) + [None] * (4 - len(p))
         q = list(q) + [None] * (3 - len(q))
-        if epi == H.EPI_GENERIC and tile == (0, 0) and os.environ.get("AIR_EXP_TILES"):      # tuning hook: "N:tm,tn;N:tm,tn"
-            for item in os.environ["AIR_EXP_TILES"].split(";"):
-                n_, t_ = item.split(":")
-                if int(n_) == N:
-                    tile = tuple(int(v) for v in t_.split(","))
         g = H.Gemm(_ptr(A), _ptr(Bm), _ptr(Cm), M, N, K, lda, ldb, ldc, ta, tb, _ptr(bias), _ptr(addend), ldadd,
                    _ptr(aux), ldaux, aux_scale, act, actgrad, accumulate, self._prec,
                    epi, tile[0], tile[1], ksplit, addend_slabs, i0,
@@ -591,7 +583,7 @@ class AIRModel:
                    flops=2 * M * N * K, kernel=kbuf.value.decode())
 
     _KERNEL_OF = {"air_lstm_first_step": "lstm_first_step_kernel", "air_step_begin": "step_begin_kernel", "air_attend_fwd": "attend_fwd_kernel",
-                  "air_attend_bwd": "attend_bwd_kernel", "air_write_fwd": "write_fwd_kernel<1024, false>",
+                  "air_attend_bwd": "attend_bwd_kernel", "air_write_fwd": "write_fwd_kernel<1024>",
                   "air_write_bwd": "write_bwd_kernel", "air_finalize": "finalize_kernel",
                   "air_grad_sqnorm": "grad_sqnorm_kernel", "air_adam_clip_step": "adam_clip_kernel",
                   "air_vae_bottleneck_fwd": "bottleneck_fwd_kernel<256>", "air_vae_bottleneck_bwd": "bottleneck_bwd_kernel<256>"}
@@ -649,7 +641,7 @@ class AIRModel:
             # largest operand is converted from fp32 inside the kernel -- correct, and a silent perf cliff otherwise
             import warnings
             warnings.warn("AIRModel(scope=%r): bf16 twins are on but x.Wx reads the fp32 Wx (the scope's store maintains only the "
-                          "panel twin of Wx; this model does not fuse the first step / use panels: D %% 4 = %d, AIR_XW_TILE / "
+                          "panel twin of Wx; this model does not fuse the first step / use panels: D %% 4 = %d, xw_tile / "
                           "AIR_NO_PANELS / AIR_STEP0_FUSION set?)" % (self.scope, D % 4), RuntimeWarning, stacklevel=3)
         if self._fuse_step0:
             # the first step rides in the x.Wx launch: h_0 = c_0 = 0 (zero_state, :540), so its gates are x.Wx + b
@@ -739,15 +731,6 @@ class AIRModel:
         fwd.append(self._gemm(x, P["out_w"], self.vrec, NB, d, k, k, d, d, bias=P["out_b"],
                               act=H.ACT_SIGMOID_NOISE, aux=self.eps_x, ldaux=d,
                               aux_scale=float(self.vae_likelihood_std), tag="vae_out", A16=x16, B16=T("out_w"), B16p=TP("out_w")))
-        # compose can run as 2 or 4 workgroups per image (AIR_COMPOSE_BANDS=2 / 4: B x bands workgroups instead of B of 1024
-        # threads); the per-image sums are then completed by the next launch in the one-workgroup order -- bit-identical
-        # (measured on MI355X: compose 7.7 us as one workgroup, 8.5 us in 4 bands, ~7.7 in 2 -- every band repeats the set-up
-        # loads, the pixel loop was never the long part; 31 -> 35.5 us at 128 x 128.  Default: one workgroup per image.)
-        bands = int(os.environ.get("AIR_COMPOSE_BANDS", "0"))
-        if bands not in (0, 2, 4):
-            raise ValueError("AIR_COMPOSE_BANDS must be 0, 2 or 4")
-        banded = bands != 0
-        self._rec_part = torch.zeros(B, 16, dtype=torch.float32, device=imgs.device) if banded else None
         # more (image, step) items than CUs: the graph-order write backward takes them longest first (one extra workgroup of
         # the compose launch sorts them; air_write_fwd_t.wb_order).  AIR_WB_ORDER=0 / 1 forces it off / on.
         env_o = os.environ.get("AIR_WB_ORDER")
@@ -756,21 +739,14 @@ class AIRModel:
                           if (want_o and self.train and self._literal >= 2 and NB <= 4096) else None)
         wf = H.WriteFwd(_ptr(self.vrec), _ptr(self.ml), _ptr(imgs), _ptr(self.dyn), _ptr(self.att),
                         _ptr(self._recon), _ptr(self._rec_loss), _ptr(self.d_recon if self.train else None),
-                        _ptr(self.run_loss), _ptr(self.run_digits), _ptr(self._loss_item), B, N, Cc, w, Z, _ptr(self._rec_part), bands,
-                        _ptr(self._wb_order))
+                        _ptr(self.run_loss), _ptr(self.run_digits), _ptr(self._loss_item), B, N, Cc, w, Z, _ptr(self._wb_order))
         keep.append(wf)
         fwd.append(self._call("air_write_fwd", C.byref(wf),
                               nbytes=NB * (d + 2 * Z) * 4 + B * D * 4 * (3 if self.train else 2), tag="compose_fwd"))
-        fwd[-1].kernel = "write_fwd_kernel<%d, true>" % (1024 // bands) if banded else "write_fwd_kernel<1024, false>"
         # batch means: their own launch after a plain forward; inside air_write_bwd in a train step
-        if banded:
-            self._finalize = self._call("air_finalize_parts", _ptr(self.run_loss), _ptr(self._rec_part), _ptr(self._rec_loss),
-                                        _ptr(self.target_num_digits), _ptr(self.run_digits), _ptr(self._loss_item),
-                                        _ptr(self.scalars), B, tag="finalize")
-        else:
-            self._finalize = self._call("air_finalize", _ptr(self.run_loss), _ptr(self._rec_loss),
-                                        _ptr(self.target_num_digits), _ptr(self.run_digits), _ptr(self._loss_item),
-                                        _ptr(self.scalars), B)
+        self._finalize = self._call("air_finalize", _ptr(self.run_loss), _ptr(self._rec_loss),
+                                    _ptr(self.target_num_digits), _ptr(self.run_digits), _ptr(self._loss_item),
+                                    _ptr(self.scalars), B)
         self._fwd = fwd
         twin_job = ((_ptr(imgs), _ptr(self.images16), imgs.numel()) if self.images16 is not None else (None, None, 0))
         self._begin_sched_only = self._call(
@@ -822,12 +798,10 @@ class AIRModel:
         lit = self._literal
         wb = H.WriteBwd(_ptr(self.d_recon), _ptr(self.vrec), _ptr(self.att), _ptr(self.d_genpre),
                         _ptr(self.d_sxyw), B, N, Cc, w, lit, None, None, None, None, _ptr(self.d_genpre16),
-                        None, None, None, None, _ptr(self._wb_order))
+                        _ptr(self._wb_order))
         wbf = H.WriteBwd(_ptr(self.d_recon), _ptr(self.vrec), _ptr(self.att), _ptr(self.d_genpre),
                          _ptr(self.d_sxyw), B, N, Cc, w, lit, _ptr(self._loss_item), _ptr(self.target_num_digits),
-                         _ptr(self.run_digits), _ptr(self.scalars), _ptr(self.d_genpre16),
-                         *((_ptr(self._rec_part), _ptr(self.run_loss), _ptr(self._rec_loss), _ptr(self._loss_item))
-                           if self._rec_part is not None else (None, None, None, None)), _ptr(self._wb_order))
+                         _ptr(self.run_digits), _ptr(self.scalars), _ptr(self.d_genpre16), _ptr(self._wb_order))
         keep += [wb, wbf]
         kbuf = C.create_string_buffer(96)
         H.check(self.lib.air_write_bwd_kernel_name(C.byref(wb), kbuf, 96), "air_write_bwd_kernel_name")

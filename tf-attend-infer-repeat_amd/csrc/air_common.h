@@ -139,24 +139,6 @@ __device__ __forceinline__ float air_block_sum_256(float v, float* red) {
     return ((red[0] + red[1]) + red[2]) + red[3];
 }
 
-// reconstruction_loss / per-item ELBO of image i from the 16 wave partials a banded compose launch left
-// (air_write_fwd_t.rec_part), added in the order of air_block_sum_n<16>: exactly what the one-workgroup compose kernel
-// stores (air_model.py:586-593)
-__device__ __forceinline__ float air_compose_finish(const float* __restrict__ rec_part, const float* __restrict__ run_loss,
-                                                    float* __restrict__ rec_loss, float* __restrict__ loss_item, int i) {
-    const float* pp = rec_part + (size_t)i * 16;
-    float v[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = pp[k];
-    float t = v[0];
-#pragma unroll
-    for (int k = 1; k < 16; ++k) t += v[k];
-    const float rl = -t, li = run_loss[i] + rl;
-    rec_loss[i] = rl;
-    loss_item[i] = li;
-    return li;
-}
-
 // clip_by_global_norm + ApplyAdam coefficients, identical in every workgroup: the partial sums are
 // re-reduced in one fixed order (air_model.py:673, TF 1.3 training_ops ApplyAdam).
 struct AirAdamCoef { float scale, lr_t, gnorm; };

@@ -889,7 +889,7 @@ int launch(const air_gemm_t* g, const Args& a0, hipStream_t s) {
                         ((epi == AIR_EPI_LSTM_BWD || epi == AIR_EPI_LSTM_BWD_TAIL || epi == AIR_EPI_REPARAM_BWD) && T11);
     if (!epi_ok) return AIR_EINVAL;
     // the four-unit column map of LSTM_FWD0 only exists in the lean kernels
-    if (epi == AIR_EPI_LSTM_FWD0 && (!use_bf16_v2(a, TA, TB) || (g->precision == 0 && getenv("AIR_GEMM_F32_V1") != nullptr))) return AIR_EALIGN;
+    if (epi == AIR_EPI_LSTM_FWD0 && !use_bf16_v2(a, TA, TB)) return AIR_EALIGN;
 #define AIR_V2_LAUNCH(KERNEL, LDS)                                                                                     \
     do {                                                                                                                \
         if (epi == AIR_EPI_GENERIC) hipLaunchKernelGGL((KERNEL<TM, TN, TB, AIR_EPI_GENERIC>), grid, dim3(THREADS), LDS, s, a);      \
@@ -904,9 +904,8 @@ int launch(const air_gemm_t* g, const Args& a0, hipStream_t s) {
     } while (0)
     if constexpr (T14 && !TB && !TA) {
         // exact-fp32 LSTM step on four-unit x four-gate tiles (as the bf16-twin path does): 4 x the workgroups, a quarter of
-        // the operand bytes each; AIR_LSTM_FWD_WIDE keeps the 64-column grouped tiles
-        if (g->precision == 0 && epi == AIR_EPI_LSTM_FWD && (a.gwidth & 3) == 0 && use_bf16_v2(a, TA, TB) &&
-            getenv("AIR_GEMM_F32_V1") == nullptr && getenv("AIR_LSTM_FWD_WIDE") == nullptr && !a.job_on) {
+        // the operand bytes each
+        if (g->precision == 0 && epi == AIR_EPI_LSTM_FWD && (a.gwidth & 3) == 0 && use_bf16_v2(a, TA, TB) && !a.job_on) {
             using CfgQ = F32V2Cfg<1, 1>;
             auto kq = gemm_f32v2_kernel<1, 1, false, EPI_LSTM_FWD_Q>;
             const int rcq = air_grant_lds(reinterpret_cast<const void*>(kq), CfgQ::BYTES);
@@ -922,7 +921,7 @@ int launch(const air_gemm_t* g, const Args& a0, hipStream_t s) {
         if (v2) AIR_V2_LAUNCH(gemm_bf16v2_kernel, 0);
         else hipLaunchKernelGGL((gemm_bf16_kernel<TM, TN, TA, TB>), grid, dim3(THREADS), 0, s, a);
     }
-    else if (use_bf16_v2(a, TA, TB) && getenv("AIR_GEMM_F32_V1") == nullptr) {   // same operand requirements
+    else if (use_bf16_v2(a, TA, TB)) {   // same operand requirements
         using Cfg = F32V2Cfg<TM, TN>;
         if (Cfg::BYTES > 48 * 1024) {
             // opt-in to the large dynamic LDS once per (kernel function, device): all epilogue variants of this tile
@@ -962,10 +961,8 @@ void resolve_tile(const air_gemm_t* g, int& tm, int& tn) {
         if (t11 <= 1024) { tm = 1; tn = 1; }
         else if (t11 <= 4096) { tm = 2; tn = 2; }
         else { tm = 2; tn = 4; }
-        // AIR_GEMM_BIG_TILE="tm,tn": the tile of the products beyond 1024 16x16 tiles (M = N*B = 1280 rows at 128 x 128), A/B
-        static const int big = [] { const char* e = getenv("AIR_GEMM_BIG_TILE"); int a = 0, b = 0;
-                                    return (e && sscanf(e, "%d,%d", &a, &b) == 2) ? a * 16 + b : 0; }();
-        if (big && t11 > 1024) { tm = big / 16; tn = big % 16; }
+        // (larger tiles for the products beyond 1024 16x16 tiles -- M = N*B = 1280 rows at 128 x 128 -- measured in round 4:
+        // 0.570 -> 0.655 .. 0.73 ms per step; these kernels split K over their waves and live on occupancy)
     }
 }
 
@@ -973,8 +970,7 @@ void resolve_tile(const air_gemm_t* g, int& tm, int& tn) {
 bool use_bf16_v2(const Args& a, bool ta, bool tb) {
     auto al8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; };
     return !ta && al8(a.A) && al8(a.B) && (a.lda & 1) == 0 && (a.ldb & 1) == 0 && (a.K & 1) == 0 &&
-           (tb || ((a.N & 1) == 0 && (a.gstride & 1) == 0 && (a.gwidth & 1) == 0)) &&
-           getenv("AIR_GEMM_BF16_V1") == nullptr;
+           (tb || ((a.N & 1) == 0 && (a.gstride & 1) == 0 && (a.gwidth & 1) == 0));
 }
 
 template <bool TA, bool TB>
@@ -1041,8 +1037,8 @@ extern "C" int air_gemm_kernel_name(const air_gemm_t* g, char* buf, int n) {
     }
     if (g->precision == 1 && use_bf16_v2(a, ta, tb))
         snprintf(buf, n, "gemm_bf16v2_kernel<%d, %d, %s, %d>", tm, tn, tb ? "true" : "false", g->epi);
-    else if (g->precision == 0 && use_bf16_v2(a, ta, tb) && getenv("AIR_GEMM_F32_V1") == nullptr) {
-        if (g->epi == AIR_EPI_LSTM_FWD && !ta && !tb && (a.gwidth & 3) == 0 && getenv("AIR_LSTM_FWD_WIDE") == nullptr && !g->step_job)
+    else if (g->precision == 0 && use_bf16_v2(a, ta, tb)) {
+        if (g->epi == AIR_EPI_LSTM_FWD && !ta && !tb && (a.gwidth & 3) == 0 && !g->step_job)
             snprintf(buf, n, "gemm_f32v2_kernel<1, 1, false, %d>", EPI_LSTM_FWD_Q);
         else
             snprintf(buf, n, "gemm_f32v2_kernel<%d, %d, %s, %d>", tm, tn, tb ? "true" : "false", g->epi);

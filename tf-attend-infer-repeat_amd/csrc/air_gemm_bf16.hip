@@ -448,7 +448,7 @@ int twin_rounds(const Args& a, int tm, int tn, bool ta, bool tb) {
     // (a panel-blocked B twin serves the untransposed 16- / 32-column tiles and the four-unit LSTM tiles; everything
     // else needs the row-major twin)
     const bool pnl_tile = !tb && a.B16p != nullptr && ((tm == 1 && tn == 1) || (tm == 2 && tn == 2) || (tm == 1 && tn == 4));
-    if (ta || (!a.B16 && !pnl_tile) || getenv("AIR_GEMM_NO_TWINS") != nullptr) return 0;
+    if (ta || (!a.B16 && !pnl_tile)) return 0;
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const bool af32 = a.A16 == nullptr;
     // whole 16-byte pieces only: the ragged shapes keep the fp32-operand kernels
@@ -465,7 +465,7 @@ int twin_rounds(const Args& a, int tm, int tn, bool ta, bool tb) {
         // (K <= 2560: all 40 images in ONE round -- one memory round trip, 160 KB of LDS, one workgroup per CU)
         if (e == AIR_EPI_LSTM_FWD0)
             return (!tb && (a.gwidth & 3) == 0 && (int)((a.K + a.kslab - 1) / a.kslab) == 1)
-                       ? ((nimg <= 40 && nimg > 16 && getenv("AIR_FWD0_ROUNDS") == nullptr) ? 40 : 16) : 0;
+                       ? ((nimg <= 40 && nimg > 16) ? 40 : 16) : 0;
         if (af32) return 0;
         if (e == AIR_EPI_GENERIC || ((e == AIR_EPI_LSTM_BWD || e == AIR_EPI_LSTM_BWD_TAIL) && tb)) return nimg <= 4 ? 4 : (nimg <= 8 ? 8 : 16);
         return 0;
@@ -497,7 +497,7 @@ int twin_launch(const Args& a, int tm, int tn, bool tb, dim3 grid, hipStream_t s
     }
     if (tm == 1 && tn == 4) {
         // AIR_EPI_LSTM_FWD: 16-column tiles of four units x four gates where the layout allows (8-byte pieces of 4 units)
-        if ((a.gwidth & 3) == 0 && getenv("AIR_LSTM_FWD_WIDE") == nullptr) {
+        if ((a.gwidth & 3) == 0) {
             dim3 gq((a.gwidth + 3) / 4, grid.y, grid.z);
             Args b = a;
             if (a.job_on) {          // the carried job's planes were sized for the wide tiles' grid: same number of workgroups
@@ -533,11 +533,10 @@ int xw_tp_ok(const Args& a, int precision, bool ta, bool tb, int ksplit) {
     return 0;
 }
 
-// 64 x 128 tiles when they still give every CU a workgroup (AIR_XW_TP_BN=64 keeps the square tiles: A/B)
+// 64 x 128 tiles when they still give every CU a workgroup
 int xw_tp_columns(const Args& a) {
-    static const int bn_env = [] { const char* e = getenv("AIR_XW_TP_BN"); return e ? atoi(e) : 0; }();
     const long slabs = (a.K + a.kslab - 1) / a.kslab;
-    const bool wide = bn_env != 64 && (a.N % 128) == 0 && (bn_env == 128 || (long)(a.N / 128) * (a.M / 64) * slabs >= 256);
+    const bool wide = (a.N % 128) == 0 && (long)(a.N / 128) * (a.M / 64) * slabs >= 256;
     return wide ? 128 : 64;
 }
 
@@ -554,7 +553,7 @@ int xw_tp_launch(const Args& a0, int job_planes_hint, hipStream_t s) {
     (void)job_planes_hint;
     grid.z = (a.K + a.kslab - 1) / a.kslab + a.job_on;
     a.slab_stride = (long)a.M * a.ldc;
-    { const char* e = getenv("AIR_XW_TP_MAP"); a.i1 = (e && e[0] == 'p') ? 1 : 0; }      // (i1: unused by this kernel otherwise)
+    a.i1 = 0;
     if (wide) hipLaunchKernelGGL(gemm_xw_tp_kernel<128>, grid, dim3(THREADS), 0, s, a);
     else hipLaunchKernelGGL(gemm_xw_tp_kernel<64>, grid, dim3(THREADS), 0, s, a);
     AIR_CHECK_LAUNCH();
@@ -562,7 +561,7 @@ int xw_tp_launch(const Args& a0, int job_planes_hint, hipStream_t s) {
 }
 
 void twin_kernel_name(const Args& a, int tm, int tn, bool tb, char* buf, int n) {
-    if (tm == 1 && tn == 4 && (a.gwidth & 3) == 0 && getenv("AIR_LSTM_FWD_WIDE") == nullptr) {
+    if (tm == 1 && tn == 4 && (a.gwidth & 3) == 0) {
         snprintf(buf, n, "gemm_bf16tw_kernel<1, 1, false, %d, false, 4>", EPI_LSTM_FWD_Q);
         return;
     }

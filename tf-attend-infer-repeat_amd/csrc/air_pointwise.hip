@@ -182,21 +182,6 @@ __global__ __launch_bounds__(THREADS) void finalize_kernel(
     if (threadIdx.x == 0) { scalars[0] = sl / (float)B; scalars[1] = sa / (float)B; }
 }
 
-__global__ __launch_bounds__(THREADS) void finalize_parts_kernel(
-    const float* __restrict__ L, const float* __restrict__ rec_part, float* __restrict__ rec_loss, const int32_t* __restrict__ targets,
-    const int32_t* __restrict__ digits, float* __restrict__ loss_item, float* __restrict__ scalars, int B)
-{
-    __shared__ float red[4];
-    float sl = 0.0f, sa = 0.0f;
-    for (int b = threadIdx.x; b < B; b += THREADS) {
-        sl += air_compose_finish(rec_part, L, rec_loss, loss_item, b);
-        sa += (targets[b] == digits[b]) ? 1.0f : 0.0f;
-    }
-    sl = air_block_sum_256(sl, red);
-    sa = air_block_sum_256(sa, red);
-    if (threadIdx.x == 0) { scalars[0] = sl / (float)B; scalars[1] = sa / (float)B; }
-}
-
 // column sums (BiasAdd_grad): blockIdx.y = problem, blockIdx.x = 64-column strip.
 // 4 waves take interleaved rows; 8 independent loads in flight per thread.
 struct ColsumTable { air_colsum_t p[16]; };
@@ -339,15 +324,6 @@ extern "C" int air_finalize(const float* run_loss, const float* rec_loss, const 
     if (!run_loss || !rec_loss || !targets || !digits || !loss_per_item || !scalars || B <= 0) return AIR_EINVAL;
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(THREADS), 0, air_stream(stream),
                        run_loss, rec_loss, targets, digits, loss_per_item, scalars, B);
-    AIR_CHECK_LAUNCH();
-    return 0;
-}
-
-extern "C" int air_finalize_parts(const float* run_loss, const float* rec_part, float* rec_loss, const int32_t* targets,
-                                  const int32_t* digits, float* loss_per_item, float* scalars, int B, void* stream) {
-    if (!run_loss || !rec_part || !rec_loss || !targets || !digits || !loss_per_item || !scalars || B <= 0) return AIR_EINVAL;
-    hipLaunchKernelGGL(finalize_parts_kernel, dim3(1), dim3(THREADS), 0, air_stream(stream),
-                       run_loss, rec_part, rec_loss, targets, digits, loss_per_item, scalars, B);
     AIR_CHECK_LAUNCH();
     return 0;
 }

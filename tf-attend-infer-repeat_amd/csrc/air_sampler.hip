@@ -642,15 +642,10 @@ __global__ __launch_bounds__(THREADS) void attend_bwd_kernel(air_attend_bwd_t a)
 // 580-593).  One workgroup per image.
 // ---------------------------------------------------------------------------
 // 16 waves per image: the pixel loop is a chain of dependent LDS gathers and two logf per pixel; 4 waves per SIMD hide
-// that latency.  BANDS = false: ONE workgroup of 1024 threads per image (any caller of the C ABI).  BANDS = true (the
-// model's launch, a.rec_part given): the same 1024 "virtual threads" of an image are FOUR workgroups of 256 (grid
-// B x 4) -- 256 workgroups at B = 64 instead of 64, one per CU.  Virtual thread v = band * 256 + tid owns the pixels
-// v, v + 1024, ... exactly as before, so every per-thread and per-wave partial sum of the Bernoulli cross-entropy is
-// unchanged; the 16 wave partials go to rec_part[b][16] and whoever runs next (air_write_bwd's finisher, air_finalize)
-// adds them in the old order: reconstruction_loss and the ELBO are BIT-IDENTICAL to the one-workgroup form.  Band 0
-// also does the per-image bookkeeping (KLs, running loss, digit count).
+// that latency.  ONE workgroup of 1024 threads per image.  (An image as 2 or 4 workgroups -- 256 workgroups at B = 64,
+// the per-image sums finished by the next launch, bit-identical -- was built and measured in round 4: 7.7 us as one
+// workgroup, 8.5 in 4 bands, 7.7 in 2; 31 -> 35.5 us at 128 x 128: every band repeats the set-up loads.  Removed.)
 constexpr int CF_THREADS = 1024;
-constexpr int CF_BANDS = 4;
 
 // LONGEST-FIRST ORDER of the (image, step) items for the graph-order write backward (air_write_fwd_t.wb_order), computed
 // by ONE extra workgroup of the compose launch.  Why: the backward's workgroups differ by two orders of magnitude in work
@@ -674,7 +669,7 @@ __device__ __forceinline__ void wb_order_block(const air_write_fwd_t& a, unsigne
     int* basep = hist + WB_BUCKETS;                         // [WB_BUCKETS]
     for (int i = tid; i < 2 * WB_BUCKETS; i += nthreads) hist[i] = 0;
     __syncthreads();
-    constexpr int PER = (WB_ORDER_MAX + CF_THREADS / CF_BANDS - 1) / (CF_THREADS / CF_BANDS);      // items per thread, at most
+    constexpr int PER = (WB_ORDER_MAX + CF_THREADS - 1) / CF_THREADS;      // items per thread, at most
     int cls[PER], pos[PER];
 #pragma unroll
     for (int r = 0; r < PER; ++r) {
@@ -718,16 +713,16 @@ __device__ __forceinline__ void wb_order_block(const air_write_fwd_t& a, unsigne
         if (cls[r] >= 0) a.wb_order[basep[cls[r]] + pos[r]] = tid + r * nthreads;
 }
 
-template <int NT, bool BANDS>
+template <int NT>
 __global__ __launch_bounds__(NT) void write_fwd_kernel(air_write_fwd_t a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if (a.wb_order && (int)blockIdx.x == a.B) {                  // the one extra workgroup of the launch (block-uniform)
-        if (!BANDS || blockIdx.y == 0) wb_order_block(a, reinterpret_cast<unsigned*>(smem));
+        wb_order_block(a, reinterpret_cast<unsigned*>(smem));
         return;
     }
-    const int b = blockIdx.x, band = BANDS ? (int)blockIdx.y : 0, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int vt = band * NT + tid;                                       // virtual thread of the image, 0 .. 1023
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int vt = tid;
     const int C = a.C, w = a.w, Z = a.Z, N = a.N, B = a.B;
     float* sh_red = smem;                                    // [16]
     float* sh_z = smem + 16;                                 // [MAX_STEPS] z_pres
@@ -751,7 +746,7 @@ __global__ __launch_bounds__(NT) void write_fwd_kernel(air_write_fwd_t a)
 
     // phase A -- everything that only needs the per-step records, for all steps at once
     // (independent loads: one memory round trip instead of one per step)
-    if (band == 0) {
+    {
         for (int t = wave; t < N; t += NT / 64) {
             // VAE KL :479-493 (a public output whether or not the item is still active): one wave per step
             const float* ml = a.ml + ((size_t)t * B + b) * 2 * Z;
@@ -790,7 +785,7 @@ __global__ __launch_bounds__(NT) void write_fwd_kernel(air_write_fwd_t a)
     }
     __syncthreads();
     float Lkeep = 0.0f;
-    if (tid == 0 && band == 0) {
+    if (tid == 0) {
         // running loss in the reference order: z KL (old mask), scale, shift, VAE KL (new mask) :411-493
         float L = 0.0f;
         int digits = 0;
@@ -842,12 +837,6 @@ __global__ __launch_bounds__(NT) void write_fwd_kernel(air_write_fwd_t a)
             a.d_recon[base + p] = pass ? -gsc * (x / p1 - (1.0f - x) / p0) : 0.0f;
         }
     }
-    if (BANDS) {
-        // this band's four wave sums; the 16 of an image are added ((w0 + w1) + ...) + w15 by the consumer
-        acc = air_wave_sum(acc);
-        if (lane == 0) a.rec_part[(size_t)b * 16 + (vt >> 6)] = acc;
-        return;
-    }
     acc = air_block_sum_n<NT / 64>(acc, sh_red);
     if (tid == 0) {
         const float rl = -acc;
@@ -884,8 +873,7 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_kernel(air_write_bwd_t a
         // loss = mean(loss_item) :593,610; accuracy = mean(target == digits) :597-611 (air_finalize)
         float r4[4] = {0.f, 0.f, 0.f, 0.f};
         for (int i = tid; i < a.B; i += WB_THREADS) {
-            // (banded compose: the per-image sums are finished here, air_write_fwd_t.rec_part)
-            r4[0] += a.fin_rec_part ? air_compose_finish(a.fin_rec_part, a.fin_run_loss, a.fin_rec_loss, a.fin_loss_item_out, i) : a.fin_loss_item[i];
+            r4[0] += a.fin_loss_item[i];
             r4[1] += (a.fin_targets[i] == a.fin_digits[i]) ? 1.0f : 0.0f;
         }
         air_block_sum4<WB_THREADS / 64>(r4, sh_red);
@@ -1209,10 +1197,8 @@ __device__ __forceinline__ void write_bwd_graph_body(const air_write_bwd_t& a, i
 {
     constexpr bool BLOCKED = ORD != WB_ORD_GRAPH, CARRIED = ORD == WB_ORD_CARRIED;
     // seq_flags (accumulators(), below): bit 0 the LDS atomic pipe applies lanes in order, bit 1 the lane-ring accumulator
-    // is exact on this part (used when the pipe is not); bits 8..15: pipe / ring MIX factor c in sixteenths (0 = every
-    // corner on the pipe), see pipe_mask below
+    // is exact on this part (used when the pipe is not)
     const bool lds_ordered = seq_flags & 1, ring_ok = seq_flags & 2;
-    const int mix16 = (seq_flags >> 8) & 0xff;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // which (image, step) item this workgroup computes: its grid position, or -- a.order given -- entry `linear block id` of
     // the longest-first permutation the compose launch left (wb_order_block)
@@ -1243,8 +1229,7 @@ __device__ __forceinline__ void write_bwd_graph_body(const air_write_bwd_t& a, i
     if (a.fin_scalars && lin == (a.order ? (int)(gridDim.x * gridDim.y) - 1 : 0)) {     // (ordered: the lightest item's workgroup)
         float r4[4] = {0.f, 0.f, 0.f, 0.f};
         for (int i = tid; i < a.B; i += WB_THREADS) {
-            // (banded compose: the per-image sums are finished here, air_write_fwd_t.rec_part)
-            r4[0] += a.fin_rec_part ? air_compose_finish(a.fin_rec_part, a.fin_run_loss, a.fin_rec_loss, a.fin_loss_item_out, i) : a.fin_loss_item[i];
+            r4[0] += a.fin_loss_item[i];
             r4[1] += (a.fin_targets[i] == a.fin_digits[i]) ? 1.0f : 0.0f;
         }
         air_block_sum4<NW>(r4, sh_red);
@@ -1330,33 +1315,11 @@ __device__ __forceinline__ void write_bwd_graph_body(const air_write_bwd_t& a, i
     }
     __syncthreads();
     AIR_STAMP(42);
-    // Which corners go through the LDS atomic pipe and which through lane rings (block-uniform, bit c = corner c on the
-    // pipe).  The pipe is ONE per CU -- every resident workgroup's corner streams queue on it at ~4 cycles per term --
-    // while a ring is private to its wave at ~12 cycles per term: with several workgroups per CU (large canvases: five per
-    // CU, two resident) the pipe is the launch's bottleneck (245 of 252 us at 128 x 128) although the rings would be idle.
-    // Cost model of one workgroup: pipe time = c * 4 * (terms on the pipe), c > 1 pricing the other workgroups' share of
-    // it; ring time = 12 * (its longest ring stream).  Corners sorted by size, the k largest on the pipe, k = argmin of
-    // max(pipe, ring).  Either accumulator adds a corner's terms in the same order: bit-identical whatever the split.
-    int pipe_mask = lds_ordered ? 0xf : 0;
-    if (lds_ordered && ring_ok && mix16 > 0) {
-        int n[4] = {sh_cn[0], sh_cn[1], sh_cn[2], sh_cn[3]}, id[4] = {0, 1, 2, 3};
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3 - i; ++j)
-                if (n[j] < n[j + 1]) { const int tn = n[j]; n[j] = n[j + 1]; n[j + 1] = tn; const int ti = id[j]; id[j] = id[j + 1]; id[j + 1] = ti; }
-        long best = -1; int bk = 4, onp = 0;
-        pipe_mask = 0;
-        int mask_k = 0;
-#pragma unroll
-        for (int k = 0; k <= 4; ++k) {
-            const long pipe_t = (long)mix16 * 4 * onp, ring_t = (long)16 * 12 * (k < 4 ? n[k] : 0);   // (both x 16)
-            const long cst = pipe_t > ring_t ? pipe_t : ring_t;
-            if (best < 0 || cst < best) { best = cst; bk = k; pipe_mask = mask_k; }
-            if (k < 4) { onp += n[k]; mask_k |= 1 << id[k]; }
-        }
-        (void)bk;
-    }
+    // bit c = corner c on the LDS atomic pipe; the lane rings take the corners when the pipe does not order lanes.  (A
+    // per-workgroup MIX -- the k largest corners on the pipe, the others as rings, k minimising max(4 x pipe terms, 12 x
+    // longest ring) -- was built and measured in rounds 3 / 4: bit-identical, no faster at either canvas size, DESIGN.md
+    // sections 8 and 9.  Removed.)
+    const int pipe_mask = lds_ordered ? 0xf : 0;
 
     // tap ph = a, b, c, d <-> (y0,x0), (y1,x0), (y0,x1), (y1,x1)
     const int di = WB_THREADS / C, dj = WB_THREADS % C;
@@ -2130,20 +2093,10 @@ extern "C" int air_write_fwd(const air_write_fwd_t* a, void* stream) {
         if ((long)a->N * a->B > WB_ORDER_MAX) return AIR_ELIMIT;
         if (lds < WB_ORDER_MAX * sizeof(unsigned)) lds = WB_ORDER_MAX * sizeof(unsigned);
     }
-    if (a->rec_part && a->bands == 2) {
-        int rc = ensure_lds(write_fwd_kernel<CF_THREADS / 2, true>, lds);
+    {
+        int rc = ensure_lds(write_fwd_kernel<CF_THREADS>, lds);
         if (rc) return rc;
-        hipLaunchKernelGGL((write_fwd_kernel<CF_THREADS / 2, true>), dim3(a->B + extra, 2), dim3(CF_THREADS / 2), lds, air_stream(stream), *a);
-    } else if (a->rec_part) {
-        if (a->bands != 0 && a->bands != CF_BANDS) return AIR_EINVAL;
-        int rc = ensure_lds(write_fwd_kernel<CF_THREADS / CF_BANDS, true>, lds);
-        if (rc) return rc;
-        hipLaunchKernelGGL((write_fwd_kernel<CF_THREADS / CF_BANDS, true>), dim3(a->B + extra, CF_BANDS), dim3(CF_THREADS / CF_BANDS), lds,
-                           air_stream(stream), *a);
-    } else {
-        int rc = ensure_lds(write_fwd_kernel<CF_THREADS, false>, lds);
-        if (rc) return rc;
-        hipLaunchKernelGGL((write_fwd_kernel<CF_THREADS, false>), dim3(a->B + extra), dim3(CF_THREADS), lds, air_stream(stream), *a);
+        hipLaunchKernelGGL((write_fwd_kernel<CF_THREADS>), dim3(a->B + extra), dim3(CF_THREADS), lds, air_stream(stream), *a);
     }
     AIR_CHECK_LAUNCH();
     return 0;
@@ -2162,7 +2115,6 @@ extern "C" int air_write_bwd_kernel_name(const air_write_bwd_t* a, char* buf, in
 extern "C" int air_write_bwd(const air_write_bwd_t* a, void* stream) {
     if (!a || !a->d_recon || !a->vrec || !a->att || !a->d_gen_pre || !a->d_sxy_write) return AIR_EINVAL;
     if (a->B <= 0 || a->N <= 0 || a->C < 2 || a->w < 2) return AIR_EINVAL;
-    if (a->fin_rec_part && (!a->fin_scalars || !a->fin_run_loss || !a->fin_rec_loss || !a->fin_loss_item_out)) return AIR_EINVAL;
     if (a->literal < 0 || a->literal > 4) return AIR_EINVAL;
     if (a->order && a->literal < 2) return AIR_EINVAL;            // (the ordered form exists in the graph-order kernels only)
     if (2 * a->w > THREADS) return AIR_ELIMIT;
@@ -2198,15 +2150,6 @@ extern "C" int air_write_bwd(const air_write_bwd_t* a, void* stream) {
         int rc = allph ? ensure_lds(write_bwd_graph_kernel<true>, lds) : ensure_lds(write_bwd_graph_kernel<false>, lds);
         if (rc) return rc;
         int flags = accumulators(air_stream(stream));
-        // pipe / ring mix (write_bwd_graph_kernel::pipe_mask): c in sixteenths; AIR_WB_MIX=<float>, default 0 = pipe only.
-        // Measured at 128 x 128 (tools/ab.sh, tools/wb_wg_stamps.py --stress): 0.715 / 0.712 / 0.721 / 0.831 ms per step at
-        // c = 0 / 1 / 2 / 3 before the items were ordered, 0.635 / 0.637 / 0.642 at c = 0 / 1 / 2 after -- a ring stream
-        // lasts as long as the pipe would have taken for the whole workgroup, and the launch was never bound by the pipe's
-        // RATE but by which CU got the most work (wb_order_block).
-        static const int mix_env = [] { const char* e = getenv("AIR_WB_MIX"); return e ? (int)(atof(e) * 16.0 + 0.5) : -1; }();
-        int mix16 = mix_env >= 0 ? mix_env : 0;
-        if (mix16 > 255) mix16 = 255;
-        if ((flags & 3) == 3) flags |= mix16 << 8;
         if (allph) hipLaunchKernelGGL(write_bwd_graph_kernel<true>, dim3(a->B, a->N), dim3(WB_THREADS), lds, air_stream(stream), *a, flags);
         else hipLaunchKernelGGL(write_bwd_graph_kernel<false>, dim3(a->B, a->N), dim3(WB_THREADS), lds, air_stream(stream), *a, flags);
         AIR_CHECK_LAUNCH();

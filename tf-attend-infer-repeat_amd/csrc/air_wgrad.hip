@@ -280,11 +280,6 @@ __global__ __launch_bounds__(THREADS) void adam_factored_bf16_kernel(Prob pr, Ad
 
 AIR_STAMPS_READER(air_debug_stamps_wgrad)
 
-// AIR_WGRAD_STRIP=<column tiles per strip workgroup> overrides the width strip_of picks (0: no strips; A/B, tests).
-static int strip_override() {
-    static const int g = [] { const char* e = getenv("AIR_WGRAD_STRIP"); return e ? atoi(e) : -1; }();
-    return g;
-}
 // Tiles from which a problem counts as BIG (shape alone): it runs in strips when it has twins, and the owners of its bias
 // columns are spread over block-rows in every precision.
 constexpr long BIG_TILES = 512;
@@ -298,7 +293,7 @@ static int strip_of(const air_wgrad_t& g, bool allow) {
     if ((g.ldb & 7) != 0 || ((uintptr_t)g.dY16 & 15) != 0) return 0;
     const long tiles = (long)((g.M + BT - 1) / BT) * ((g.N + BT - 1) / BT);
     if (tiles < BIG_TILES) return 0;
-    int w = strip_override() >= 0 ? strip_override() : (tiles >= 2048 ? 4 : 2);
+    int w = tiles >= 2048 ? 4 : 2;
     if (w > STRIP_MAXG) w = STRIP_MAXG;
     while (w > 1 && (g.N % (BT * w)) != 0) w >>= 1;
     return w > 1 ? w : 0;
