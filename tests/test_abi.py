@@ -186,3 +186,13 @@ def test_gemm_dispatch_is_pinned_per_shape(H):
         args.update(kw)
         n1, n0 = name(**args), name(prec=0, **args)
         assert n1.startswith("gemm_bf16_kernel<") and n0.startswith("gemm_f32_kernel<"), (kw, n1, n0)
+
+
+def test_no_undefined_names_in_the_gpu_only_code():
+    """The model's code paths need a GPU and never run in the build container: a static pass over the product, the bench
+    and the entry points for names that are bound nowhere (tools/undefined_names.py) -- the NameError class of mistakes."""
+    import glob
+    files = (glob.glob(os.path.join(ROOT, "tf-attend-infer-repeat_amd", "*.py")) + glob.glob(os.path.join(ROOT, "tf-attend-infer-repeat_amd", "*", "*.py")) +
+             [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")] + glob.glob(os.path.join(ROOT, "tests", "*.py")))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "undefined_names.py")] + files, capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout

@@ -300,6 +300,15 @@ class AIRModel:
         self.input_images = input_images
         self.target_num_digits = target_num_digits
         self.batch_size = int(input_images.shape[0])
+        # the shape limits of the kernels, checked HERE with the limit in the message (a caller never meets them as an
+        # error code of a launch): include/air_hip.h
+        limits = (("max_steps", max_steps, 16, "the per-image records of the compose / attend kernels hold 16 steps"),
+                  ("windows_size", windows_size, 32, "the sampler backward gives every glimpse pixel a thread of a 1024-thread workgroup"),
+                  ("len(vae_recognition_units) + len(vae_generative_units)", len(vae_recognition_units) + len(vae_generative_units), 10,
+                   "the grouped weight-gradient launch takes 16 problems"))
+        for name, val, cap, why in limits:
+            if val > cap:
+                raise NotImplementedError("%s = %d exceeds the HIP path's limit of %d (%s)" % (name, val, cap, why))
 
         self.max_steps = max_steps
         self.max_digits = max_digits
@@ -359,6 +368,7 @@ class AIRModel:
         # by Adam), so the GEMMs read 2-byte operands and convert nothing -- bit-identical results (the twin IS
         # the rounding the fp32-operand kernels apply on the way into LDS).  bf16_twins=False keeps fp32 operands.
         self._twins = (True if bf16_twins is None else bool(bf16_twins)) and self._prec == 1
+        self._xw_tile_arg = xw_tile
 
         dev = input_images.device
         if tuple(input_images.shape) != (self.batch_size, canvas_size * canvas_size) or \
@@ -487,6 +497,7 @@ class AIRModel:
         if self._twins and D > 4096 and B % 64 == 0 and R % 16 == 0 and D % 512 == 0:
             # full batches of a large canvas: the throughput tiling (64 x 64 per workgroup, 8 K-slabs), gemm_xw_tp_kernel
             self._xw_ksplit, self._xw_tile = 8, (8, 4)
+        xw_tile = self._xw_tile_arg
         if xw_tile is not None:                              # (tile_m, tile_n, ksplit <= 8) in 16-row / 16-column units: the split-K
             tm_, tn_, ks_ = (int(v) for v in xw_tile)        # product on THAT tiling (tests: a common tiling for bit-identity)
             self._xw_ksplit, self._xw_tile = ks_, (tm_, tn_)
@@ -788,8 +799,7 @@ class AIRModel:
         # the input-weight gradient contracts over B rows only (sum_t dgates): its many light
         # workgroups go LAST so that they fill the tail of the launch behind the K = N*B ones
         wg(imgs, self.dgsum, Gx, G["lstm_bias"], D, 4 * R, B, self.images16, self.dgsum16)
-        if len(probs) > 16:
-            raise NotImplementedError("more than 16 weight matrices (a VAE of more than 10 layers) need a second grouped launch")
+        assert len(probs) <= 16                              # (constructor: at most 10 VAE layers)
         arr = (H.Wgrad * len(probs))(*probs)
         keep.append(arr)
         self._wgrad_arr = arr
