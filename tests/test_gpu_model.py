@@ -558,7 +558,9 @@ def test_multi_step_graphs_are_bit_identical_to_eager_steps(am, prec, twins):
         assert int(model.global_step) == 8
         res[mode] = [st.params.clone(), st.m.clone(), st.v.clone(), st.params16.clone(), st.gnorm.clone(), model.scalars.clone()]
         if twins:
-            assert torch.equal(st.params16.view(torch.bfloat16), st.params.to(torch.bfloat16))
+            # the row-major shadow follows the variables -- except over Wx when the store keeps only its panel twin
+            lo = HP["canvas_size"] ** 2 * 4 * HP["rnn_units"] if st.wx_exclusive else 0
+            assert torch.equal(st.params16[lo:].view(torch.bfloat16), st.params[lo:].to(torch.bfloat16))
     for a, b in zip(res["eager"], res["graph"]):
         assert torch.equal(a, b)
 
