@@ -4,6 +4,9 @@ Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
 leg may import this module.  The product path (``tf-attend-infer-repeat_amd/``)
 never imports it and fails loudly when the HIP library is missing.
 
+PARITY UNPINNED in the brief's sense: no golden vector held by the reference's own tests and no output of the reference
+RUN here exists (neither can: see below).  What stands in for them, and how far it reaches:
+
 PARITY PIN: the reference (aakhundov/tf-attend-infer-repeat) ships no tests, golden
 vectors or fixtures for this path, and its arithmetic lives in TensorFlow 1.3.0
 (un-vendored, not installable here: no cp310 wheel, no network) -- so no output
