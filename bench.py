@@ -583,11 +583,11 @@ def main():
                                  "mode": ("one hipGraph replay per forward" if us_graph <= us_eager else "eager launches") + ", train=False"}
         if not args.no_extras and world == 1 and args.workload == "configs[1]":
             # the same step at the reference's own precision (fp32 operands, exact-fp32 MFMA) ...
-            def secondary(tag, prec, hp2, B2, steps):
+            def secondary(tag, prec, hp2, B2, steps, backward=args.backward):
                 im2, tg2 = synthetic_canvases(B2, hp2["canvas_size"], hp2["max_digits"], seed=2000)
                 m2 = am.AIRModel(torch.tensor(im2, device=dev), torch.tensor(tg2, device=dev), cnn=False, train=True,
                                  scope=tag, annealing_schedules=ANNEAL, seed=0, gemm_precision=prec,
-                                 backward=args.backward, **hp2)
+                                 backward=backward, **hp2)
                 g2 = 1 if args.no_graph else 4
                 if not args.no_graph:
                     m2.capture_graph(steps=g2)
@@ -613,6 +613,17 @@ def main():
             P3 = sum(int(np.prod(v)) for v in [(128 * 128 + 256, 1024)]) + (model.store.num_trainable - (2756 * 1024))
             line["stress_configs3"]["frac_of_hbm_peak"] = round(
                 (40 * P3 + 4 * 256 * 128 * 128) / (line["stress_configs3"]["ms_per_step"] * 1e-3) * 1e-9 / HBM_PEAK_GBS, 4)
+            # the same two configurations under the chunked sampler-backward orders (opt-in: bit for bit against their oracle
+            # orders, faster, and NOT the default because the 24-seed learning sweeps of round 5 favour the reference's order --
+            # DESIGN.md section 10)
+            if args.backward == "reference":
+                line["backward_orders"] = {}
+                for mode in ("reference", "reference_carried", "reference_blocked"):
+                    line["backward_orders"][mode] = {
+                        "configs[1]": secondary("air_" + mode, args.precision, hp, B, 100, backward=mode)["ms_per_step"],
+                        "configs[3]": (line["stress_configs3"]["ms_per_step"] if mode == "reference" else
+                                       secondary("air_stress_" + mode, args.precision, hp3, 256, 40, backward=mode)["ms_per_step"])}
+                line["backward_orders"]["unit"] = "ms per step (secondary blocks: 4 steps per replay, 100 / 40 steps)"
         phase["extras"] = round(time.perf_counter() - t_ph, 3)      # per-kernel events, inference, fp32 and stress blocks
         if not args.no_cpu_baseline and world == 1 and args.workload == "configs[1]":
             t_ph = time.perf_counter()
