@@ -711,7 +711,12 @@ class AIRModel:
             x, x16, k = self.rec_act[i], self.rec_act16[i], u
         # the bottleneck (last recognition product -> reparameterised sample -> first generative layer) is
         # ONE launch where the fused kernel's limits hold (bf16 operands; vae.py:16-30); else two GEMMs
-        nofuse = os.environ.get("AIR_NO_BOTTLENECK_FUSION") == "1"
+        # bf16 path: on.  fp32 path (the parity precision): OFF -- its exact-fp32 form is 3e-6 from the two launches (another
+        # fp32 order of a K = 256 sum) and saves 7 us, but over 32 seeds x 60 k iterations 4 runs never separate one count
+        # class with it against 0 of 32 with two launches (profiles/r04_seed_sweep_fp32_bottleneck_*, r05_sweep_fp32_bottleneck_*).
+        # AIR_BOTTLENECK_FUSION=0 / 1 forces it off / on (AIR_NO_BOTTLENECK_FUSION=1: the older spelling of off).
+        env_b = os.environ.get("AIR_BOTTLENECK_FUSION")
+        nofuse = ((env_b == "0") if env_b in ("0", "1") else self._prec == 0) or os.environ.get("AIR_NO_BOTTLENECK_FUSION") == "1"
         # (fp32 path: the exact-fp32 form of the kernel, 2 Z <= 104)
         fuse_f = (not nofuse and len(gen_u) >= 1 and k == 256 and Z <= (64 if self._prec == 1 else 52) and Z % 2 == 0
                   and gen_u[0] % 4 == 0)
