@@ -820,8 +820,10 @@ class AIRModel:
         keep += [wb, wbf]
         kbuf = C.create_string_buffer(96)
         H.check(self.lib.air_write_bwd_kernel_name(C.byref(wb), kbuf, 96), "air_write_bwd_kernel_name")
-        bwd.append(self._call("air_write_bwd", C.byref(wb), nbytes=NB * ((D + 2 * d) * 4 + 32), tag="write_bwd"))
-        self._write_bwd_fin = self._call("air_write_bwd", C.byref(wbf), nbytes=NB * ((D + 2 * d) * 4 + 32), tag="write_bwd")
+        # (algorithmic bytes as SURVEY 8(d) counts them: the write's (d + D) * 4 + 16 again + 12 bytes of theta gradient = 13 164 per
+        # (image, step) at 50 x 50 -- the bf16 twin and the second read of the window are traffic, not algorithm)
+        bwd.append(self._call("air_write_bwd", C.byref(wb), nbytes=NB * ((D + d) * 4 + 16 + 12), tag="write_bwd"))
+        self._write_bwd_fin = self._call("air_write_bwd", C.byref(wbf), nbytes=NB * ((D + d) * 4 + 16 + 12), tag="write_bwd")
         bwd[-1].kernel = self._write_bwd_fin.kernel = kbuf.value.decode()
         # decoder data-grads over all N*B rows: dX = dY . W^T, times softplus'(saved activation)
         dy, dy16, n_out, wname = self.d_genpre, self.d_genpre16, d, "out_w"
