@@ -1132,26 +1132,6 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_kernel(air_write_bwd_t a
 //            every other LDS request of the CU starves, so the short chains go first and the coordinate-gradient
 //            pixel loop -- rewritten to touch no LDS at all -- runs on the other twelve waves underneath it.
 // ---------------------------------------------------------------------------
-// Sum of one value per lane over the wave WITHOUT the LDS (ds_bpermute shuffles would queue behind the atomics the feeding
-// wave has in flight): four row_shr DPP steps leave every 16-lane row's total in its last lane, the four totals are read as
-// scalars.  Used for BOUNDS only (its own summation order is irrelevant: the error of a 6-level fp32 tree, 2^-21 of the
-// summed magnitudes, is inside the bracket's slack).
-__device__ __forceinline__ float wave_sum_dpp(float v) {
-#define AIR_ROW_SHR(x, n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x110 + (n), 0xf, 0xf, true))
-    v += AIR_ROW_SHR(v, 1); v += AIR_ROW_SHR(v, 2); v += AIR_ROW_SHR(v, 4); v += AIR_ROW_SHR(v, 8);
-#undef AIR_ROW_SHR
-    const int b = __builtin_bit_cast(int, v);
-    return ((__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 15)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 31))) +
-            __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 47))) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 63));
-}
-// A term t with |t| < ulp(s) / 4 leaves an fp32 accumulator s EXACTLY unchanged (round to nearest: less than half the spacing
-// on either side, also at a power of two, where the spacing below is half).  With L <= |s|: ulp(L) <= ulp(s), so
-// |t| < 2^(exponent(L) - 25) suffices.  0 when L is too small to absorb anything.
-__device__ __forceinline__ float absorb_threshold(float L) {
-    const int e = (__builtin_bit_cast(int, L) >> 23) & 0xff;
-    return e > 26 ? __builtin_bit_cast(float, (e - 25) << 23) : 0.0f;
-}
-
 __device__ __forceinline__ float stream_add(float acc, const float* T, int start, int n) {
     int k = start;
     const int end = start + n;
@@ -1503,33 +1483,9 @@ __device__ __forceinline__ void write_bwd_graph_body(const air_write_bwd_t& a, i
                                  : "v"(ad[h]), "v"(ad[h + 1]), "v"(ad[h + 2]), "v"(ad[h + 3]),
                                    "v"(ad[h + 4]), "v"(ad[h + 5]), "v"(ad[h + 6]), "v"(ad[h + 7])
                                  : "memory");
-                // ABSORBED INSTRUCTIONS ARE NOT ISSUED.  The accumulator itself is read back with the batch (a wave's LDS
-                // operations execute in order: the value is the exact sum of everything this wave has fed so far -- the
-                // read costs nothing, the batch's own reads drain the same queue).  [lo, hi] brackets the accumulator from
-                // there on: an instruction whose 64 terms are all below a quarter ulp of a lower bound of |accumulator|
-                // would change nothing, term by term, and is skipped -- the result stays bit for bit the sequential sum
-                // (absorb_threshold).  An issued instruction moves the bracket by the sum S of its terms, widened by the
-                // roundings of its 64 adds and of S itself (2^-18 of the largest partial sum + 2^-21 of the magnitudes;
-                // 2^-16 (max(|lo|, |hi|) + A) taken; two DPP reductions, off the LDS, under the ~255 cycles the pipe spends
-                // on the instruction).  Where the streams carry the poles of the Bernoulli gradient (unexplained ink:
-                // 1e9 / B against 1e-2 elsewhere) the instructions between two poles are absorbed; a stream without poles
-                // issues everything, as before.
-                float s_now;
-                asm volatile("ds_read_b32 %0, %1\n s_waitcnt lgkmcnt(0)" : "=&v"(s_now) : "v"(acc_addr) : "memory");
-                float lo = s_now, hi = s_now;
 #pragma unroll
-                for (int u = 0; u < NB; ++u) {
-                    if (d[u] <= 0) continue;                                                 // (uniform: past the end of the list)
-                    const bool valid = lane < d[u];
-                    const float mag = valid ? fabsf(r[u]) : 0.0f;
-                    const float thr = absorb_threshold(lo > 0.0f ? lo : (hi < 0.0f ? -hi : 0.0f));
-                    if (__builtin_amdgcn_ballot_w64(!(mag < thr)) == 0) continue;            // (a NaN term is never "absorbed")
-                    if (valid) asm volatile("ds_add_f32 %0, %1" :: "v"(acc_addr), "v"(r[u]) : "memory");   // valid lanes only (EXEC)
-                    const float A = wave_sum_dpp(mag), S = wave_sum_dpp(valid ? r[u] : 0.0f);
-                    const float dl = (fmaxf(fabsf(lo), fabsf(hi)) + A) * 1.52587890625e-05f;
-                    lo = (lo + S) - dl;
-                    hi = (hi + S) + dl;
-                }
+                for (int u = 0; u < NB; ++u)
+                    if (lane < d[u]) asm volatile("ds_add_f32 %0, %1" :: "v"(acc_addr), "v"(r[u]) : "memory");   // valid lanes only (EXEC)
             };
 #pragma unroll 1
             for (int j0 = 0; j0 < m; j0 += NB) batch(j0);
