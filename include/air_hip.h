@@ -10,8 +10,12 @@
  *
  * Conventions (all entry points):
  *   - every pointer is a CALLER-OWNED DEVICE pointer, contiguous row-major fp32
- *     unless stated; the library never allocates, frees or synchronises
- *     (hipGraph-capture safe), is stateless and re-entrant;
+ *     unless stated; the library never allocates or frees, keeps no state but two per-device caches (the LDS grant of a
+ *     kernel function, the lane-order probe below), is re-entrant, and does not synchronise -- with ONE exception: the
+ *     first EAGER air_write_bwd(literal 2) / air_transformer_bwd of a process on a device probes the lane order of the LDS
+ *     atomic pipe (one tiny kernel, an 8-byte copy back, one stream synchronise).  Under stream capture nothing is probed:
+ *     a capture-first caller takes the register-chain accumulator (same bits, slower; a message on stderr).  Every other
+ *     call is hipGraph-capture safe from the first call;
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*);
  *   - return value: 0 on success, a positive hipError_t from the launch, or a
  *     negative AIR_E* argument error; no C++ exception crosses the boundary.
