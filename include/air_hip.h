@@ -35,7 +35,7 @@ extern "C" {
  *    air_adam_clip_step_panels)
  * 4: measured-negative paths removed (DESIGN.md sections 8-10 keep the record): the deferred Adam slices
  *    (air_step_job_t.ad_*, air_adam_clip_step_blocks), the banded compose (air_write_fwd_t.rec_part / bands,
- *    air_finalize_parts, air_write_bwd_t.fin_rec_part ..); added: `literal` 3 / 4 of air_write_bwd, air_shuffle_batch_* */
+ *    air_finalize_parts, air_write_bwd_t.fin_rec_part ..), air_adam_clip_step_factored; added: `literal` 3 / 4 of air_write_bwd, air_shuffle_batch_* */
 #define AIR_ABI_VERSION 4
 
 #define AIR_EINVAL   (-1)   /* bad dimension / null pointer            */
@@ -241,8 +241,8 @@ typedef struct {
  * air_adam_clip_step instead of a separate air_grad_sqnorm pass (single-GPU path; with data
  * parallelism the norm is taken after the all-reduce).  istate (nullable, only with sq_partials):
  * istate[GLOBAL_STEP] += 1, as air_grad_sqnorm does.  A plain problem may have dW == NULL when
- * sq_partials is given: its tiles are computed and squared but not stored (the gradient is rebuilt
- * from its factors by air_adam_clip_step_factored). */
+ * sq_partials is given: its tiles are computed and squared but not stored (a caller that rebuilds the
+ * gradient from its factors elsewhere). */
 /* air_wgrad_num_blocks(): the number of global-norm partials = 64 x 64 tiles of all problems + one per bias column tile of
  * the problems with K >= 384 (their db is summed by workgroups of their own, the launch's first, instead of by a tile). */
 int air_wgrad_num_blocks(const air_wgrad_t* probs, int count);
@@ -481,19 +481,6 @@ int air_adam_clip_step_panels(float* params, const float* grads, float* m, float
                               float grad_prescale, float beta1, float beta2, float epsilon,
                               uint16_t* bf16_shadow /*nullable*/, const air_panel_t* panels /*HOST array*/, int npanels,
                               uint16_t* panel_shadow, float* gnorm_out /*nullable*/, void* stream);
-/* The same step with ONE gradient block taken from its factors instead of from `grads`:
- * `factored` (HOST pointer, one plain problem, db NULL, ldc == N, N % 4 == 0) names a block
- * dW = A^T.dY [M,N] that lies inside the flat buffer (dW points into `grads`; the matching ranges
- * of params / m / v are updated).  Its workgroups rebuild the block tile by tile exactly as
- * air_wgrad_grouped(precision) would have stored it, so params / m / v end bit-identical to the
- * stored path; the grads range of the block is never read.  Pair it with an air_wgrad_grouped launch
- * in which that problem has dW == NULL (sum of squares only).  Meant for the input-weight gradient
- * of the LSTM, dWx = X^T.(sum_t dgates): rank <= B, 64 % of all gradient elements (air_model.py:286). */
-int air_adam_clip_step_factored(float* params, const float* grads, float* m, float* v, int64_t n,
-                                const air_wgrad_t* factored, int precision,
-                                const float* partials, int npartials, const float* dyn, const int32_t* istate,
-                                float grad_prescale, float beta1, float beta2, float epsilon,
-                                float* gnorm_out /*nullable*/, void* stream);
 
 /* ---- input pipeline: tf.train.shuffle_batch on the device (the reference's multi_mnist.py:228-249) -------------
  * A RandomShuffleQueue of `capacity` record indices resident in HBM over the epoch-repeating record stream

@@ -410,31 +410,6 @@ def test_inference_graph_replay_equals_eager(am):
     assert float(inf.loss) != l0
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
-def test_factored_input_weight_gradient_equals_stored_bit_for_bit(am, prec):
-    """input_weight_gradient="factored": training() never writes dWx = X^T.(sum_t dgates) to memory -- the
-    weight-gradient launch takes its norm, the Adam launch rebuilds its tiles.  Variables, both Adam slots, the global norm
-    and the loss must equal the run that stores every gradient, bit for bit, over several steps
-    (MatMul_grad of air_model.py:286's [x, h] kernel; clip + ApplyAdam :673-694)."""
-    D = HP["canvas_size"] ** 2
-    res = {}
-    for mode in ("stored", "factored"):
-        model, *_ = _make(am, 64, True, prec=prec, backward="reference", input_weight_gradient=mode)
-        model.store.grads.zero_()
-        for _ in range(3):
-            model.training()
-        torch.cuda.synchronize()
-        st = model.store
-        res[mode] = (st.params.clone(), st.m.clone(), st.v.clone(), float(st.gnorm), float(model.loss))
-        gx = model.gradients["rnn/kernel"][:D]
-        assert bool((gx != 0).any()) == (mode == "stored")        # factored: the block is never materialised
-        assert float(model.gradients["rnn/bias"].abs().max()) > 0  # ... but its bias gradient is
-        assert int(model.global_step) == 3
-    for a, b in zip(res["stored"][:3], res["factored"][:3]):
-        assert torch.equal(a, b)
-    assert res["stored"][3:] == res["factored"][3:]
-
-
 def test_first_lstm_step_in_the_xwx_launch_matches_the_default_path(am, monkeypatch):
     """AIR_STEP0_FUSION=1 (x.Wx un-split with the zero-state first LSTM step in its epilogue, AIR_EPI_LSTM_FWD0)
     gives the same forward as the default split-K product + pointwise first step, up to the summation order
@@ -603,11 +578,10 @@ def test_state_dict_carries_adam_slots_per_variable(am):
     assert torch.equal(before[1], model.store.m)
 
 
-@pytest.mark.parametrize("train_kw", [dict(prec="fp32"), dict(prec="bf16", bf16_twins=False),
-                                      dict(prec="bf16", input_weight_gradient="factored")])
+@pytest.mark.parametrize("train_kw", [dict(prec="fp32"), dict(prec="bf16", bf16_twins=False)])
 def test_bf16_shadow_follows_a_train_model_that_does_not_maintain_it(am, train_kw):
     """The bf16 shadow of the variables lives on the shared VariableStore, but only an Adam launch of a model with
-    bf16 twins rewrites it.  A train model WITHOUT twins (fp32 precision, bf16_twins=False, factored dWx) changes the
+    bf16 twins rewrites it.  A train model WITHOUT twins (fp32 precision, bf16_twins=False) changes the
     variables every step: a reuse=True evaluation model WITH twins on the same scope (training.py:95-123 builds such a
     pair) must see the new variables -- its forward equals that of a model without twins, bit for bit, after every
     train step -- instead of running its GEMMs on a stale shadow."""

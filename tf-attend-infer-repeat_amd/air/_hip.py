@@ -158,8 +158,6 @@ _SIGNATURES = {
     "air_vae_bottleneck_fwd": (C.c_int, [C.POINTER(BottleneckFwd), _p]),
     "air_vae_bottleneck_bwd": (C.c_int, [C.POINTER(BottleneckBwd), _p]),
     "air_adam_clip_step": (C.c_int, [_p, _p, _p, _p, C.c_int64, _p, C.c_int, _p, _p, _f, _f, _f, _f, _p, _p, _p]),
-    "air_adam_clip_step_factored": (C.c_int, [_p, _p, _p, _p, C.c_int64, C.POINTER(Wgrad), C.c_int, _p, C.c_int, _p, _p,
-                                              _f, _f, _f, _f, _p, _p]),
     "air_shuffle_batch_init": (C.c_int, [C.POINTER(ShuffleBatch), _p]),
     "air_shuffle_batch_dequeue": (C.c_int, [C.POINTER(ShuffleBatch), _p]),
 }

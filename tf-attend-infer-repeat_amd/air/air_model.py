@@ -290,7 +290,7 @@ class AIRModel:
                  learning_rate=1e-3, gradient_clipping_norm=100.0, cnn=True, cnn_filters=8,
                  num_summary_images=60, train=False, reuse=False, scope="air",
                  annealing_schedules=None, seed=0, gemm_precision=None, backward="reference", noise_seed=None,
-                 input_weight_gradient="stored", bf16_twins=None, dp_exchange=None, xw_tile=None):
+                 bf16_twins=None, dp_exchange=None, xw_tile=None):
         if cnn:
             # reference :510-533; every caller passes cnn=False (training.py:108, demo.py:24)
             raise NotImplementedError("cnn=True front-end is outside the accelerated hot path; pass cnn=False")
@@ -402,17 +402,6 @@ class AIRModel:
         # (default: seed) keys the device Philox stream -- DP ranks pass different ones, otherwise
         # every shard would draw the same noise
         self._seed = (seed if noise_seed is None else noise_seed) + (0 if train else 7919)
-        # "stored" (default): every gradient is materialised.  "factored": the single-GPU train step never
-        # writes dWx = X^T.(sum_t dgates) (64 % of the gradient elements, rank <= B) to memory -- the
-        # weight-gradient launch takes its norm, the Adam launch rebuilds its tiles (bit-identical update);
-        # gradients["rnn/kernel"][:D] is then NOT refreshed by training().  Measured on MI355X: the 10 MB
-        # not written and not read are worth ~1 us in the weight-gradient launch, the tiles rebuilt inside
-        # Adam cost ~7 us (instruction-issue bound) -- a net loss at B = 64, kept as an option.
-        if input_weight_gradient not in ("factored", "stored"):
-            raise ValueError("input_weight_gradient must be 'factored' or 'stored'")
-        self._factor_dwx = input_weight_gradient == "factored"
-        if self._factor_dwx:
-            self._twins = False      # air_adam_clip_step_factored does not maintain the bf16 shadow of the variables
         # data parallel, what crosses xGMI per step.  "flat" (default): ONE all_reduce of the whole flat gradient
         # (16 MB at the default shapes).  "factors": the LSTM input-weight gradient dWx = X^T.(sum_t dgates) -- 64 % of
         # the gradient elements, rank <= B per GPU -- is never reduced: its FACTORS (X and sum_t dgates, 0.9 MB per
@@ -609,8 +598,6 @@ class AIRModel:
                       else "bottleneck_%s_f32_kernel<256>" % name[-3:])
         if name == "air_wgrad_grouped":
             kernel = "wgrad_grouped_bf16_kernel" if self._prec else "wgrad_grouped_kernel"
-        if name == "air_adam_clip_step_factored":
-            kernel = "adam_factored_bf16_kernel" if self._prec else "adam_factored_kernel"
         return _Op(tag or name, lambda s, fn=fn, args=args, name=name: H.check(fn(*args, s), name),
                    nbytes=nbytes, flops=flops, kernel=kernel)
 
@@ -907,19 +894,10 @@ class AIRModel:
             H.check(self._wgrad_blocks, "air_wgrad_num_blocks")
         if st.partials.numel() < self._wgrad_blocks:
             raise NotImplementedError("weight-gradient launch of %d workgroups exceeds the partial-sum buffer" % self._wgrad_blocks)
-        self._dwx_factors = None
-        if self._factor_dwx:
-            # same launch with dWx norm-only (its bias gradient is still stored); the factors go to Adam
-            fx = probs[-1]
-            probs_f = probs[:-1] + [H.Wgrad(fx.A, fx.dY, None, fx.db, fx.M, fx.N, fx.K, fx.lda, fx.ldb, fx.ldc, 0, 0, 0, 0)]
-            arr_f = (H.Wgrad * len(probs_f))(*probs_f)
-            self._dwx_factors = (H.Wgrad * 1)(H.Wgrad(fx.A, fx.dY, fx.dW, None, fx.M, fx.N, fx.K, fx.lda, fx.ldb, fx.ldc, 0, 0, 0, 0))
-            keep.extend([arr_f, self._dwx_factors])
-            self._wgrad_fused = self._call("air_wgrad_grouped", arr_f, len(probs_f), self._prec, _ptr(st.partials),
-                                           _ptr(st.istate), nbytes=wbytes - 4 * fx.M * fx.N, flops=wflops, tag="wgrad_grouped")
-        else:
-            self._wgrad_fused = self._call("air_wgrad_grouped", arr, len(probs), self._prec, _ptr(st.partials),
-                                           _ptr(st.istate), nbytes=wbytes, flops=wflops, tag="wgrad_grouped")
+        # (Adam rebuilding dWx = X^T.(sum_t dgates) from its factors instead of reading the stored 10 MB -- bit-identical, the
+        # tiles rebuilt inside Adam cost ~7 us against ~1 us saved in this launch -- was an option until round 5: removed)
+        self._wgrad_fused = self._call("air_wgrad_grouped", arr, len(probs), self._prec, _ptr(st.partials),
+                                       _ptr(st.istate), nbytes=wbytes, flops=wflops, tag="wgrad_grouped")
 
         self._sqnorm = self._call("air_grad_sqnorm", _ptr(st.grads), st.n, _ptr(st.partials), _ptr(st.istate),
                                   nbytes=4 * st.n, tag="grad_sqnorm")
@@ -1023,13 +1001,7 @@ class AIRModel:
             st = self.store
             fused = not self._dp()
             npart = self._wgrad_blocks if fused else self.lib.air_optim_num_partials(st.n)
-            if fused and self._dwx_factors is not None:
-                fx = self._dwx_factors[0]
-                adam = self._call("air_adam_clip_step_factored", _ptr(st.params), _ptr(st.grads), _ptr(st.m), _ptr(st.v),
-                                  st.n, self._dwx_factors, self._prec, _ptr(st.partials), npart, _ptr(self.dyn),
-                                  _ptr(st.istate), 1.0, 0.9, 0.999, 1e-8, _ptr(st.gnorm),
-                                  nbytes=28 * st.n - 4 * fx.M * fx.N, flops=2 * fx.M * fx.N * fx.K, tag="adam_clip")
-            elif self._twins and len(st.panels) and os.environ.get("AIR_NO_PANELS") != "1":
+            if self._twins and len(st.panels) and os.environ.get("AIR_NO_PANELS") != "1":
                 # (with the panels whether or not THIS model reads them: another model on the scope may)
                 adam = self._call("air_adam_clip_step_panels", _ptr(st.params), _ptr(st.grads), _ptr(st.m), _ptr(st.v),
                                   st.n, _ptr(st.partials), npart, _ptr(self.dyn), _ptr(st.istate), 1.0 / world,

@@ -182,100 +182,6 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
     run_tile_bf16(tab, (int)blockIdx.x, Img, sq_partials, istate, sq_red);
 }
 
-// ---------------------------------------------------------------------------
-// clip + Adam with ONE gradient taken from its factors instead of from memory.
-// dWx = X^T . (sum_t dgates) has rank <= B and is 64 % of all gradient elements
-// (air_model.py:286: the [x, h] kernel's x rows): the weight-gradient launch
-// only takes its sum of squares (dW == NULL above), and the workgroups here that
-// own its 64 x 64 blocks rebuild each block with the same tile function (so the
-// values are the ones a stored gradient would hold) and apply ApplyAdam to the
-// matching block of var / m / v.  The other workgroups stream the rest of the flat
-// buffer as adam_clip_kernel does.  -10 MB written, -10 MB read per step.
-// ---------------------------------------------------------------------------
-struct AdamFac {
-    float* p; const float* g; float* m; float* v; long n;
-    long roff, rlen;                   // region [roff, roff + rlen) of the flat buffers = the factored M x N block
-    const float* partials; int npartials; const float* dyn; const int32_t* istate;
-    float prescale, b1, b2, eps; float* gnorm_out; int tile_blocks;
-};
-
-template <int PREC>
-__device__ __forceinline__ void adam_factored_body(const Prob& pr, const AdamFac& a, unsigned char* smem)
-{
-    __shared__ float red[4];
-    const float omb1 = 1.0f - a.b1, omb2 = 1.0f - a.b2, eps = a.eps;
-    const int tid = threadIdx.x;
-
-    if ((int)blockIdx.x < a.tile_blocks) {
-        const int m0 = ((int)blockIdx.x / pr.tiles_n) * BT, n0 = ((int)blockIdx.x % pr.tiles_n) * BT;
-        const int M = pr.M, N = pr.N;                      // ldc == N, N % 4 == 0 (checked on the host)
-        float* P = a.p + a.roff; float* Mo = a.m + a.roff; float* V = a.v + a.roff;
-        // var / m / v of this block are requested first: they arrive while the tile is rebuilt
-        float4 pp[4], mm[4], vv[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + (tid >> 4) + 16 * r, n = n0 + (tid & 15) * 4;
-            const size_t i = (m < M && n < N) ? (size_t)m * N + n : 0;
-            pp[r] = *reinterpret_cast<const float4*>(P + i);
-            mm[r] = *reinterpret_cast<const float4*>(Mo + i);
-            vv[r] = *reinterpret_cast<const float4*>(V + i);
-        }
-        const AirAdamCoef cf = air_adam_coef(a.partials, a.npartials, a.dyn, a.istate, a.prescale, a.b1, a.b2, red);
-        if (a.gnorm_out && blockIdx.x == 0 && tid == 0) *a.gnorm_out = cf.gnorm;
-        if (PREC) tile_bf16<1>(pr, m0, n0, reinterpret_cast<unsigned short*>(smem));
-        else tile_f32<2>(pr, m0, n0, reinterpret_cast<float (*)[KC * LS]>(smem), reinterpret_cast<float (*)[KC * LS]>(smem) + 2);
-        const float* Ct = reinterpret_cast<const float*>(smem);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = (tid >> 4) + 16 * r, col = (tid & 15) * 4;
-            const int m = m0 + row, n = n0 + col;
-            if (m >= M || n >= N) continue;
-            const float4 gg = *reinterpret_cast<const float4*>(&Ct[row * LS + col]);
-            const size_t i = (size_t)m * N + n;
-            float* pa = &pp[r].x; float* ma = &mm[r].x; float* va = &vv[r].x; const float* ga = &gg.x;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) air_adam_update(pa[k], ma[k], va[k], ga[k], cf, omb1, omb2, eps);
-            *reinterpret_cast<float4*>(P + i) = pp[r]; *reinterpret_cast<float4*>(Mo + i) = mm[r]; *reinterpret_cast<float4*>(V + i) = vv[r];
-        }
-        return;
-    }
-    // everything outside the region: the flat stream of adam_clip_kernel with the region skipped
-    const AirAdamCoef cf = air_adam_coef(a.partials, a.npartials, a.dyn, a.istate, a.prescale, a.b1, a.b2, red);
-    const long bid = (long)blockIdx.x - a.tile_blocks, nb = (long)gridDim.x - a.tile_blocks;
-    const long n4 = a.n / 4, roff4 = a.roff / 4, rlen4 = a.rlen / 4, plain4 = n4 - rlen4;
-    float4* p4 = reinterpret_cast<float4*>(a.p);
-    const float4* g4 = reinterpret_cast<const float4*>(a.g);
-    float4* m4 = reinterpret_cast<float4*>(a.m);
-    float4* v4 = reinterpret_cast<float4*>(a.v);
-    for (long j = bid * THREADS + tid; j < plain4; j += nb * THREADS) {
-        const long i = j < roff4 ? j : j + rlen4;
-        float4 pp = p4[i], mm = m4[i], vv = v4[i];
-        const float4 gg = g4[i];
-        float* pa = &pp.x; float* ma = &mm.x; float* va = &vv.x; const float* ga = &gg.x;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) air_adam_update(pa[k], ma[k], va[k], ga[k], cf, omb1, omb2, eps);
-        p4[i] = pp; m4[i] = mm; v4[i] = vv;
-    }
-    if (bid == 0 && tid < (int)(a.n - n4 * 4)) {           // the region is 4-aligned, so the tail is outside it
-        const long i = n4 * 4 + tid;
-        float pk = a.p[i], mk = a.m[i], vk = a.v[i];
-        air_adam_update(pk, mk, vk, a.g[i], cf, omb1, omb2, eps);
-        a.p[i] = pk; a.m[i] = mk; a.v[i] = vk;
-    }
-}
-
-__global__ __launch_bounds__(THREADS) void adam_factored_kernel(Prob pr, AdamFac a)
-{
-    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * KC * LS * sizeof(float)];
-    adam_factored_body<0>(pr, a, smem);
-}
-__global__ __launch_bounds__(THREADS) void adam_factored_bf16_kernel(Prob pr, AdamFac a)
-{
-    // one 64-row image per operand (16 KB: the contraction is over B rows) or the 20 KB fp32 tile
-    __shared__ __attribute__((aligned(16))) unsigned char smem[BT * LS * sizeof(float)];
-    adam_factored_body<1>(pr, a, smem);
-}
-
 }  // namespace
 
 AIR_STAMPS_READER(air_debug_stamps_wgrad)
@@ -373,31 +279,3 @@ extern "C" int air_wgrad_grouped(const air_wgrad_t* probs, int count, int precis
     return 0;
 }
 
-extern "C" int air_adam_clip_step_factored(float* params, const float* grads, float* m, float* v, int64_t n,
-                                           const air_wgrad_t* factored, int precision,
-                                           const float* partials, int npartials, const float* dyn, const int32_t* istate,
-                                           float grad_prescale, float beta1, float beta2, float epsilon,
-                                           float* gnorm_out, void* stream) {
-    if (!params || !grads || !m || !v || !partials || npartials <= 0 || !dyn || !istate || n <= 0 || !factored) return AIR_EINVAL;
-    if ((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)m | (uintptr_t)v) & 15) != 0) return AIR_EALIGN;
-    if (precision != 0 && precision != 1) return AIR_EINVAL;
-    Table tab;
-    const int rc = fill_table(factored, 1, tab, false);
-    if (rc) return rc;
-    const air_wgrad_t& f = *factored;
-    if (f.head_pack || f.db || f.ldc != f.N) return AIR_EINVAL;
-    if ((f.N & 3) != 0) return AIR_EALIGN;
-    const long roff = (long)(f.dW - grads), rlen = (long)f.M * f.N;
-    if (f.dW < grads || roff + rlen > n) return AIR_EINVAL;      // the block must lie inside the flat buffer
-    if ((roff & 3) != 0) return AIR_EALIGN;
-    long plain = ((n - rlen) / 4 + THREADS - 1) / THREADS;
-    if (plain < 1) plain = 1;
-    if (plain > 2048) plain = 2048;
-    AdamFac a{params, grads, m, v, (long)n, roff, rlen, partials, npartials, dyn, istate,
-              grad_prescale, beta1, beta2, epsilon, gnorm_out, tab.total_blocks};
-    const dim3 grid((unsigned)(tab.total_blocks + plain));
-    if (precision == 1) hipLaunchKernelGGL(adam_factored_bf16_kernel, grid, dim3(THREADS), 0, air_stream(stream), tab.p[0], a);
-    else hipLaunchKernelGGL(adam_factored_kernel, grid, dim3(THREADS), 0, air_stream(stream), tab.p[0], a);
-    AIR_CHECK_LAUNCH();
-    return 0;
-}

@@ -91,7 +91,7 @@ __device__ __forceinline__ void publish_sq(float sq, float* sq_partials, int32_t
 
 // Epilogue of the weight-gradient kernels: the tile in Ct goes to pr.dW (whole rows per store
 // instruction) and its sum of squares to the caller.  pr.dW == NULL: nothing is stored, only the
-// sum of squares is taken (a gradient that air_adam_clip_step_factored rebuilds from its factors).
+// sum of squares is taken (a gradient its caller rebuilds from the factors elsewhere).
 __device__ __forceinline__ float store_tile(const Prob& pr, int m0, int n0, const float* Ct, float sq)
 {
     const int tid = threadIdx.x;

@@ -24,7 +24,7 @@ if STRESS:
 HP = hp
 images, targets = synthetic_canvases(256 if STRESS else 64, hp["canvas_size"], hp["max_digits"], 1)
 m = am.AIRModel(torch.tensor(images, device="cuda"), torch.tensor(targets, device="cuda"), cnn=False, train=True,
-                annealing_schedules=ANNEAL, gemm_precision="bf16", input_weight_gradient="stored", **HP)
+                annealing_schedules=ANNEAL, gemm_precision="bf16", **HP)
 for _ in range(3):
     m.training()
 torch.cuda.synchronize()
