@@ -128,8 +128,10 @@ class VariableStore:
             pan.append(H.Panel(src_off, poff, K, N, 4 if gates else 0, 1 if exclusive else 0))
             poff += _align8(K * N if gates else ((N + 15) // 16) * 16 * K)
         o = self.offsets["lstm_kernel"]
-        if self.fuse_step0 and D <= 4096:       # (its one reader is the x.Wx launch that also runs the first step; the throughput
-            add_panel("Wx", o, D, 4 * R, True, exclusive=True)     # tiling of a large canvas reads row-major lines: no panel twin there)
+        # (its one reader is the x.Wx launch that also runs the first step -- which needs D % 4 == 0 and R % 4 == 0: a shape that
+        # cannot fuse keeps the row-major shadow of Wx; the throughput tiling of a large canvas reads row-major lines: no panel)
+        if self.fuse_step0 and D <= 4096 and D % 4 == 0 and R % 4 == 0:
+            add_panel("Wx", o, D, 4 * R, True, exclusive=True)
         add_panel("Wh", o + D * 4 * R, R, 4 * R, True)
         for k, shp in fused.items():
             if k.endswith("_w") and k not in ("ml_w", "gen0_w") or k == "whid":
