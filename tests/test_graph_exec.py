@@ -414,20 +414,26 @@ def _carried_rule_by_hand(streams, chunks=16, chunk_min=64):
             for v in t:
                 acc = f(acc + v)
         return acc
-    P = R = f(0)
+    chunks_ = []
     for t in streams:
         n = len(t)
         if n == 0:
             continue
         cs = max(-(-n // chunks), chunk_min)
-        for k0 in range(0, n, cs):
-            C, Q = f(0), P
-            for v in t[k0:k0 + cs]:
-                C = f(C + v)
-                Q = f(Q + v)
-            R = f(R + f(Q - P))
-            P = f(P + C)
-    return R
+        chunks_ += [t[k0:k0 + cs] for k0 in range(0, n, cs)]
+    P, Ps, Qs = f(0), [], []
+    for ch in chunks_:
+        C, Q = f(0), P
+        for v in ch:
+            C = f(C + v)
+            Q = f(Q + v)
+        Ps.append(P); Qs.append(Q)
+        P = f(P + C)
+    Ps.append(P)
+    corr = f(0)
+    for k in range(len(chunks_) - 1):
+        corr = f(corr + f(Qs[k] - Ps[k + 1]))
+    return f(Qs[-1] + corr)
 
 
 def test_carried_segment_sum_is_the_stated_rule():
@@ -484,18 +490,19 @@ def test_carried_order_keeps_the_size_of_the_cancellation_residue():
 
 def test_carried_fixture_residue_norms_against_the_sequential_graph(gold, golden_dir):
     """tests/golden/graph_b64_carried.npz = the saved graph executed with its ONE UnsortedSegmentSum in the carried16 order.
-    One realisation of the residue each: per variable within 0.25x..6x of the sequential order's (the device's own
-    sequential realisation sits at 2.7x of the graph's, tests/test_gpu_graph_golden.py), far above the exact gradient;
-    the z_pres heads (no sampler residue) unchanged."""
+    One realisation of the residue each, and one 8 000-term corner stream carries most of this one's norm: per variable
+    within 0.05x..6x of the sequential order's (the device's own sequential realisation sits at 2.7x of the graph's,
+    tests/test_gpu_graph_golden.py; what the order does to the residue's SIZE is measured over 700 streams below), far
+    above the exact gradient; the z_pres heads (no sampler residue) unchanged."""
     car = np.load(os.path.join(golden_dir, "graph_b64_carried.npz"))
     r = float(car["train0/global_norm_fp32"]) / float(gold["train0/global_norm_fp32"])
-    assert 0.25 < r < 4.0, r
+    assert 0.1 < r < 4.0, r
     assert float(car["train0/global_norm_fp32"]) > 100 * float(gold["train0/global_norm_fp64"])
     for k in car.files:
         if not k.startswith("train0/grad32_norm/"):
             continue
         ratio = float(car[k]) / float(gold[k])
-        assert 0.25 < ratio < 6.0, (k, ratio)
+        assert 0.05 < ratio < 6.0, (k, ratio)
         if "/z_pres/" in k:
             assert abs(ratio - 1.0) < 1e-3, (k, ratio)
 
@@ -529,3 +536,51 @@ def test_carried_fixture_is_what_the_graph_gives_with_the_carried_scatter(graph,
         act = gold[k + "mask"].astype(bool)
         got = ((dU.reshape(n, -1) * v) * (f(1) - v)).astype(f)
         assert np.array_equal(got[act], car[k + "d_gen_pre"][act])
+
+
+def test_carried_order_keeps_the_residue_of_real_corner_streams():
+    """The corner streams of the write backward as the model makes them at initialisation (two batches of 64 blob canvases
+    through the oracle forward; d loss / d canvas with the poles of the Bernoulli ELBO): the error of each order against the
+    exact (fp64) sum.  carried16 leaves the sequential order's mean |error| (measured 1.0x over 2116 streams; asserted
+    0.6x..1.6x over ~700), blocked16 does not keep the distribution (twice the mean, a 5x heavier tail)."""
+    from oracle.synth import blob_canvases
+    f = np.float32
+    hp = dict(ao.TRAINING_HP)
+    err = {"seq": [], "car": [], "blk": []}
+    for seed in range(2):
+        B = 64
+        images, targets = blob_canvases(B, 50, 2, seed=100 + seed)
+        o = ao.air_forward(ao.init_params(hp, seed), images, targets, ao.make_noise(hp, B, seed + 50), hp, True, 9.21)
+        r = o["_running_recon"]
+        rc = np.clip(r, 0, 1).astype(f)
+        p1, p0 = rc + f(ao.EPS), (f(1) - rc) + f(ao.EPS)
+        g = np.where((r <= 1) & (np.minimum(r, 1) >= 0), -(f(1) / f(B)) * (images / p1 - (f(1) - images) / p0), 0).astype(f)
+        for t in range(o["rec_scales"].shape[1]):
+            s, xs, ys = o["rec_scales"][:, t, 0], o["rec_shifts"][:, t, 0], o["rec_shifts"][:, t, 1]
+            th = np.zeros((B, 2, 3), f)
+            th[:, 0, 0] = th[:, 1, 1] = f(1) / s
+            th[:, 0, 2], th[:, 1, 2] = (-xs) / s, (-ys) / s
+            _, aux = ao.transformer(o["rec_windows"][:, t].reshape(B, 28, 28).astype(f), th, (50, 50), return_aux=True)
+            X, Y, x0, x1, y0, y1 = (aux[q] for q in ("x", "y", "x0", "x1", "y0", "y1"))
+            gg = (o["_z_pres"][:, t][:, None] * g).astype(f)
+            wx0, wx1, wy0, wy1 = x1.astype(f) - X, X - x0.astype(f), y1.astype(f) - Y, Y - y0.astype(f)
+            for b in range(B):
+                idx = [y0[b] * 28 + x0[b], y1[b] * 28 + x0[b], y0[b] * 28 + x1[b], y1[b] * 28 + x1[b]]
+                val = [(wx0[b] * wy0[b]) * gg[b], (wx0[b] * wy1[b]) * gg[b], (wx1[b] * wy0[b]) * gg[b], (wx1[b] * wy1[b]) * gg[b]]
+                for sl in (0, 27, 756, 783):
+                    st = [v[i == sl] for i, v in zip(idx, val)]
+                    if max(len(q) for q in st) <= 64:
+                        continue
+                    ids = [np.zeros(len(q), np.int64) for q in st]
+                    exact = float(np.concatenate(st).astype(np.float64).sum())
+                    seq = np.zeros(1, f)
+                    np.add.at(seq, np.concatenate(ids), np.concatenate(st))
+                    parts = [ao.blocked_segment_sum(i, v, 1) for i, v in zip(ids, st)]
+                    blk = np.zeros(1, f)
+                    np.add.at(blk, np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]))
+                    err["seq"].append(float(seq[0]) - exact)
+                    err["car"].append(float(ao.carried_segment_sum(ids, st, 1)[0]) - exact)
+                    err["blk"].append(float(blk[0]) - exact)
+    mean = {k: float(np.mean(np.abs(v))) for k, v in err.items()}
+    assert len(err["seq"]) > 500
+    assert 0.6 < mean["car"] / mean["seq"] < 1.6, mean

@@ -1167,11 +1167,13 @@ __device__ __forceinline__ int wb_chunk_len(int n) { return max((n + WB_CHUNKS -
 // CARRIED (ORD == 2, literal == 4, backward="reference_carried"): the layout, the term pass and the chunks of BLOCKED, but
 //   * a slot whose four streams all fit one chunk (<= 64 terms each: every slot but the corners and a few long borders) is
 //     summed exactly as the reference sums it -- one accumulator through its a-, b-, c-, d-terms;
-//   * a slot with a longer stream walks every chunk TWICE: C = the chunk from +0.0, Q = the chunk from P, with P the running
-//     sum of the C's before it (a deterministic stand-in for the reference's accumulator at the chunk's start);
-//     R += Q - P; P += C in stream order; R is the slot's sum.  Every add of the Q chains rounds at the magnitude it rounds
-//     at in the reference's one long chain, so the cancellation residue the out-of-range terms leave keeps its size --
-//     BLOCKED shrinks it 10x..300x on the border / corner slots, and training notices.
+//   * a slot with a longer stream walks every chunk TWICE: C_k = chunk k from +0.0, Q_k = chunk k from P_k, with P_k the
+//     running sum of the C's before it (a deterministic stand-in for the reference's accumulator at the chunk's start);
+//     the slot's sum is Q_last + sum_{k < last} (Q_k - P_k+1), the corrections added left to right: Q_k and P_k+1 are two
+//     roundings of the same real number, their difference is a few ulps and exact.  Every add of the Q chains rounds at
+//     the magnitude it rounds at in the reference's one long chain and nothing else rounds at that magnitude, so the
+//     cancellation residue the out-of-range terms leave keeps its size (mean |error| 1.0x the sequential order's over 2116
+//     corner streams; BLOCKED: 2x with a 5x heavier tail) -- DESIGN.md section 10.
 //   Two chains of n / 16 adds per corner instead of one of 4 n; no LDS atomics, no probe.
 constexpr int WB_ORD_GRAPH = 0, WB_ORD_BLOCKED = 1, WB_ORD_CARRIED = 2;
 // c += every term, q += every term: the two chains of one chunk in ONE pass over its terms (independent: they overlap)
@@ -1623,8 +1625,8 @@ __device__ __forceinline__ void write_bwd_graph_body(const air_write_bwd_t& a, i
     };
     // CARRIED: this thread's slot, taps [PH0, PH1).  short_s: all four of its streams are single chunks -> the reference's
     // chain (acc); otherwise P_s / R_s carry the scheme above from tap to tap (and from pass to pass on large canvases)
-    float P_s = 0.0f, R_s = 0.0f;
-    bool short_s = true;
+    float P_s = 0.0f, corr_s = 0.0f, Q_s = 0.0f;
+    bool short_s = true, have_s = false;
     if (CARRIED && is_slot) {
 #pragma unroll
         for (int ph = 0; ph < 4; ++ph) { int st, n; slot_run(ph, sp, sq, st, n); short_s = short_s && n <= WB_CHUNK_MIN; }
@@ -1640,12 +1642,14 @@ __device__ __forceinline__ void write_bwd_graph_body(const air_write_bwd_t& a, i
             if (short_s) { acc = stream_add(acc, sh_T, start, n); continue; }
             const int cs = wb_chunk_len(n);
             for (int k0 = 0; k0 < n; k0 += cs) {
+                if (have_s) corr_s += Q_s - P_s;                 // the previous chunk's chain against the prefix behind it (exact)
                 float c = 0.0f, q = P_s;
                 stream_add2(c, q, sh_T, start + k0, min(cs, n - k0));
-                R_s += q - P_s;
+                Q_s = q;
                 P_s += c;
+                have_s = true;
             }
-            acc = R_s;
+            acc = Q_s + corr_s;                                  // (final after the last tap)
         }
     };
     // BLOCKED: chunk k of corner (cp, cq)'s stream of tap ph, summed from +0.0 (empty chunks: +0.0, the identity)
@@ -1725,11 +1729,19 @@ __device__ __forceinline__ void write_bwd_graph_body(const air_write_bwd_t& a, i
                     pk = lane == l ? run : pk;
                     run += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ck), l));
                 }
-                const float dk = stream_add(pk, sh_T, start + off, len) - pk;
-                float du = 0.0f;
+                const float qk = stream_add(pk, sh_T, start + off, len);
+                // Q_last + the corrections Q_k - P_k+1 of the chunks before it, in stream order (empty chunks: nothing)
+                float corr = 0.0f, qprev = 0.0f;
+                bool have = false;
 #pragma unroll
-                for (int l = 0; l < 64; ++l) du += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dk), l));
-                if (lane == 0) publish_corner(wave, du);
+                for (int l = 0; l < 64; ++l) {
+                    if (__builtin_amdgcn_readlane(len, l) > 0) {             // (uniform)
+                        if (have) corr += qprev - __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pk), l));
+                        qprev = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qk), l));
+                        have = true;
+                    }
+                }
+                if (lane == 0) publish_corner(wave, qprev + corr);
             }
         }
         if (wave == NW - 1) finish_theta();
@@ -1749,9 +1761,11 @@ __device__ __forceinline__ void write_bwd_graph_body(const air_write_bwd_t& a, i
         // and carries the corner accumulators from pass to pass; the coordinate gradients ride in pass 0
         using std::integral_constant;
         float cacc[4] = {0.f, 0.f, 0.f, 0.f};
-        // CARRIED: cacc = R of the four corners, cP = their P; cshort: all four streams of the corner are single chunks
-        float cP[4] = {0.f, 0.f, 0.f, 0.f};
-        bool cshort[4] = {true, true, true, true};
+        // CARRIED: cP = the four corners' prefixes P, cQ / ccorr / chave = the last chain's end, the corrections so far and
+        // whether a chain has run (cacc = cQ + ccorr; a short corner -- all four streams single chunks -- keeps the
+        // reference's chain in cacc)
+        float cP[4] = {0.f, 0.f, 0.f, 0.f}, cQ[4] = {0.f, 0.f, 0.f, 0.f}, ccorr[4] = {0.f, 0.f, 0.f, 0.f};
+        bool cshort[4] = {true, true, true, true}, chave[4] = {false, false, false, false};
         if (CARRIED && wave == 1) {
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc)
@@ -1796,14 +1810,18 @@ __device__ __forceinline__ void write_bwd_graph_body(const air_write_bwd_t& a, i
                     cP[cc] = run;
                 }
                 const float qk = stream_add(pk, sh_T, start + off, len);
-                const float dk = qk - pk;
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) {
-                    if (cshort[cc]) cacc[cc] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qk), cc * 16));
-                    else
+                    if (cshort[cc]) { cacc[cc] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qk), cc * 16)); continue; }
 #pragma unroll
-                        for (int k = 0; k < 16; ++k)
-                            cacc[cc] += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dk), cc * 16 + k));
+                    for (int k = 0; k < 16; ++k) {
+                        if (__builtin_amdgcn_readlane(len, cc * 16 + k) > 0) {       // (uniform)
+                            if (chave[cc]) ccorr[cc] += cQ[cc] - __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pk), cc * 16 + k));
+                            cQ[cc] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qk), cc * 16 + k));
+                            chave[cc] = true;
+                        }
+                    }
+                    cacc[cc] = cQ[cc] + ccorr[cc];
                 }
             }
             if (ph == 0 && wave == NW - 1) finish_theta();
