@@ -385,10 +385,11 @@ typedef struct {
                                                16 chunks of at least 64 terms that are summed from +0.0 side by side and added
                                                left to right (backward="reference_blocked"; no LDS atomics, no probe);
                                             4: as 2 for every window pixel whose four streams have at most 64 terms each; a
-                                               pixel with a longer stream walks the chunks of 3 TWICE -- C from +0.0, Q from P =
-                                               the running sum of the earlier C's -- and sums Q - P left to right, so that every
-                                               add rounds at the magnitude it has in the one long chain of 2
-                                               (backward="reference_carried")                                                */
+                                               pixel with a longer stream walks the chunks of 3 TWICE -- C_k from +0.0, Q_k from
+                                               P_k = the running sum of the earlier C's -- and returns
+                                               Q_last + sum_{k < last} (Q_k - P_k+1), the (exact) differences added left to right:
+                                               every add of the Q chains rounds at the magnitude it has in the one long chain
+                                               of 2, and nothing else does (backward="reference_carried")                    */
     /* optional: workgroup (0,0) also does air_finalize's batch means (train step: saves a launch).
      * fin_scalars == NULL disables; loss_item is the [B] output of air_write_fwd */
     const float* fin_loss_item; const int32_t* fin_targets; const int32_t* fin_digits;
