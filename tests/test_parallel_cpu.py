@@ -63,11 +63,16 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_dp2_allreduce_equals_full_batch():
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_dp_allreduce_equals_full_batch(world):
+    """world 2 and world 4 (one image per rank): sum over the ranks / world == the full-batch mean"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     avg, loss_avg, n, ntrain = q.get(timeout=300)
