@@ -364,7 +364,7 @@ class AIRModel:
         if backward not in ("reference", "reference_blocked", "reference_carried", "taps", "exact"):
             raise ValueError("backward must be 'reference', 'reference_carried', 'reference_blocked', 'taps' or 'exact'")
         self.backward = backward
-        self._literal = {"reference_carried": 4, "reference_blocked": 3, "reference": 2, "taps": 1, "exact": 0}[backward]
+        self._literal = self._ORDERS[backward]
         self._prec = 1 if prec == "bf16" else 0
         # bf16 path: every GEMM operand also exists as a bf16 twin in memory (written by the producing kernel /
         # by Adam), so the GEMMs read 2-byte operands and convert nothing -- bit-identical results (the twin IS
@@ -917,6 +917,22 @@ class AIRModel:
             getattr(self, k).copy_(torch.as_tensor(np.asarray(noise[k]), dtype=torch.float32).reshape(getattr(self, k).shape))
         self._injected_noise = True
         self._dirty = True
+
+    _ORDERS = {"reference_carried": 4, "reference_blocked": 3, "reference": 2, "taps": 1, "exact": 0}
+
+    def set_backward(self, backward):
+        """Switches the sampler-backward order of a built train model (AIRModel(backward=...)): the launch lists are rebuilt,
+        a captured graph is released and has to be captured again.  The variables, the Adam slots and global_step are
+        untouched.  (training.py --late-backward: the reference's order while the out-of-range residue rules the gradient,
+        a chunked order once ink is explained -- DESIGN.md section 10.1.)"""
+        if backward not in self._ORDERS:
+            raise ValueError("backward must be one of %s" % sorted(self._ORDERS))
+        if backward == self.backward:
+            return
+        self.release_graph()
+        self.backward = backward
+        self._literal = self._ORDERS[backward]
+        self._build_programs()
 
     def use_device_rng(self, seed=None):
         if seed is not None:

@@ -125,6 +125,10 @@ def main():
     parser.add_argument("--backward", default="reference", choices=["reference", "reference_carried", "reference_blocked", "taps", "exact"],
                         help="sampler backward: the reference graph's op order (default), the same streams in 16 chunks per tap, "
                              "per-tap sums, or the exact adjoint")
+    parser.add_argument("--late-backward", default="", choices=["", "reference", "reference_carried", "reference_blocked", "taps", "exact"],
+                        help="switch the sampler backward to this order from iteration --late-backward-from on")
+    parser.add_argument("--late-backward-from", type=int, default=5000,
+                        help="(a multiple of 50) by then ink is explained and the out-of-range residue no longer rules the gradient")
     args = parser.parse_args()
 
     # results folder handling, training.py:41-61
@@ -204,7 +208,11 @@ def main():
     if not args.no_graph:
         if args.print_every == 0 and NUM_SUMMARIES_EACH_ITERATIONS % args.graph_steps == 0:
             gsteps = args.graph_steps
-        train_model.capture_graph(steps=gsteps, between_steps=next_batch if gsteps > 1 else None)
+
+    def capture():
+        if not args.no_graph:
+            train_model.capture_graph(steps=gsteps, between_steps=next_batch if gsteps > 1 else None)
+    capture()
     H.check(H.lib().air_shuffle_batch_init(C.byref(sq), _s()), "air_shuffle_batch_init")   # (after the capture: nothing consumed)
 
     print("Training...")
@@ -236,6 +244,9 @@ def main():
             torch.save(train_model.state_dict(), models_folder + "air-model-%d.pt" % step)
             if args.tf_checkpoints:                                   # training.py:203-207 saver.save(..., global_step)
                 train_model.save_tf_checkpoint(models_folder + "air-model-%d" % step)
+        if args.late_backward and step == args.late_backward_from:
+            train_model.set_backward(args.late_backward)            # launch lists rebuilt; the graph is captured again
+            capture()
         if gsteps == 1:
             next_batch()
         train_model.training()
