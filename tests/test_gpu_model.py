@@ -608,3 +608,39 @@ def test_bf16_shadow_follows_a_train_model_that_does_not_maintain_it(am, train_k
         tr.training()
         assert tr.store.shadow_stale                      # the step changed the variables without touching the shadow
     assert len(set(losses)) == 3
+
+
+def test_set_backward_switches_the_order_of_a_built_model(am):
+    """AIRModel.set_backward (training.py --late-backward): the launch lists are rebuilt for the other order, a captured
+    graph is released, variables / Adam slots / global_step carry on; switching there and back gives the same step as a
+    model that never switched (same state, same noise key)."""
+    model, *_ = _make(am, 16, True, backward="reference")
+    model.use_device_rng(seed=5)
+    model.capture_graph(steps=2)
+    model.training()
+    torch.cuda.synchronize()
+    assert int(model.global_step) == 2
+    kern = lambda m: [op.kernel for op in m.train_step_ops() if "write_bwd" in op.kernel]   # noqa: E731
+    assert kern(model) == ["write_bwd_graph_kernel<true>"]
+    model.set_backward("reference_carried")
+    assert model._graph is None and kern(model) == ["write_bwd_carried_kernel<true>"]
+    snap = (model.store.params.clone(), model.store.m.clone(), model.store.v.clone())
+    model.set_backward("reference")                        # ... and back: nothing but the launch lists changed
+    for a, b in zip(snap, (model.store.params, model.store.m, model.store.v)):
+        assert torch.equal(a, b)
+    model.training()
+    torch.cuda.synchronize()
+    ref, *_ = _make(am, 16, True, backward="reference")
+    ref.use_device_rng(seed=5)
+    for _ in range(3):
+        ref.training()
+    torch.cuda.synchronize()
+    assert int(model.global_step) == int(ref.global_step) == 3
+    assert torch.equal(model.store.params, ref.store.params) and torch.equal(model.store.m, ref.store.m)
+    model.set_backward("reference_carried")
+    model.capture_graph(steps=2)
+    model.training()
+    torch.cuda.synchronize()
+    assert int(model.global_step) == 5 and bool(torch.isfinite(model.store.params).all())
+    with pytest.raises(ValueError):
+        model.set_backward("sequential")
