@@ -35,8 +35,10 @@ extern "C" {
  *    air_adam_clip_step_panels)
  * 4: measured-negative paths removed (DESIGN.md sections 8-10 keep the record): the deferred Adam slices
  *    (air_step_job_t.ad_*, air_adam_clip_step_blocks), the banded compose (air_write_fwd_t.rec_part / bands,
- *    air_finalize_parts, air_write_bwd_t.fin_rec_part ..), air_adam_clip_step_factored; added: `literal` 3 / 4 of air_write_bwd, air_shuffle_batch_* */
-#define AIR_ABI_VERSION 4
+ *    air_finalize_parts, air_write_bwd_t.fin_rec_part ..), air_adam_clip_step_factored; added: `literal` 3 / 4 of air_write_bwd, air_shuffle_batch_*
+ * 5: added air_shuffle_batch_dequeue_many, air_batch_gather, air_summaries; removed `literal` 1 and 3 of the sampler
+ *    backward (backward="taps" / "reference_blocked") */
+#define AIR_ABI_VERSION 5
 
 #define AIR_EINVAL   (-1)   /* bad dimension / null pointer            */
 #define AIR_ELIMIT   (-2)   /* size exceeds what the kernel supports    */
@@ -331,7 +333,7 @@ typedef struct {
                                                in air_write_bwd, ONE fp32 accumulator per window pixel through the four
                                                concatenated Gather gradients (the graph's single UnsortedSegmentSum) --
                                                keeps the out-of-range rounding residue, bit-identical to the executed graph.
-                                            1: per-tap partial sums added ((d+c)+b)+a (a much smaller residue)        */
+                                            (air_attend_bwd: any non-zero value selects the graph order)               */
     uint16_t* d_hid16;                   /* bf16 twin of d_hid (nullable)   */
 } air_attend_bwd_t;
 int air_attend_bwd(const air_attend_bwd_t* a, void* stream);
@@ -380,16 +382,21 @@ typedef struct {
     float* d_gen_pre;                    /* [N,B,w*w] grad wrt gen_mean pre-sigmoid input */
     float* d_sxy_write;                  /* [N,B,4]: ds,dx,dy (via theta_recon), dz */
     int32_t B, N, C, w;
-    int32_t literal;                     /* 0, 1, 2: see air_attend_bwd_t.  air_write_bwd only:
-                                            3: the graph's term streams (2), every (window pixel, tap) stream cut into at most
-                                               16 chunks of at least 64 terms that are summed from +0.0 side by side and added
-                                               left to right (backward="reference_blocked"; no LDS atomics, no probe);
-                                            4: as 2 for every window pixel whose four streams have at most 64 terms each; a
-                                               pixel with a longer stream walks the chunks of 3 TWICE -- C_k from +0.0, Q_k from
-                                               P_k = the running sum of the earlier C's -- and returns
-                                               Q_last + sum_{k < last} (Q_k - P_k+1), the (exact) differences added left to right:
-                                               every add of the Q chains rounds at the magnitude it has in the one long chain
-                                               of 2, and nothing else does (backward="reference_carried")                    */
+    int32_t literal;                     /* 0, 2: see air_attend_bwd_t.  air_write_bwd only:
+                                            4: as 2 for every window pixel whose four term streams have at most 64 terms each
+                                               (all but the four corners and a few long borders); a pixel with a longer stream
+                                               has every tap's stream cut into at most 16 chunks of at least 64 terms and walks
+                                               each chunk TWICE -- C_k from +0.0, Q_k from P_k = the running sum of the earlier
+                                               C's -- and returns Q_last + sum_{k < last} (Q_k - P_k+1), the (exact) differences
+                                               added left to right: every add of the Q chains rounds at the magnitude it has in
+                                               the one long chain of 2, and nothing else does (backward="reference_carried"; no
+                                               LDS atomics, no probe).  The coordinate / z gradients d_sxy_write of 4 are
+                                               per-column thread sums in the graph's AddN order per pixel (rows whose y taps clip
+                                               to one index are exact zeros and skipped): equal to 2's to ~1e-7 relative, not bit
+                                               for bit -- pinned against the executed graph's tensors by
+                                               tests/test_gpu_graph_golden.py.
+                                            (1, the per-tap order, and 3, chunks from +0.0 added left to right, were removed
+                                             with ABI 5: measured to train worse, DESIGN.md section 10.1.  AIR_EINVAL.)      */
     /* optional: workgroup (0,0) also does air_finalize's batch means (train step: saves a launch).
      * fin_scalars == NULL disables; loss_item is the [B] output of air_write_fwd */
     const float* fin_loss_item; const int32_t* fin_targets; const int32_t* fin_digits;
@@ -507,6 +514,42 @@ typedef struct {
 /* queue <- the first `capacity` records of the stream, state <- (capacity, 0) */
 int air_shuffle_batch_init(const air_shuffle_batch_t* q, void* stream);
 int air_shuffle_batch_dequeue(const air_shuffle_batch_t* q, void* stream);
+/* `n_batches` consecutive dequeues in one launch, pick for pick what n_batches calls of air_shuffle_batch_dequeue make:
+ * picks_out[k * batch + i] = pick i of the k-th of them (q->picks is not written).  training.py records it on a forked
+ * branch of its hipGraph replay: the picks of the NEXT half replay are made while this one's train steps run, so the 64
+ * dependent picks of a batch are off the critical path of every step. */
+int air_shuffle_batch_dequeue_many(const air_shuffle_batch_t* q, int n_batches, int32_t* picks_out, void* stream);
+/* the decoded tensors of a dequeued batch (read_and_decode, multi_mnist.py:228-238, after the queue):
+ * out_images[i] = images[picks[i]] ([batch, D] fp32 rows, D % 4 == 0, 16-byte aligned), out_digits[i] = digits[picks[i]]
+ * (out_digits / digits nullable together). */
+int air_batch_gather(const float* images, const int32_t* digits, const int32_t* picks, float* out_images,
+                     int32_t* out_digits, int batch, int D, void* stream);
+
+/* ---- numeric summaries (the reference's air_model.py:160-209, 608-632; evaluated by training.py:169-200 on the test
+ * model every 50 iterations) as one launch over the outputs of a forward pass --------------------------------------
+ * out[0] = loss, out[1] = accuracy (copies of `scalars`), then one ROW of max_digits + 2 masked means per summarised
+ * quantity -- the images with exactly 0 .. max_digits target digits, then all images ("_<i>_dig", "_all_dig"; an empty
+ * group is NaN as tf.reduce_mean of an empty tensor) -- in the order the reference appends them:
+ *   rows 0..3          steps (= rec_num_digits as float), rec_loss, digit_acc (digits == targets), total_loss (loss_item)
+ *   rows 4 + q * N + i quantity q of step i + 1, q = scale, z_pres_prob (all_steps=True), z_pres_kl (one_more_step=True),
+ *                      scale_kl, shift_kl, vae_kl; masked to the images with rec_num_digits > i (> i - 1: one_more_step; no
+ *                      mask: all_steps); a step the while_loop did not reach (i >= T', derived from AIR_ATT_MASK) is the
+ *                      zero padding of :187.
+ * air_summaries_count(N, max_digits) = 2 + (4 + 6 N)(max_digits + 2) floats.  N <= 16, max_digits <= 6.  Stream work,
+ * capturable, deterministic (fp64 sums in a fixed order, rounded once). */
+#define AIR_MAX_STEPS_SUMMARY 16
+typedef struct {
+    const float* att;            /* [N,B,AIR_ATT_STRIDE] of the pass */
+    const int32_t* targets;      /* [B] target_num_digits */
+    const int32_t* digits;       /* [B] rec_num_digits */
+    const float* rec_loss;       /* [B] reconstruction_loss */
+    const float* loss_item;      /* [B] loss before the batch mean (:598-600) */
+    const float* scalars;        /* [2] loss, accuracy (air_finalize) */
+    float* out;                  /* [air_summaries_count(N, max_digits)] */
+    int32_t B, N, max_digits;
+} air_summaries_t;
+int air_summaries_count(int N, int max_digits);
+int air_summaries(const air_summaries_t* a, void* stream);
 
 #ifdef __cplusplus
 }

@@ -267,35 +267,8 @@ def transformer(U, theta, out_size, return_aux=False):
     return out
 
 
-BLOCKED_CHUNKS = 16     # at most this many chunks per (input pixel, tap) term stream of order="blocked16" ...
-BLOCKED_CHUNK_MIN = 64  # ... none of them shorter than this (a stream of up to 64 terms is one chunk)
-
-
-def blocked_segment_sum(ids, vals, num, chunks=BLOCKED_CHUNKS, chunk_min=BLOCKED_CHUNK_MIN):
-    """The accumulation order of backward="reference_blocked" for ONE tap's Gather gradient: the terms that go
-    to one input pixel ("slot"), n of them in output-pixel order, are cut into contiguous pieces of
-    cs = max(ceil(n / chunks), chunk_min) terms (the last one shorter); each piece is summed sequentially from
-    +0.0 in fp32.  Returns (slot, chunk_sum) pairs ordered by slot, then by chunk -- the caller adds them onto
-    one accumulator per slot, tap after tap (a, b, c, d), chunk after chunk.  The in-range window pixels of the
-    AIR write (a handful of terms per tap) therefore keep per-tap sequential sums; only the border pixels that
-    collect the out-of-range canvas -- thousands of terms, the reference's 10 000-term chain
-    (transformer.py:108-116 under tf.gradients) -- are cut."""
-    order = np.argsort(ids, kind="stable")
-    si, sv = ids[order], vals[order]
-    if si.size == 0:
-        return si, sv
-    first = np.concatenate([[True], si[1:] != si[:-1]])
-    start = np.flatnonzero(first)                                  # first term of every slot
-    n = np.diff(np.concatenate([start, [si.size]]))
-    cs = np.maximum(-(-n // chunks), chunk_min)
-    rank = np.arange(si.size) - np.repeat(start, n)                # position within the slot's stream
-    chunk = rank // np.repeat(cs, n)
-    nch = -(-n // cs)
-    cbase = np.concatenate([[0], np.cumsum(nch)[:-1]])
-    gchunk = np.repeat(cbase, n) + chunk
-    sums = np.zeros(int(nch.sum()), vals.dtype)
-    np.add.at(sums, gchunk, sv)                                    # sequential within every chunk, from +0.0
-    return np.repeat(si[start], nch), sums
+CARRIED_CHUNKS = 16     # at most this many chunks per (input pixel, tap) term stream of order="carried16" ...
+CARRIED_CHUNK_MIN = 64  # ... none of them shorter than this (a stream of up to 64 terms is one chunk)
 
 
 def _seq_sum(start, terms):
@@ -305,7 +278,7 @@ def _seq_sum(start, terms):
     return np.add.accumulate(np.concatenate([[start], terms]).astype(terms.dtype))[-1]
 
 
-def carried_segment_sum(ids4, vals4, num, chunks=BLOCKED_CHUNKS, chunk_min=BLOCKED_CHUNK_MIN):
+def carried_segment_sum(ids4, vals4, num, chunks=CARRIED_CHUNKS, chunk_min=CARRIED_CHUNK_MIN):
     """The accumulation order of backward="reference_carried" (order="carried16"): the four Gather gradients ids4 / vals4
     (taps a, b, c, d) into `num` accumulators.
 
@@ -315,7 +288,7 @@ def carried_segment_sum(ids4, vals4, num, chunks=BLOCKED_CHUNKS, chunk_min=BLOCK
     A slot with a longer stream keeps the reference's left-to-right structure AND the magnitude of its roundings, on chunks
     that can be walked side by side.  Every tap's stream of n terms is cut into contiguous chunks of
     cs = max(ceil(n / chunks), chunk_min) terms; over all chunks of the slot in stream order (a, b, c, d), with P_0 = +0.0:
-        C_k = chunk k summed sequentially from +0.0                  (what order="blocked16" adds up)
+        C_k = chunk k summed sequentially from +0.0
         Q_k = chunk k summed sequentially from P_k                   (the chain the reference runs there: P_k stands for
                                                                       the reference's accumulator at the chunk's start,
                                                                       so every add rounds at the magnitude it rounds at
@@ -325,11 +298,12 @@ def carried_segment_sum(ids4, vals4, num, chunks=BLOCKED_CHUNKS, chunk_min=BLOCK
     P_k+1 are two roundings of the same real number -- the accumulator after chunk k -- so their difference is a few ulps
     and EXACT (Sterbenz); the sum is the telescoped form of sum_k (Q_k - P_k), evaluated without the two roundings per
     chunk at full magnitude that the plain form costs (2116 corner streams at initialisation: mean |error| 4.37e3 against
-    the sequential order's 4.34e3; the plain form 6.3e3, blocked16 8.8e3 with a 5.7x heavier tail -- tests/test_graph_exec.py).
+    the sequential order's 4.34e3; the plain form 6.3e3, the C_k alone added left to right 8.8e3 with a 5.7x heavier tail --
+    tests/test_graph_exec.py).
     All C of a slot are independent, P is their running sum, all Q are independent given P: two chains of n / chunks adds
     instead of one of 4 n.  The out-of-range terms cancel pairwise in exact arithmetic (a against c, b against d); what is
     left of them is rounding residue, and its size is set by the magnitude of the accumulator the terms are added to --
-    which `blocked16` (every chunk from +0.0) changes and this order keeps."""
+    which summing every chunk from +0.0 changes and this order keeps."""
     dtype = vals4[0].dtype
     f = dtype.type
     per_tap = []
@@ -369,12 +343,7 @@ def transformer_backward(U, theta, out_size, d_out, order="sequential"):
 
       * d U: the four Gather gradients are concatenated (a, b, c, d) and reduced by ONE
         UnsortedSegmentSum -- np.add.at visits the terms in that order, like the TF CPU kernel
-        (order="sequential", the default).  order="blocked16" (AIRModel(backward="reference_blocked")) keeps the
-        same concatenated a, b, c, d stream per input pixel but cuts every tap's piece of it into up to 16
-        contiguous chunks (of at least 64 terms) that are summed independently and then added left to right
-        (blocked_segment_sum): the same terms,
-        the same left-to-right structure, a sum tree a GPU can evaluate in parallel -- the realisation a
-        parallel UnsortedSegmentSum (TF's GPU kernel uses unordered atomics) stands for, made deterministic;
+        (order="sequential", the default).
         order="carried16" (AIRModel(backward="reference_carried")): the reference's order for every slot with short streams,
         chunks walked from a carried estimate of the reference's accumulator for the long ones (carried_segment_sum);
       * coordinate gradients: mul_10..13_grad / mul_6..9_grad products, Sub negations, then AddN_10
@@ -394,15 +363,13 @@ def transformer_backward(U, theta, out_size, d_out, order="sequential"):
     Ia, Ib, Ic, Id = U[bidx, y0, x0], U[bidx, y1, x0], U[bidx, y0, x1], U[bidx, y1, x1]
     # d U: [a-terms of every output pixel, then b, c, d] into one accumulator per input pixel
     d_U = np.zeros((B, Hi * Wi), dtype)
-    assert order in ("sequential", "blocked16", "carried16"), order
+    assert order in ("sequential", "carried16"), order
     for b in range(B):
         idx = [y0[b] * Wi + x0[b], y1[b] * Wi + x0[b], y0[b] * Wi + x1[b], y1[b] * Wi + x1[b]]
         val = [(wx0[b] * wy0[b]) * g[b], (wx0[b] * wy1[b]) * g[b], (wx1[b] * wy0[b]) * g[b], (wx1[b] * wy1[b]) * g[b]]
         if order == "carried16":
             d_U[b] = carried_segment_sum(idx, val, Hi * Wi)
             continue
-        if order == "blocked16":
-            idx, val = zip(*(blocked_segment_sum(i, v, Hi * Wi) for i, v in zip(idx, val)))
         np.add.at(d_U[b], np.concatenate(idx), np.concatenate(val))
     ga, gb, gc, gd = g * Ia, g * Ib, g * Ic, g * Id
     dX = ((-(ga * wy0) + -(gb * wy1)) + gc * wy0) + gd * wy1

@@ -337,10 +337,9 @@ def _k_addn(n, *xs):
     return acc
 
 
-# "sequential": TF's CPU kernel.  "blocked16": what backward="reference_blocked" computes -- the graph's one
-# UnsortedSegmentSum takes the four Gather gradients concatenated (taps a, b, c, d); every tap's quarter goes through
-# oracle.air_oracle.blocked_segment_sum (up to 16 chunks per segment and tap, summed side by side) and the chunk sums
-# are then added in the same a, b, c, d stream order.  "carried16": backward="reference_carried" (carried_segment_sum).
+# "sequential": TF's CPU kernel.  "carried16": what backward="reference_carried" computes -- the graph's one
+# UnsortedSegmentSum takes the four Gather gradients concatenated (taps a, b, c, d); segments with short streams are summed
+# as the CPU kernel sums them, the long ones through oracle.air_oracle.carried_segment_sum.
 # A module switch for tests / tests/golden/make_graph_golden.py:
 # the whole saved graph executed with that ONE kernel swapped shows what the order does to the 36 gradients.
 SEGMENT_SUM_ORDER = "sequential"
@@ -350,15 +349,7 @@ def _k_unsorted_segment_sum(n, data, ids, num):
     ids = np.asarray(ids)
     out = np.zeros((int(num),) + data.shape[ids.ndim:], data.dtype)
     flat_ids, flat = ids.reshape(-1), data.reshape((-1,) + data.shape[ids.ndim:])
-    if SEGMENT_SUM_ORDER == "blocked16":
-        from oracle.air_oracle import blocked_segment_sum
-        tail = flat.shape[1:]
-        assert int(np.prod(tail)) == 1 and flat.shape[0] % 4 == 0, "the sampler's scatter: four concatenated tap gradients"
-        flat, q = flat.reshape(-1), flat.shape[0] // 4
-        parts = [blocked_segment_sum(flat_ids[k * q:(k + 1) * q], flat[k * q:(k + 1) * q], int(num)) for k in range(4)]
-        flat_ids = np.concatenate([p[0] for p in parts])
-        flat = np.concatenate([p[1] for p in parts]).reshape((-1,) + tail)
-    elif SEGMENT_SUM_ORDER == "carried16":
+    if SEGMENT_SUM_ORDER == "carried16":
         # backward="reference_carried": short streams as the CPU kernel, long ones through oracle.air_oracle.carried_segment_sum
         from oracle.air_oracle import carried_segment_sum
         assert int(np.prod(flat.shape[1:])) == 1 and flat.shape[0] % 4 == 0, "the sampler's scatter: four concatenated tap gradients"

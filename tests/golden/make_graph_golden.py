@@ -124,8 +124,7 @@ def main():
           (len(out), os.path.getsize(path) / 1024, out["train0/loss"], out["train0/loss_fp64"],
            out["train0/global_norm_fp32"], out["train0/global_norm_fp64"], trips))
     compose(nodes)
-    blocked(nodes)
-    blocked(nodes, "carried16")
+    carried(nodes)
     chain(nodes)
 
 
@@ -155,11 +154,11 @@ def compose(nodes=None):
     print("wrote %d arrays, %.0f KB -> %s" % (len(out), os.path.getsize(path) / 1024, path))
 
 
-def blocked(nodes=None, order="blocked16"):
-    """tests/golden/graph_b64_blocked.npz (graph_b64_carried.npz): the fp32 backward of the train0 run once more with the
-    graph's ONE UnsortedSegmentSum evaluated in the blocked16 (carried16) order (oracle.blocked_segment_sum /
-    carried_segment_sum; AIRModel(backward="reference_blocked" / "reference_carried")) -- per-variable gradient norms and the
-    global norm, next to graph_b64.npz's grad32_norm/* (the sequential order) and grad64_norm/* (exact)."""
+def carried(nodes=None, order="carried16"):
+    """tests/golden/graph_b64_carried.npz: the fp32 backward of the train0 run once more with the graph's ONE
+    UnsortedSegmentSum evaluated in the carried16 order (oracle.carried_segment_sum; AIRModel(backward="reference_carried"))
+    -- per-variable gradient norms and the global norm, next to graph_b64.npz's grad32_norm/* (the sequential order) and
+    grad64_norm/* (exact)."""
     if nodes is None:
         _, nodes = gx.load_graph(META)
     images, targets, params, noise = inputs()
@@ -241,9 +240,7 @@ if __name__ == "__main__":
         compose()
     elif "--chain-only" in sys.argv:
         chain()
-    elif "--blocked-only" in sys.argv:
-        blocked()
     elif "--carried-only" in sys.argv:
-        blocked(order="carried16")
+        carried()
     else:
         main()

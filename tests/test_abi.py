@@ -44,7 +44,7 @@ def test_every_declared_symbol_is_exported_and_bound(H):
 
 
 def test_abi_version_and_strerror(H):
-    assert H.lib().air_abi_version() == H.ABI_VERSION == 4
+    assert H.lib().air_abi_version() == H.ABI_VERSION == 5
     assert b"invalid argument" in H.lib().air_strerror(-1)
     assert H.lib().air_strerror(0) == b"success"
 

@@ -816,16 +816,15 @@ def _write_theta(s, x, y):
     return th
 
 
-@pytest.mark.parametrize("literal,order", [(2, "sequential"), (3, "blocked16"), (4, "carried16")])
+@pytest.mark.parametrize("literal,order", [(2, "sequential"), (4, "carried16")])
 @pytest.mark.parametrize("Cc,w,N,B", [(50, 28, 3, 6), (71, 28, 2, 5), (128, 28, 5, 4), (128, 20, 2, 3), (50, 32, 2, 3), (40, 9, 2, 4)])
 def test_write_bwd_graph_order_matches_oracle_all_canvas_sizes(H, Cc, w, N, B, literal, order):
     """air_write_bwd(literal=2) -- backward="reference" -- against oracle.transformer_backward
     (pinned to the reference's executed graph, transformer.py:56-117 under tf.gradients) on random inputs, and
-    air_write_bwd(literal=3) -- backward="reference_blocked" -- against the same function with order="blocked16"
-    (every tap's piece of a window pixel's term stream in 16 chunks, oracle.blocked_segment_sum), air_write_bwd(literal=4)
-    -- backward="reference_carried" -- with order="carried16" (short streams as the reference, the chunks of long ones walked
-    from a carried stand-in for the reference's accumulator, oracle.carried_segment_sum).
-    C = 50 takes write_bwd_{graph,blocked}_kernel<true> (all four taps' terms resident), C >= 63 the per-tap staged
+    air_write_bwd(literal=4) -- backward="reference_carried" -- against the same function with order="carried16" (short
+    streams as the reference, the chunks of long ones walked from a carried stand-in for the reference's accumulator,
+    oracle.carried_segment_sum).
+    C = 50 takes write_bwd_{graph,carried}_kernel<true> (all four taps' terms resident), C >= 63 the per-tap staged
     <false> variant that every large canvas (BASELINE configs[3]: 128x128, N = 5) runs.  d_gen_pre (the
     UnsortedSegmentSum result times SigmoidGrad) BIT FOR BIT, residue included; theta / z legs <= 2e-5."""
     name = C.create_string_buffer(96)
@@ -849,7 +848,7 @@ def test_write_bwd_graph_order_matches_oracle_all_canvas_sizes(H, Cc, w, N, B, l
     dsx = torch.full((N, B, 4), 7.0, device="cuda")
     wb = H.WriteBwd(_p(g_d), _p(v_d), _p(att_d), _p(dgen), _p(dsx), B, N, Cc, w, literal, None, None, None, None)
     H.check(H.lib().air_write_bwd_kernel_name(C.byref(wb), name, 96))
-    assert name.value.decode() == "write_bwd_%s_kernel<%s>" % ({2: "graph", 3: "blocked", 4: "carried"}[literal], "true" if Cc <= 62 else "false")
+    assert name.value.decode() == "write_bwd_%s_kernel<%s>" % ({2: "graph", 4: "carried"}[literal], "true" if Cc <= 62 else "false")
     H.check(H.lib().air_write_bwd(C.byref(wb), _stream()), "air_write_bwd")
     torch.cuda.synchronize()
     dgen, dsx = dgen.cpu().numpy(), dsx.cpu().numpy()

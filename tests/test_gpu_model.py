@@ -277,21 +277,18 @@ def test_annealed_training_runs_and_loss_drops(am):
     REPORT["train60_losses"] = losses
 
 
-def test_taps_backward_matches_the_torch_autograd_twin_residue(am):
-    """backward="taps" evaluates the sampler gradients the way torch-CPU fp32 autograd orders them
-    (four separate Gather_grad scatters added ((d+c)+b)+a, per-product (x1-x)/(x-x0) nodes); the
-    reference's own graph order -- backward="reference" -- is pinned in tests/test_gpu_graph_golden.py
-    against the executed graph and carries a ~400x larger residue.  At out-of-range taps
-    the +/- pairs cancel only to rounding and are multiplied by g ~ 1/(r + 1e-9): the where-heads,
-    the LSTM and the VAE decoder then receive gradients several times the exact ones -- same
-    orders of magnitude as the torch-fp32 autograd twin of the reference graph."""
+def test_reference_backward_carries_a_residue_the_exact_adjoint_does_not(am):
+    """backward="reference" evaluates the sampler gradients in the op order of the reference's saved graph (pinned bit for
+    bit in tests/test_gpu_graph_golden.py).  At out-of-range taps the +/- pairs cancel only to rounding and are multiplied
+    by g ~ 1/(r + 1e-9): the where-heads, the LSTM and the VAE decoder then receive gradients far above the exact ones
+    (backward="exact"), while the paths without out-of-range taps are unaffected."""
     B = 64
     import multi_mnist as mm
     ds = mm.generate_dataset(2, 100, 10)
     images, targets = ds["train_images"][:B], ds["train_digits"][:B]
     params, noise = ao.init_params(HP, 0), ao.make_noise(HP, B, 5)
     norms = {}
-    for mode in ("taps", "exact"):
+    for mode in ("reference", "exact"):
         am.reset_default_graph()
         m = am.AIRModel(torch.tensor(images, device="cuda"), torch.tensor(targets, device="cuda"), cnn=False,
                         train=True, backward=mode, **HP)
@@ -303,23 +300,10 @@ def test_taps_backward_matches_the_torch_autograd_twin_residue(am):
         m._run_backward(s)
         torch.cuda.synchronize()
         norms[mode] = {k: float(v.norm()) for k, v in m.gradients.items()}
-    pt = at.to_torch(params, requires_grad=True)
-    _, g32 = at.loss_and_grads(pt, torch.tensor(images), torch.tensor(targets), at.to_torch(noise), HP, 9.21)
-    n32 = {k: float(v.norm()) for k, v in g32.items()}
-    norms["reference"] = norms["taps"]
-    REPORT["residue_norms"] = {k: [norms["taps"][k], norms["exact"][k], n32[k]] for k in n32}
-    # Which tensors carry most residue depends on the images (ink mass): with the 16x16 glyphs the
-    # decoder was 7-8x the exact norm, with the 12x12 default the LSTM kernel and the scale head are
-    # (7x) and the decoder 1.3x.  Data-independent statements: (a) several tensors are far above
-    # their exact norms, (b) every tensor is within a factor ~2.5 of the torch-fp32 autograd twin.
-    inflated = [k for k in n32 if norms["reference"][k] > 2.0 * norms["exact"][k]]
+    REPORT["residue_norms"] = {k: [norms["reference"][k], norms["exact"][k]] for k in norms["exact"]}
+    inflated = [k for k in norms["exact"] if norms["reference"][k] > 2.0 * norms["exact"][k]]
     assert len(inflated) >= 3, inflated
     assert norms["reference"]["rnn/kernel"] > 1.15 * norms["exact"]["rnn/kernel"]
-    for k in n32:
-        if g32[k].numel() < 16:
-            continue                      # one- and two-element biases: a single residue realisation each
-        ratio = norms["reference"][k] / n32[k]
-        assert 0.4 < ratio < 2.5, (k, norms["reference"][k], n32[k])
     for k in ("z_pres/log_odds/output/weights",):       # paths without out-of-range taps are unaffected
         assert abs(norms["reference"][k] - norms["exact"][k]) / norms["exact"][k] < 0.2
 
@@ -335,7 +319,7 @@ def test_reference_backward_learns_exact_does_not(am):
     td = torch.tensor(ds["train_digits"], device=dev)
     hp = dict(HP, learning_rate=1e-3)
     out = {}
-    for mode in ("reference", "taps", "exact"):
+    for mode in ("reference", "exact"):
         am.reset_default_graph()
         xin = torch.zeros(64, 2500, device=dev)
         tin = torch.zeros(64, dtype=torch.int32, device=dev)
@@ -353,12 +337,8 @@ def test_reference_backward_learns_exact_does_not(am):
                 rec.append(float(m.reconstruction_loss.mean()))
         out[mode] = float(np.mean(rec))
     REPORT["rec_loss_after_1500_steps"] = out
-    # the per-tap order ("taps", round 1's) is only recorded: whether it has started to learn after 1500
-    # steps flips with rounding-level changes elsewhere (a different split-K of x.Wx is enough) -- the seed
-    # lottery of DESIGN.md section 2; the graph order learns every time
     assert out["reference"] < 600.0, out
     assert out["exact"] > 2.0 * out["reference"], out
-    assert np.isfinite(out["taps"]), out
 
 
 def test_reference_and_exact_backward_agree_without_residues(am):
@@ -366,7 +346,7 @@ def test_reference_and_exact_backward_agree_without_residues(am):
     d loss / d canvas stays O(1) and the fp32 residue of the out-of-range taps is ~1e-7 of it) the
     reference-order backward must equal the exact adjoint to rounding, for every variable."""
     grads = {}
-    for mode in ("exact", "reference", "taps"):
+    for mode in ("exact", "reference", "reference_carried"):
         model, *_ = _make(am, 64, True, blank=True, backward=mode)
         s = model._stream()
         model._run_forward(s)
@@ -375,11 +355,10 @@ def test_reference_and_exact_backward_agree_without_residues(am):
         grads[mode] = {k: v.detach().cpu().double().clone() for k, v in model.gradients.items()}
     worst = 0.0
     for k, ge in grads["exact"].items():
-        for mode in ("reference", "taps"):
+        for mode in ("reference", "reference_carried"):
             err = float((grads[mode][k] - ge).norm() / (ge.norm() + 1e-30))
             worst = max(worst, err)
-            # the graph-order accumulator keeps a larger residue than the per-tap sums even here
-            assert err <= (2e-3 if mode == "reference" else 2e-4), (mode, k, err)
+            assert err <= 2e-3, (mode, k, err)
     REPORT["reference_vs_exact_smooth_regime_worst_rel"] = worst
 
 
@@ -644,3 +623,73 @@ def test_set_backward_switches_the_order_of_a_built_model(am):
     assert int(model.global_step) == 5 and bool(torch.isfinite(model.store.params).all())
     with pytest.raises(ValueError):
         model.set_backward("sequential")
+    for removed in ("taps", "reference_blocked"):                     # measured-worse orders of rounds 1 / 5: gone with ABI 5
+        with pytest.raises(ValueError):
+            model.set_backward(removed)
+
+
+@pytest.mark.parametrize("graph_steps", [0, 2])
+def test_backward_schedule_switches_at_its_iteration(am, graph_steps):
+    """AIRModel(backward=("reference", "reference_carried", N)): the reference's order while global_step < N, the carried
+    order from then on; training() makes the switch between two steps (a captured graph is captured again), and the run is
+    step for step the one a hand-switched model makes.  A checkpoint load re-reads global_step and picks the order it
+    asks for."""
+    kern = lambda m: [op.kernel for op in m.train_step_ops() if "write_bwd" in op.kernel]   # noqa: E731
+    with pytest.raises(ValueError):
+        _make(am, 16, True, backward=("reference", "sequential", 4))
+    with pytest.raises(ValueError):
+        _make(am, 16, True, backward=("reference", "reference_carried"))
+    model, *_ = _make(am, 16, True, backward=("reference", "reference_carried", 4))
+    model.use_device_rng(seed=5)
+    assert model.backward_schedule == ("reference", "reference_carried", 4) and model.backward == "reference"
+    hand, *_ = _make(am, 16, True, backward="reference", scope="hand")
+    hand.use_device_rng(seed=5)
+    if graph_steps:
+        model.capture_graph(steps=graph_steps)
+    seen = []
+    for it in range(0, 8, max(graph_steps, 1)):
+        model.training()
+        seen.append(kern(model)[0])
+        for _ in range(max(graph_steps, 1)):
+            if int(hand.global_step) == 4:
+                hand.set_backward("reference_carried")
+            hand.training()
+        torch.cuda.synchronize()
+        assert int(model.global_step) == int(hand.global_step) == it + max(graph_steps, 1)
+        assert torch.equal(model.store.params, hand.store.params), it
+    n_first = 4 // max(graph_steps, 1)
+    assert seen[:n_first] == ["write_bwd_graph_kernel<true>"] * n_first
+    assert set(seen[n_first:]) == {"write_bwd_carried_kernel<true>"}
+    assert (model._graph is not None) == bool(graph_steps)              # the graph was captured again after the switch
+    # back before the switch point: the order follows the loaded global_step
+    sd = model.state_dict()
+    sd["global_step"] = torch.tensor(1)
+    model.load_state_dict(sd)
+    model.training()
+    assert kern(model) == ["write_bwd_graph_kernel<true>"] and model.backward == "reference"
+    # an explicit order ends the schedule
+    model.set_backward("reference_carried")
+    assert model.backward_schedule is None
+
+
+def test_load_state_dict_validates_before_it_writes(am):
+    model, *_ = _make(am, 8, True)
+    model.training()
+    torch.cuda.synchronize()
+    before = (model.store.params.clone(), model.store.m.clone(), int(model.global_step))
+    sd = model.state_dict()
+    k = "rnn/kernel"
+    bad = dict(sd)
+    bad[k] = torch.zeros_like(sd[k]) + 3.0
+    bad[k + "/Adam_1"] = torch.zeros(7)                              # a slot of the wrong size
+    bad["global_step"] = torch.tensor(99)
+    with pytest.raises(ValueError):
+        model.load_state_dict(bad)
+    assert torch.equal(model.store.params, before[0]) and torch.equal(model.store.m, before[1])
+    assert int(model.global_step) == before[2]
+    bad = dict(sd)
+    bad["global_step"] = "not a number"
+    bad[k] = torch.zeros_like(sd[k]) + 3.0
+    with pytest.raises(ValueError):
+        model.load_state_dict(bad)
+    assert torch.equal(model.store.params, before[0])

@@ -121,3 +121,105 @@ def test_dequeue_and_gather_captured_in_a_graph():
         rows += [t[:, 0].cpu().numpy().astype(np.int64) for t in seen]
     ref = sq.tf_queue_batches(N_REC, CAP, BATCH, MIN_AFTER, 15, lambda n, k: sq.device_draws(seed, n, k))
     assert np.array_equal(np.stack(rows), ref)
+
+
+@needs_gpu
+@pytest.mark.parametrize("cap,batch,mad,n_rec,per_call", [(CAP, BATCH, MIN_AFTER, N_REC, 25), (100, 8, 50, 37, 7), (640, 64, 0, 1000, 1)])
+def test_dequeue_many_equals_the_queue_model_pick_for_pick(cap, batch, mad, n_rec, per_call):
+    from air import _hip as H
+    calls, seed = 12, 0xabcdef12345
+    q = torch.zeros(cap, dtype=torch.int32, device="cuda")
+    st = torch.zeros(2, dtype=torch.int64, device="cuda")
+    picks = torch.zeros(batch, dtype=torch.int32, device="cuda")
+    many = torch.zeros(per_call, batch, dtype=torch.int32, device="cuda")
+    a = _struct(H, q, st, picks, seed, cap, batch, mad, n_rec)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    H.check(H.lib().air_shuffle_batch_init(C.byref(a), s))
+    got = []
+    for k in range(calls):
+        if k == 5:                                                     # the single-batch call continues the same sequence
+            H.check(H.lib().air_shuffle_batch_dequeue(C.byref(a), s))
+            got.append(picks.clone()[None])
+        H.check(H.lib().air_shuffle_batch_dequeue_many(C.byref(a), per_call, many.data_ptr(), s))
+        got.append(many.clone())
+    torch.cuda.synchronize()
+    got = torch.cat(got).cpu().numpy()
+    nb = calls * per_call + 1
+    ref = sq.tf_queue_batches(n_rec, cap, batch, mad, nb, lambda n, k: sq.device_draws(seed, n, k))
+    assert np.array_equal(got, ref)
+    assert st.tolist() == [cap + nb * batch, nb]
+
+
+@needs_gpu
+def test_batch_gather_copies_the_picked_records():
+    from air import _hip as H
+    g = torch.Generator(device="cuda").manual_seed(1)
+    images = torch.rand(5000, 2500, device="cuda", generator=g)
+    digits = torch.randint(0, 3, (5000,), device="cuda", dtype=torch.int32, generator=g)
+    picks = torch.randint(0, 5000, (64,), device="cuda", dtype=torch.int32, generator=g)
+    out_i, out_d = torch.zeros(64, 2500, device="cuda"), torch.zeros(64, dtype=torch.int32, device="cuda")
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    H.check(H.lib().air_batch_gather(images.data_ptr(), digits.data_ptr(), picks.data_ptr(), out_i.data_ptr(), out_d.data_ptr(),
+                                     64, 2500, s))
+    assert torch.equal(out_i, images[picks.long()]) and torch.equal(out_d, digits[picks.long()])
+    big = torch.rand(300, 128 * 128, device="cuda", generator=g)      # configs[3] canvases: several slices per row
+    out_b = torch.zeros(64, 128 * 128, device="cuda")
+    pk = torch.randint(0, 300, (64,), device="cuda", dtype=torch.int32, generator=g)
+    H.check(H.lib().air_batch_gather(big.data_ptr(), None, pk.data_ptr(), out_b.data_ptr(), None, 64, 128 * 128, s))
+    assert torch.equal(out_b, big[pk.long()])
+
+
+@needs_gpu
+def test_pipelined_queue_in_a_graph_delivers_the_same_batches():
+    """multi_mnist.ShuffleBatchQueue.graph_hooks: the picks of half a replay made on a forked branch ahead of their steps --
+    the batches that reach the consumer's buffers are, in order, the ones next_batch() delivers (= the queue model's)."""
+    from multi_mnist import ShuffleBatchQueue
+    n, D, B, steps, seed = 3000, 16, 8, 6, 21
+    images = torch.arange(n, device="cuda", dtype=torch.float32)[:, None].repeat(1, D).contiguous()
+    digits = (torch.arange(n, device="cuda", dtype=torch.int32) % 3).contiguous()
+
+    def consumer():
+        return torch.zeros(B, D, device="cuda"), torch.zeros(B, dtype=torch.int32, device="cuda")
+    oi, od = consumer()
+    plain = ShuffleBatchQueue(images, digits, B, oi, od, seed=seed, min_after_dequeue=200)
+    ref_rows = []
+    for _ in range(4 * steps):
+        plain.next_batch()
+        ref_rows.append((oi[:, 0].clone(), od.clone()))
+    pi, pd = consumer()
+    piped = ShuffleBatchQueue(images, digits, B, pi, pd, seed=seed, min_after_dequeue=200)
+    with pytest.raises(ValueError):
+        piped.graph_hooks(5)
+    between, after = piped.graph_hooks(steps)
+    with pytest.raises(RuntimeError):
+        piped.next_batch()
+    seen = []
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for i in range(steps):
+            between(i)
+            seen.append((pi[:, 0].clone(), pd.clone()))                # "the train step": reads the input buffers
+        after()
+    got = []
+    for _ in range(4):
+        g.replay()
+        torch.cuda.synchronize()
+        got += [(a.clone(), b.clone()) for a, b in seen]
+    for (ra, rb), (ga, gb) in zip(ref_rows, got):
+        assert torch.equal(ra, ga) and torch.equal(rb, gb)
+    model = sq.tf_queue_batches(n, 200 + 10 * B, B, 200, 4 * steps, lambda k, b: sq.device_draws(seed, k, b))
+    assert np.array_equal(torch.stack([a for a, _ in got]).cpu().numpy().astype(np.int64), model)
+    # a second capture (training.py re-captures when the sampler-backward order switches) continues the sequence
+    between, after = piped.graph_hooks(steps)
+    g2 = torch.cuda.CUDAGraph()
+    seen2 = []
+    with torch.cuda.graph(g2):
+        for i in range(steps):
+            between(i)
+            seen2.append(pi[:, 0].clone())
+        after()
+    g2.replay()
+    torch.cuda.synchronize()
+    more = sq.tf_queue_batches(n, 200 + 10 * B, B, 200, 5 * steps, lambda k, b: sq.device_draws(seed, k, b))[4 * steps:]
+    assert np.array_equal(torch.stack(seen2).cpu().numpy().astype(np.int64), more)

@@ -15,7 +15,7 @@ import torch  # noqa: F401  -- FIRST: torch brings its own libamdhip64; loading 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AIR_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "libair_hip.so")   # override: A/B builds in tools/
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # enums (keep in sync with include/air_hip.h)
 DYN_PRIOR_LOG_ODDS, DYN_TEMPERATURE, DYN_STOP_THRESHOLD, DYN_LEARNING_RATE, DYN_CLIP_NORM = 0, 1, 2, 3, 4
@@ -123,6 +123,11 @@ class ShuffleBatch(C.Structure):
                 ("n_records", _i), ("seed", C.c_uint64)]
 
 
+class Summaries(C.Structure):
+    _fields_ = [("att", _p), ("targets", _p), ("digits", _p), ("rec_loss", _p), ("loss_item", _p), ("scalars", _p),
+                ("out", _p), ("B", _i), ("N", _i), ("max_digits", _i)]
+
+
 _SIGNATURES = {
     "air_abi_version": (C.c_int, []),
     "air_strerror": (C.c_char_p, [C.c_int]),
@@ -160,6 +165,10 @@ _SIGNATURES = {
     "air_adam_clip_step": (C.c_int, [_p, _p, _p, _p, C.c_int64, _p, C.c_int, _p, _p, _f, _f, _f, _f, _p, _p, _p]),
     "air_shuffle_batch_init": (C.c_int, [C.POINTER(ShuffleBatch), _p]),
     "air_shuffle_batch_dequeue": (C.c_int, [C.POINTER(ShuffleBatch), _p]),
+    "air_shuffle_batch_dequeue_many": (C.c_int, [C.POINTER(ShuffleBatch), C.c_int, _p, _p]),
+    "air_batch_gather": (C.c_int, [_p, _p, _p, _p, _p, C.c_int, C.c_int, _p]),
+    "air_summaries_count": (C.c_int, [C.c_int, C.c_int]),
+    "air_summaries": (C.c_int, [C.POINTER(Summaries), _p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -245,11 +245,17 @@ class VariableStore:
                 raise ValueError("state dict carries flat Adam slots (_adam_m / _adam_v) of an unknown buffer layout; it needs "
                                  "per-variable slots (<var>/Adam, <var>/Adam_1) -- or load_state_dict(sd, load_optimizer=False) "
                                  "for the variables alone")
+            for k in slots:
+                for slot in ("/Adam", "/Adam_1"):
+                    if int(np.prod(np.shape(sd[k + slot]))) != self.variables[k].numel():
+                        raise ValueError("slot %s has %r elements, expected %r" % (k + slot, np.shape(sd[k + slot]),
+                                                                                   tuple(self.variables[k].shape)))
+        global_step = int(sd["global_step"]) if "global_step" in sd else None       # (converted before the first write too)
         for k, v in self.variables.items():
             if k in sd:
                 v.copy_(torch.as_tensor(np.asarray(sd[k])).to(v.dtype).reshape(v.shape))
-        if "global_step" in sd:
-            self.istate[H.IST_GLOBAL_STEP] = int(sd["global_step"])
+        if global_step is not None:
+            self.istate[H.IST_GLOBAL_STEP] = global_step
         if load_optimizer:
             for k in slots:
                 v = self.variables[k]
@@ -352,19 +358,26 @@ class AIRModel:
         #   pixel through the four concatenated Gather gradients (UnsortedSegmentSum order), AddN_10/11
         #   order for the coordinate gradients -- keeps the out-of-range rounding residue the
         #   reference's training signal carries; bit-identical to the graph at kernel level.
-        # "taps": per-tap sums added ((d+c)+b)+a (the order torch-CPU autograd happens to use; the
-        #   residue is ~400x smaller than the reference graph's).  "exact": the mathematical adjoint.
-        # "reference_blocked": the reference graph's term streams (a, b, c, d per window pixel, canvas-pixel order) with
-        #   every tap's piece cut into 16 chunks that are summed side by side and added left to right
-        #   (the order tests call "blocked16"): the same residue mechanism without the 10 000-term chain -- and a residue
-        #   10x..300x smaller on the slots that collect the out-of-range canvas, which training notices.
         # "reference_carried": the reference's order for every window pixel whose streams are short (all but the four corners
         #   and a few borders); the long streams in 16 chunks per tap, every chunk walked from a carried stand-in for the
         #   reference's accumulator, so that every add rounds at the reference's magnitude (the order tests call "carried16").
-        if backward not in ("reference", "reference_blocked", "reference_carried", "taps", "exact"):
-            raise ValueError("backward must be 'reference', 'reference_carried', 'reference_blocked', 'taps' or 'exact'")
+        # "exact": the mathematical adjoint (the fp64-gradient tests; the model does not learn to localise with it).
+        # (first, second, N): `first` while global_step < N, `second` from then on -- e.g. ("reference", "reference_carried",
+        #   5000): the reference's own order while the out-of-range residue rules the gradient (the z_pres prior anneals over
+        #   the first 3 000 iterations), the faster carried order for the rest of the run.  The switch is made by training()
+        #   between two steps (launch lists rebuilt, a captured graph captured again); forward outputs are not affected.
+        self._schedule = None
+        if isinstance(backward, (tuple, list)):
+            if len(backward) != 3 or backward[0] not in self._ORDERS or backward[1] not in self._ORDERS or int(backward[2]) < 0:
+                raise ValueError("a backward schedule is (first order, second order, switch iteration >= 0)")
+            self._schedule = (backward[0], backward[1], int(backward[2]))
+            backward = backward[0]
+        if backward not in self._ORDERS:
+            raise ValueError("backward must be one of %s or a (first, second, iteration) schedule" % sorted(self._ORDERS))
         self.backward = backward
         self._literal = self._ORDERS[backward]
+        self._host_step = None                    # global_step as the host follows it (schedules only; None: read it once)
+        self._capture_args = None
         self._prec = 1 if prec == "bf16" else 0
         # bf16 path: every GEMM operand also exists as a bf16 twin in memory (written by the producing kernel /
         # by Adam), so the GEMMs read 2-byte operands and convert nothing -- bit-identical results (the twin IS
@@ -918,7 +931,7 @@ class AIRModel:
         self._injected_noise = True
         self._dirty = True
 
-    _ORDERS = {"reference_carried": 4, "reference_blocked": 3, "reference": 2, "taps": 1, "exact": 0}
+    _ORDERS = {"reference_carried": 4, "reference": 2, "exact": 0}      # air_write_bwd_t.literal
 
     def set_backward(self, backward):
         """Switches the sampler-backward order of a built train model (AIRModel(backward=...)): the launch lists are rebuilt,
@@ -927,12 +940,35 @@ class AIRModel:
         a chunked order once ink is explained -- DESIGN.md section 10.1.)"""
         if backward not in self._ORDERS:
             raise ValueError("backward must be one of %s" % sorted(self._ORDERS))
+        self._schedule = None                     # an explicit order ends a schedule
+        self._set_order(backward)
+
+    def _set_order(self, backward):
         if backward == self.backward:
-            return
+            return False
         self.release_graph()
         self.backward = backward
         self._literal = self._ORDERS[backward]
         self._build_programs()
+        return True
+
+    @property
+    def backward_schedule(self):
+        """(first order, second order, switch iteration) or None"""
+        return self._schedule
+
+    def _follow_schedule(self):
+        """AIRModel(backward=(first, second, N)): the order global_step asks for, before a train step is launched.  The host
+        follows global_step by counting the steps it launches (one read of the device counter after construction / a
+        checkpoint load); with a multi-step graph the switch happens at the first replay that starts at or after N."""
+        if self._schedule is None:
+            return
+        if self._host_step is None:
+            self._host_step = int(self.store.istate[H.IST_GLOBAL_STEP])
+        first, second, n = self._schedule
+        args = self._capture_args if self._graph is not None else None
+        if self._set_order(first if self._host_step < n else second) and args is not None:
+            self.capture_graph(**args)
 
     def use_device_rng(self, seed=None):
         if seed is not None:
@@ -1116,7 +1152,7 @@ class AIRModel:
         for op in self._optimizer_ops():
             op(s)
 
-    def capture_graph(self, steps=1, between_steps=None):
+    def capture_graph(self, steps=1, between_steps=None, after_steps=None):
         """Captures the train step into hipGraphs (fixed N, no host sync, no allocation inside).
         Single GPU: ONE graph of `steps` consecutive train steps.  Data parallel over RCCL: the same -- the gradient
         exchange is stream work and is recorded between the backward and the optimizer of every step,
@@ -1124,9 +1160,12 @@ class AIRModel:
         Data parallel over a backend whose collectives cannot be captured (gloo): [fwd+bwd] | collective | [clip+Adam],
         one step per replay.  Noise and schedules are keyed by the device-side global_step, so the steps of a replay
         differ as they would in separate replays; `between_steps(i)` (optional, graph-capturable device work such as
-        the next batch's gather) is captured before step i.  training() then advances `steps` steps."""
+        the next batch's gather) is captured before step i, `after_steps()` after the last one (e.g. the join of a branch
+        that between_steps forked: multi_mnist.ShuffleBatchQueue.graph_hooks).  training() then advances `steps` steps."""
         if not self.train:
             return self._capture_forward_graph()
+        self._capture_args = dict(steps=steps, between_steps=between_steps, after_steps=after_steps)
+        self._follow_schedule()
         self._optimizer_ops()
         world = self._world()
         if self.store.synced_world != world:
@@ -1166,6 +1205,8 @@ class AIRModel:
                 elif in_graph:
                     self._dp_exchange_gradients()
                     self._train_phase_b(self._stream())
+            if after_steps is not None:
+                after_steps()
             if dp and in_graph and world > 1:
                 self.scalars[:2].mul_(1.0 / world)       # loss / accuracy rode in the all-reduce as sums over ranks
         gb = None
@@ -1209,8 +1250,11 @@ class AIRModel:
         world = self._world()
         if self.store.synced_world != world:
             self.sync_parameters()
+        self._follow_schedule()
         self._fresh_shadow()
         dp = self._dp()
+        if self._host_step is not None:
+            self._host_step += self._graph_steps if (self._graph is not None and not eager) else 1
         if self._graph is not None and not eager:
             ga, gb = self._graph
             if self._graph_dp[0] != dp:
@@ -1278,6 +1322,35 @@ class AIRModel:
     shift_kls = property(lambda self: self._stack(self.att[:, :, H.ATT_KL_SHIFT]))
     vae_kls = property(lambda self: self._stack(self.att[:, :, H.ATT_KL_VAE]))
 
+    def summary_names(self):
+        """Names of the reference's numeric summaries (self.num_summaries of air_model.py:160-209, 608-625), in its order."""
+        names = ["loss", "accuracy"]
+
+        def by_digit(name):
+            names.extend("%s_%d_dig" % (name, i) for i in range(self.max_digits + 1))
+            names.append(name + "_all_dig")
+        for n in ("steps", "rec_loss", "digit_acc", "total_loss"):
+            by_digit(n)
+        for n in ("scale", "z_pres_prob", "z_pres_kl", "scale_kl", "shift_kl", "vae_kl"):
+            for i in range(self.max_steps):
+                by_digit("%s_%d_step" % (n, i + 1))
+        return names
+
+    def numeric_summaries(self, out=None):
+        """The values of summary_names() for the last pass, as ONE launch on the current stream (air_summaries,
+        include/air_hip.h) into the float32 device vector `out` (allocated when None) -- what sess.run(num_summaries)
+        evaluates at training.py:171-180.  No host synchronisation: the caller copies `out` when it wants the numbers."""
+        self._ensure()
+        n = self.lib.air_summaries_count(self.max_steps, self.max_digits)
+        if out is None:
+            out = torch.empty(n, dtype=torch.float32, device=self.input_images.device)
+        if out.numel() != n or out.dtype != torch.float32 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous float32 vector of %d elements" % n)
+        a = H.Summaries(_ptr(self.att), _ptr(self.target_num_digits), _ptr(self.run_digits), _ptr(self._rec_loss),
+                        _ptr(self._loss_item), _ptr(self.scalars), _ptr(out), self.batch_size, self.max_steps, self.max_digits)
+        H.check(self.lib.air_summaries(C.byref(a), self._stream()), "air_summaries")
+        return out
+
     @property
     def rec_st_back(self):
         a = self._stack(self.att[:, :, H.ATT_ST_BACK:H.ATT_ST_BACK + 3])        # [B,T',3] = 1/s, -x/s, -y/s
@@ -1317,8 +1390,10 @@ class AIRModel:
             st.istate[H.IST_GLOBAL_STEP] = int(sd["global_step"])
         st.touch()
         self._dirty = True
+        self._host_step = None
         return self
 
     def load_state_dict(self, sd, strict=True, load_optimizer=True):
         self.store.load_state_dict(sd, strict, load_optimizer)
         self._dirty = True
+        self._host_step = None

@@ -323,7 +323,7 @@ __global__ __launch_bounds__(THREADS) void gemm_xw_tp_kernel(Args a)
     // counters showed it: 167 MB read for 50 MB of operands.  Now a K SLAB is an XCD's: all (row tile, column tile) pairs
     // of slab z run on XCD z % 8, stepping through k together (two workgroups per CU, 64 per XCD at the stress shape), so
     // every line of BOTH operands is fetched from memory by one L2 only and its other users hit there.
-    // AIR_XW_TP_MAP=pair restores the old map (A/B).
+    // (The old map was an environment switch until ABI 4 removed it.)
     int tile_m = blockIdx.y, tile_n = blockIdx.x, zslab = (int)blockIdx.z;
     {
         const int nx = gridDim.x, ny = gridDim.y, pairs = ny * nz;

@@ -76,27 +76,12 @@ __device__ __forceinline__ float bilinear4(const Tap& tx, const Tap& ty,
     return ((wa * Ia + wb * Ib) + wc * Ic) + wd * Id;
 }
 
-// Gradient of one output pixel wrt its source coordinates (X, Y), evaluated the way
-// reverse-mode autodiff of the reference's expression does it in fp32 (transformer.py:108-116):
-// the four products wa..wd each own their (x1-x), (x-x0), (y1-y), (y-y0) nodes, their
-// gradients g*I*t reach x and y one by one (last-created node first: wd, wc, wb, wa) and are
-// summed as they arrive.  For an out-of-range pixel (both taps clipped to one index) the four
-// terms cancel exactly in real arithmetic but NOT in fp32 -- the rounding residue of
-// (D + C) is multiplied by g ~ 1/(residue + 1e-9) at unexplained ink.  That residue is not
-// noise to be cleaned up: it is the force that pulls glimpses towards unexplained ink, and the
-// reference's training dynamics depend on it (with the exact adjoint the model does not learn
-// to localise).  cx = (n_in - 1.001): x = (x_s + 1) * cx / 2.
-__device__ __forceinline__ void literal_dxy(float g, float Ia, float Ib, float Ic, float Id,
-                                            const Tap& tx, const Tap& ty, float cx, float& dxs, float& dys) {
-    const float ga = g * Ia, gb = g * Ib, gc = g * Ic, gd = g * Id;          // d out / d wa..wd
-    const float dX = ((gd * ty.w1 + gc * ty.w0) - gb * ty.w1) - ga * ty.w0;  // via (x-x0) [wd, wc], (x1-x) [wb, wa]
-    const float dY = ((gd * tx.w1 - gc * tx.w1) + gb * tx.w0) - ga * tx.w0;  // via (y-y0) [wd], (y1-y) [wc], (y-y0) [wb], (y1-y) [wa]
-    dxs = (dX / 2.0f) * cx;
-    dys = (dY / 2.0f) * cx;
-}
-
-// The same gradient in the op order of the reference's SAVED graph (model/air-model.meta, executed by
-// the graph executor of tests/test_graph_exec.py): d wa..wd = g*Ia..Id (mul_10..13_grad), each product's two factors get
+// Gradient of one output pixel wrt its source coordinates (X, Y) in the op order of the reference's SAVED graph
+// (model/air-model.meta, executed by the graph executor of tests/test_graph_exec.py).  For an out-of-range pixel (both
+// taps clipped to one index) the four legs cancel exactly in real arithmetic but NOT in fp32: the rounding residue,
+// multiplied by g ~ 1 / (r + 1e-9) at unexplained ink, is not noise to be cleaned up -- it is the force that pulls glimpses
+// towards unexplained ink, and the reference's training dynamics depend on it (with the exact adjoint the model does not
+// learn to localise).  cx = (n_in - 1.001): x = (x_s + 1) * cx / 2.  d wa..wd = g*Ia..Id (mul_10..13_grad), each product's two factors get
 // grad*other (mul_6..9_grad), the Sub nodes negate the (x1-x)/(y1-y) legs, and the four legs that
 // reach x (y) are summed by AddN_10 / AddN_20 (AddN_11 / AddN_21) left to right in the order
 // wa, wb, wc, wd.  Then x = (x_s + 1)*(W - 1.001)/2: truediv_grad then mul_grad.
@@ -107,32 +92,6 @@ __device__ __forceinline__ void graph_dxy(float g, float Ia, float Ib, float Ic,
     const float dY = ((-(tx.w0 * ga) + tx.w0 * gb) + -(tx.w1 * gc)) + tx.w1 * gd;
     dxs = (dX / 2.0f) * cx;
     dys = (dY / 2.0f) * cx;
-}
-
-// inclusive segmented scan inside a wave: lanes with equal (contiguous) keys are summed in a fixed
-// tree order; the last lane of each run holds the run's total
-__device__ __forceinline__ float seg_scan(float v, int key, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const float pv = __shfl_up(v, off, 64);
-        const int pk = __shfl_up(key, off, 64);
-        if (lane >= off && pk == key) v += pv;
-    }
-    return v;
-}
-// two / four values scanned against the same key run structure (key shuffles shared, value
-// shuffles independent -> they overlap in the LDS pipeline)
-__device__ __forceinline__ void seg_scan2(float& v0, float& v1, int key, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int pk = __shfl_up(key, off, 64);
-        const float p0 = __shfl_up(v0, off, 64), p1 = __shfl_up(v1, off, 64);
-        if (lane >= off && pk == key) { v0 += p0; v1 += p1; }
-    }
-}
-__device__ __forceinline__ bool seg_end(int key, int lane, int nvalid) {
-    const int nk = __shfl_down(key, 1, 64);
-    return lane < nvalid && (lane == nvalid - 1 || nk != key);
 }
 
 // ---------------------------------------------------------------------------
@@ -555,8 +514,7 @@ __global__ __launch_bounds__(THREADS) void attend_bwd_kernel(air_attend_bwd_t a)
             else { Ia = img[r0 + tx.i0]; Ib = img[r1 + tx.i0]; Ic = img[r0 + tx.i1]; Id = img[r1 + tx.i1]; }
             const float gv = k < GF ? gf[k < GF ? k : 0] : g[p];
             float gX, gY;
-            if (a.literal == 2) graph_dxy(gv, Ia, Ib, Ic, Id, tx, ty, (float)C - 1.001f, gX, gY);
-            else if (a.literal) literal_dxy(gv, Ia, Ib, Ic, Id, tx, ty, (float)C - 1.001f, gX, gY);
+            if (a.literal) graph_dxy(gv, Ia, Ib, Ic, Id, tx, ty, (float)C - 1.001f, gX, gY);
             else {
                 gX = gv * ((Ic - Ia) * ty.w0 + (Id - Ib) * ty.w1) * half_c;
                 gY = gv * ((Ib - Ia) * tx.w0 + (Id - Ic) * tx.w1) * half_c;
@@ -846,9 +804,10 @@ __global__ __launch_bounds__(NT) void write_fwd_kernel(air_write_fwd_t a)
 }
 
 // ---------------------------------------------------------------------------
-// write backward: gradient wrt the window (exact separable adjoint, gather
-// form), wrt theta_recon -> (s,x,y), and wrt z_pres.  One workgroup per
-// (image, time step): every step sees the same d loss / d canvas.
+// write backward, EXACT adjoint (literal == 0, backward="exact": the fp64-gradient tests): gradient wrt the window
+// (separable, gather form, degenerate taps merged -- their two weights cancel exactly in real arithmetic), wrt
+// theta_recon -> (s,x,y), and wrt z_pres.  One workgroup per (image, time step): every step sees the same
+// d loss / d canvas.
 // ---------------------------------------------------------------------------
 // 16 waves per workgroup: every phase is a latency chain, 4 waves per SIMD hide it
 constexpr int WB_THREADS = 1024;
@@ -863,11 +822,10 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_kernel(air_write_bwd_t a
     Tap* sh_tx = reinterpret_cast<Tap*>(smem + 64);        // [C]
     Tap* sh_ty = sh_tx + C;                                // [C]
     float* sh_t = reinterpret_cast<float*>(sh_ty + C);     // [C] linspace
-    int* sh_rng = reinterpret_cast<int*>(sh_t + C);        // [8*w]: per source index, ranges of outputs whose tap0 / tap1 hit it
-    int* sh_run = sh_rng + 8 * w;                          // [4][w+2][2]: literal mode, run [lo,hi] of every key of x0/x1/y0/y1
-    float* sh_win = reinterpret_cast<float*>(sh_run + 8 * (w + 2));   // [w*w]
-    float* sh_T = sh_win + w * w;                          // [2][C*w]
-    float* sh_g = sh_T + 2 * C * (w + 2);                  // [C*C] d loss / d canvas of this image
+    int* sh_rng = reinterpret_cast<int*>(sh_t + C);        // [8*w]: per source index, the range of outputs whose taps hit it
+    float* sh_win = reinterpret_cast<float*>(sh_rng + 8 * w);   // [w*w]
+    float* sh_T = sh_win + w * w;                          // [C*w]
+    float* sh_g = sh_T + C * w;                            // [C*C] d loss / d canvas of this image
 
     if (a.fin_scalars && b == 0 && t == 0) {
         // loss = mean(loss_item) :593,610; accuracy = mean(target == digits) :597-611 (air_finalize)
@@ -897,7 +855,6 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_kernel(air_write_bwd_t a
         sh_ty[j] = axis_tap(j, C, w, ia, by);
         sh_t[j] = tv;
     }
-    if (a.literal) for (int it = tid; it < 4 * (w + 2); it += WB_THREADS) { sh_run[2 * it] = 0; sh_run[2 * it + 1] = -1; }
     const float* v = a.vrec + row * w * w;
     for (int p = tid; p < w * w; p += WB_THREADS) sh_win[p] = v[p];
     {
@@ -912,13 +869,10 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_kernel(air_write_bwd_t a
         }
     }
     __syncthreads();
-    // source index q is touched by a contiguous range of output coordinates (taps are monotone).
-    // exact mode: one merged range per index, degenerate (both taps clipped to one index) outputs
-    // skipped -- their two weights cancel exactly in real arithmetic.
-    // literal mode: tap0 and tap1 keep separate ranges and degenerate outputs stay in, as in the
-    // reference's four Gather_grad scatters.
+    // source index q is touched by a contiguous range of output coordinates (taps are monotone): one merged range
+    // per index, degenerate (both taps clipped to one index) outputs skipped
     AIR_STAMP(1);
-    if (!a.literal && tid < 2 * w) {         // (the literal path uses segmented scans, no ranges)
+    if (tid < 2 * w) {
         const Tap* tp = (tid < w) ? sh_tx : sh_ty;
         const int q = (tid < w) ? tid : tid - w;
         int lo0 = C, hi0 = -1;
@@ -929,62 +883,19 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_kernel(air_write_bwd_t a
         int* r = sh_rng + (tid < w ? 0 : 4 * w) + 4 * q;
         r[0] = lo0; r[1] = hi0; r[2] = C; r[3] = -1;
     }
-    if (!a.literal) __syncthreads();
+    __syncthreads();
 
     const float* g = sh_g;
-    const int tstride = a.literal ? w + 2 : w;              // literal mode keeps 2 extra slots per row
-    float* T0 = sh_T;
-    float* T1 = sh_T + C * tstride;
-    if (!a.literal) {
-        // stage 1: T[I][q] = sum_J g[I][J] * Rx[J][q]
-        for (int it = tid; it < C * w; it += WB_THREADS) {
-            const int I = it / w, q = it % w;
-            float acc = 0.0f;
-            for (int J = sh_rng[4 * q]; J <= sh_rng[4 * q + 1]; ++J) {
-                const Tap tt = sh_tx[J];
-                const float wq = (tt.i0 != tt.i1) ? ((tt.i0 == q ? tt.w0 : 0.0f) + (tt.i1 == q ? tt.w1 : 0.0f)) : 0.0f;
-                acc += g[I * C + J] * wq;
-            }
-            T0[I * tstride + q] = acc;
+    // stage 1: T[I][q] = sum_J g[I][J] * Rx[J][q]
+    for (int it = tid; it < C * w; it += WB_THREADS) {
+        const int I = it / w, q = it % w;
+        float acc = 0.0f;
+        for (int J = sh_rng[4 * q]; J <= sh_rng[4 * q + 1]; ++J) {
+            const Tap tt = sh_tx[J];
+            const float wq = (tt.i0 != tt.i1) ? ((tt.i0 == q ? tt.w0 : 0.0f) + (tt.i1 == q ? tt.w1 : 0.0f)) : 0.0f;
+            acc += g[I * C + J] * wq;
         }
-    } else {
-        // stage 1, per tap: T0[I][q] through the x0 taps, T1[I][q] through the x1 taps (g scaled by
-        // z_pres).  Taps are monotone, so every key (tap index) is ONE contiguous run of canvas
-        // columns; out-of-range (degenerate) columns form their own runs, keyed w (left) and w+1
-        // (right), so that the +w and -w partners see identical summation orders.  Run boundaries
-        // are found in O(1) per column; then one task per (row, tap array, key) sums its run left
-        // to right (the sequential order of a scatter-add) -- short in-range runs and the long
-        // degenerate runs are separate, balanced task groups.  The degenerate sums are folded into
-        // the border slots afterwards: the residue left is the rounding of (in-range sum + huge run).
-        const int ws = w + 2;
-        for (int it = tid; it < 4 * C; it += WB_THREADS) {
-            const int arr = it / C, J = it % C;             // arr: x0, x1, y0, y1
-            const Tap* tp = (arr < 2) ? sh_tx : sh_ty;
-            auto keyof = [&](int jj) {
-                const Tap tt = tp[jj];
-                const int idx = (arr & 1) ? tt.i1 : tt.i0;
-                return (tt.i0 == tt.i1) ? (idx == 0 ? w : w + 1) : idx;
-            };
-            const int k = keyof(J);
-            if (J == 0 || keyof(J - 1) != k) sh_run[(arr * ws + k) * 2] = J;
-            if (J == C - 1 || keyof(J + 1) != k) sh_run[(arr * ws + k) * 2 + 1] = J;
-        }
-        __syncthreads();
-        const int nA = 2 * C * w, nB = 4 * C;
-        for (int it = tid; it < nA + nB; it += WB_THREADS) {
-            int I, tap, key;                                 // the long (degenerate) runs are scheduled first
-            if (it >= nB) { const int u = it - nB; key = u % w; tap = (u / w) & 1; I = u / (2 * w); }
-            else { key = w + (it & 1); tap = (it >> 1) & 1; I = it >> 2; }
-            const int lo = sh_run[(tap * ws + key) * 2], hi = sh_run[(tap * ws + key) * 2 + 1];
-            const float* gr = g + I * C;
-            float acc = 0.0f;
-#pragma unroll 4
-            for (int J = lo; J <= hi; ++J) {
-                const Tap tt = sh_tx[J];
-                acc += (gr[J] * z) * (tap ? tt.w1 : tt.w0);
-            }
-            sh_T[(size_t)tap * C * ws + (size_t)I * ws + key] = acc;
-        }
+        sh_T[I * w + q] = acc;
     }
     AIR_STAMP(2);
     // theta / z gradients, per canvas pixel (independent of stage 1)
@@ -1004,15 +915,11 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_kernel(air_write_bwd_t a
         // a degenerate axis (both taps clipped to one index) is exactly 0 in real arithmetic;
         // the fp32 residue the forward keeps there (~1e-7) would be multiplied by g ~ 1e9/B
         // (d log(r + 1e-9) at r ~ 0) and drown d z_pres in rounding noise.
-        // (exact mode only; the reference's autodiff multiplies the residue by g like any other value)
-        if (a.literal || (tx.i0 != tx.i1 && ty.i0 != ty.i1)) dz += gv * bilinear4(tx, ty, Ia, Ib, Ic, Id);
+        // (the reference's autodiff multiplies the residue by g like any other value: the graph-order kernels below)
+        if (tx.i0 != tx.i1 && ty.i0 != ty.i1) dz += gv * bilinear4(tx, ty, Ia, Ib, Ic, Id);
         const float gz = gv * z;
-        float gX, gY;
-        if (a.literal) literal_dxy(gz, Ia, Ib, Ic, Id, tx, ty, (float)w - 1.001f, gX, gY);
-        else {
-            gX = gz * ((Ic - Ia) * ty.w0 + (Id - Ib) * ty.w1) * half_w;
-            gY = gz * ((Ib - Ia) * tx.w0 + (Id - Ic) * tx.w1) * half_w;
-        }
+        const float gX = gz * ((Ic - Ia) * ty.w0 + (Id - Ib) * ty.w1) * half_w;
+        const float gY = gz * ((Ib - Ia) * tx.w0 + (Id - Ic) * tx.w1) * half_w;
         da += gX * sh_t[cj] + gY * sh_t[ci];
         dbx += gX;
         dby += gY;
@@ -1032,66 +939,17 @@ __global__ __launch_bounds__(WB_THREADS) void write_bwd_kernel(air_write_bwd_t a
         dsx[3] = dz;
     }
     AIR_STAMP(4);
-    float* sh_S = sh_g + C * C;                            // [4][(w+2)*w]: per-tap sums a, b, c, d (literal mode)
-    const int ss = (w + 2) * w;
-    if (a.literal) {
-        // fold the degenerate runs of stage 1 into the border slots (stage 1 finished at the barrier
-        // inside the block reduction above)
-        const int ws = w + 2;
-        for (int it = tid; it < 2 * C; it += WB_THREADS) {
-            float* Wr = sh_T + (size_t)it * ws;               // (tap, I) rows are contiguous
-            Wr[0] += Wr[w];
-            Wr[w - 1] += Wr[w + 1];
-        }
-        __syncthreads();
-        // one task per (window column q, tap array a/b/c/d, key = window row): the run of canvas
-        // rows of that key, top to bottom; degenerate runs (keys w, w+1) are their own tasks
-        const int nA = 4 * w * w, nB = 8 * w;
-        for (int it = tid; it < nA + nB; it += WB_THREADS) {
-            int q, arr, key;
-            if (it >= nB) { const int u = it - nB; q = u % w; arr = (u / w) & 3; key = u / (4 * w); }
-            else { q = it % w; arr = (it / w) & 3; key = w + it / (4 * w); }
-            const float* Tsrc = (arr & 2) ? T1 : T0;       // a=(y0,x0) b=(y1,x0) c=(y0,x1) d=(y1,x1)
-            const bool y1tap = arr & 1;
-            const int lo = sh_run[((2 + (arr & 1)) * ws + key) * 2], hi = sh_run[((2 + (arr & 1)) * ws + key) * 2 + 1];
-            float acc = 0.0f;
-#pragma unroll 4
-            for (int I = lo; I <= hi; ++I) {
-                const Tap tt = sh_ty[I];
-                acc += Tsrc[I * tstride + q] * (y1tap ? tt.w1 : tt.w0);
-            }
-            sh_S[(size_t)arr * ss + key * w + q] = acc;
-        }
-        __syncthreads();
-        for (int it = tid; it < 4 * w; it += WB_THREADS) {
-            float* Sr = sh_S + (size_t)(it / w) * ss;
-            const int q = it % w;
-            Sr[q] += Sr[w * w + q];
-            Sr[(w - 1) * w + q] += Sr[(w + 1) * w + q];
-        }
-        __syncthreads();
-    }
-    AIR_STAMP(5);
     // stage 2: dU[p][q] = z * sum_I Ry[I][p] * T[I][q]; fold the sigmoid of vae.py:39-41
     for (int it = tid; it < w * w; it += WB_THREADS) {
         const int p = it / w, q = it % w;
         const int* ry = sh_rng + 4 * w + 4 * p;
-        float du;
-        if (!a.literal) {
-            float acc = 0.0f;
-            for (int I = ry[0]; I <= ry[1]; ++I) {
-                const Tap tt = sh_ty[I];
-                const float wp = (tt.i0 != tt.i1) ? ((tt.i0 == p ? tt.w0 : 0.0f) + (tt.i1 == p ? tt.w1 : 0.0f)) : 0.0f;
-                acc += T0[I * tstride + q] * wp;
-            }
-            du = z * acc;
-        } else {
-            // the four Gather_grad scatters of the reference (taps a=(y0,x0), b=(y1,x0), c=(y0,x1),
-            // d=(y1,x1)), summed as reverse-mode autodiff delivers them: ((d + c) + b) + a.  For a
-            // border source pixel the out-of-range contributions of a/c (b/d) are equal and opposite;
-            // in fp32 they leave the rounding residue the reference's gradients carry.
-            du = ((sh_S[3 * ss + it] + sh_S[2 * ss + it]) + sh_S[ss + it]) + sh_S[it];
+        float acc = 0.0f;
+        for (int I = ry[0]; I <= ry[1]; ++I) {
+            const Tap tt = sh_ty[I];
+            const float wp = (tt.i0 != tt.i1) ? ((tt.i0 == p ? tt.w0 : 0.0f) + (tt.i1 == p ? tt.w1 : 0.0f)) : 0.0f;
+            acc += sh_T[I * w + q] * wp;
         }
+        const float du = z * acc;
         const float r = sh_win[it];
         const float dgv = du * (r * (1.0f - r));
         dgen[it] = dgv;
@@ -1155,16 +1013,13 @@ __device__ __forceinline__ float stream_add(float acc, const float* T, int start
 
 // ALLPH: the terms of all four taps are resident (4*C*C floats of LDS, no barrier between taps);
 // otherwise one tap at a time through one buffer (large canvases)
-// BLOCKED (literal == 3, backward="reference_blocked"): the same term streams -- per window pixel the a-, b-, c-, d-tap
-// terms in canvas-pixel order -- but every (slot, tap) stream of n terms is cut into at most WB_CHUNKS contiguous chunks
-// of max(ceil(n / WB_CHUNKS), WB_CHUNK_MIN) terms, each summed from +0.0 by a lane of its own (register chain), and the
-// chunk sums are added onto the slot's accumulator left to right, tap after tap (the test-side
-// order="blocked16"): a sum tree of depth n/16 + 64 instead of one chain of 4n adds.  A stream of up to 64 terms is ONE
-// chunk (its tap's sum), so only the border slots that collect the out-of-range pixels are cut at all.
-// No LDS atomics, no lane-order property, no probe; the coordinate / z gradients are taken in the term pass.
-constexpr int WB_CHUNKS = 16, WB_CHUNK_MIN = 64;
-__device__ __forceinline__ int wb_chunk_len(int n) { return max((n + WB_CHUNKS - 1) / WB_CHUNKS, WB_CHUNK_MIN); }
-// CARRIED (ORD == 2, literal == 4, backward="reference_carried"): the layout, the term pass and the chunks of BLOCKED, but
+// CARRIED (literal == 4, backward="reference_carried"): the same term streams -- per window pixel the a-, b-, c-, d-tap
+// terms in canvas-pixel order -- with every (slot, tap) stream of n terms cut into at most WB_CHUNKS contiguous chunks of
+// max(ceil(n / WB_CHUNKS), WB_CHUNK_MIN) terms that are walked side by side on register chains.  A stream of up to 64 terms
+// is ONE chunk, so only the border slots that collect the out-of-range pixels are cut at all.  No LDS atomics, no lane-order
+// property, no probe; the coordinate / z gradients are taken in the term pass.
+// (Round 5 also shipped the plain chunked form -- every chunk from +0.0, the chunk sums added left to right, "blocked16":
+// 13.4 us against 17.7, and 4 of 24 training runs stuck on a count class.  Removed)
 //   * a slot whose four streams all fit one chunk (<= 64 terms each: every slot but the corners and a few long borders) is
 //     summed exactly as the reference sums it -- one accumulator through its a-, b-, c-, d-terms;
 //   * a slot with a longer stream walks every chunk TWICE: C_k = chunk k from +0.0, Q_k = chunk k from P_k, with P_k the
@@ -1173,9 +1028,10 @@ __device__ __forceinline__ int wb_chunk_len(int n) { return max((n + WB_CHUNKS -
 //     roundings of the same real number, their difference is a few ulps and exact.  Every add of the Q chains rounds at
 //     the magnitude it rounds at in the reference's one long chain and nothing else rounds at that magnitude, so the
 //     cancellation residue the out-of-range terms leave keeps its size (mean |error| 1.0x the sequential order's over 2116
-//     corner streams; BLOCKED: 2x with a 5x heavier tail) -- DESIGN.md section 10.
+//     corner streams) -- DESIGN.md section 10.
 //   Two chains of n / 16 adds per corner instead of one of 4 n; no LDS atomics, no probe.
-constexpr int WB_ORD_GRAPH = 0, WB_ORD_BLOCKED = 1, WB_ORD_CARRIED = 2;
+constexpr int WB_CHUNKS = 16, WB_CHUNK_MIN = 64;
+__device__ __forceinline__ int wb_chunk_len(int n) { return max((n + WB_CHUNKS - 1) / WB_CHUNKS, WB_CHUNK_MIN); }
 // c += every term, q += every term: the two chains of one chunk in ONE pass over its terms (independent: they overlap)
 __device__ __forceinline__ void stream_add2(float& c, float& q, const float* T, int start, int n) {
     int k = start;
@@ -1194,10 +1050,9 @@ __device__ __forceinline__ void stream_add2(float& c, float& q, const float* T, 
     }
     while (k < end) { const float t = T[k]; c += t; q += t; ++k; }
 }
-template <bool ALLPH, int ORD>
+template <bool ALLPH, bool CARRIED>
 __device__ __forceinline__ void write_bwd_graph_body(const air_write_bwd_t& a, int seq_flags)
 {
-    constexpr bool BLOCKED = ORD != WB_ORD_GRAPH, CARRIED = ORD == WB_ORD_CARRIED;
     // seq_flags (accumulators(), below): bit 0 the LDS atomic pipe applies lanes in order, bit 1 the lane-ring accumulator
     // is exact on this part (used when the pipe is not)
     const bool lds_ordered = seq_flags & 1, ring_ok = seq_flags & 2;
@@ -1326,7 +1181,7 @@ __device__ __forceinline__ void write_bwd_graph_body(const air_write_bwd_t& a, i
     // tap ph = a, b, c, d <-> (y0,x0), (y1,x0), (y0,x1), (y1,x1)
     const int di = WB_THREADS / C, dj = WB_THREADS % C;
     float d00 = 0.f, d02 = 0.f, d11 = 0.f, d12 = 0.f, dz = 0.f;
-    // BLOCKED: the terms of taps PH0 .. PH1-1 (and, THETA, the theta / z gradients, taken where the pixel's taps and
+    // CARRIED: the terms of taps PH0 .. PH1-1 (and, THETA, the theta / z gradients, taken where the pixel's taps and
     // d_recon are in registers anyway: the window from LDS -- nothing starves the LDS in this mode).  A thread owns ONE
     // canvas column j and the rows i0, i0 + RPP, ...: the column's tap, its runs and its linspace value are loop
     // invariants, the row's are wave-wide broadcasts.  Per-thread sums over a fixed pixel set, combined over the waves in a
@@ -1335,7 +1190,7 @@ __device__ __forceinline__ void write_bwd_graph_body(const air_write_bwd_t& a, i
     // bilinear sum cancel pairwise before anything rounds -- and is skipped; an out-of-range COLUMN does not cancel
     // exactly (that is the x residue) and is not.
     const int RPP = WB_THREADS / C, bj = tid % C, bi0 = tid / C;
-    auto blocked_terms = [&](auto ph0c, auto ph1c, auto thetac) __attribute__((always_inline)) {
+    auto carried_terms = [&](auto ph0c, auto ph1c, auto thetac) __attribute__((always_inline)) {
         constexpr int PH0 = decltype(ph0c)::value, PH1 = decltype(ph1c)::value;
         constexpr bool THETA = decltype(thetac)::value;
         if (bi0 >= RPP) return;
@@ -1398,13 +1253,13 @@ __device__ __forceinline__ void write_bwd_graph_body(const air_write_bwd_t& a, i
         start = (ALLPH ? ph * CCp : 0) + rlo * C + nrows * clo;
         n = nrows * ncols;
     };
-    // which window pixel ("slot") this thread accumulates.  BLOCKED: waves 0..3 take the corner slots' chunks, so the other
+    // which window pixel ("slot") this thread accumulates.  CARRIED: waves 0..3 take the corner slots' chunks, so the other
     // slots start at thread 256 and whatever does not fit behind it falls to the first threads (after their corner work);
     // the 4 (w - 2) border slots -- the only other long streams: a row or a column of out-of-range pixels each -- come
     // first, packed into the same waves, the interior slots (a handful of terms per tap) fill the rest
     int sl = tid, sp = tid / w, sq = tid % w;
     bool is_slot = tid < w * w;
-    if (BLOCKED) {
+    if (CARRIED) {
         const int u = tid >= 4 * 64 ? tid - 4 * 64 : tid + (WB_THREADS - 4 * 64);
         const int wm = max(w - 2, 1), ne = 4 * (w - 2);
         is_slot = u < w * w - 4;
@@ -1420,7 +1275,7 @@ __device__ __forceinline__ void write_bwd_graph_body(const air_write_bwd_t& a, i
     }
     // (a part whose LDS atomics are not lane-ordered -- lds_order_probe -- has no "corner" slots: their four long runs go
     // through the register chains like every other slot's; slow, but the same sequential order by construction)
-    const bool corner = !BLOCKED && (lds_ordered || ring_ok) && is_slot && (sp == 0 || sp == w - 1) && (sq == 0 || sq == w - 1);
+    const bool corner = !CARRIED && (lds_ordered || ring_ok) && is_slot && (sp == 0 || sp == w - 1) && (sq == 0 || sq == w - 1);
     float acc = 0.0f;
     // The corner slots' streams -> ds_add_f32 on one LDS word per corner: wave c feeds corner c, 64
     // consecutive terms per instruction, tap after tap (an instruction costs ~140 + 1.8 cycles per active
@@ -1594,35 +1449,6 @@ __device__ __forceinline__ void write_bwd_graph_body(const air_write_bwd_t& a, i
             if (dgen16) dgen16[sl] = air_bf16_of(dgv);
         }
     };
-    // BLOCKED: this thread's slot, taps [PH0, PH1): the stream descriptors of all of them first (independent LDS reads), then
-    // the first four terms of every stream (clamped addresses; a term past the end is replaced by +0.0, the identity of a
-    // sum that starts at +0.0) -- for an interior slot that is all there is, two LDS round trips in total --, then whatever
-    // a longer stream has left: the rest of its first chunk, its further chunks, each from +0.0, added in order
-    auto blocked_slot = [&](auto ph0c, auto ph1c) __attribute__((always_inline)) {
-        constexpr int PH0 = decltype(ph0c)::value, PH1 = decltype(ph1c)::value;
-        if (!is_slot) return;
-        int st[4], nn[4];
-        float t4[4][4];
-#pragma unroll
-        for (int ph = PH0; ph < PH1; ++ph) slot_run(ph, sp, sq, st[ph], nn[ph]);
-#pragma unroll
-        for (int ph = PH0; ph < PH1; ++ph)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) t4[ph][k] = sh_T[st[ph] + min(k, max(nn[ph] - 1, 0))];
-#pragma unroll
-        for (int ph = PH0; ph < PH1; ++ph) {
-            const int n = nn[ph];
-            float sk = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) sk += k < n ? t4[ph][k] : 0.0f;
-            if (n > 4) {
-                const int cs = wb_chunk_len(n);
-                sk = stream_add(sk, sh_T, st[ph] + 4, min(n, cs) - 4);
-                acc += sk;
-                for (int k0 = cs; k0 < n; k0 += cs) acc += stream_add(0.0f, sh_T, st[ph] + k0, min(cs, n - k0));
-            } else acc += sk;
-        }
-    };
     // CARRIED: this thread's slot, taps [PH0, PH1).  short_s: all four of its streams are single chunks -> the reference's
     // chain (acc); otherwise P_s / R_s carry the scheme above from tap to tap (and from pass to pass on large canvases)
     float P_s = 0.0f, corr_s = 0.0f, Q_s = 0.0f;
@@ -1652,14 +1478,6 @@ __device__ __forceinline__ void write_bwd_graph_body(const air_write_bwd_t& a, i
             acc = Q_s + corr_s;                                  // (final after the last tap)
         }
     };
-    // BLOCKED: chunk k of corner (cp, cq)'s stream of tap ph, summed from +0.0 (empty chunks: +0.0, the identity)
-    auto corner_chunk = [&](int ph, int cp, int cq, int k) -> float {
-        int start, n;
-        slot_run(ph, cp, cq, start, n);
-        n = max(n, 0);
-        const int cs = wb_chunk_len(n), off = k * cs;
-        return stream_add(0.0f, sh_T, start + off, min(max(n - off, 0), cs));
-    };
     auto publish_corner = [&](int c, float du) {
         const int it = ((c & 2) ? w - 1 : 0) * w + ((c & 1) ? w - 1 : 0);
         const float r = sh_win[it];
@@ -1686,24 +1504,17 @@ __device__ __forceinline__ void write_bwd_graph_body(const air_write_bwd_t& a, i
     };
     // waves 0..3 feed one corner each to the atomic pipe; the pixel loop runs beside them on the other twelve
     constexpr int TH0 = 4 * 64, THN = WB_THREADS - TH0;
-    if (BLOCKED && ALLPH) {
+    if (CARRIED && ALLPH) {
         // [terms of all taps + coordinate gradients] | [waves 0..3: corner c's 4 x 16 chunks, one per lane, then their 64
         // sums added in stream order || the other slots' streams, one lane each || last wave: the theta / z outputs]
         using std::integral_constant;
         AIR_STAMP_WG(1);
-        blocked_terms(integral_constant<int, 0>{}, integral_constant<int, 4>{}, integral_constant<bool, true>{});
+        carried_terms(integral_constant<int, 0>{}, integral_constant<int, 4>{}, integral_constant<bool, true>{});
         theta_publish();
         __syncthreads();
         AIR_STAMP(43);
         AIR_STAMP_WG(2);
-        if (wave < 4 && !CARRIED) {
-            const float sk = corner_chunk(lane >> 4, (wave & 2) ? w - 1 : 0, (wave & 1) ? w - 1 : 0, lane & 15);
-            float du = 0.0f;
-#pragma unroll
-            for (int l = 0; l < 64; ++l) du += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sk), l));
-            if (lane == 0) publish_corner(wave, du);
-        }
-        if (wave < 4 && CARRIED) {
+        if (wave < 4) {
             // corner `wave`: lane = tap * 16 + chunk.  [C of every chunk] -> [P: their exclusive running sum in stream order]
             // -> [Q of every chunk from its P] -> [R: the running sum of Q - P in stream order]
             const int cp = (wave & 2) ? w - 1 : 0, cq = (wave & 1) ? w - 1 : 0;
@@ -1747,8 +1558,7 @@ __device__ __forceinline__ void write_bwd_graph_body(const air_write_bwd_t& a, i
         if (wave == NW - 1) finish_theta();
         AIR_STAMP(44);
         AIR_STAMP_WG(3);
-        if (CARRIED) carried_slot(integral_constant<int, 0>{}, integral_constant<int, 4>{});
-        else blocked_slot(integral_constant<int, 0>{}, integral_constant<int, 4>{});
+        carried_slot(integral_constant<int, 0>{}, integral_constant<int, 4>{});
         AIR_STAMP_WG(4);
         AIR_STAMP_WG_T(5, 4 * 64);
         publish();
@@ -1756,17 +1566,17 @@ __device__ __forceinline__ void write_bwd_graph_body(const air_write_bwd_t& a, i
         AIR_STAMP_WG(6);
         AIR_STAMP_WG_T(7, 15 * 64);
         return;
-    } else if (BLOCKED) {
+    } else if (CARRIED) {
         // one tap per pass (large canvases).  Wave 1 holds the four corners' chunks of the pass (lane = corner * 16 + chunk)
         // and carries the corner accumulators from pass to pass; the coordinate gradients ride in pass 0
         using std::integral_constant;
         float cacc[4] = {0.f, 0.f, 0.f, 0.f};
-        // CARRIED: cP = the four corners' prefixes P, cQ / ccorr / chave = the last chain's end, the corrections so far and
+        // cP = the four corners' prefixes P, cQ / ccorr / chave = the last chain's end, the corrections so far and
         // whether a chain has run (cacc = cQ + ccorr; a short corner -- all four streams single chunks -- keeps the
         // reference's chain in cacc)
         float cP[4] = {0.f, 0.f, 0.f, 0.f}, cQ[4] = {0.f, 0.f, 0.f, 0.f}, ccorr[4] = {0.f, 0.f, 0.f, 0.f};
         bool cshort[4] = {true, true, true, true}, chave[4] = {false, false, false, false};
-        if (CARRIED && wave == 1) {
+        if (wave == 1) {
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc)
 #pragma unroll
@@ -1778,19 +1588,10 @@ __device__ __forceinline__ void write_bwd_graph_body(const air_write_bwd_t& a, i
         }
         auto pass = [&](auto phc) __attribute__((always_inline)) {
             constexpr int ph = decltype(phc)::value;
-            blocked_terms(integral_constant<int, ph>{}, integral_constant<int, ph + 1>{}, integral_constant<bool, ph == 0>{});
+            carried_terms(integral_constant<int, ph>{}, integral_constant<int, ph + 1>{}, integral_constant<bool, ph == 0>{});
             if (ph == 0) theta_publish();
             __syncthreads();
-            if (wave == 1 && !CARRIED) {
-                const int c = lane >> 4;
-                const float sk = corner_chunk(ph, (c & 2) ? w - 1 : 0, (c & 1) ? w - 1 : 0, lane & 15);
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc)
-#pragma unroll
-                    for (int k = 0; k < 16; ++k)
-                        cacc[cc] += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sk), cc * 16 + k));
-            }
-            if (wave == 1 && CARRIED) {
+            if (wave == 1) {
                 // lane = corner * 16 + chunk of this pass's tap
                 const int c = lane >> 4;
                 int start, n;
@@ -1825,8 +1626,7 @@ __device__ __forceinline__ void write_bwd_graph_body(const air_write_bwd_t& a, i
                 }
             }
             if (ph == 0 && wave == NW - 1) finish_theta();
-            if (CARRIED) carried_slot(integral_constant<int, ph>{}, integral_constant<int, ph + 1>{});
-            else blocked_slot(integral_constant<int, ph>{}, integral_constant<int, ph + 1>{});
+            carried_slot(integral_constant<int, ph>{}, integral_constant<int, ph + 1>{});
             if (ph < 3) __syncthreads();
         };
         pass(integral_constant<int, 0>{}); pass(integral_constant<int, 1>{});
@@ -1921,17 +1721,12 @@ __device__ __forceinline__ void write_bwd_graph_body(const air_write_bwd_t& a, i
 template <bool ALLPH>
 __global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_bwd_t a, int seq_flags)
 {
-    write_bwd_graph_body<ALLPH, WB_ORD_GRAPH>(a, seq_flags);
-}
-template <bool ALLPH>
-__global__ __launch_bounds__(WB_THREADS) void write_bwd_blocked_kernel(air_write_bwd_t a)
-{
-    write_bwd_graph_body<ALLPH, WB_ORD_BLOCKED>(a, 0);
+    write_bwd_graph_body<ALLPH, false>(a, seq_flags);
 }
 template <bool ALLPH>
 __global__ __launch_bounds__(WB_THREADS) void write_bwd_carried_kernel(air_write_bwd_t a)
 {
-    write_bwd_graph_body<ALLPH, WB_ORD_CARRIED>(a, 0);
+    write_bwd_graph_body<ALLPH, true>(a, 0);
 }
 
 // the canvas is staged in LDS only when one prefetch pass covers it (PF * THREADS floats, see the kernels)
@@ -1947,7 +1742,7 @@ size_t write_bwd_graph_smem(int C, int w, bool allph) {
     return (136 + 8 * C + ((C + 3) & ~3) + 8 * C + ((8 * w + 3) & ~3) + (((size_t)w * w + 3) & ~3) +
             (allph ? 5 : 1) * (((size_t)C * C + 3) & ~3)) * sizeof(float);
 }
-size_t write_bwd_smem(int C, int w) { return (64 + 8 * C + C + 8 * w + 8 * (w + 2) + (size_t)w * w + 4 * (size_t)(w + 2) * w + 2 * (size_t)C * (w + 2) + (size_t)C * C) * sizeof(float); }
+size_t write_bwd_smem(int C, int w) { return (64 + 8 * C + C + 8 * w + (size_t)w * w + (size_t)C * w + (size_t)C * C) * sizeof(float); }
 
 // ---------------------------------------------------------------------------
 // The bit-for-bit reproduction of the reference's UnsortedSegmentSum rests on a property of gfx950 that no manual
@@ -2123,8 +1918,8 @@ extern "C" int air_write_fwd(const air_write_fwd_t* a, void* stream) {
 /* name of the kernel function air_write_bwd dispatches this descriptor to, as rocprofv3 prints it */
 extern "C" int air_write_bwd_kernel_name(const air_write_bwd_t* a, char* buf, int n) {
     if (!a || !buf || n <= 0 || a->C < 2 || a->w < 2) return AIR_EINVAL;
-    if (a->literal >= 2 && a->literal <= 4)
-        snprintf(buf, n, "write_bwd_%s_kernel<%s>", a->literal == 4 ? "carried" : a->literal == 3 ? "blocked" : "graph",
+    if (a->literal == 2 || a->literal == 4)
+        snprintf(buf, n, "write_bwd_%s_kernel<%s>", a->literal == 4 ? "carried" : "graph",
                  write_bwd_graph_smem(a->C, a->w, true) <= 80 * 1024 ? "true" : "false");
     else snprintf(buf, n, "write_bwd_kernel");
     return 0;
@@ -2133,23 +1928,11 @@ extern "C" int air_write_bwd_kernel_name(const air_write_bwd_t* a, char* buf, in
 extern "C" int air_write_bwd(const air_write_bwd_t* a, void* stream) {
     if (!a || !a->d_recon || !a->vrec || !a->att || !a->d_gen_pre || !a->d_sxy_write) return AIR_EINVAL;
     if (a->B <= 0 || a->N <= 0 || a->C < 2 || a->w < 2) return AIR_EINVAL;
-    if (a->literal < 0 || a->literal > 4) return AIR_EINVAL;
+    if (a->literal != 0 && a->literal != 2 && a->literal != 4) return AIR_EINVAL;     // (1 and 3 were removed with ABI 5)
     if (a->order && a->literal < 2) return AIR_EINVAL;            // (the ordered form exists in the graph-order kernels only)
     if (2 * a->w > THREADS) return AIR_ELIMIT;
-    if (a->literal == 3) {
-        // the blocked graph order: register chains only -- no LDS-atomic lane order to probe, capture-safe from the first call
-        if (a->w * a->w > WB_THREADS) return AIR_ELIMIT;
-        const bool allph = write_bwd_graph_smem(a->C, a->w, true) <= 80 * 1024;
-        const size_t lds = write_bwd_graph_smem(a->C, a->w, allph);
-        int rc = allph ? ensure_lds(write_bwd_blocked_kernel<true>, lds) : ensure_lds(write_bwd_blocked_kernel<false>, lds);
-        if (rc) return rc;
-        if (allph) hipLaunchKernelGGL(write_bwd_blocked_kernel<true>, dim3(a->B, a->N), dim3(WB_THREADS), lds, air_stream(stream), *a);
-        else hipLaunchKernelGGL(write_bwd_blocked_kernel<false>, dim3(a->B, a->N), dim3(WB_THREADS), lds, air_stream(stream), *a);
-        AIR_CHECK_LAUNCH();
-        return 0;
-    }
     if (a->literal == 4) {
-        // the carried graph order: as above -- register chains only, capture-safe from the first call
+        // the carried graph order: register chains only -- no LDS-atomic lane order to probe, capture-safe from the first call
         if (a->w * a->w > WB_THREADS) return AIR_ELIMIT;
         const bool allph = write_bwd_graph_smem(a->C, a->w, true) <= 80 * 1024;
         const size_t lds = write_bwd_graph_smem(a->C, a->w, allph);

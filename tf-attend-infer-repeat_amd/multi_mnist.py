@@ -246,6 +246,87 @@ def write_to_records(filename, images, indices, positions, boxes, labels, digits
     return tfrecord.write_records(filename + ".tfrecords", recs)
 
 
+class ShuffleBatchQueue:
+    """read_and_decode (:228-249) on the device: tf.train.shuffle_batch([image, digits], batch_size,
+    capacity=10000 + 10 * batch_size, min_after_dequeue=10000) over the epoch-repeating record stream of ONE reader
+    (training.py:76-81), the decoded records resident in HBM.  `images` [n, D] float32 / `digits` [n] int32 are device
+    tensors; every batch lands in the caller's `out_images` [B, D] / `out_digits` [B] (the train model's input buffers).
+
+    next_batch(): dequeue + gather on the current stream (three launches in front of the step that consumes the batch).
+    graph_hooks(steps): the pipelined form for AIRModel.capture_graph(steps, between_steps=, after_steps=) -- `steps` even:
+    the picks of half a replay are made by ONE launch on a forked branch while the other half's train steps run
+    (air_shuffle_batch_dequeue_many), so only the row gather (one launch) stays in front of a step.  The batches are the
+    same sequence either way, pick for pick the numpy model of the reference's queue that tests/test_shuffle_queue.py holds."""
+
+    def __init__(self, images, digits, batch_size, out_images, out_digits, seed=0, min_after_dequeue=10000):
+        import ctypes as C
+        import torch
+        from air import _hip as H
+        self._C, self._torch, self._H = C, torch, H
+        dev = images.device
+        self.images, self.digits, self.out_images, self.out_digits = images, digits, out_images, out_digits
+        self.batch, self.D = int(batch_size), int(images.shape[1])
+        self.capacity = min_after_dequeue + 10 * self.batch                       # :246
+        self.queue = torch.zeros(self.capacity, dtype=torch.int32, device=dev)
+        self.state = torch.zeros(2, dtype=torch.int64, device=dev)
+        self.picks = torch.zeros(self.batch, dtype=torch.int32, device=dev)
+        self._sq = H.ShuffleBatch(self.queue.data_ptr(), self.state.data_ptr(), self.picks.data_ptr(), self.capacity,
+                                  self.batch, min_after_dequeue, int(images.shape[0]), seed)
+        self._ahead = None          # [2, half, batch] picks made ahead of their steps (graph_hooks)
+        self._side = None
+        H.check(H.lib().air_shuffle_batch_init(C.byref(self._sq), self._s()), "air_shuffle_batch_init")
+
+    def _s(self):
+        return self._C.c_void_p(self._torch.cuda.current_stream(self.images.device).cuda_stream)
+
+    def _gather(self, picks):
+        H = self._H
+        H.check(H.lib().air_batch_gather(self.images.data_ptr(), self.digits.data_ptr(), picks.data_ptr(),
+                                         self.out_images.data_ptr(), self.out_digits.data_ptr(), self.batch, self.D, self._s()),
+                "air_batch_gather")
+
+    def next_batch(self, _i=0):
+        H = self._H
+        if self._ahead is not None:
+            raise RuntimeError("this queue runs ahead of its consumer (graph_hooks): batches come out of the captured graph")
+        H.check(H.lib().air_shuffle_batch_dequeue(self._C.byref(self._sq), self._s()), "air_shuffle_batch_dequeue")
+        self._gather(self.picks)
+
+    def _dequeue_many(self, half_index):
+        H = self._H
+        H.check(H.lib().air_shuffle_batch_dequeue_many(self._C.byref(self._sq), self._ahead.shape[1],
+                                                       self._ahead[half_index].data_ptr(), self._s()),
+                "air_shuffle_batch_dequeue_many")
+
+    def graph_hooks(self, steps):
+        """-> (between_steps, after_steps).  The first call also makes the first half replay's picks (eagerly)."""
+        torch = self._torch
+        if steps < 2 or steps % 2:
+            raise ValueError("the pipelined queue needs an even number of steps per replay")
+        half = steps // 2
+        if self._ahead is None:
+            self._ahead = torch.zeros(2, half, self.batch, dtype=torch.int32, device=self.images.device)
+            self._side = torch.cuda.Stream(self.images.device)
+            self._dequeue_many(0)
+        elif self._ahead.shape[1] != half:
+            raise ValueError("graph_hooks was set up for %d steps per replay" % (2 * self._ahead.shape[1]))
+        side = self._side
+
+        def between_steps(i):
+            main = torch.cuda.current_stream(self.images.device)
+            if i == half:
+                main.wait_stream(side)                      # the second half's picks are complete
+            if i == 0 or i == half:
+                side.wait_stream(main)                      # (and every gather that read the half about to be rewritten)
+                with torch.cuda.stream(side):
+                    self._dequeue_many(1 if i == 0 else 0)
+            self._gather(self._ahead[0 if i < half else 1, i % half])
+
+        def after_steps():
+            torch.cuda.current_stream(self.images.device).wait_stream(side)
+        return between_steps, after_steps
+
+
 def read_test_data(filename, shift_zero_digits_images=False):
     """:254-296 -- reads a .tfrecords file written by the reference (or by write_to_records)."""
     import tfrecord

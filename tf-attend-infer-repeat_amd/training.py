@@ -9,12 +9,13 @@ shift_zero_digits_images ordering (:143-156, 169-200), checkpoints every 10 000 
 AIRModel._summarize_by_digit_count (air_model.py:160-182, 614-617).
 
 The whole dataset lives in HBM.  A batch comes out of tf.train.shuffle_batch's queue, kept on the
-device (multi_mnist.py:240-249: capacity 10 000 + 10 * batch, min_after_dequeue 10 000, over the epoch-repeating
-record stream of training.py:76-81; air_shuffle_batch_dequeue, include/air_hip.h) and is gathered into the
-train model's input buffer; queue, gather and train step are captured together in the hipGraph replay.
+device (multi_mnist.ShuffleBatchQueue; multi_mnist.py:240-249: capacity 10 000 + 10 * batch, min_after_dequeue
+10 000, over the epoch-repeating record stream of training.py:76-81) and is gathered into the train model's input
+buffer; with --print-every 0 fifty train steps and their batches are one hipGraph replay, the queue's picks made on
+a forked branch ahead of the steps that consume them, and the evaluation every 50 iterations is one replay of the
+test model's forward + one summaries launch whose numbers are fetched without blocking (SummaryWriter).
 """
 import argparse
-import ctypes as C
 import json
 import os
 import shutil
@@ -23,8 +24,7 @@ import time
 import numpy as np
 import torch
 
-from air import _hip as H
-from multi_mnist import generate_dataset, shift_zero_digits_images
+from multi_mnist import ShuffleBatchQueue, generate_dataset, shift_zero_digits_images
 from air.air_model import AIRModel
 
 EPOCHS = 300
@@ -72,39 +72,41 @@ def load_data(bg_path="", bg_max_intensity=1.0):
     return ds["train_images"], ds["train_digits"], ds["test_images"], ds["test_digits"]
 
 
-class Summaries:
-    """Scalar summaries of the reference (air_model.py:160-209, 614-632), collected as device
-    scalars and fetched with ONE device->host copy per evaluation."""
+class SummaryWriter:
+    """The reference's numeric summaries (air_model.py:160-209, 608-625; training.py:171-180 evaluates them on the test
+    model every NUM_SUMMARIES_EACH_ITERATIONS) as rows of summary/scalars.jsonl.  AIRModel.numeric_summaries() is one
+    launch into a device vector; the vector is copied into a pinned host ring without blocking and a row is written
+    when the NEXT evaluation has been enqueued, so the host never waits for the step it has just launched."""
 
-    def __init__(self, targets, max_digits, max_steps):
-        self.targets, self.max_digits, self.max_steps = targets, max_digits, max_steps
-        self.names, self.vals = [], []
+    def __init__(self, model, path, t0, slots=2):
+        self.model, self.t0 = model, t0
+        self.names = model.summary_names()
+        self.dev = torch.empty(len(self.names), dtype=torch.float32, device=model.input_images.device)
+        self.host = torch.empty(slots, len(self.names), dtype=torch.float32).pin_memory()
+        self.events = [torch.cuda.Event() for _ in range(slots)]
+        self.pending, self.k, self.file = [], 0, open(path, "w")
 
-    def _mean(self, v, mask):
-        m = mask.float()
-        return (v * m).sum() / m.sum()                              # NaN when the group is empty, as tf.reduce_mean
+    def push(self, step):
+        slot = self.k % len(self.events)
+        self.k += 1
+        self.model.numeric_summaries(self.dev)
+        self.host[slot].copy_(self.dev, non_blocking=True)
+        self.events[slot].record()
+        self.pending.append((slot, step))
+        while len(self.pending) > 1:
+            self._drain_one()
 
-    def by_digit_count(self, name, values, mask=None):
-        """_summarize_by_digit_count :160-182"""
-        v = values.float()
-        ok = torch.ones_like(v, dtype=torch.bool) if mask is None else mask
-        for i in range(self.max_digits + 1):
-            self.names.append("%s_%d_dig" % (name, i))
-            self.vals.append(self._mean(v, ok & (self.targets == i)))
-        self.names.append(name + "_all_dig")
-        self.vals.append(self._mean(v, ok))
+    def _drain_one(self):
+        slot, step = self.pending.pop(0)
+        self.events[slot].synchronize()
+        row = {"step": step, "wall_s": round(time.perf_counter() - self.t0, 3)}
+        row.update({k: (round(v, 5) if v == v else None) for k, v in zip(self.names, self.host[slot].tolist())})
+        self.file.write(json.dumps(row) + "\n")
+        self.file.flush()
 
-    def by_step(self, tensor, steps, name, one_more_step=False, all_steps=False):
-        """_summarize_by_step :184-209 (tensor [B, T'] is padded to max_steps columns)"""
-        T = tensor.shape[1]
-        for i in range(self.max_steps):
-            col = tensor[:, i] if i < T else torch.zeros_like(tensor[:, 0])
-            mask = None if all_steps else steps > (i - (1 if one_more_step else 0))
-            self.by_digit_count("%s_%d_step" % (name, i + 1), col, mask)
-
-    def fetch(self):
-        vals = torch.stack(self.vals).cpu().tolist()
-        return dict(zip(self.names, vals))
+    def flush(self):
+        while self.pending:
+            self._drain_one()
 
 
 def main():
@@ -120,15 +122,17 @@ def main():
                         help="also write TensorFlow bundles models/air-model-<step>.{index,data-00000-of-00001} (tf.train.Saver layout)")
     parser.add_argument("--bg-path", default="", help="clutter background for the in-memory dataset (png, or file.npz:key)")
     parser.add_argument("--bg-max-intensity", type=float, default=1.0)
-    parser.add_argument("--graph-steps", type=int, default=10, help="train steps per hipGraph replay when --print-every 0")
+    parser.add_argument("--graph-steps", type=int, default=50,
+                        help="train steps per hipGraph replay when --print-every 0 (even, a divisor of 50)")
     parser.add_argument("--seed", type=int, default=0)
-    parser.add_argument("--backward", default="reference", choices=["reference", "reference_carried", "reference_blocked", "taps", "exact"],
-                        help="sampler backward: the reference graph's op order (default), the same streams in 16 chunks per tap, "
-                             "per-tap sums, or the exact adjoint")
-    parser.add_argument("--late-backward", default="", choices=["", "reference", "reference_carried", "reference_blocked", "taps", "exact"],
-                        help="switch the sampler backward to this order from iteration --late-backward-from on")
+    parser.add_argument("--backward", default="reference", choices=["reference", "reference_carried", "exact"],
+                        help="sampler backward: the reference graph's op order, the same streams with the long ones in 16 "
+                             "carried chunks per tap, or the exact adjoint")
+    parser.add_argument("--late-backward", default="", choices=["", "reference", "reference_carried", "exact"],
+                        help="switch the sampler backward to this order from iteration --late-backward-from on "
+                             "(AIRModel(backward=(first, late, iteration)))")
     parser.add_argument("--late-backward-from", type=int, default=5000,
-                        help="(a multiple of 50) by then ink is explained and the out-of-range residue no longer rules the gradient")
+                        help="by then ink is explained and the out-of-range residue no longer rules the gradient")
     args = parser.parse_args()
 
     # results folder handling, training.py:41-61
@@ -157,6 +161,11 @@ def main():
     train_data = torch.zeros(BATCH_SIZE, CANVAS_SIZE ** 2, device=dev)
     train_targets = torch.zeros(BATCH_SIZE, dtype=torch.int32, device=dev)
 
+    backward = args.backward
+    if args.late_backward and args.late_backward != args.backward:
+        if args.late_backward_from < 0:
+            parser.error("--late-backward-from must be >= 0")
+        backward = (args.backward, args.late_backward, args.late_backward_from)
     models = []
     model_inputs = [[train_data, train_targets], [test_data, test_targets]]
     for i in range(2):
@@ -179,82 +188,62 @@ def main():
                         "staircase": False, "log": True
                     },
                 },
-                seed=args.seed, gemm_precision=args.precision, backward=args.backward,
+                seed=args.seed, gemm_precision=args.precision, backward=backward,
             )
         )
     train_model, test_model = models
     n_train = train_images.shape[0]
     total = args.iterations if args.iterations > 0 else (n_train // BATCH_SIZE) * EPOCHS
-    scalars = open(summaries_folder + "scalars.jsonl", "w")
 
     # The input queue is device work too (read_and_decode, multi_mnist.py:228-249): the RandomShuffleQueue's resident
-    # record indices and the stream position live in HBM, so several train steps (dequeue + gather + step) are captured
-    # per hipGraph replay when nothing is printed per step.
-    queue = torch.zeros(MIN_AFTER_DEQUEUE + 10 * BATCH_SIZE, dtype=torch.int32, device=dev)
-    queue_state = torch.zeros(2, dtype=torch.int64, device=dev)
-    picks = torch.zeros(BATCH_SIZE, dtype=torch.int32, device=dev)
-    sq = H.ShuffleBatch(queue.data_ptr(), queue_state.data_ptr(), picks.data_ptr(), queue.numel(), BATCH_SIZE,
-                        MIN_AFTER_DEQUEUE, n_train, 0x5348554646 + args.seed)
-
-    def _s():
-        return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-
-    def next_batch(_i=0):
-        H.check(H.lib().air_shuffle_batch_dequeue(C.byref(sq), _s()), "air_shuffle_batch_dequeue")
-        torch.index_select(train_images, 0, picks, out=train_data)
-        torch.index_select(train_digits, 0, picks, out=train_targets)
-
+    # record indices and the stream position live in HBM.  When nothing is printed per step, --graph-steps train steps
+    # are captured per hipGraph replay together with their batches: the picks of half a replay are made on a forked
+    # branch while the other half's steps run, the row gather is the one launch in front of a step.
+    batches = ShuffleBatchQueue(train_images, train_digits, BATCH_SIZE, train_data, train_targets,
+                                seed=0x5348554646 + args.seed, min_after_dequeue=MIN_AFTER_DEQUEUE)
     gsteps = 1
     if not args.no_graph:
-        if args.print_every == 0 and NUM_SUMMARIES_EACH_ITERATIONS % args.graph_steps == 0:
+        if args.print_every == 0 and NUM_SUMMARIES_EACH_ITERATIONS % args.graph_steps == 0 and args.graph_steps % 2 == 0:
             gsteps = args.graph_steps
 
     def capture():
-        if not args.no_graph:
-            train_model.capture_graph(steps=gsteps, between_steps=next_batch if gsteps > 1 else None)
+        if args.no_graph:
+            return
+        if gsteps > 1:
+            between, after = batches.graph_hooks(gsteps)
+            train_model.capture_graph(steps=gsteps, between_steps=between, after_steps=after)
+        else:
+            train_model.capture_graph(steps=1)
     capture()
-    H.check(H.lib().air_shuffle_batch_init(C.byref(sq), _s()), "air_shuffle_batch_init")   # (after the capture: nothing consumed)
+    if not args.no_graph:
+        test_model.capture_graph()                                   # the evaluation pass: one replay
 
     print("Training...")
     print()
     step = 0
+    order = train_model.backward
     t0 = time.perf_counter()
+    writer = SummaryWriter(test_model, summaries_folder + "scalars.jsonl", t0)
     while step < total:
         if step % NUM_SUMMARIES_EACH_ITERATIONS == 0:
             test_model.forward()
-            digs = test_model.rec_num_digits
-            sm = Summaries(test_targets, 2, 3)
-            sm.names += ["loss", "accuracy"]
-            sm.vals += [test_model.loss.float(), test_model.accuracy.float()]
-            sm.by_digit_count("steps", digs)                                        # :614-617
-            sm.by_digit_count("rec_loss", test_model.reconstruction_loss)
-            sm.by_digit_count("digit_acc", digs == test_targets)
-            sm.by_digit_count("total_loss", test_model.loss_per_item)
-            sm.by_step(test_model.rec_scales[:, :, 0], digs, "scale")               # :620-625
-            sm.by_step(test_model.z_pres_probs, digs, "z_pres_prob", all_steps=True)
-            sm.by_step(test_model.z_pres_kls, digs, "z_pres_kl", one_more_step=True)
-            sm.by_step(test_model.scale_kls, digs, "scale_kl")
-            sm.by_step(test_model.shift_kls, digs, "shift_kl")
-            sm.by_step(test_model.vae_kls, digs, "vae_kl")
-            row = {"step": step, "wall_s": round(time.perf_counter() - t0, 3)}
-            row.update({k: (round(v, 5) if v == v else None) for k, v in sm.fetch().items()})
-            scalars.write(json.dumps(row) + "\n")
-            scalars.flush()
+            writer.push(step)
         if step % SAVE_PARAMS_EACH_ITERATIONS == 0:
             torch.save(train_model.state_dict(), models_folder + "air-model-%d.pt" % step)
             if args.tf_checkpoints:                                   # training.py:203-207 saver.save(..., global_step)
                 train_model.save_tf_checkpoint(models_folder + "air-model-%d" % step)
-        if args.late_backward and step == args.late_backward_from:
-            train_model.set_backward(args.late_backward)            # launch lists rebuilt; the graph is captured again
-            capture()
+        if train_model.backward != order:                            # (a backward schedule: the model switched by itself)
+            order = train_model.backward
+            print("iteration {}: sampler backward order -> {}".format(step - gsteps, order))
         if gsteps == 1:
-            next_batch()
+            batches.next_batch()
         train_model.training()
         step += gsteps
         if args.print_every and step % args.print_every == 0:
             print("iteration {}\tloss {:.3f}\taccuracy {:.2f}".format(
                 int(train_model.global_step), float(train_model.loss), float(train_model.accuracy)))
     torch.cuda.synchronize()
+    writer.flush()
     test_model.forward()
     print()
     print("training has ended")

@@ -25,13 +25,13 @@ from air import air_model as am
 STRESS = "--stress" in sys.argv                      # configs[3]: 128x128 canvas, 5 steps, batch 256
 if STRESS:
     sys.argv.remove("--stress")
-BLOCKED = "--blocked" in sys.argv                    # backward="reference_blocked" (write_bwd_blocked_kernel)
-if BLOCKED:
-    sys.argv.remove("--blocked")
+CARRIED = "--carried" in sys.argv                    # backward="reference_carried" (write_bwd_carried_kernel)
+if CARRIED:
+    sys.argv.remove("--carried")
 hp = dict(HP, canvas_size=128, max_steps=5, max_digits=4) if STRESS else dict(HP)
 images, targets = synthetic_canvases(256 if STRESS else 64, hp["canvas_size"], hp["max_digits"], 1)
 m = am.AIRModel(torch.tensor(images, device="cuda"), torch.tensor(targets, device="cuda"), cnn=False, train=True,
-                annealing_schedules=ANNEAL, gemm_precision="bf16", backward="reference_blocked" if BLOCKED else "reference", **hp)
+                annealing_schedules=ANNEAL, gemm_precision="bf16", backward="reference_carried" if CARRIED else "reference", **hp)
 for _ in range(5):
     m.training()
 torch.cuda.synchronize()
@@ -76,7 +76,7 @@ if STRESS:
                   len(cus), per[:, 0].mean(), per[:, 0].max(), per[:, 1].mean(), per[:, 1].max(), per[:, 2].mean(), per[:, 2].max(),
                   per[:, 3].mean(), per[:, 4].mean(), per[:, 4].max(), per[:, 4].max() * 4.06 / 2100.0))
     sys.exit(0)
-if BLOCKED and not STRESS:
+if CARRIED and not STRESS:
     # stamps of the blocked kernel: [0] start, [1] set-up done, [2] terms + coordinate gradients + barrier, wave 0: [3] corner
     # chunks + combine, [4] its slots' streams, [6] end; [5] wave 8 after its slots' streams, [7] wave 15 at its end
     for rep in range(3):
