@@ -133,7 +133,7 @@ def source_sha16():
 def bound_of(kernel):
     if kernel.startswith("write_bwd_graph_kernel"):
         return "lds-atomic-pipe"      # one sequential fp32 accumulator per corner slot on ds_add_f32 (4 cycles per term)
-    if kernel.startswith(("write_bwd_blocked_kernel", "write_bwd_carried_kernel")):
+    if kernel.startswith("write_bwd_carried_kernel"):
         return "latency"              # 16 register chains of <= C*C/16 dependent fp32 adds per corner and tap + the term pass
     if kernel.startswith(("adam", "grad_sqnorm")):
         return "hbm"
@@ -283,7 +283,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary blocks (fp32 step, stress config, inference)")
-    ap.add_argument("--backward", default="reference", choices=["reference", "reference_carried", "reference_blocked", "taps", "exact"])
+    ap.add_argument("--backward", default=None,
+                    help="sampler-backward order: reference | reference_carried | exact, or a schedule FIRST>SECOND@N (AIRModel(backward=(FIRST, "
+                         "SECOND, N))).  Default: what training.py runs (air_model.TRAINING_BACKWARD).  With a schedule the line's "
+                         "headline is the step after the switch and `init_phase` holds the step before it")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -312,7 +315,14 @@ def main():
     torch.cuda.set_device(dev)
 
     from air import air_model as am
+    from air import _hip as H
     phase = {"import": round(time.perf_counter() - T_START, 3)}
+    backward = am.TRAINING_BACKWARD if args.backward is None else args.backward
+    if isinstance(backward, str) and ">" in backward:
+        first, rest = backward.split(">", 1)
+        second, at = rest.split("@", 1)
+        backward = (first, second, int(at))
+    backward_name = backward if isinstance(backward, str) else "%s>%s@%d" % tuple(backward)
     B = args.batch
     hp = dict(HP)
     if args.workload == "configs[3]":
@@ -342,7 +352,7 @@ def main():
         model, err = None, None
         try:
             model = am.AIRModel(images_d, targets_d, cnn=False, train=True, scope=scope, annealing_schedules=ANNEAL, seed=0,
-                                noise_seed=rank, gemm_precision=args.precision, backward=args.backward, dp_exchange=exchange, **hp)
+                                noise_seed=rank, gemm_precision=args.precision, backward=backward, dp_exchange=exchange, **hp)
         except Exception as e:
             if not optional or world == 1:
                 raise
@@ -386,23 +396,44 @@ def main():
                 model.release_graph()
                 model.capture_graph(steps=1)
                 gsteps, mode = 1, "[fwd+bwd graph] -> collective -> [clip+Adam graph] (in-graph capture failed)"
-        warm_replays, warm_eager = args.warmup // gsteps, args.warmup % gsteps
-        if warm_replays == 0 and gsteps > 1 and args.warmup > 0:
-            warm_replays, warm_eager = 1, 0              # the timed region must not hold the graph's first replay: one whole replay (>= W steps)
-        for _ in range(warm_replays):
-            model.training()
-        for _ in range(warm_eager):                     # remainder of the warm-up: single eager steps
-            model.training(eager=True)
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(args.steps // gsteps):          # one replay = gsteps train steps: exactly args.steps steps
-            model.training()
-        sync()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t)
+        def timed_region():
+            """W warm-up steps, then exactly K timed steps between barrier + synchronize; max over ranks"""
+            warm_replays, warm_eager = args.warmup // gsteps, args.warmup % gsteps
+            if warm_replays == 0 and gsteps > 1 and args.warmup > 0:
+                warm_replays, warm_eager = 1, 0          # the timed region must not hold the graph's first replay: one whole replay (>= W steps)
+            for _ in range(warm_replays):
+                model.training()
+            for _ in range(warm_eager):                 # remainder of the warm-up: single eager steps
+                model.training(eager=True)
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(args.steps // gsteps):      # one replay = gsteps train steps: exactly args.steps steps
+                model.training()
+            sync()
+            dt = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([dt], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t)
+            return dt
+        init_phase = None
+        sched = model.backward_schedule
+        if sched is not None:
+            # A backward schedule (training.py's default): the step BEFORE the switch is timed first, from global_step 0 -- the
+            # same W + K protocol --, then global_step is set to the switch iteration and the model changes its launch list (and
+            # captures its graph again) by itself: what is timed below and reported as the headline is the step the driver
+            # runs from iteration N to the end of training (276 250 iterations: >= 98 % of them for N = 5 000).
+            if (args.warmup + args.steps + gsteps) >= sched[2]:
+                raise SystemExit("bench.py: W + K steps reach the schedule's switch iteration %d" % sched[2])
+            dt0 = timed_region()
+            init_phase = {"backward": sched[0], "iterations": "global_step < %d" % sched[2], "ms_per_step": round(dt0 / args.steps * 1e3, 4),
+                          "images_per_sec": round(world * B * args.steps / dt0, 1), "steps": args.steps, "warmup": args.warmup}
+            model.store.istate[H.IST_GLOBAL_STEP] = sched[2]
+            model._host_step = None
+            model.training()                            # the switch: launch lists rebuilt, graph captured again (not timed)
+            sync()
+            assert model.backward == sched[1], model.backward
+        dt = timed_region()
         # ... and the SAME K steps once more, outside the timed region, cut into >= MIN_REPLAYS replays with a HIP event
         # between them: the spread of the step time over the run (min / median / max per replay).  Not the headline: a
         # replay boundary costs ~18 us, which K / 5 steps amortise less well than K.
@@ -427,12 +458,12 @@ def main():
                           "max": round(per[-1], 4), "unit": "ms per step, per replay (HIP events)",
                           "note": "a second pass of the same K steps after the timed region, in shorter replays; `value` is the "
                                   "timed region above (%d steps per replay)" % gsteps}
-        return model, dt, gsteps, mode, spread
+        return model, dt, gsteps, mode, spread, init_phase
 
     exchange = os.environ.get("AIR_DP_EXCHANGE") or "flat"
     phase["build_models"] = 0.0
     t_ph = time.perf_counter()
-    model, dt, gsteps, graph_mode, spread = build_and_time("air", exchange)
+    model, dt, gsteps, graph_mode, spread, init_phase = build_and_time("air", exchange)
     phase["timed"] = round(dt, 3)
     phase["build_models"] = round(time.perf_counter() - t_ph - dt, 3)      # construction, capture and warm-up
     exchange_runs = {exchange: round(dt / args.steps * 1e3, 4)}
@@ -445,10 +476,10 @@ def main():
         if res is None:
             exchange_runs[other] = "skipped: a rank could not build it"
         else:
-            m2, dt2, g2, mode2, spread2 = res
+            m2, dt2, g2, mode2, spread2, init2 = res
             exchange_runs[other] = round(dt2 / args.steps * 1e3, 4)
             if dt2 < dt:
-                model, dt, gsteps, graph_mode, exchange, spread = m2, dt2, g2, mode2, other, spread2
+                model, dt, gsteps, graph_mode, exchange, spread, init_phase = m2, dt2, g2, mode2, other, spread2, init2
     loss = float(model.loss)
     replicas_identical = None
     if world > 1:
@@ -499,10 +530,16 @@ def main():
                        "global_batch": world * B,
                        "hipgraph": not args.no_graph, "steps_per_graph_replay": gsteps, "graph_mode": graph_mode,
                        "parallelism": "dp%d" % world,
-                       "backward": args.backward},
+                       "backward": backward_name,
+                       "phase": ("steady: the step training.py runs from iteration %d on (>= 98 %% of its 276 250 iterations); the "
+                                 "step before the switch is in init_phase" % model.backward_schedule[2])
+                                if model.backward_schedule is not None else "single order"},
             "per_gpu_images_per_sec": round(value / world, 1), "final_loss": round(loss, 3),
             "ms_per_step_by_replay": spread,
         }
+        if init_phase is not None:
+            line["init_phase"] = init_phase
+            line["init_phase_ms_per_step"] = init_phase["ms_per_step"]
         t_ph = time.perf_counter()
         if not args.no_roofline and world == 1:
             model.release_graph()
@@ -537,7 +574,7 @@ def main():
                     r["note"] = ("the reference's UnsortedSegmentSum order needs ONE sequential fp32 accumulator per corner slot, "
                                  "ds_add_f32 delivers 4.0 cycles per term and the slowest workgroup owns up to 4*C*C terms (16.9 of its "
                                  "24 us at 50x50) -- DESIGN.md section 8; the step's HBM-bound kernel is the Adam launch (roofline_all)")
-                elif name.startswith(("write_bwd_blocked_kernel", "write_bwd_carried_kernel")):
+                elif name.startswith("write_bwd_carried_kernel"):
                     r["note"] = ("the same term streams in at most 16 chunks per slot and tap, one register chain per chunk "
                                  "(DESIGN.md section 10): as long as its term pass + the longest chunk of its heaviest item")
                 return r
@@ -583,7 +620,7 @@ def main():
                                  "mode": ("one hipGraph replay per forward" if us_graph <= us_eager else "eager launches") + ", train=False"}
         if not args.no_extras and world == 1 and args.workload == "configs[1]":
             # the same step at the reference's own precision (fp32 operands, exact-fp32 MFMA) ...
-            def secondary(tag, prec, hp2, B2, steps, backward=args.backward):
+            def secondary(tag, prec, hp2, B2, steps, backward=model.backward):
                 im2, tg2 = synthetic_canvases(B2, hp2["canvas_size"], hp2["max_digits"], seed=2000)
                 m2 = am.AIRModel(torch.tensor(im2, device=dev), torch.tensor(tg2, device=dev), cnn=False, train=True,
                                  scope=tag, annealing_schedules=ANNEAL, seed=0, gemm_precision=prec,
@@ -613,17 +650,16 @@ def main():
             P3 = sum(int(np.prod(v)) for v in [(128 * 128 + 256, 1024)]) + (model.store.num_trainable - (2756 * 1024))
             line["stress_configs3"]["frac_of_hbm_peak"] = round(
                 (40 * P3 + 4 * 256 * 128 * 128) / (line["stress_configs3"]["ms_per_step"] * 1e-3) * 1e-9 / HBM_PEAK_GBS, 4)
-            # the same two configurations under the chunked sampler-backward orders (opt-in: bit for bit against their oracle
-            # orders, faster, and NOT the default because the 24-seed learning sweeps of round 5 favour the reference's order --
-            # DESIGN.md section 10)
-            if args.backward == "reference":
-                line["backward_orders"] = {}
-                for mode in ("reference", "reference_carried", "reference_blocked"):
-                    line["backward_orders"][mode] = {
-                        "configs[1]": secondary("air_" + mode, args.precision, hp, B, 100, backward=mode)["ms_per_step"],
-                        "configs[3]": (line["stress_configs3"]["ms_per_step"] if mode == "reference" else
-                                       secondary("air_stress_" + mode, args.precision, hp3, 256, 40, backward=mode)["ms_per_step"])}
-                line["backward_orders"]["unit"] = "ms per step (secondary blocks: 4 steps per replay, 100 / 40 steps)"
+            # the same two configurations under each sampler-backward order on its own (both bit for bit against their oracle
+            # orders; the reference's order is the one training.py starts with, the carried one the one it continues with --
+            # DESIGN.md sections 10 and 11)
+            line["backward_orders"] = {}
+            for mode in ("reference", "reference_carried"):
+                line["backward_orders"][mode] = {
+                    "configs[1]": secondary("air_" + mode, args.precision, hp, B, 100, backward=mode)["ms_per_step"],
+                    "configs[3]": (line["stress_configs3"]["ms_per_step"] if mode == model.backward else
+                                   secondary("air_stress_" + mode, args.precision, hp3, 256, 40, backward=mode)["ms_per_step"])}
+            line["backward_orders"]["unit"] = "ms per step (secondary blocks: 4 steps per replay, 100 / 40 steps)"
         phase["extras"] = round(time.perf_counter() - t_ph, 3)      # per-kernel events, inference, fp32 and stress blocks
         if not args.no_cpu_baseline and world == 1 and args.workload == "configs[1]":
             t_ph = time.perf_counter()

@@ -74,11 +74,23 @@ def _fc(x, W, b, act=None, head_out=False):
     return y
 
 
+_CONSTS = {}
+
+
+def _const(value, dtype):
+    """a 0-d tensor of `value` on the default device, made once: a host-to-device copy per use would be the one thing in
+    this op sequence a hipGraph capture (tools/twin_train_gpu.py) cannot record"""
+    key = (float(value), dtype, str(torch.get_default_device()) if hasattr(torch, "get_default_device") else "")
+    if key not in _CONSTS:
+        _CONSTS[key] = torch.tensor(float(value), dtype=dtype)
+    return _CONSTS[key]
+
+
 def _linspace(n, dtype):
     if n == 1:
         return torch.tensor([-1.0], dtype=dtype)
-    step = torch.tensor(2.0, dtype=dtype) / torch.tensor(float(n - 1), dtype=dtype)
-    return torch.tensor(-1.0, dtype=dtype) + step * torch.arange(n, dtype=dtype)
+    step = _const(2.0, dtype) / _const(float(n - 1), dtype)
+    return _const(-1.0, dtype) + step * torch.arange(n, dtype=dtype)
 
 
 def transformer(U, theta, out_size):
@@ -91,8 +103,8 @@ def transformer(U, theta, out_size):
     y_t = _linspace(Ho, dtype).repeat_interleave(Wo)
     x_s = (theta[:, 0, 0:1] * x_t[None] + theta[:, 0, 1:2] * y_t[None]) + theta[:, 0, 2:3]
     y_s = (theta[:, 1, 0:1] * x_t[None] + theta[:, 1, 1:2] * y_t[None]) + theta[:, 1, 2:3]
-    cx = torch.tensor(float(Wi), dtype=dtype) - torch.tensor(1.001, dtype=dtype)
-    cy = torch.tensor(float(Hi), dtype=dtype) - torch.tensor(1.001, dtype=dtype)
+    cx = _const(float(Wi), dtype) - _const(1.001, dtype)
+    cy = _const(float(Hi), dtype) - _const(1.001, dtype)
     x = (x_s + 1.0) * cx / 2.0
     y = (y_s + 1.0) * cy / 2.0
     x0 = torch.floor(x.detach()).to(torch.int64)
@@ -136,7 +148,8 @@ def air_forward(params, images, targets, noise, hp, train=True, z_pres_prior_log
     R_units = hp["rnn_units"]
     thr = hp["stopping_threshold"]
     temp = hp["z_pres_temperature"]
-    prior_lo = hp["z_pres_prior_log_odds"] if z_pres_prior_log_odds is None else float(z_pres_prior_log_odds)
+    prior_lo = hp["z_pres_prior_log_odds"] if z_pres_prior_log_odds is None else (
+        z_pres_prior_log_odds if torch.is_tensor(z_pres_prior_log_odds) else float(z_pres_prior_log_odds))
     scale_plv = math.log(hp["scale_prior_variance"])
     shift_plv = math.log(hp["shift_prior_variance"])
     vae_plv = math.log(hp["vae_prior_variance"])

@@ -36,6 +36,12 @@ GEMM_PRECISION = os.environ.get("AIR_GEMM_PRECISION", "fp32")
 _SCOPES = {}
 
 
+# The sampler-backward schedule the training driver and the benchmark run (training.py, bench.py): the reference graph's own
+# accumulation order while the out-of-range residue rules the gradient, the carried order from iteration 5 000 on
+# (DESIGN.md section 11 holds the learning sweeps that gate it).  AIRModel's own default stays backward="reference".
+TRAINING_BACKWARD = ("reference", "reference_carried", 5000)
+
+
 def reset_default_graph():
     """Drops all variable scopes (the tf.reset_default_graph() of this runtime)."""
     _SCOPES.clear()

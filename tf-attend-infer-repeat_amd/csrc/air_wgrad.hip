@@ -185,6 +185,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
 }  // namespace
 
 AIR_STAMPS_READER(air_debug_stamps_wgrad)
+#ifdef AIR_STAMPS
+extern "C" int air_debug_stamps_wgrad_wg(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(airw::air_wgrad_wg_stamps), sizeof(unsigned long long) * (n < 2048 * 4 ? n : 2048 * 4));
+}
+#endif
 
 // Tiles from which a problem counts as BIG (shape alone): it runs in strips when it has twins, and the owners of its bias
 // columns are spread over block-rows in every precision.

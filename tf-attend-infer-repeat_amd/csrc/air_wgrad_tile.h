@@ -817,12 +817,33 @@ __device__ __forceinline__ void run_bias_block(const Table& tab, int block, floa
 // One rider / grouped-launch workgroup of the bf16 path: tile `block` of the table; Img = 48 KB of LDS (16-byte aligned;
 // STRIP_LDS when the table holds a strip problem), sq_red = 4 more floats.  sq_partials == NULL: no global-norm partial is
 // published.
+// per-workgroup stamps of the grouped launch (debug builds with -DAIR_STAMPS only; tools/wgrad_wg_stamps.py): [block][4] =
+// start, end, hardware id (XCC_ID << 16 | HW_ID), K of its problem
+#ifdef AIR_STAMPS
+static __device__ unsigned long long air_wgrad_wg_stamps[2048 * 4];
+#define WG_STAMP(b, i, v) do { if (threadIdx.x == 0 && (b) < 2048) air_wgrad_wg_stamps[(b) * 4 + (i)] = (unsigned long long)(v); } while (0)
+#define WG_HWID() ((__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 16) | __builtin_amdgcn_s_getreg(4 | (0 << 6) | (15 << 11)))
+#else
+#define WG_STAMP(b, i, v) do { } while (0)
+#define WG_HWID() 0
+#endif
+__device__ __forceinline__ void run_tile_bf16_body(const Table& tab, int block, unsigned short* Img, float* __restrict__ sq_partials,
+                                                   int32_t* __restrict__ istate, float* sq_red);
 __device__ __forceinline__ void run_tile_bf16(const Table& tab, int block, unsigned short* Img, float* __restrict__ sq_partials,
                                               int32_t* __restrict__ istate, float* sq_red)
+{
+    WG_STAMP(block, 0, wall_clock64());
+    WG_STAMP(block, 2, WG_HWID());
+    run_tile_bf16_body(tab, block, Img, sq_partials, istate, sq_red);
+    WG_STAMP(block, 1, wall_clock64());
+}
+__device__ __forceinline__ void run_tile_bf16_body(const Table& tab, int block, unsigned short* Img, float* __restrict__ sq_partials,
+                                                   int32_t* __restrict__ istate, float* sq_red)
 {
     if (block < tab.nbias) { run_bias_block(tab, block, sq_partials, sq_red); return; }
     int m0, n0;
     const Prob& pr = find_tile(tab, block, m0, n0);
+    WG_STAMP(block, 3, pr.K * 16 + pr.strip);
     AIR_STAMP(0);
     if (pr.strip > 0) {                      // K = 64 / 128 / 192 / 256 (strip_of)
         const bool a16 = (pr.lda & 7) == 0 && (reinterpret_cast<uintptr_t>(pr.A16) & 15) == 0 && (pr.M % BT) == 0;
