@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--deadline-min", type=float, default=1e9)
     ap.add_argument("--done", action="append", default=[])
     ap.add_argument("--tag", default="")
+    ap.add_argument("--job-timeout-s", type=float, default=900.0)
     ap.add_argument("extra", nargs="*")
     args = ap.parse_args()
     extra = " ".join(args.extra)
@@ -85,7 +86,11 @@ def main():
                 cmd += ["--late-backward", job["late_backward"], "--late-backward-from", str(job["switch_at"])]
             cmd += args.extra
             t0 = time.time()
-            p = subprocess.run(cmd, cwd=PKG, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            try:
+                p = subprocess.run(cmd, cwd=PKG, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=args.job_timeout_s)
+            except subprocess.TimeoutExpired as e:                   # a hung run must not eat the whole call
+                p = subprocess.CompletedProcess(cmd, -9, stdout=(e.stdout or b"").decode(errors="replace") if isinstance(e.stdout, bytes)
+                                                else (e.stdout or ""))
             row = dict(job)
             row["process_s"] = round(time.time() - t0, 2)
             try:
