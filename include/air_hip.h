@@ -501,8 +501,11 @@ int air_adam_clip_step_panels(float* params, const float* grads, float* m, float
  * number lo, hi, k / 4, 0x53485546)).  TF's own queue is unseeded here (seed 0 -> nondeterministic): the distribution is
  * the contract, and tests/test_shuffle_queue.py holds a numpy model of the queue that this kernel matches pick for pick.
  * state[0] = records enqueued so far (the stream position), state[1] = batches dequeued so far.
- * One workgroup, the queue staged in LDS: capacity * 4 + batch * 8 <= 48 KB (capacity 10 640, batch 64: 43 KB), batch a
- * multiple of 4, capacity - batch >= min_after_dequeue >= 0 (the reference: 10 000).  No allocation, no synchronisation;
+ * One workgroup per call; the picks of a batch are resolved in parallel (the content of a slot at pick k is found by walking
+ * the earlier picks of the batch backwards: csrc/air_input.hip), the same picks as the sequential queue.  Limits:
+ * capacity * 4 + batch * 8 <= 48 KB (capacity 10 640, batch 64: 43 KB -- air_shuffle_batch_dequeue_many stages the queue
+ * in LDS), batch a multiple of 4 and <= 1024, capacity - batch >= min_after_dequeue >= 0 (the reference: 10 000).  No
+ * allocation, no synchronisation;
  * both calls are stream work and capturable. */
 typedef struct {
     int32_t* queue;            /* [capacity] record indices in the queue */
@@ -515,9 +518,8 @@ typedef struct {
 int air_shuffle_batch_init(const air_shuffle_batch_t* q, void* stream);
 int air_shuffle_batch_dequeue(const air_shuffle_batch_t* q, void* stream);
 /* `n_batches` consecutive dequeues in one launch, pick for pick what n_batches calls of air_shuffle_batch_dequeue make:
- * picks_out[k * batch + i] = pick i of the k-th of them (q->picks is not written).  training.py records it on a forked
- * branch of its hipGraph replay: the picks of the NEXT half replay are made while this one's train steps run, so the 64
- * dependent picks of a batch are off the critical path of every step. */
+ * picks_out[k * batch + i] = pick i of the k-th of them (q->picks is not written).  In training.py it is the first launch
+ * of every hipGraph replay of n_batches train steps, whose row gathers read picks_out (multi_mnist.ShuffleBatchQueue). */
 int air_shuffle_batch_dequeue_many(const air_shuffle_batch_t* q, int n_batches, int32_t* picks_out, void* stream);
 /* the decoded tensors of a dequeued batch (read_and_decode, multi_mnist.py:228-238, after the queue):
  * out_images[i] = images[picks[i]] ([batch, D] fp32 rows, D % 4 == 0, 16-byte aligned), out_digits[i] = digits[picks[i]]

@@ -57,3 +57,29 @@ def tf_queue_batches(n_records, capacity, batch, min_after_dequeue, num_batches,
             queue.pop()
         out.append(picks)
     return np.asarray(out, np.int64)
+
+
+def parallel_dequeue(queue, batch, r, stream_pos, n_records):
+    """ONE dequeue as the device kernel resolves it (csrc/air_input.hip: dequeue_batch) -- every pick on its own instead of
+    the chain of swaps: idx_k = r_k mod (capacity - k) does not depend on the earlier picks, and the content of slot s at the
+    time of pick t is found by walking the earlier picks backwards, V(s, t) = V(capacity - 1 - j, j) for the last j < t with
+    idx_j == s (that pick moved the back of its time into s), else the original queue[s].  Pick k emits V(idx_k, k); the last
+    pick on a surviving slot leaves V(back_k, k) there; the freed slots at the back are refilled from the stream.
+    Returns (picks, new queue); tests hold it against the literal queue above."""
+    cap = len(queue)
+    idx = [int(r[k]) % (cap - k) for k in range(batch)]
+    new = list(queue)
+    picks = []
+    for k in range(batch):
+        s, sb = idx[k], cap - 1 - k
+        for j in range(k - 1, -1, -1):
+            if idx[j] == s:
+                s = cap - 1 - j
+            if idx[j] == sb:
+                sb = cap - 1 - j
+        picks.append(queue[s])
+        if idx[k] < cap - batch and all(idx[j] != idx[k] for j in range(k + 1, batch)):
+            new[idx[k]] = queue[sb]
+    for t in range(batch):
+        new[cap - batch + t] = (stream_pos + t) % n_records
+    return picks, new

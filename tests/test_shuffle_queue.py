@@ -50,6 +50,42 @@ def test_queue_model_statistics_are_the_shuffle_queues():
     assert (row < 5000).any() and (row > 40000).any()
 
 
+def test_parallel_pick_resolution_is_the_sequential_queue():
+    """the rule the device kernel uses (every pick resolved on its own by walking the earlier picks of the batch backwards,
+    oracle.shuffle_queue.parallel_dequeue) against the literal pop-and-swap queue: tiny capacities and draws that collide
+    all the time, batches that consume most of the queue, the reference's geometry"""
+    rng = np.random.RandomState(0)
+    for trial in range(400):
+        batch = int(rng.choice([4, 8, 16, 64]))
+        cap = batch + int(rng.randint(0, 3 * batch)) + (0 if rng.rand() < 0.5 else 200)
+        n_rec = 997
+        q = [int(v) for v in rng.permutation(cap + 1000)[:cap]]
+        pos = int(rng.randint(0, 1000))
+        for _ in range(3):
+            r = [int(v) for v in rng.randint(0, 2 ** 32, size=batch, dtype=np.uint64)]
+            if rng.rand() < 0.3:
+                r = [int(v) for v in rng.randint(0, 5, size=batch)]         # nearly every pick collides with an earlier one
+            lit, size, picks = list(q), cap, []
+            for k in range(batch):                                         # RandomShuffleQueue::TryDequeueMany, literally
+                i = r[k] % size
+                picks.append(lit[i])
+                lit[i] = lit[size - 1]
+                size -= 1
+            for t in range(batch):
+                lit[cap - batch + t] = (pos + t) % n_rec
+            got, new = sq.parallel_dequeue(q, batch, r, pos, n_rec)
+            assert got == picks and new == lit
+            q, pos = lit, pos + batch
+    # the reference's geometry, against the batch-level model
+    seed, nb = 11, 30
+    ref = sq.tf_queue_batches(N_REC, CAP, BATCH, MIN_AFTER, nb, lambda n, k: sq.device_draws(seed, n, k))
+    q, pos = [i % N_REC for i in range(CAP)], CAP
+    for n in range(nb):
+        got, q = sq.parallel_dequeue(q, BATCH, sq.device_draws(seed, n, BATCH), pos, N_REC)
+        pos += BATCH
+        assert got == list(ref[n])
+
+
 needs_gpu = pytest.mark.gpu
 
 
@@ -171,10 +207,11 @@ def test_batch_gather_copies_the_picked_records():
 
 @needs_gpu
 def test_pipelined_queue_in_a_graph_delivers_the_same_batches():
-    """multi_mnist.ShuffleBatchQueue.graph_hooks: the picks of half a replay made on a forked branch ahead of their steps --
-    the batches that reach the consumer's buffers are, in order, the ones next_batch() delivers (= the queue model's)."""
+    """multi_mnist.ShuffleBatchQueue.graph_hooks: the picks of a replay's batches made by its first launch, one row gather
+    per step -- the batches that reach the consumer's buffers are, in order, the ones next_batch() delivers (= the queue
+    model's)."""
     from multi_mnist import ShuffleBatchQueue
-    n, D, B, steps, seed = 3000, 16, 8, 6, 21
+    n, D, B, steps, seed = 3000, 16, 8, 5, 21
     images = torch.arange(n, device="cuda", dtype=torch.float32)[:, None].repeat(1, D).contiguous()
     digits = (torch.arange(n, device="cuda", dtype=torch.int32) % 3).contiguous()
 
@@ -188,38 +225,37 @@ def test_pipelined_queue_in_a_graph_delivers_the_same_batches():
         ref_rows.append((oi[:, 0].clone(), od.clone()))
     pi, pd = consumer()
     piped = ShuffleBatchQueue(images, digits, B, pi, pd, seed=seed, min_after_dequeue=200)
-    with pytest.raises(ValueError):
-        piped.graph_hooks(5)
     between, after = piped.graph_hooks(steps)
+    assert after is None
     with pytest.raises(RuntimeError):
         piped.next_batch()
-    seen = []
-    torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        for i in range(steps):
-            between(i)
-            seen.append((pi[:, 0].clone(), pd.clone()))                # "the train step": reads the input buffers
-        after()
+    with pytest.raises(ValueError):
+        piped.graph_hooks(steps + 1)
+
+    def capture():
+        seen = []
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for i in range(steps):
+                between(i)
+                seen.append((pi[:, 0].clone(), pd.clone()))            # "the train step": reads the input buffers
+        return g, seen
+    g, seen = capture()
     got = []
     for _ in range(4):
         g.replay()
-        torch.cuda.synchronize()
-        got += [(a.clone(), b.clone()) for a, b in seen]
+        got.append([(a.clone(), b.clone()) for a, b in seen])
+    torch.cuda.synchronize()
+    got = [ab for rep in got for ab in rep]
     for (ra, rb), (ga, gb) in zip(ref_rows, got):
         assert torch.equal(ra, ga) and torch.equal(rb, gb)
     model = sq.tf_queue_batches(n, 200 + 10 * B, B, 200, 4 * steps, lambda k, b: sq.device_draws(seed, k, b))
     assert np.array_equal(torch.stack([a for a, _ in got]).cpu().numpy().astype(np.int64), model)
-    # a second capture (training.py re-captures when the sampler-backward order switches) continues the sequence
-    between, after = piped.graph_hooks(steps)
-    g2 = torch.cuda.CUDAGraph()
-    seen2 = []
-    with torch.cuda.graph(g2):
-        for i in range(steps):
-            between(i)
-            seen2.append(pi[:, 0].clone())
-        after()
+    # a second capture (AIRModel captures again when a sampler-backward schedule switches) continues the sequence
+    between, _ = piped.graph_hooks(steps)
+    g2, seen2 = capture()
     g2.replay()
     torch.cuda.synchronize()
     more = sq.tf_queue_batches(n, 200 + 10 * B, B, 200, 5 * steps, lambda k, b: sq.device_draws(seed, k, b))[4 * steps:]
-    assert np.array_equal(torch.stack(seen2).cpu().numpy().astype(np.int64), more)
+    assert np.array_equal(torch.stack([a for a, _ in seen2]).cpu().numpy().astype(np.int64), more)

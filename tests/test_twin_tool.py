@@ -11,20 +11,25 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_graph_replayed_twin_iteration_equals_the_eager_one(capsys):
+    """Same seed, same noise, same batches: the first iteration's ELBO of the graph-replayed run is the eager run's to the
+    last bit (the forward has no atomics), and both move the parameters by Adam's first steps.  (The gradients themselves
+    are not comparable run to run: at initialisation they ARE the out-of-range residue, and autograd's scatter-adds sum it in
+    a different order every time -- this twin's own realisation of the reference's residue.)"""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import twin_train_gpu as tw
+    from oracle import air_oracle as ao
     try:
         outs = []
         for extra in ([], ["--no-graph"]):
-            p = tw.main(["3", "6", "--eval-every", "4"] + extra)
-            outs.append({k: v.detach().clone() for k, v in p.items()})
+            p, first_loss = tw.main(["3", "3", "--eval-every", "3"] + extra)
+            outs.append(({k: v.detach().clone() for k, v in p.items()}, first_loss))
+        init = {k: torch.tensor(v, device="cuda") for k, v in ao.init_params(dict(ao.TRAINING_HP), 3).items()}
     finally:
         torch.set_default_device("cpu")
-    worst = max(float((outs[0][k] - outs[1][k]).abs().max()) for k in outs[0])
-    moved = max(float((outs[0][k] - torch.tensor(__import__("oracle.air_oracle", fromlist=["x"]).init_params(
-        dict(__import__("oracle.air_oracle", fromlist=["x"]).TRAINING_HP), 3)[k], device="cuda")).abs().max()) for k in outs[0])
-    print("twin: graph vs eager max |d param| %.3e after 6 iterations (parameters moved by %.3e)" % (worst, moved))
-    assert moved > 1e-4
-    assert worst == 0.0
+    moved = [max(float((o[k] - init[k]).abs().max()) for k in o) for o, _ in outs]
+    print("twin: first-iteration loss graph %.6f, eager %.6f; largest parameter move after 3 iterations %.2e / %.2e"
+          % (outs[0][1], outs[1][1], moved[0], moved[1]))
+    assert outs[0][1] == outs[1][1] and outs[0][1] == outs[0][1]          # bit-equal and not NaN
+    assert all(1e-4 < m < 1e-3 for m in moved), moved                    # three steps of ~lr = 1e-4 each

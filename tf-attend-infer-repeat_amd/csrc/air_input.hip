@@ -1,7 +1,6 @@
 // tf.train.shuffle_batch as device work (multi_mnist.py:228-249; training.py:76-81): see air_shuffle_batch_t in air_hip.h.
-// One workgroup: the queue (43 KB of record indices at the reference's capacity) is staged in LDS, the `batch` dependent
-// picks are made by one lane on LDS words (64 x (one read of the picked slot, one of the back, one write)), the freed back
-// slots are refilled from the stream, the queue goes back to HBM.  ~6 us; the batch's rows are then gathered by the caller.
+// One workgroup per dequeue: the `batch` picks of RandomShuffleQueue::TryDequeueMany, resolved in parallel (dequeue_batch),
+// the freed back slots refilled from the stream; the batch's rows are then gathered (batch_gather_kernel).
 #include "air_common.h"
 #include "air_philox.h"
 
@@ -12,76 +11,87 @@ __global__ __launch_bounds__(SQ_THREADS) void shuffle_init_kernel(air_shuffle_ba
     if (threadIdx.x == 0) { a.state[0] = a.capacity; a.state[1] = 0; }
 }
 
-__global__ __launch_bounds__(SQ_THREADS) void shuffle_dequeue_kernel(air_shuffle_batch_t a) {
-    extern __shared__ int sq_lds[];
-    int* q = sq_lds;                                                   // [capacity]
-    uint32_t* r = reinterpret_cast<uint32_t*>(sq_lds + a.capacity);    // [batch] the draws
-    int* out = sq_lds + a.capacity + a.batch;                          // [batch] the picks
-    const int tid = threadIdx.x;
-    const long pos = a.state[0], n = a.state[1];
-    for (int i = tid; i < a.capacity; i += SQ_THREADS) q[i] = a.queue[i];
-    if (tid * 4 < a.batch) {
+// One dequeue of `batch` elements, by all threads of the workgroup, on the queue image `q` (LDS or memory).
+// RandomShuffleQueue::TryDequeueMany makes the picks one after the other -- pick k: idx_k = r_k mod (capacity - k), emit
+// q[idx_k], q[idx_k] = q[capacity - 1 - k] (the back), pop -- a chain of `batch` dependent read-modify-writes (64 LDS round
+// trips: the ~6-12 us of the first version of this kernel).  The chain is resolved in parallel instead: idx_k does not
+// depend on the earlier picks (the size at pick k is capacity - k), and the content of a slot at the time of pick k is the
+// ORIGINAL content of the slot found by walking the earlier picks backwards -- V(s, t): the last j < t with idx_j == s moved
+// the back of that time into s, so V(s, t) = V(capacity - 1 - j, j); no such j: q0[s].  t only decreases, so ONE descending
+// pass over j resolves it.  Thread k resolves V(idx_k, k) (what it emits) and V(back_k, k) (what it moves into idx_k); the
+// last pick that hits a surviving slot writes it; the `batch` freed slots at the back are refilled from the stream.  Pick
+// for pick the sequential queue (tests/test_shuffle_queue.py: 400 batches x 3 geometries against the numpy model).
+__device__ __forceinline__ void dequeue_batch(int* q, const air_shuffle_batch_t& a, long n, long pos, int* sh_idx, int32_t* picks_out) {
+    const int tid = threadIdx.x, cap = a.capacity, batch = a.batch;
+    if (tid * 4 < batch) {
         uint32_t c[4] = {(uint32_t)n, (uint32_t)((unsigned long)n >> 32), (uint32_t)tid, 0x53485546u};
         air_philox4x32_10(c, (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
 #pragma unroll
-        for (int k = 0; k < 4; ++k) r[tid * 4 + k] = c[k];
+        for (int k = 0; k < 4; ++k) sh_idx[tid * 4 + k] = (int)(c[k] % (uint32_t)(cap - (tid * 4 + k)));
     }
     __syncthreads();
-    if (tid == 0) {
-        int size = a.capacity;
-        for (int k = 0; k < a.batch; ++k) {                            // RandomShuffleQueue: uniform index, swap with the back, pop
-            const int idx = (int)(r[k] % (uint32_t)size);
-            out[k] = q[idx];
-            q[idx] = q[size - 1];
-            --size;
+    const int k = tid;
+    int my = -1, s = 0, sb = 0, emit = 0, moved = 0;
+    bool last_writer = true;
+    if (batch <= 64) {
+        // the reference's batch: the picks live in the lanes of ONE wave, the walk reads them by v_readlane (no LDS round trip
+        // per step: 64 dependent LDS reads were 6 us of a 7.5 us dequeue)
+        if (tid < 64) {
+            my = k < batch ? sh_idx[k] : -1;
+            s = my;                   // -> the original slot whose content pick k emits
+            sb = cap - 1 - k;         // -> the original slot whose content pick k moves into idx_k
+            for (int j = batch - 1; j >= 0; --j) {                   // uniform loop: j is a scalar
+                const int ij = __builtin_amdgcn_readlane(my, j), bj = cap - 1 - j;
+                if (j > k) last_writer = last_writer && ij != my;
+                else if (j < k) {
+                    if (ij == s) s = bj;
+                    if (ij == sb) sb = bj;
+                }
+            }
+            if (k < batch) { emit = q[s]; moved = q[sb]; }
         }
+    } else if (k < batch) {
+        my = sh_idx[k];
+        s = my;
+        sb = cap - 1 - k;
+        for (int j = batch - 1; j > k; --j) last_writer = last_writer && sh_idx[j] != my;
+        for (int j = k - 1; j >= 0; --j) {
+            const int ij = sh_idx[j], bj = cap - 1 - j;
+            if (ij == s) s = bj;
+            if (ij == sb) sb = bj;
+        }
+        emit = q[s];
+        moved = q[sb];
+    }
+    __syncthreads();                  // every read of the old image before any write
+    if (k < batch) {
+        picks_out[k] = emit;
+        if (last_writer && my < cap - batch) q[my] = moved;
+        q[cap - batch + k] = (int)((pos + k) % a.n_records);          // enqueue appends at the back, in stream order
     }
     __syncthreads();
-    if (tid < a.batch) {
-        a.picks[tid] = out[tid];
-        q[a.capacity - a.batch + tid] = (int)((pos + tid) % a.n_records);   // enqueue appends at the back, in stream order
-    }
-    __syncthreads();
-    for (int i = tid; i < a.capacity; i += SQ_THREADS) a.queue[i] = q[i];
-    if (tid == 0) { a.state[0] = pos + a.batch; a.state[1] = n + 1; }
 }
 
-// `nb` dequeues in ONE launch (the picks of a whole hipGraph replay, made on a side branch while the previous replay's steps
-// run): the queue is staged once, every batch draws with its own dequeue number -- pick for pick what `nb` calls of
-// shuffle_dequeue_kernel make.  picks_out[k * batch + i] = pick i of batch k.
+__global__ __launch_bounds__(SQ_THREADS) void shuffle_dequeue_kernel(air_shuffle_batch_t a) {
+    __shared__ int sh_idx[SQ_THREADS];
+    const long pos = a.state[0], n = a.state[1];
+    dequeue_batch(a.queue, a, n, pos, sh_idx, a.picks);               // on the queue in memory: 2 x batch scattered reads, <= 2 x batch writes
+    if (threadIdx.x == 0) { a.state[0] = pos + a.batch; a.state[1] = n + 1; }
+}
+
+// `nb` dequeues in ONE launch (the picks of a whole hipGraph replay): the queue is staged in LDS once, every batch draws
+// with its own dequeue number -- pick for pick what `nb` calls of shuffle_dequeue_kernel make.  picks_out[k * batch + i] =
+// pick i of batch k.
 __global__ __launch_bounds__(SQ_THREADS) void shuffle_dequeue_many_kernel(air_shuffle_batch_t a, int nb, int32_t* __restrict__ picks_out) {
     extern __shared__ int sq_lds[];
-    int* q = sq_lds;
-    uint32_t* r = reinterpret_cast<uint32_t*>(sq_lds + a.capacity);
-    int* out = sq_lds + a.capacity + a.batch;
+    int* q = sq_lds;                                                   // [capacity]
+    int* sh_idx = sq_lds + a.capacity;                                 // [batch]
     const int tid = threadIdx.x;
     const long pos0 = a.state[0], n0 = a.state[1];
     for (int i = tid; i < a.capacity; i += SQ_THREADS) q[i] = a.queue[i];
-    for (int kb = 0; kb < nb; ++kb) {
-        const long n = n0 + kb, pos = pos0 + (long)kb * a.batch;
-        if (tid * 4 < a.batch) {
-            uint32_t c[4] = {(uint32_t)n, (uint32_t)((unsigned long)n >> 32), (uint32_t)tid, 0x53485546u};
-            air_philox4x32_10(c, (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
-#pragma unroll
-            for (int k = 0; k < 4; ++k) r[tid * 4 + k] = c[k];
-        }
-        __syncthreads();
-        if (tid == 0) {
-            int size = a.capacity;
-            for (int k = 0; k < a.batch; ++k) {
-                const int idx = (int)(r[k] % (uint32_t)size);
-                out[k] = q[idx];
-                q[idx] = q[size - 1];
-                --size;
-            }
-        }
-        __syncthreads();
-        if (tid < a.batch) {
-            picks_out[(size_t)kb * a.batch + tid] = out[tid];
-            q[a.capacity - a.batch + tid] = (int)((pos + tid) % a.n_records);
-        }
-        __syncthreads();
-    }
+    __syncthreads();
+    for (int kb = 0; kb < nb; ++kb)
+        dequeue_batch(q, a, n0 + kb, pos0 + (long)kb * a.batch, sh_idx, picks_out + (size_t)kb * a.batch);
     for (int i = tid; i < a.capacity; i += SQ_THREADS) a.queue[i] = q[i];
     if (tid == 0) { a.state[0] = pos0 + (long)nb * a.batch; a.state[1] = n0 + nb; }
 }
@@ -117,8 +127,7 @@ extern "C" int air_shuffle_batch_init(const air_shuffle_batch_t* a, void* stream
 
 extern "C" int air_shuffle_batch_dequeue(const air_shuffle_batch_t* a, void* stream) {
     if (int rc = sq_check(a)) return rc;
-    const size_t lds = (size_t)a->capacity * 4 + (size_t)a->batch * 8;
-    hipLaunchKernelGGL(shuffle_dequeue_kernel, dim3(1), dim3(SQ_THREADS), lds, air_stream(stream), *a);
+    hipLaunchKernelGGL(shuffle_dequeue_kernel, dim3(1), dim3(SQ_THREADS), 0, air_stream(stream), *a);
     AIR_CHECK_LAUNCH();
     return 0;
 }
@@ -126,7 +135,7 @@ extern "C" int air_shuffle_batch_dequeue(const air_shuffle_batch_t* a, void* str
 extern "C" int air_shuffle_batch_dequeue_many(const air_shuffle_batch_t* a, int n_batches, int32_t* picks_out, void* stream) {
     if (int rc = sq_check(a)) return rc;
     if (n_batches <= 0 || !picks_out) return AIR_EINVAL;
-    const size_t lds = (size_t)a->capacity * 4 + (size_t)a->batch * 8;
+    const size_t lds = (size_t)a->capacity * 4 + (size_t)a->batch * 4;
     hipLaunchKernelGGL(shuffle_dequeue_many_kernel, dim3(1), dim3(SQ_THREADS), lds, air_stream(stream), *a, n_batches, picks_out);
     AIR_CHECK_LAUNCH();
     return 0;

@@ -252,11 +252,14 @@ class ShuffleBatchQueue:
     (training.py:76-81), the decoded records resident in HBM.  `images` [n, D] float32 / `digits` [n] int32 are device
     tensors; every batch lands in the caller's `out_images` [B, D] / `out_digits` [B] (the train model's input buffers).
 
-    next_batch(): dequeue + gather on the current stream (three launches in front of the step that consumes the batch).
-    graph_hooks(steps): the pipelined form for AIRModel.capture_graph(steps, between_steps=, after_steps=) -- `steps` even:
-    the picks of half a replay are made by ONE launch on a forked branch while the other half's train steps run
-    (air_shuffle_batch_dequeue_many), so only the row gather (one launch) stays in front of a step.  The batches are the
-    same sequence either way, pick for pick the numpy model of the reference's queue that tests/test_shuffle_queue.py holds."""
+    next_batch(): dequeue + gather on the current stream (two launches in front of the step that consumes the batch).
+    graph_hooks(steps): the form for AIRModel.capture_graph(steps, between_steps=): the captured replay starts with ONE
+    launch that makes the picks of all its `steps` batches into a device table (air_shuffle_batch_dequeue_many, the queue
+    staged in LDS once) and holds one more launch per step, the row gather of that step's batch.  The batches are the same
+    sequence either way, pick for pick the numpy model of the reference's queue that tests/test_shuffle_queue.py holds.
+    (Measured on one MI355X, 50 steps per replay, ms per train step: no input work 0.1751; gather only 0.1706; the
+    first version's serial dequeue + gather in front of every step 0.1901; a dequeue_many concurrent with the steps -- on
+    a forked branch of the graph or on a second stream -- 0.2085: DESIGN.md section 11.)"""
 
     def __init__(self, images, digits, batch_size, out_images, out_digits, seed=0, min_after_dequeue=10000):
         import ctypes as C
@@ -272,8 +275,7 @@ class ShuffleBatchQueue:
         self.picks = torch.zeros(self.batch, dtype=torch.int32, device=dev)
         self._sq = H.ShuffleBatch(self.queue.data_ptr(), self.state.data_ptr(), self.picks.data_ptr(), self.capacity,
                                   self.batch, min_after_dequeue, int(images.shape[0]), seed)
-        self._ahead = None          # [2, half, batch] picks made ahead of their steps (graph_hooks)
-        self._side = None
+        self._table = None          # [steps, batch] picks of the replay about to run (read by the captured gathers)
         H.check(H.lib().air_shuffle_batch_init(C.byref(self._sq), self._s()), "air_shuffle_batch_init")
 
     def _s(self):
@@ -287,44 +289,27 @@ class ShuffleBatchQueue:
 
     def next_batch(self, _i=0):
         H = self._H
-        if self._ahead is not None:
-            raise RuntimeError("this queue runs ahead of its consumer (graph_hooks): batches come out of the captured graph")
+        if self._table is not None:
+            raise RuntimeError("this queue feeds a captured graph (graph_hooks): batches come out of its replays")
         H.check(H.lib().air_shuffle_batch_dequeue(self._C.byref(self._sq), self._s()), "air_shuffle_batch_dequeue")
         self._gather(self.picks)
 
-    def _dequeue_many(self, half_index):
-        H = self._H
-        H.check(H.lib().air_shuffle_batch_dequeue_many(self._C.byref(self._sq), self._ahead.shape[1],
-                                                       self._ahead[half_index].data_ptr(), self._s()),
-                "air_shuffle_batch_dequeue_many")
-
     def graph_hooks(self, steps):
-        """-> (between_steps, after_steps).  The first call also makes the first half replay's picks (eagerly)."""
-        torch = self._torch
-        if steps < 2 or steps % 2:
-            raise ValueError("the pipelined queue needs an even number of steps per replay")
-        half = steps // 2
-        if self._ahead is None:
-            self._ahead = torch.zeros(2, half, self.batch, dtype=torch.int32, device=self.images.device)
-            self._side = torch.cuda.Stream(self.images.device)
-            self._dequeue_many(0)
-        elif self._ahead.shape[1] != half:
-            raise ValueError("graph_hooks was set up for %d steps per replay" % (2 * self._ahead.shape[1]))
-        side = self._side
+        """-> (between_steps, after_steps) for AIRModel.capture_graph"""
+        if steps < 1:
+            raise ValueError("steps per replay must be positive")
+        if self._table is None:
+            self._table = self._torch.zeros(steps, self.batch, dtype=self._torch.int32, device=self.images.device)
+        elif self._table.shape[0] != steps:
+            raise ValueError("graph_hooks was set up for %d steps per replay" % self._table.shape[0])
 
         def between_steps(i):
-            main = torch.cuda.current_stream(self.images.device)
-            if i == half:
-                main.wait_stream(side)                      # the second half's picks are complete
-            if i == 0 or i == half:
-                side.wait_stream(main)                      # (and every gather that read the half about to be rewritten)
-                with torch.cuda.stream(side):
-                    self._dequeue_many(1 if i == 0 else 0)
-            self._gather(self._ahead[0 if i < half else 1, i % half])
-
-        def after_steps():
-            torch.cuda.current_stream(self.images.device).wait_stream(side)
-        return between_steps, after_steps
+            H = self._H
+            if i == 0:                                   # the picks of the replay's batches: the replay's first launch
+                H.check(H.lib().air_shuffle_batch_dequeue_many(self._C.byref(self._sq), steps, self._table.data_ptr(), self._s()),
+                        "air_shuffle_batch_dequeue_many")
+            self._gather(self._table[i])
+        return between_steps, None
 
 
 def read_test_data(filename, shift_zero_digits_images=False):

@@ -11,8 +11,8 @@ AIRModel._summarize_by_digit_count (air_model.py:160-182, 614-617).
 The whole dataset lives in HBM.  A batch comes out of tf.train.shuffle_batch's queue, kept on the
 device (multi_mnist.ShuffleBatchQueue; multi_mnist.py:240-249: capacity 10 000 + 10 * batch, min_after_dequeue
 10 000, over the epoch-repeating record stream of training.py:76-81) and is gathered into the train model's input
-buffer; with --print-every 0 fifty train steps and their batches are one hipGraph replay, the queue's picks made on
-a forked branch ahead of the steps that consume them, and the evaluation every 50 iterations is one replay of the
+buffer; with --print-every 0 fifty train steps and their batches are one hipGraph replay (the queue's picks for the
+fifty batches in its first launch, a row gather in front of every step), and the evaluation every 50 iterations is one replay of the
 test model's forward + one summaries launch whose numbers are fetched without blocking (SummaryWriter).
 """
 import argparse
@@ -123,7 +123,7 @@ def main():
     parser.add_argument("--bg-path", default="", help="clutter background for the in-memory dataset (png, or file.npz:key)")
     parser.add_argument("--bg-max-intensity", type=float, default=1.0)
     parser.add_argument("--graph-steps", type=int, default=50,
-                        help="train steps per hipGraph replay when --print-every 0 (even, a divisor of 50)")
+                        help="train steps per hipGraph replay when --print-every 0 (a divisor of 50)")
     parser.add_argument("--seed", type=int, default=0)
     parser.add_argument("--backward", default="reference", choices=["reference", "reference_carried", "exact"],
                         help="sampler backward: the reference graph's op order, the same streams with the long ones in 16 "
@@ -197,13 +197,13 @@ def main():
 
     # The input queue is device work too (read_and_decode, multi_mnist.py:228-249): the RandomShuffleQueue's resident
     # record indices and the stream position live in HBM.  When nothing is printed per step, --graph-steps train steps
-    # are captured per hipGraph replay together with their batches: the picks of half a replay are made on a forked
-    # branch while the other half's steps run, the row gather is the one launch in front of a step.
+    # are captured per hipGraph replay together with their batches: one launch at the head of the replay makes the picks of
+    # all its batches, one row gather sits in front of every step.
     batches = ShuffleBatchQueue(train_images, train_digits, BATCH_SIZE, train_data, train_targets,
                                 seed=0x5348554646 + args.seed, min_after_dequeue=MIN_AFTER_DEQUEUE)
     gsteps = 1
     if not args.no_graph:
-        if args.print_every == 0 and NUM_SUMMARIES_EACH_ITERATIONS % args.graph_steps == 0 and args.graph_steps % 2 == 0:
+        if args.print_every == 0 and NUM_SUMMARIES_EACH_ITERATIONS % args.graph_steps == 0 and args.graph_steps > 1:
             gsteps = args.graph_steps
 
     def capture():

@@ -7,9 +7,10 @@ implementation of "the reference's fp32 autodiff" to compare success rates with.
 
 One train iteration (noise, forward, autograd backward, global-norm clip, TF-style Adam: ~1 700 small launches) is recorded
 ONCE as a hipGraph and replayed -- the un-fused op sequence is unchanged, only its launch cost goes (130 ms -> a few ms per
-iteration with eight runs side by side); the annealed prior log-odds, Adam's step size and the batch's record indices are
-device tensors the host refreshes between replays.  --no-graph runs the same step eagerly (a few iterations of both agree
-to the last bit: tests/test_twin_tool.py on the GPU box).  --deadline-min stops early, still printing a last evaluation."""
+iteration with eight runs side by side); the noise, the annealed prior log-odds, Adam's step size and the batch's record
+indices are device tensors the host refreshes between replays.  --no-graph runs the same step eagerly on the same noise: the
+same first loss to the last bit (tests/test_twin_tool.py on the GPU box); the gradients of either mode carry autograd's
+scatter-add atomics, i.e. their own realisation of the out-of-range residue on every run.  --deadline-min stops early, still printing a last evaluation."""
 import json, math, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tf-attend-infer-repeat_amd"))
@@ -49,15 +50,14 @@ def main(argv):
     params = {k: torch.tensor(v, requires_grad=True) for k, v in ao.init_params(hp, seed).items()}
     m = {k: torch.zeros_like(p) for k, p in params.items()}
     v = {k: torch.zeros_like(p) for k, p in params.items()}
-    torch.manual_seed(seed)                                # the default device generator: its Philox offset is graph-safe
-    g = torch.Generator(device="cuda").manual_seed(seed)   # batch order (outside the graph)
+    g = torch.Generator(device="cuda").manual_seed(seed)   # noise and batch order: drawn OUTSIDE the graph, into static tensors
     N, Z, d, B = hp["max_steps"], hp["vae_latent_dimensions"], hp["windows_size"] ** 2, 64
     sched = ao.TRAINING_ANNEALING["z_pres_prior_log_odds"]
     c = hp["gradient_clipping_norm"]
 
     def noise(b):
-        return dict(eps_scale=torch.randn(N, b, 1), eps_shift=torch.randn(N, b, 2), eps_z=torch.randn(N, b, Z),
-                    eps_x=torch.randn(N, b, d), u=torch.rand(N, b))
+        return dict(eps_scale=torch.randn(N, b, 1, generator=g), eps_shift=torch.randn(N, b, 2, generator=g),
+                    eps_z=torch.randn(N, b, Z, generator=g), eps_x=torch.randn(N, b, d, generator=g), u=torch.rand(N, b, generator=g))
 
     def evaluate(lo):
         with torch.no_grad():
@@ -68,12 +68,15 @@ def main(argv):
 
     # what changes from iteration to iteration, as device tensors
     idx = torch.zeros(B, dtype=torch.int64)
+    nz = noise(B)
     lo_t = torch.zeros(())
     lr_t = torch.zeros(())
+    loss_t = torch.zeros(())
     inv_c = torch.tensor(1.0 / c)
 
     def step():
-        out, grads = at.loss_and_grads(params, tr_im[idx], tr_dg[idx], noise(B), hp, lo_t)
+        out, grads = at.loss_and_grads(params, tr_im[idx], tr_dg[idx], nz, hp, lo_t)
+        loss_t.copy_(out["loss"].detach())
         gn = torch.sqrt(sum((x.detach() ** 2).sum() for x in grads.values()))
         scale = c * torch.minimum(1.0 / gn, inv_c)
         with torch.no_grad():
@@ -85,19 +88,19 @@ def main(argv):
 
     def set_iteration(it, batch):
         idx.copy_(batch)
+        for k, fresh in noise(B).items():
+            nz[k].copy_(fresh)
         lo_t.fill_(float(ao.annealed_value(sched, it)))
         t = it + 1
         lr_t.fill_(hp["learning_rate"] * math.sqrt(1.0 - 0.999 ** t) / (1.0 - 0.9 ** t))
 
     t0 = time.time()
-    perm = torch.randperm(len(tr_im), generator=g)
-    ptr = 0
     graph = None
     if use_graph:
         # the constants the op sequence caches (air_oracle_torch._const) and the lazily initialised libraries exist before the
         # capture: one throw-away forward + backward on a side stream (no update: lr = 0, and m / v are restored)
         snap = {k: (p.detach().clone(), m[k].clone(), v[k].clone()) for k, p in params.items()}
-        set_iteration(0, perm[:B])
+        set_iteration(0, torch.arange(B))
         lr_t.zero_()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -109,11 +112,13 @@ def main(argv):
         with torch.no_grad():
             for k, p in params.items():
                 p.copy_(snap[k][0]); m[k].copy_(snap[k][1]); v[k].copy_(snap[k][2])
-        torch.manual_seed(seed)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             step()
-    stopped = None
+    g.manual_seed(seed)                                    # (the throw-away passes drew noise: both modes start from the same state)
+    perm = torch.randperm(len(tr_im), generator=g)
+    ptr = 0
+    stopped, first_loss = None, None
     for it in range(iters):
         if it % eval_every == 0:
             a, acc = evaluate(float(ao.annealed_value(sched, it)))
@@ -129,11 +134,13 @@ def main(argv):
             graph.replay()
         else:
             step()
+        if it == 0:
+            first_loss = float(loss_t)
     if stopped is None:
         a, acc = evaluate(float(ao.annealed_value(sched, iters)))
         print(json.dumps({"seed": seed, "step": iters, "accuracy": round(a, 3), "acc012": [round(x, 2) for x in acc],
                           "wall_s": round(time.time() - t0, 1), "final": True}), flush=True)
-    return params
+    return params, first_loss
 
 
 if __name__ == "__main__":
