@@ -1,11 +1,13 @@
 """Driver-run learning gate (BASELINE.json: ">= 98 % digit-count accuracy reproduced"; reference README.md:18: 10 of 10
 runs converge towards 98 % over ~25 000 iterations, training.py:100-122 hyper-parameters).
 
-The full evidence (8 seeds x 120 k iterations per precision, 300-epoch runs) is builder-run and lives under profiles/;
-this test puts the learning behaviour of the DEFAULT product path -- training.py, bf16 GEMM operands, backward="reference",
-hipGraph replays of 10 steps with the in-graph batch gather -- under `pytest -m gpu`: two seeds, 30 000 iterations each
-(~10 s per run on one MI355X), held-out count accuracy on the fixed 1 000-image test set.  Stand-in glyphs: MNIST is not
-available offline."""
+The full evidence (48 seeds x 60 000 iterations per precision, switch-point sweeps, 300-epoch runs) is builder-run and lives
+under profiles/ (tools/gate_report.py prints its counts: 39 of 48 bf16 runs and 42 of 48 fp32 runs reach 0.98, 1 and 2 end
+below 0.9); these tests put the learning behaviour of the DEFAULT product path -- training.py, bf16 GEMM operands,
+backward="reference", hipGraph replays of 50 steps with the in-graph batches -- under `pytest -m gpu`: two seeds at 30 000
+iterations (>= 0.95, every count class >= 0.90) and one run of 60 000 iterations (some evaluation >= 0.98, final >= 0.95),
+held-out count accuracy on the fixed 1 000-image test set.  Stand-in glyphs: MNIST is not available offline (DESIGN.md
+section 2)."""
 import json
 import os
 import re

@@ -59,3 +59,19 @@ def test_training_driver_end_to_end(tmp_path, print_every, precision):
                          "--precision", precision], cwd=PKG, capture_output=True, text=True, timeout=900)
     assert p2.returncode == 0, p2.stderr[-2000:]
     assert os.path.isdir(res + "_0") and os.path.exists(os.path.join(res, "models", "air-model-300.pt"))
+
+
+def test_training_driver_backward_schedule(tmp_path):
+    """--late-backward / --late-backward-from: AIRModel(backward=(first, late, N)) -- the driver reports the switch at its
+    iteration and the run goes on (the schedule is opt-in: DESIGN.md section 11.1)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    res = str(tmp_path / "air_results")
+    cmd = [sys.executable, "training.py", "-r", res, "-o", "1", "--iterations", "300", "--print-every", "0", "--precision", "bf16",
+           "--late-backward", "reference_carried", "--late-backward-from", "100"]
+    p = subprocess.run(cmd, cwd=PKG, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "iteration 100: sampler backward order -> reference_carried" in p.stdout, p.stdout[-1500:]
+    rows = [json.loads(l) for l in open(os.path.join(res, "summary", "scalars.jsonl"))]
+    assert [r["step"] for r in rows] == list(range(0, 300, 50)) and all(np.isfinite(r["loss"]) for r in rows)
+    assert len(rows[0]) == 92                                                     # step, wall_s + the reference's 90 numeric summaries
