@@ -60,6 +60,8 @@ def test_struct_layout_matches_c(H, tmp_path):
                     'sizeof(air_bottleneck_fwd_t), offsetof(air_bottleneck_fwd_t, ldx), sizeof(air_bottleneck_bwd_t), offsetof(air_bottleneck_bwd_t, H));'
                     'printf("%zu %zu %zu %zu %d\\n", sizeof(air_panel_t), offsetof(air_panel_t, K), offsetof(air_panel_t, exclusive), offsetof(air_gemm_t, B16p),'
                     'AIR_MAX_PANELS);'
+                    'printf("%zu %zu %zu %zu\\n", sizeof(air_summaries_t), offsetof(air_summaries_t, out), offsetof(air_summaries_t, B),'
+                    'sizeof(air_shuffle_batch_t));'
                     'return 0;}')
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
@@ -69,7 +71,8 @@ def test_struct_layout_matches_c(H, tmp_path):
            C.sizeof(H.Schedule), C.sizeof(H.AttendFwd), H.AttendFwd.B.offset, C.sizeof(H.AttendBwd),
            C.sizeof(H.WriteFwd), C.sizeof(H.WriteBwd), C.sizeof(H.Colsum),
            C.sizeof(H.BottleneckFwd), H.BottleneckFwd.ldx.offset, C.sizeof(H.BottleneckBwd), H.BottleneckBwd.H.offset,
-           C.sizeof(H.Panel), H.Panel.K.offset, H.Panel.exclusive.offset, H.Gemm.B16p.offset, H.MAX_PANELS]
+           C.sizeof(H.Panel), H.Panel.K.offset, H.Panel.exclusive.offset, H.Gemm.B16p.offset, H.MAX_PANELS,
+           C.sizeof(H.Summaries), H.Summaries.out.offset, H.Summaries.B.offset, C.sizeof(H.ShuffleBatch)]
     assert got == exp, (got, exp)
 
 
