@@ -21,7 +21,8 @@ __global__ __launch_bounds__(SQ_THREADS) void shuffle_init_kernel(air_shuffle_ba
 // pass over j resolves it.  Thread k resolves V(idx_k, k) (what it emits) and V(back_k, k) (what it moves into idx_k); the
 // last pick that hits a surviving slot writes it; the `batch` freed slots at the back are refilled from the stream.  Pick
 // for pick the sequential queue (tests/test_shuffle_queue.py: 400 batches x 3 geometries against the numpy model).
-__device__ __forceinline__ void dequeue_batch(int* q, const air_shuffle_batch_t& a, long n, long pos, int* sh_idx, int32_t* picks_out) {
+__device__ __forceinline__ void dequeue_batch(int* q, const air_shuffle_batch_t& a, long n, unsigned pos_mod /* stream position mod n_records */,
+                                              int* sh_idx, int32_t* picks_out) {
     const int tid = threadIdx.x, cap = a.capacity, batch = a.batch;
     if (tid * 4 < batch) {
         uint32_t c[4] = {(uint32_t)n, (uint32_t)((unsigned long)n >> 32), (uint32_t)tid, 0x53485546u};
@@ -67,7 +68,7 @@ __device__ __forceinline__ void dequeue_batch(int* q, const air_shuffle_batch_t&
     if (k < batch) {
         picks_out[k] = emit;
         if (last_writer && my < cap - batch) q[my] = moved;
-        q[cap - batch + k] = (int)((pos + k) % a.n_records);          // enqueue appends at the back, in stream order
+        q[cap - batch + k] = (int)((pos_mod + (unsigned)k) % (unsigned)a.n_records);   // enqueue appends at the back, in stream order
     }
     __syncthreads();
 }
@@ -75,7 +76,7 @@ __device__ __forceinline__ void dequeue_batch(int* q, const air_shuffle_batch_t&
 __global__ __launch_bounds__(SQ_THREADS) void shuffle_dequeue_kernel(air_shuffle_batch_t a) {
     __shared__ int sh_idx[SQ_THREADS];
     const long pos = a.state[0], n = a.state[1];
-    dequeue_batch(a.queue, a, n, pos, sh_idx, a.picks);               // on the queue in memory: 2 x batch scattered reads, <= 2 x batch writes
+    dequeue_batch(a.queue, a, n, (unsigned)(pos % a.n_records), sh_idx, a.picks);   // on the queue in memory: 2 x batch scattered reads, <= 2 x batch writes
     if (threadIdx.x == 0) { a.state[0] = pos + a.batch; a.state[1] = n + 1; }
 }
 
@@ -90,8 +91,11 @@ __global__ __launch_bounds__(SQ_THREADS) void shuffle_dequeue_many_kernel(air_sh
     const long pos0 = a.state[0], n0 = a.state[1];
     for (int i = tid; i < a.capacity; i += SQ_THREADS) q[i] = a.queue[i];
     __syncthreads();
-    for (int kb = 0; kb < nb; ++kb)
-        dequeue_batch(q, a, n0 + kb, pos0 + (long)kb * a.batch, sh_idx, picks_out + (size_t)kb * a.batch);
+    unsigned pm = (unsigned)(pos0 % a.n_records);                      // (one 64-bit division per launch, not one per record)
+    for (int kb = 0; kb < nb; ++kb) {
+        dequeue_batch(q, a, n0 + kb, pm, sh_idx, picks_out + (size_t)kb * a.batch);
+        pm = (pm + (unsigned)a.batch) % (unsigned)a.n_records;
+    }
     for (int i = tid; i < a.capacity; i += SQ_THREADS) a.queue[i] = q[i];
     if (tid == 0) { a.state[0] = pos0 + (long)nb * a.batch; a.state[1] = n0 + nb; }
 }

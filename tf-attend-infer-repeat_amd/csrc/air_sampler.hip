@@ -13,86 +13,11 @@
 // reference arithmetic.  The backward of the write uses
 // the exact adjoint in separable form (R_y^T g R_x) as a deterministic gather:
 // no atomics anywhere.
-#include "air_common.h"
-#include <cstdio>
-#include <atomic>
-#include <type_traits>
-#include <cstdlib>
-#include <cstring>
-#include <cmath>
+#include "air_sampler_common.h"
 
 AIR_STAMPS_READER(air_debug_stamps)
-// per-workgroup phase stamps of the graph-order write backward (debug builds only): [workgroup][8]
-#ifdef AIR_STAMPS
-static __device__ unsigned long long air_stamps_wg[4096 * 8];
-extern "C" int air_debug_stamps_wg(unsigned long long* out, int n) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(air_stamps_wg), sizeof(unsigned long long) * (n < 4096 * 8 ? n : 4096 * 8));
-}
-#define AIR_STAMP_WG(i) do { if (threadIdx.x == 0) air_stamps_wg[((blockIdx.y * gridDim.x + blockIdx.x) & 4095) * 8 + (i)] = wall_clock64(); } while (0)
-#define AIR_STAMP_WG_T(i, t) do { if (threadIdx.x == (t)) air_stamps_wg[((blockIdx.y * gridDim.x + blockIdx.x) & 4095) * 8 + (i)] = wall_clock64(); } while (0)
-// accumulating form (large canvases: four passes per workgroup): slot i += now - t0, and plain values
-#define AIR_STAMP_WG_ADD(i, t0) do { if (threadIdx.x == 0) air_stamps_wg[((blockIdx.y * gridDim.x + blockIdx.x) & 4095) * 8 + (i)] += wall_clock64() - (t0); } while (0)
-#define AIR_STAMP_WG_SET(i, v) do { if (threadIdx.x == 0) air_stamps_wg[((blockIdx.y * gridDim.x + blockIdx.x) & 4095) * 8 + (i)] = (unsigned long long)(v); } while (0)
-#define AIR_NOW() wall_clock64()
-#else
-#define AIR_STAMP_WG(i) do { } while (0)
-#define AIR_STAMP_WG_T(i, t) do { } while (0)
-#define AIR_STAMP_WG_ADD(i, t0) do { } while (0)
-#define AIR_STAMP_WG_SET(i, v) do { } while (0)
-#define AIR_NOW() 0ull
-#endif
 
 namespace {
-
-constexpr int THREADS = 256;
-
-struct Tap { float w0, w1; int i0, i1; };   // w0 = (x1_f - x), w1 = (x - x0_f)
-
-// transformer.py:75-87,108-115 for one output coordinate of one axis
-__device__ __forceinline__ Tap axis_tap(int j, int n_out, int n_in, float a, float b, float* t_out = nullptr) {
-    const float step = 2.0f / (float)(n_out - 1);
-    const float t = (n_out > 1) ? (-1.0f + step * (float)j) : -1.0f;   // tf.linspace(-1, 1, n)
-    const float xs = a * t + b;                                         // theta . (x_t, y_t, 1)
-    const float X = ((xs + 1.0f) * ((float)n_in - 1.001f)) / 2.0f;
-    const float f0 = floorf(X);
-    const float lim = (float)(n_in - 1);
-    const float c0 = fminf(fmaxf(f0, 0.0f), lim);          // clip AFTER floor / +1
-    const float c1 = fminf(fmaxf(f0 + 1.0f, 0.0f), lim);
-    Tap tp;
-    tp.i0 = (int)c0; tp.i1 = (int)c1;
-    tp.w0 = c1 - X;
-    tp.w1 = X - c0;
-    if (t_out) *t_out = t;
-    return tp;
-}
-
-// literal transformer.py:108-116: wa*Ia + wb*Ib + wc*Ic + wd*Id, add_n left to right
-__device__ __forceinline__ float bilinear4(const Tap& tx, const Tap& ty,
-                                           float Ia, float Ib, float Ic, float Id) {
-    const float wa = tx.w0 * ty.w0;
-    const float wb = tx.w0 * ty.w1;
-    const float wc = tx.w1 * ty.w0;
-    const float wd = tx.w1 * ty.w1;
-    return ((wa * Ia + wb * Ib) + wc * Ic) + wd * Id;
-}
-
-// Gradient of one output pixel wrt its source coordinates (X, Y) in the op order of the reference's SAVED graph
-// (model/air-model.meta, executed by the graph executor of tests/test_graph_exec.py).  For an out-of-range pixel (both
-// taps clipped to one index) the four legs cancel exactly in real arithmetic but NOT in fp32: the rounding residue,
-// multiplied by g ~ 1 / (r + 1e-9) at unexplained ink, is not noise to be cleaned up -- it is the force that pulls glimpses
-// towards unexplained ink, and the reference's training dynamics depend on it (with the exact adjoint the model does not
-// learn to localise).  cx = (n_in - 1.001): x = (x_s + 1) * cx / 2.  d wa..wd = g*Ia..Id (mul_10..13_grad), each product's two factors get
-// grad*other (mul_6..9_grad), the Sub nodes negate the (x1-x)/(y1-y) legs, and the four legs that
-// reach x (y) are summed by AddN_10 / AddN_20 (AddN_11 / AddN_21) left to right in the order
-// wa, wb, wc, wd.  Then x = (x_s + 1)*(W - 1.001)/2: truediv_grad then mul_grad.
-__device__ __forceinline__ void graph_dxy(float g, float Ia, float Ib, float Ic, float Id,
-                                          const Tap& tx, const Tap& ty, float cx, float& dxs, float& dys) {
-    const float ga = g * Ia, gb = g * Ib, gc = g * Ic, gd = g * Id;
-    const float dX = ((-(ga * ty.w0) + -(gb * ty.w1)) + gc * ty.w0) + gd * ty.w1;
-    const float dY = ((-(tx.w0 * ga) + tx.w0 * gb) + -(tx.w1 * gc)) + tx.w1 * gd;
-    dxs = (dX / 2.0f) * cx;
-    dys = (dY / 2.0f) * cx;
-}
 
 // ---------------------------------------------------------------------------
 // generic transformer (any theta): one thread per output pixel
@@ -121,112 +46,6 @@ __global__ __launch_bounds__(THREADS) void transformer_fwd_kernel(
         const float Ic = img[(int)y0 * Wi + (int)x1], Id = img[(int)y1 * Wi + (int)x1];
         Tap tx{x1 - X, X - x0, 0, 0}, ty{y1 - Y, Y - y0, 0, 0};
         out[p] = bilinear4(tx, ty, Ia, Ib, Ic, Id);
-    }
-}
-
-typedef __attribute__((address_space(3))) float air_lds_float;
-// no-return LDS float add (inline asm: no compare-and-swap loop may be substituted)
-__device__ __forceinline__ void lds_fadd(float* p, float v) {
-    asm volatile("ds_add_f32 %0, %1" :: "v"((unsigned)(size_t)(air_lds_float*)p), "v"(v) : "memory");
-}
-
-// ---------------------------------------------------------------------------
-// generic transformer backward (any theta): gradients wrt the input image U and wrt theta, in the
-// op order of the reference's graph (transformer.py:56-171 differentiated by tf.gradients; node
-// orders from model/air-model.meta):
-//   * d theta: per output pixel, graph_dxy's AddN order for the coordinate gradients, then the
-//     MatMul_grad contraction over the output pixels with (x_t, y_t, 1);
-//   * d U: the four Gather gradients concatenated and reduced by one UnsortedSegmentSum -- every input
-//     pixel is ONE fp32 accumulator receiving its a-terms in output-pixel order, then b, c, d.  For an
-//     arbitrary theta the contributors of a slot are not a rectangle, so the accumulation is done
-//     where the hardware already provides that order: one wave walks the 4*Ho*Wo terms in sequence,
-//     64 per ds_add_f32; gfx950's LDS applies the lanes of an instruction in ascending order and a
-//     wave's instructions in program order (tools/exp/lds_atomic_order.hip), i.e. exactly the scatter
-//     order of the reference's CPU kernel.  One workgroup per image; U and d U live in LDS.
-// ---------------------------------------------------------------------------
-struct GenTap { float wx0, wx1, wy0, wy1; int x0, x1, y0, y1; float xt, yt; };
-__device__ __forceinline__ GenTap generic_tap(const float* th, int i, int j, int Hi, int Wi, int Ho, int Wo) {
-    GenTap t;
-    t.xt = (Wo > 1) ? (-1.0f + (2.0f / (float)(Wo - 1)) * (float)j) : -1.0f;
-    t.yt = (Ho > 1) ? (-1.0f + (2.0f / (float)(Ho - 1)) * (float)i) : -1.0f;
-    const float xs = (th[0] * t.xt + th[1] * t.yt) + th[2] * 1.0f;
-    const float ys = (th[3] * t.xt + th[4] * t.yt) + th[5] * 1.0f;
-    const float X = ((xs + 1.0f) * ((float)Wi - 1.001f)) / 2.0f;
-    const float Y = ((ys + 1.0f) * ((float)Hi - 1.001f)) / 2.0f;
-    const float fx = floorf(X), fy = floorf(Y);
-    const float x0 = fminf(fmaxf(fx, 0.f), (float)(Wi - 1)), x1 = fminf(fmaxf(fx + 1.f, 0.f), (float)(Wi - 1));
-    const float y0 = fminf(fmaxf(fy, 0.f), (float)(Hi - 1)), y1 = fminf(fmaxf(fy + 1.f, 0.f), (float)(Hi - 1));
-    t.wx0 = x1 - X; t.wx1 = X - x0; t.wy0 = y1 - Y; t.wy1 = Y - y0;
-    t.x0 = (int)x0; t.x1 = (int)x1; t.y0 = (int)y0; t.y1 = (int)y1;
-    return t;
-}
-
-__global__ __launch_bounds__(THREADS) void transformer_bwd_kernel(
-    const float* __restrict__ U, const float* __restrict__ theta, const float* __restrict__ d_out,
-    float* __restrict__ d_U, float* __restrict__ d_theta, int Hi, int Wi, int Ho, int Wo, int lds_ordered)
-{
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int NI = Hi * Wi, NO = Ho * Wo;
-    float* sh_red = smem;                      // [32]
-    float* sh_th = smem + 32;                  // [8]
-    float* sh_U = smem + 40;                   // [NI]
-    float* sh_dU = sh_U + ((NI + 3) & ~3);     // [NI]
-    const float* img = U + (size_t)b * NI;
-    const float* g = d_out + (size_t)b * NO;
-    if (tid < 6) sh_th[tid] = theta[(size_t)b * 6 + tid];
-    for (int p = tid; p < NI; p += THREADS) { sh_U[p] = img[p]; sh_dU[p] = 0.0f; }
-    __syncthreads();
-    if (d_theta) {
-        float s6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int p = tid; p < NO; p += THREADS) {
-            const GenTap t = generic_tap(sh_th, p / Wo, p % Wo, Hi, Wi, Ho, Wo);
-            const float Ia = sh_U[t.y0 * Wi + t.x0], Ib = sh_U[t.y1 * Wi + t.x0];
-            const float Ic = sh_U[t.y0 * Wi + t.x1], Id = sh_U[t.y1 * Wi + t.x1];
-            // graph_dxy's order (AddN over wa, wb, wc, wd); the two axes have their own (W - 1.001) here
-            const float ga = g[p] * Ia, gb = g[p] * Ib, gc = g[p] * Ic, gd = g[p] * Id;
-            const float dX = ((-(ga * t.wy0) + -(gb * t.wy1)) + gc * t.wy0) + gd * t.wy1;
-            const float dY = ((-(t.wx0 * ga) + t.wx0 * gb) + -(t.wx1 * gc)) + t.wx1 * gd;
-            const float gX = (dX / 2.0f) * ((float)Wi - 1.001f);
-            const float gY = (dY / 2.0f) * ((float)Hi - 1.001f);
-            s6[0] += gX * t.xt; s6[1] += gX * t.yt; s6[2] += gX;
-            s6[3] += gY * t.xt; s6[4] += gY * t.yt; s6[5] += gY;
-        }
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const float v = air_block_sum_256(s6[k], sh_red + 4 * k);
-            if (tid == 0) d_theta[(size_t)b * 6 + k] = v;
-        }
-    }
-    if (d_U) {
-        __syncthreads();
-        if (!lds_ordered) {
-            // fallback for a part whose LDS atomics do not apply lanes in ascending order (lds_order_probe): ONE lane
-            // walks the terms -- slow, but the reference's scatter order by construction
-            if (tid == 0)
-                for (int ph = 0; ph < 4; ++ph)
-                    for (int p = 0; p < NO; ++p) {
-                        const GenTap t = generic_tap(sh_th, p / Wo, p % Wo, Hi, Wi, Ho, Wo);
-                        const float wgt = ((ph & 2) ? t.wx1 : t.wx0) * ((ph & 1) ? t.wy1 : t.wy0);
-                        const int idx = ((ph & 1) ? t.y1 : t.y0) * Wi + ((ph & 2) ? t.x1 : t.x0);
-                        sh_dU[idx] = sh_dU[idx] + wgt * g[p];
-                    }
-        } else if (wave == 0) {
-            for (int ph = 0; ph < 4; ++ph)
-                for (int p0 = 0; p0 < NO; p0 += 64) {
-                    const int p = p0 + lane;
-                    if (p < NO) {
-                        const GenTap t = generic_tap(sh_th, p / Wo, p % Wo, Hi, Wi, Ho, Wo);
-                        const float wgt = ((ph & 2) ? t.wx1 : t.wx0) * ((ph & 1) ? t.wy1 : t.wy0);   // wa, wb, wc, wd
-                        const int idx = ((ph & 1) ? t.y1 : t.y0) * Wi + ((ph & 2) ? t.x1 : t.x0);
-                        lds_fadd(sh_dU + idx, wgt * g[p]);
-                    }
-                }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        __syncthreads();
-        float* dst = d_U + (size_t)b * NI;
-        for (int p = tid; p < NI; p += THREADS) dst[p] = sh_dU[p];
     }
 }
 
@@ -803,932 +622,6 @@ __global__ __launch_bounds__(NT) void write_fwd_kernel(air_write_fwd_t a)
     }
 }
 
-// ---------------------------------------------------------------------------
-// write backward, EXACT adjoint (literal == 0, backward="exact": the fp64-gradient tests): gradient wrt the window
-// (separable, gather form, degenerate taps merged -- their two weights cancel exactly in real arithmetic), wrt
-// theta_recon -> (s,x,y), and wrt z_pres.  One workgroup per (image, time step): every step sees the same
-// d loss / d canvas.
-// ---------------------------------------------------------------------------
-// 16 waves per workgroup: every phase is a latency chain, 4 waves per SIMD hide it
-constexpr int WB_THREADS = 1024;
-__global__ __launch_bounds__(WB_THREADS) void write_bwd_kernel(air_write_bwd_t a)
-{
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int b = blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
-    const int C = a.C, w = a.w;
-    const size_t row = (size_t)t * a.B + b;
-    AIR_STAMP(0);
-    float* sh_red = smem;                                  // [64]
-    Tap* sh_tx = reinterpret_cast<Tap*>(smem + 64);        // [C]
-    Tap* sh_ty = sh_tx + C;                                // [C]
-    float* sh_t = reinterpret_cast<float*>(sh_ty + C);     // [C] linspace
-    int* sh_rng = reinterpret_cast<int*>(sh_t + C);        // [8*w]: per source index, the range of outputs whose taps hit it
-    float* sh_win = reinterpret_cast<float*>(sh_rng + 8 * w);   // [w*w]
-    float* sh_T = sh_win + w * w;                          // [C*w]
-    float* sh_g = sh_T + C * w;                            // [C*C] d loss / d canvas of this image
-
-    if (a.fin_scalars && b == 0 && t == 0) {
-        // loss = mean(loss_item) :593,610; accuracy = mean(target == digits) :597-611 (air_finalize)
-        float r4[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int i = tid; i < a.B; i += WB_THREADS) {
-            r4[0] += a.fin_loss_item[i];
-            r4[1] += (a.fin_targets[i] == a.fin_digits[i]) ? 1.0f : 0.0f;
-        }
-        air_block_sum4<WB_THREADS / 64>(r4, sh_red);
-        if (tid == 0) { a.fin_scalars[0] = r4[0] / (float)a.B; a.fin_scalars[1] = r4[1] / (float)a.B; }
-        __syncthreads();                                   // sh_red is reused below
-    }
-    const float* at = a.att + row * AIR_ATT_STRIDE;
-    float* dgen = a.d_gen_pre + row * w * w;
-    unsigned short* dgen16 = a.d_gen_pre16 ? a.d_gen_pre16 + row * w * w : nullptr;
-    float* dsx = a.d_sxy_write + row * 4;
-    if (at[AIR_ATT_MASK] == 0.0f) {                        // where(active, ., 0): no gradient
-        for (int p = tid; p < w * w; p += WB_THREADS) { dgen[p] = 0.0f; if (dgen16) dgen16[p] = 0; }
-        if (tid < 4) dsx[tid] = 0.0f;
-        return;
-    }
-    const float s = at[AIR_ATT_S], x = at[AIR_ATT_X], y = at[AIR_ATT_Y], z = at[AIR_ATT_Z];
-    const float ia = 1.0f / s, bx = (-x) / s, by = (-y) / s;
-    for (int j = tid; j < C; j += WB_THREADS) {
-        float tv;
-        sh_tx[j] = axis_tap(j, C, w, ia, bx, &tv);
-        sh_ty[j] = axis_tap(j, C, w, ia, by);
-        sh_t[j] = tv;
-    }
-    const float* v = a.vrec + row * w * w;
-    for (int p = tid; p < w * w; p += WB_THREADS) sh_win[p] = v[p];
-    {
-        // one coalesced pass with 8 loads in flight per thread; every later access is LDS
-        const float* gsrc = a.d_recon + (size_t)b * C * C;
-        for (int p0 = 0; p0 < C * C; p0 += 8 * WB_THREADS) {
-            float r[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { const int p = p0 + k * WB_THREADS + tid; r[k] = p < C * C ? gsrc[p] : 0.0f; }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { const int p = p0 + k * WB_THREADS + tid; if (p < C * C) sh_g[p] = r[k]; }
-        }
-    }
-    __syncthreads();
-    // source index q is touched by a contiguous range of output coordinates (taps are monotone): one merged range
-    // per index, degenerate (both taps clipped to one index) outputs skipped
-    AIR_STAMP(1);
-    if (tid < 2 * w) {
-        const Tap* tp = (tid < w) ? sh_tx : sh_ty;
-        const int q = (tid < w) ? tid : tid - w;
-        int lo0 = C, hi0 = -1;
-        for (int j = 0; j < C; ++j) {
-            const Tap tt = tp[j];
-            if (tt.i0 != tt.i1 && (tt.i0 == q || tt.i1 == q)) { lo0 = min(lo0, j); hi0 = max(hi0, j); }
-        }
-        int* r = sh_rng + (tid < w ? 0 : 4 * w) + 4 * q;
-        r[0] = lo0; r[1] = hi0; r[2] = C; r[3] = -1;
-    }
-    __syncthreads();
-
-    const float* g = sh_g;
-    // stage 1: T[I][q] = sum_J g[I][J] * Rx[J][q]
-    for (int it = tid; it < C * w; it += WB_THREADS) {
-        const int I = it / w, q = it % w;
-        float acc = 0.0f;
-        for (int J = sh_rng[4 * q]; J <= sh_rng[4 * q + 1]; ++J) {
-            const Tap tt = sh_tx[J];
-            const float wq = (tt.i0 != tt.i1) ? ((tt.i0 == q ? tt.w0 : 0.0f) + (tt.i1 == q ? tt.w1 : 0.0f)) : 0.0f;
-            acc += g[I * C + J] * wq;
-        }
-        sh_T[I * w + q] = acc;
-    }
-    AIR_STAMP(2);
-    // theta / z gradients, per canvas pixel (independent of stage 1)
-    const float half_w = ((float)w - 1.001f) / 2.0f;
-    float da = 0.f, dbx = 0.f, dby = 0.f, dz = 0.f;
-    const int di = WB_THREADS / C, dj = WB_THREADS % C;          // (i, j) advance per WB_THREADS pixels
-    int i = tid / C, j = tid % C;
-#pragma unroll 2
-    for (int p = tid; p < C * C; p += WB_THREADS) {
-        const Tap tx = sh_tx[j], ty = sh_ty[i];
-        const float Ia = sh_win[ty.i0 * w + tx.i0], Ib = sh_win[ty.i1 * w + tx.i0];
-        const float Ic = sh_win[ty.i0 * w + tx.i1], Id = sh_win[ty.i1 * w + tx.i1];
-        const float gv = g[p];
-        const int ci = i, cj = j;
-        i += di; j += dj;
-        if (j >= C) { j -= C; ++i; }
-        // a degenerate axis (both taps clipped to one index) is exactly 0 in real arithmetic;
-        // the fp32 residue the forward keeps there (~1e-7) would be multiplied by g ~ 1e9/B
-        // (d log(r + 1e-9) at r ~ 0) and drown d z_pres in rounding noise.
-        // (the reference's autodiff multiplies the residue by g like any other value: the graph-order kernels below)
-        if (tx.i0 != tx.i1 && ty.i0 != ty.i1) dz += gv * bilinear4(tx, ty, Ia, Ib, Ic, Id);
-        const float gz = gv * z;
-        const float gX = gz * ((Ic - Ia) * ty.w0 + (Id - Ib) * ty.w1) * half_w;
-        const float gY = gz * ((Ib - Ia) * tx.w0 + (Id - Ic) * tx.w1) * half_w;
-        da += gX * sh_t[cj] + gY * sh_t[ci];
-        dbx += gX;
-        dby += gY;
-    }
-    AIR_STAMP(3);
-    {
-        float red4[4] = {da, dbx, dby, dz};
-        air_block_sum4<WB_THREADS / 64>(red4, sh_red);   // contains the __syncthreads() that publishes sh_T
-        da = red4[0]; dbx = red4[1]; dby = red4[2]; dz = red4[3];
-    }
-    if (tid == 0) {
-        // a = 1/s, bx = -x/s, by = -y/s
-        const float is2 = 1.0f / (s * s);
-        dsx[0] = (-da + dbx * x + dby * y) * is2;
-        dsx[1] = -dbx / s;
-        dsx[2] = -dby / s;
-        dsx[3] = dz;
-    }
-    AIR_STAMP(4);
-    // stage 2: dU[p][q] = z * sum_I Ry[I][p] * T[I][q]; fold the sigmoid of vae.py:39-41
-    for (int it = tid; it < w * w; it += WB_THREADS) {
-        const int p = it / w, q = it % w;
-        const int* ry = sh_rng + 4 * w + 4 * p;
-        float acc = 0.0f;
-        for (int I = ry[0]; I <= ry[1]; ++I) {
-            const Tap tt = sh_ty[I];
-            const float wp = (tt.i0 != tt.i1) ? ((tt.i0 == p ? tt.w0 : 0.0f) + (tt.i1 == p ? tt.w1 : 0.0f)) : 0.0f;
-            acc += sh_T[I * w + q] * wp;
-        }
-        const float du = z * acc;
-        const float r = sh_win[it];
-        const float dgv = du * (r * (1.0f - r));
-        dgen[it] = dgv;
-        if (dgen16) dgen16[it] = air_bf16_of(dgv);
-    }
-    AIR_STAMP(6);
-}
-
-
-// ---------------------------------------------------------------------------
-// write backward in the op order of the reference's SAVED graph (literal == 2; the default
-// backward="reference" of AIRModel).  What the graph does with d loss / d window_recon
-// (model/air-model.meta, executed node by node by the graph executor of tests/test_graph_exec.py):
-//   * the four Gather gradients (taps a=(y0,x0), b=(y1,x0), c=(y0,x1), d=(y1,x1)) are CONCATENATED and
-//     reduced by ONE UnsortedSegmentSum: every window pixel ("slot") is a single fp32 accumulator
-//     that receives its a-terms in canvas-pixel order, then its b-, c- and d-terms.  The terms of an
-//     out-of-range canvas pixel cancel exactly in real arithmetic (both taps clip to one border
-//     index), but not in this accumulation order: the border slots keep a rounding residue of
-//     ~ulp(sum of |terms|), which at unexplained ink (d log(r + 1e-9) ~ 1e9/B) is orders of magnitude
-//     above the exact gradient -- that residue is part of the reference's training signal
-//     (tests/golden/graph_b64.npz: |g| 1.6e6 in fp32 vs 1.1e3 in fp64 at initialisation).
-//   * per canvas pixel, the gradients wrt the sampling coordinates are summed by AddN_10 / AddN_11 in
-//     the order wa, wb, wc, wd (graph_dxy).
-// Reproduced here bit for bit (tests/test_gpu_graph_golden.py) and deterministically:
-//   stage T: all threads compute term = (wx*wy) * (z*g) of every tap of every canvas pixel and store it
-//            in a "rectangle-blocked" layout: taps are monotone, so the pixels of one slot form a
-//            rectangle (row run x column run) and each slot's terms of a tap are one contiguous
-//            stream in exactly the accumulation order;
-//   stage C: one lane per slot streams its four runs through a single fp32 register accumulator
-//            (a lone wave issues a dependent v_add_f32 every ~8 cycles -- fine for the short
-//            in-range and edge runs).  The FOUR CORNER slots own every pixel that is outside the
-//            glimpse in both axes -- (C - s*C)^2 terms per tap, most of the canvas -- and go through
-//            the LDS instead: after everything else is published, waves 0..3 feed one corner each, 64 terms per
-//            instruction, to ds_add_f32 on one LDS word per corner.  gfx950's LDS applies the lanes of one
-//            instruction in ascending lane order and a wave's instructions in program order
-//            (measured: tools/exp/lds_atomic_order.hip; pinned by the bit-for-bit test), i.e. it IS
-//            a sequential fp32 accumulator, at ~4 cycles per term and without occupying the VALU.  While it runs,
-//            every other LDS request of the CU starves, so the short chains go first and the coordinate-gradient
-//            pixel loop -- rewritten to touch no LDS at all -- runs on the other twelve waves underneath it.
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ float stream_add(float acc, const float* T, int start, int n) {
-    int k = start;
-    const int end = start + n;
-    while (k < end && (k & 3)) { acc += T[k]; ++k; }
-    const int nb = (end - k) >> 2;
-    if (nb > 0) {
-        // two 16-byte LDS reads in flight ahead of the dependent adds; the look-ahead index is clamped
-        // (a harmless re-read) so that every access stays an LDS access of this stream
-        const float4* p4 = reinterpret_cast<const float4*>(T + k);
-        float4 c0 = p4[0], c1 = p4[min(1, nb - 1)];
-        for (int b = 0; b < nb; ++b) {
-            const float4 nx = p4[min(b + 2, nb - 1)];
-            acc += c0.x; acc += c0.y; acc += c0.z; acc += c0.w;
-            c0 = c1; c1 = nx;
-        }
-        k += nb * 4;
-    }
-    while (k < end) { acc += T[k]; ++k; }
-    return acc;
-}
-
-// ALLPH: the terms of all four taps are resident (4*C*C floats of LDS, no barrier between taps);
-// otherwise one tap at a time through one buffer (large canvases)
-// CARRIED (literal == 4, backward="reference_carried"): the same term streams -- per window pixel the a-, b-, c-, d-tap
-// terms in canvas-pixel order -- with every (slot, tap) stream of n terms cut into at most WB_CHUNKS contiguous chunks of
-// max(ceil(n / WB_CHUNKS), WB_CHUNK_MIN) terms that are walked side by side on register chains.  A stream of up to 64 terms
-// is ONE chunk, so only the border slots that collect the out-of-range pixels are cut at all.  No LDS atomics, no lane-order
-// property, no probe; the coordinate / z gradients are taken in the term pass.
-// (Round 5 also shipped the plain chunked form -- every chunk from +0.0, the chunk sums added left to right, "blocked16":
-// 13.4 us against 17.7, and 4 of 24 training runs stuck on a count class.  Removed)
-//   * a slot whose four streams all fit one chunk (<= 64 terms each: every slot but the corners and a few long borders) is
-//     summed exactly as the reference sums it -- one accumulator through its a-, b-, c-, d-terms;
-//   * a slot with a longer stream walks every chunk TWICE: C_k = chunk k from +0.0, Q_k = chunk k from P_k, with P_k the
-//     running sum of the C's before it (a deterministic stand-in for the reference's accumulator at the chunk's start);
-//     the slot's sum is Q_last + sum_{k < last} (Q_k - P_k+1), the corrections added left to right: Q_k and P_k+1 are two
-//     roundings of the same real number, their difference is a few ulps and exact.  Every add of the Q chains rounds at
-//     the magnitude it rounds at in the reference's one long chain and nothing else rounds at that magnitude, so the
-//     cancellation residue the out-of-range terms leave keeps its size (mean |error| 1.0x the sequential order's over 2116
-//     corner streams) -- DESIGN.md section 10.
-//   Two chains of n / 16 adds per corner instead of one of 4 n; no LDS atomics, no probe.
-constexpr int WB_CHUNKS = 16, WB_CHUNK_MIN = 64;
-__device__ __forceinline__ int wb_chunk_len(int n) { return max((n + WB_CHUNKS - 1) / WB_CHUNKS, WB_CHUNK_MIN); }
-// c += every term, q += every term: the two chains of one chunk in ONE pass over its terms (independent: they overlap)
-__device__ __forceinline__ void stream_add2(float& c, float& q, const float* T, int start, int n) {
-    int k = start;
-    const int end = start + n;
-    while (k < end && (k & 3)) { const float t = T[k]; c += t; q += t; ++k; }
-    const int nb = (end - k) >> 2;
-    if (nb > 0) {
-        const float4* p4 = reinterpret_cast<const float4*>(T + k);
-        float4 c0 = p4[0], c1 = p4[min(1, nb - 1)];
-        for (int b = 0; b < nb; ++b) {
-            const float4 nx = p4[min(b + 2, nb - 1)];
-            c += c0.x; q += c0.x; c += c0.y; q += c0.y; c += c0.z; q += c0.z; c += c0.w; q += c0.w;
-            c0 = c1; c1 = nx;
-        }
-        k += nb * 4;
-    }
-    while (k < end) { const float t = T[k]; c += t; q += t; ++k; }
-}
-template <bool ALLPH, bool CARRIED>
-__device__ __forceinline__ void write_bwd_graph_body(const air_write_bwd_t& a, int seq_flags)
-{
-    // seq_flags (accumulators(), below): bit 0 the LDS atomic pipe applies lanes in order, bit 1 the lane-ring accumulator
-    // is exact on this part (used when the pipe is not)
-    const bool lds_ordered = seq_flags & 1, ring_ok = seq_flags & 2;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    // which (image, step) item this workgroup computes: its grid position, or -- a.order given -- entry `linear block id` of
-    // the longest-first permutation the compose launch left (wb_order_block)
-    const int lin = (int)(blockIdx.y * gridDim.x + blockIdx.x);
-    const int item = a.order ? a.order[lin] : lin;
-    const int b = item % a.B, t = item / a.B;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int NW = WB_THREADS / 64;
-    const int C = a.C, w = a.w, CC = C * C, CCp = (CC + 3) & ~3;
-    const size_t row = (size_t)t * a.B + b;
-    float* sh_red = smem;                                  // [128]: fin sums / per-wave partials [NW][8]
-    float* sh_acc = smem + 128;                            // [4] corner accumulators (+4 pad)
-    Tap* sh_tx = reinterpret_cast<Tap*>(smem + 136);       // [C]
-    Tap* sh_ty = sh_tx + C;                                // [C]
-    float* sh_t = reinterpret_cast<float*>(sh_ty + C);     // [C] linspace
-    int4* sh_ci = reinterpret_cast<int4*>(sh_t + ((C + 3) & ~3));  // [C] per canvas column: {first, count} of the run of its x0 key, of its x1 key
-    int4* sh_ri = sh_ci + C;                                       // [C] per canvas row: the same for y0 / y1
-    int* sh_run = reinterpret_cast<int*>(sh_ri + C);               // [4][w][2]: run [lo,hi] of every key of x0 / x1 / y0 / y1
-    float* sh_win = reinterpret_cast<float*>(sh_run + ((8 * w + 3) & ~3));   // [w*w]
-    // d loss / d (masked z * window_recon): staged in LDS when all taps are resident (small canvases); a large canvas
-    // reads it from memory where needed (its 5 uses per pixel hit L2: every step of an image reads the same row) --
-    // 76 KB instead of 140 KB of LDS at 128x128, i.e. two workgroups per CU: one's LDS-atomic corner phase runs under
-    // the other's term / pixel-loop phases
-    float* sh_g = sh_win + ((w * w + 3) & ~3);             // [C*C] (ALLPH only)
-    float* sh_T = ALLPH ? sh_g + CCp : sh_g;               // [4 or 1][C*C] terms, rectangle-blocked per tap (16-byte aligned)
-    const float* gsrc = a.d_recon + (size_t)b * CC;
-
-    if (a.fin_scalars && lin == (a.order ? (int)(gridDim.x * gridDim.y) - 1 : 0)) {     // (ordered: the lightest item's workgroup)
-        float r4[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int i = tid; i < a.B; i += WB_THREADS) {
-            r4[0] += a.fin_loss_item[i];
-            r4[1] += (a.fin_targets[i] == a.fin_digits[i]) ? 1.0f : 0.0f;
-        }
-        air_block_sum4<NW>(r4, sh_red);
-        if (tid == 0) { a.fin_scalars[0] = r4[0] / (float)a.B; a.fin_scalars[1] = r4[1] / (float)a.B; }
-        __syncthreads();
-    }
-    AIR_STAMP(40);
-    AIR_STAMP_WG(0);
-    const float* at = a.att + row * AIR_ATT_STRIDE;
-    float* dgen = a.d_gen_pre + row * w * w;
-    unsigned short* dgen16 = a.d_gen_pre16 ? a.d_gen_pre16 + row * w * w : nullptr;
-    float* dsx = a.d_sxy_write + row * 4;
-    // the window and (small canvases) the first pass over d_recon do not depend on the record: their loads go out
-    // BEFORE the mask test waits for it -- one memory round trip for the set-up instead of two
-    const float* v = a.vrec + row * w * w;
-    const float win_pre = tid < w * w ? v[tid] : 0.0f;      // (w * w <= WB_THREADS: checked by the launcher)
-    float g_pre[8];
-    if (ALLPH) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { const int p = k * WB_THREADS + tid; g_pre[k] = p < CC ? gsrc[p] : 0.0f; }
-    }
-    if (at[AIR_ATT_MASK] == 0.0f) {                        // Select(active, ., 0): no gradient
-        for (int p = tid; p < w * w; p += WB_THREADS) { dgen[p] = 0.0f; if (dgen16) dgen16[p] = 0; }
-        if (tid < 4) dsx[tid] = 0.0f;
-        return;
-    }
-    const float s = at[AIR_ATT_S], x = at[AIR_ATT_X], y = at[AIR_ATT_Y], z = at[AIR_ATT_Z];
-    const float ia = 1.0f / s, bx = (-x) / s, by = (-y) / s;
-    for (int j = tid; j < C; j += WB_THREADS) {
-        float tv;
-        sh_tx[j] = axis_tap(j, C, w, ia, bx, &tv);
-        sh_ty[j] = axis_tap(j, C, w, ia, by);
-        sh_t[j] = tv;
-    }
-    for (int it = tid; it < 4 * w; it += WB_THREADS) { sh_run[2 * it] = 0; sh_run[2 * it + 1] = -1; }
-    if (tid < 8) sh_acc[tid] = 0.0f;
-    if (tid >= 64 && tid < 64 + NW * 8) sh_red[tid - 64] = 0.0f;          // the feeding waves publish no pixel-loop partials
-    if (tid < w * w) sh_win[tid] = win_pre;
-    if (ALLPH) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { const int p = k * WB_THREADS + tid; if (p < CC) sh_g[p] = g_pre[k]; }
-        for (int p0 = 8 * WB_THREADS; p0 < CC; p0 += 8 * WB_THREADS) {
-            float r[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { const int p = p0 + k * WB_THREADS + tid; r[k] = p < CC ? gsrc[p] : 0.0f; }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { const int p = p0 + k * WB_THREADS + tid; if (p < CC) sh_g[p] = r[k]; }
-        }
-    }
-    __syncthreads();
-    AIR_STAMP(41);
-    // every key (tap index) owns ONE contiguous run of canvas columns / rows (taps are monotone)
-    for (int it = tid; it < 4 * C; it += WB_THREADS) {
-        const int arr = it / C, J = it % C;                 // arr: x0, x1, y0, y1
-        const Tap* tp = (arr < 2) ? sh_tx : sh_ty;
-        const int k = (arr & 1) ? tp[J].i1 : tp[J].i0;
-        const int kp = J > 0 ? ((arr & 1) ? tp[J - 1].i1 : tp[J - 1].i0) : -1;
-        const int kn = J < C - 1 ? ((arr & 1) ? tp[J + 1].i1 : tp[J + 1].i0) : -1;
-        if (kp != k) sh_run[(arr * w + k) * 2] = J;
-        if (kn != k) sh_run[(arr * w + k) * 2 + 1] = J;
-    }
-    __syncthreads();
-    // ... and every canvas column / row the runs of its two keys: the term phase then needs ONE LDS round trip per
-    // pixel (two taps + two run records, all independent) instead of eight run lookups that wait for the taps
-    for (int it = tid; it < 2 * C; it += WB_THREADS) {
-        const int ax = it / C, J = it - ax * C;
-        const Tap tp = ax ? sh_ty[J] : sh_tx[J];
-        const int* r0 = sh_run + ((2 * ax) * w + tp.i0) * 2;
-        const int* r1 = sh_run + ((2 * ax + 1) * w + tp.i1) * 2;
-        (ax ? sh_ri : sh_ci)[J] = make_int4(r0[0], r0[1] - r0[0] + 1, r1[0], r1[1] - r1[0] + 1);
-    }
-    // terms of corner slot c over its four taps (sh_red[64 + 8 * NW ..] is free until the pixel loop's partials are combined)
-    int* sh_cn = reinterpret_cast<int*>(sh_acc) + 4;       // [4] (the pad words behind the four accumulators)
-    if (tid < 4) {
-        int tot = 0;
-        for (int ph = 0; ph < 4; ++ph) {
-            const int xa = ph >> 1, ya = 2 + (ph & 1), q = (tid & 1) ? w - 1 : 0, pp = (tid & 2) ? w - 1 : 0;
-            const int ncols = sh_run[(xa * w + q) * 2 + 1] - sh_run[(xa * w + q) * 2] + 1;
-            const int nrows = sh_run[(ya * w + pp) * 2 + 1] - sh_run[(ya * w + pp) * 2] + 1;
-            tot += max(nrows, 0) * max(ncols, 0);
-        }
-        sh_cn[tid] = tot;
-    }
-    __syncthreads();
-    AIR_STAMP(42);
-    // bit c = corner c on the LDS atomic pipe; the lane rings take the corners when the pipe does not order lanes.  (A
-    // per-workgroup MIX -- the k largest corners on the pipe, the others as rings, k minimising max(4 x pipe terms, 12 x
-    // longest ring) -- was built and measured in rounds 3 / 4: bit-identical, no faster at either canvas size, DESIGN.md
-    // sections 8 and 9.  Removed.)
-    const int pipe_mask = lds_ordered ? 0xf : 0;
-
-    // tap ph = a, b, c, d <-> (y0,x0), (y1,x0), (y0,x1), (y1,x1)
-    const int di = WB_THREADS / C, dj = WB_THREADS % C;
-    float d00 = 0.f, d02 = 0.f, d11 = 0.f, d12 = 0.f, dz = 0.f;
-    // CARRIED: the terms of taps PH0 .. PH1-1 (and, THETA, the theta / z gradients, taken where the pixel's taps and
-    // d_recon are in registers anyway: the window from LDS -- nothing starves the LDS in this mode).  A thread owns ONE
-    // canvas column j and the rows i0, i0 + RPP, ...: the column's tap, its runs and its linspace value are loop
-    // invariants, the row's are wave-wide broadcasts.  Per-thread sums over a fixed pixel set, combined over the waves in a
-    // fixed order at the end.  A row outside the glimpse (both y taps clipped to one index: ty.w1 == -ty.w0, Ia == Ib,
-    // Ic == Id) contributes EXACT zeros to all five sums -- the a / b and c / d legs of AddN_10 / AddN_11 and of the
-    // bilinear sum cancel pairwise before anything rounds -- and is skipped; an out-of-range COLUMN does not cancel
-    // exactly (that is the x residue) and is not.
-    const int RPP = WB_THREADS / C, bj = tid % C, bi0 = tid / C;
-    auto carried_terms = [&](auto ph0c, auto ph1c, auto thetac) __attribute__((always_inline)) {
-        constexpr int PH0 = decltype(ph0c)::value, PH1 = decltype(ph1c)::value;
-        constexpr bool THETA = decltype(thetac)::value;
-        if (bi0 >= RPP) return;
-        const Tap tx = sh_tx[bj];
-        const int4 ci = sh_ci[bj];
-        const float tjv = sh_t[bj];
-        const int jc0 = bj - ci.x, jc1 = bj - ci.z;
-        const float cw = (float)w - 1.001f;
-        for (int i = bi0; i < C; i += RPP) {
-            const Tap ty = sh_ty[i];
-            const int4 ri = sh_ri[i];
-            const float g0 = ALLPH ? sh_g[i * C + bj] : gsrc[i * C + bj];
-            const float gp = z * g0;                                                // canvas/mul_grad: z * Select_grad
-            const float wq[4] = {tx.w0 * ty.w0, tx.w0 * ty.w1, tx.w1 * ty.w0, tx.w1 * ty.w1};   // wa..wd (transformer.py:108-115)
-            const int rb0 = ri.x * C, rb1 = ri.z * C, di0 = i - ri.x, di1 = i - ri.z;
-#pragma unroll
-            for (int ph = PH0; ph < PH1; ++ph) {
-                const bool x1 = ph >> 1, y1 = ph & 1;
-                const int pos = (y1 ? rb1 : rb0) + (y1 ? ri.w : ri.y) * (x1 ? ci.z : ci.x) + (y1 ? di1 : di0) * (x1 ? ci.w : ci.y) + (x1 ? jc1 : jc0);
-                sh_T[(ALLPH ? ph * CCp : 0) + pos] = wq[ph] * gp;
-            }
-            if (THETA && ty.i0 != ty.i1) {
-                const float Ia = sh_win[ty.i0 * w + tx.i0], Ib = sh_win[ty.i1 * w + tx.i0];
-                const float Ic = sh_win[ty.i0 * w + tx.i1], Id = sh_win[ty.i1 * w + tx.i1];
-                dz += g0 * (((wq[0] * Ia + wq[1] * Ib) + wq[2] * Ic) + wq[3] * Id);   // canvas/mul_grad: Select_grad * window_recon
-                float gX, gY;
-                graph_dxy(gp, Ia, Ib, Ic, Id, tx, ty, cw, gX, gY);
-                d00 += gX * tjv; d02 += gX;                                         // MatMul_grad: rows of theta x (x_t, y_t, 1)
-                d11 += gY * sh_t[i]; d12 += gY;
-            }
-        }
-    };
-    auto theta_publish = [&]() {
-        d00 = air_wave_sum(d00); d02 = air_wave_sum(d02); d11 = air_wave_sum(d11); d12 = air_wave_sum(d12); dz = air_wave_sum(dz);
-        if (lane == 0) { float* r = sh_red + wave * 8; r[0] = d00; r[1] = d02; r[2] = d11; r[3] = d12; r[4] = dz; }
-    };
-    auto stage_T = [&](int ph0, int ph1) {
-        int i = tid / C, j = tid % C;
-        for (int p = tid; p < CC; p += WB_THREADS) {
-            const Tap tx = sh_tx[j], ty = sh_ty[i];
-            const float gp = z * (ALLPH ? sh_g[p] : gsrc[p]);                       // canvas/mul_grad: z * Select_grad
-            const int4 ci = sh_ci[j], ri = sh_ri[i];
-            const int cl0 = ci.x, cn0 = ci.y, cl1 = ci.z, cn1 = ci.w;               // runs of this column's x0 / x1 key
-            const int rl0 = ri.x, rn0 = ri.y, rl1 = ri.z, rn1 = ri.w;               // runs of this row's y0 / y1 key
-            for (int ph = ph0; ph < ph1; ++ph) {
-                const bool x1 = ph >> 1, y1 = ph & 1;
-                const float wgt = (x1 ? tx.w1 : tx.w0) * (y1 ? ty.w1 : ty.w0);      // wa..wd (transformer.py:108-115)
-                const int clo = x1 ? cl1 : cl0, ncols = x1 ? cn1 : cn0, rlo = y1 ? rl1 : rl0, nrows = y1 ? rn1 : rn0;
-                sh_T[(ALLPH ? ph * CCp : 0) + rlo * C + nrows * clo + (i - rlo) * ncols + (j - clo)] = wgt * gp;
-            }
-            i += di; j += dj;
-            if (j >= C) { j -= C; ++i; }
-        }
-    };
-    // start / length of slot (p, q)'s stream of tap ph
-    auto slot_run = [&](int ph, int p, int q, int& start, int& n) {
-        const int xa = ph >> 1, ya = 2 + (ph & 1);
-        const int clo = sh_run[(xa * w + q) * 2], ncols = sh_run[(xa * w + q) * 2 + 1] - clo + 1;
-        const int rlo = sh_run[(ya * w + p) * 2], nrows = sh_run[(ya * w + p) * 2 + 1] - rlo + 1;
-        start = (ALLPH ? ph * CCp : 0) + rlo * C + nrows * clo;
-        n = nrows * ncols;
-    };
-    // which window pixel ("slot") this thread accumulates.  CARRIED: waves 0..3 take the corner slots' chunks, so the other
-    // slots start at thread 256 and whatever does not fit behind it falls to the first threads (after their corner work);
-    // the 4 (w - 2) border slots -- the only other long streams: a row or a column of out-of-range pixels each -- come
-    // first, packed into the same waves, the interior slots (a handful of terms per tap) fill the rest
-    int sl = tid, sp = tid / w, sq = tid % w;
-    bool is_slot = tid < w * w;
-    if (CARRIED) {
-        const int u = tid >= 4 * 64 ? tid - 4 * 64 : tid + (WB_THREADS - 4 * 64);
-        const int wm = max(w - 2, 1), ne = 4 * (w - 2);
-        is_slot = u < w * w - 4;
-        if (u < ne) {
-            const int side = u / wm, r = u - side * wm + 1;
-            sp = side == 0 ? 0 : side == 1 ? w - 1 : r;
-            sq = side < 2 ? r : (side == 2 ? 0 : w - 1);
-        } else {
-            const int v = u - ne, vr = v / wm;
-            sp = 1 + vr; sq = 1 + (v - vr * wm);
-        }
-        sl = sp * w + sq;
-    }
-    // (a part whose LDS atomics are not lane-ordered -- lds_order_probe -- has no "corner" slots: their four long runs go
-    // through the register chains like every other slot's; slow, but the same sequential order by construction)
-    const bool corner = !CARRIED && (lds_ordered || ring_ok) && is_slot && (sp == 0 || sp == w - 1) && (sq == 0 || sq == w - 1);
-    float acc = 0.0f;
-    // The corner slots' streams -> ds_add_f32 on one LDS word per corner: wave c feeds corner c, 64
-    // consecutive terms per instruction, tap after tap (an instruction costs ~140 + 1.8 cycles per active
-    // lane, tools/exp/lds_atomic_cost.hip).  16 instructions per batch; reads, adds and waits are inline asm
-    // (the compiler's own s_waitcnt bookkeeping would put an lgkmcnt(0) in front of every add).
-    auto feed_corner = [&](int c, int ph0, int ph1) {
-        constexpr int NB = 16;
-        // stream descriptors of this corner: lane ph computes tap ph's run, broadcast to scalars
-        int my_start = 0, my_n = 0;
-        if (lane < 4) slot_run(lane, (c & 2) ? w - 1 : 0, (c & 1) ? w - 1 : 0, my_start, my_n);
-        int st[4], ln[4], cum[5];
-        cum[0] = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            st[k] = __builtin_amdgcn_readlane(my_start, k);
-            ln[k] = (k >= ph0 && k < ph1) ? __builtin_amdgcn_readlane(my_n, k) : 0;
-            cum[k + 1] = cum[k] + ((ln[k] + 63) >> 6);           // instructions of taps 0..k
-        }
-        const int ninstr = cum[4];
-        const unsigned acc_addr = (unsigned)(size_t)(air_lds_float*)(sh_acc + c);
-        for (int base = 0; base < ninstr; base += 128) {
-            // the instruction list is tabulated in registers, lane l holding entries base + l and
-            // base + 64 + l (first-term offset, valid lanes); the issue loop below reads them with
-            // v_readlane and stays a few hundred instructions long (a fully unrolled state machine
-            // over taps x chunks grew to tens of thousands and ran out of the instruction cache)
-            int ent_a[2], ent_n[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int i = base + h * 64 + lane;
-                const int ph = (i >= cum[1]) + (i >= cum[2]) + (i >= cum[3]);
-                const int k0 = (i - (ph == 0 ? cum[0] : ph == 1 ? cum[1] : ph == 2 ? cum[2] : cum[3])) * 64;
-                ent_a[h] = (ph == 0 ? st[0] : ph == 1 ? st[1] : ph == 2 ? st[2] : st[3]) + k0;
-                ent_n[h] = i < ninstr ? min(64, (ph == 0 ? ln[0] : ph == 1 ? ln[1] : ph == 2 ? ln[2] : ln[3]) - k0) : 0;
-            }
-            const int m = min(128, ninstr - base);
-            // One batch: 16 reads in two asm statements of 8, each statement ENDING with its own s_waitcnt -- when the
-            // statement is over its outputs are architecturally valid, so the compiler may move, copy or spill them freely
-            // (it cannot see LDS returns in flight across asm statements).  The reads queue behind the previous
-            // batch's adds (a wave's LDS operations execute in order), i.e. the wait also drains those: the atomic pipe
-            // idles only for the ~2 x 100 cycles of the two read round trips per 16 x 255-cycle batch.
-            auto batch = [&](int j0) {
-                float r[NB];
-                int d[NB];
-                unsigned ad[NB];
-#pragma unroll
-                for (int u = 0; u < NB; ++u) {
-                    const int j = j0 + u;                          // uniform
-                    d[u] = 0; ad[u] = (unsigned)(size_t)(air_lds_float*)sh_T;
-                    if (j < m) {
-                        const int a0 = __builtin_amdgcn_readlane(j < 64 ? ent_a[0] : ent_a[1], j & 63);
-                        d[u] = __builtin_amdgcn_readlane(j < 64 ? ent_n[0] : ent_n[1], j & 63);
-                        ad[u] = (unsigned)(size_t)(air_lds_float*)(sh_T + a0 + min(lane, max(d[u] - 1, 0)));
-                    }
-                }
-#pragma unroll
-                for (int h = 0; h < NB; h += 8)
-                    asm volatile("ds_read_b32 %0, %8\n ds_read_b32 %1, %9\n ds_read_b32 %2, %10\n ds_read_b32 %3, %11\n"
-                                 "ds_read_b32 %4, %12\n ds_read_b32 %5, %13\n ds_read_b32 %6, %14\n ds_read_b32 %7, %15\n"
-                                 "s_waitcnt lgkmcnt(0)"
-                                 : "=&v"(r[h]), "=&v"(r[h + 1]), "=&v"(r[h + 2]), "=&v"(r[h + 3]),
-                                   "=&v"(r[h + 4]), "=&v"(r[h + 5]), "=&v"(r[h + 6]), "=&v"(r[h + 7])
-                                 : "v"(ad[h]), "v"(ad[h + 1]), "v"(ad[h + 2]), "v"(ad[h + 3]),
-                                   "v"(ad[h + 4]), "v"(ad[h + 5]), "v"(ad[h + 6]), "v"(ad[h + 7])
-                                 : "memory");
-#pragma unroll
-                for (int u = 0; u < NB; ++u)
-                    if (lane < d[u]) asm volatile("ds_add_f32 %0, %1" :: "v"(acc_addr), "v"(r[u]) : "memory");   // valid lanes only (EXEC)
-            };
-#pragma unroll 1
-            for (int j0 = 0; j0 < m; j0 += NB) batch(j0);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    };
-    // The SECOND sequential accumulator: a ring over the lanes of one wave.  Lane k holds term k of a batch of 64 (one
-    // coalesced ds_read_b32), the running sum travels S[k] = S[k-1] + r[k] with one v_add_f32 ... wave_ror:1 per term, lane
-    // 63 carries it into the next batch (lane 0 reads lane 63); padding lanes hold -0.0f (x + -0 == x).  12 cycles per
-    // term against the pipe's 4 and a register chain's 8.4 -- but it needs ONE LDS request per 64 terms and no per-lane
-    // control flow, and the four corners run on the four SIMDs at once: tools/exp/dpp_chain.hip.
-    // A DPP operand reading the previous instruction's result formally wants two wait states; gfx950 interlocks it
-    // (bit-exact over 10^4-term streams without them, 16.4 cycles with s_nop 0, 18.2 with s_nop 1) -- probed at load time
-    // like the pipe's lane order (accumulators()).
-    auto ring_corner = [&](int c, int ph0, int ph1) {
-        float S = sh_acc[c];                                  // (lane 63's copy is the accumulator)
-        // a ring issues one dependent instruction every 12 cycles and idles in between: at the top issue priority it keeps
-        // that cadence beside the other waves of its SIMD (the pixel loop, the other workgroup's term phase)
-        __builtin_amdgcn_s_setprio(3);
-        for (int ph = ph0; ph < ph1; ++ph) {
-            int start, n;
-            slot_run(ph, (c & 2) ? w - 1 : 0, (c & 1) ? w - 1 : 0, start, n);
-            start = __builtin_amdgcn_readfirstlane(start); n = __builtin_amdgcn_readfirstlane(n);
-            if (n <= 0) continue;
-            // RD batches of 64 terms are read ahead of the adds: beside a feeding wave the LDS serves a read only after the
-            // atomics queued in front of it (up to 16 instructions of ~255 cycles per feeding wave), i.e. thousands of cycles
-            // late -- with ONE batch in flight (768 cycles of adds) a ring beside the pipe ran at a fraction of its 12
-            // cycles per term
-            constexpr int RD = 8;
-            float r[RD];
-#pragma unroll
-            for (int d = 0; d < RD; ++d) { const int ix = d * 64 + lane; r[d] = ix < n ? sh_T[start + ix] : -0.0f; }
-            for (int b = 0; b < n; b += 64 * RD) {
-#pragma unroll
-                for (int d = 0; d < RD; ++d) {
-                    if (b + d * 64 < n) {                                   // (uniform)
-#pragma unroll
-                        for (int k = 0; k < 64; ++k)
-                            asm volatile("v_add_f32_dpp %0, %0, %1 wave_ror:1 row_mask:0xf bank_mask:0xf" : "+v"(S) : "v"(r[d]));
-                    }
-                    const int nx = b + (d + RD) * 64 + lane;
-                    r[d] = nx < n ? sh_T[start + nx] : -0.0f;               // refill this slot: RD batches ahead
-                }
-            }
-        }
-        __builtin_amdgcn_s_setprio(0);
-        if (lane == 63) sh_acc[c] = S;
-    };
-    // (A per-workgroup split -- the longest corner streams on the pipe, the others as rings beside it, the count chosen
-    // to balance 4 against 12 cycles per term -- was built and measured: bit-identical, and no faster at either
-    // configuration (0.1806 / 0.716 ms with the pipe alone, 0.1807 / 0.715-0.726 split): the pipe runs at its uncontended
-    // 4.0 cycles per term even with two workgroups per CU, and the launch waits for the workgroup whose ONE corner owns
-    // everything.  The rings are the fallback of a part whose pipe is not ordered: 0.195 / 0.840 ms, against
-    // 0.207 / 1.214 ms for the register chains.)
-    // theta / z gradients, per canvas pixel: the NT threads tid0 .. tid0 + NT - 1 share the canvas, three pixels in flight
-    // per thread.  NO LDS access: the loop runs on waves 4..15 WHILE waves 0..3 push the corner terms through the LDS
-    // atomic pipe (whose traffic starves every other LDS request of the CU), so the taps are recomputed per pixel
-    // (axis_tap: the same function of the same inputs as the tables) and d_recon / the window come from memory (L1 / L2:
-    // 10 KB + 3 KB per workgroup at 50 x 50).
-    auto theta_loop = [&](int tid0, int NT) {
-        const int tt = tid - tid0;
-        if (tt < 0 || tt >= NT) return;
-        for (int p0 = tt; p0 < CC; p0 += 3 * NT) {
-            Tap tx[3], ty[3];
-            float Iv[3][4], gv[3], tj[3], ti[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int p = min(p0 + k * NT, CC - 1), i = p / C, j = p - i * C;
-                gv[k] = (p0 + k * NT < CC) ? gsrc[p] : 0.0f;     // a pixel past the end contributes exact zeros
-                tx[k] = axis_tap(j, C, w, ia, bx, &tj[k]); ty[k] = axis_tap(i, C, w, ia, by, &ti[k]);
-            }
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                Iv[k][0] = v[ty[k].i0 * w + tx[k].i0]; Iv[k][1] = v[ty[k].i1 * w + tx[k].i0];
-                Iv[k][2] = v[ty[k].i0 * w + tx[k].i1]; Iv[k][3] = v[ty[k].i1 * w + tx[k].i1];
-            }
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                dz += gv[k] * bilinear4(tx[k], ty[k], Iv[k][0], Iv[k][1], Iv[k][2], Iv[k][3]);   // canvas/mul_grad: Select_grad * window_recon
-                float gX, gY;
-                graph_dxy(z * gv[k], Iv[k][0], Iv[k][1], Iv[k][2], Iv[k][3], tx[k], ty[k], (float)w - 1.001f, gX, gY);
-                d00 += gX * tj[k]; d02 += gX;                    // MatMul_grad: rows of theta x (x_t, y_t, 1)
-                d11 += gY * ti[k]; d12 += gY;
-            }
-        }
-        // this wave's coordinate / z gradient partials (combined over the waves in a fixed order at the end)
-        d00 = air_wave_sum(d00); d02 = air_wave_sum(d02); d11 = air_wave_sum(d11); d12 = air_wave_sum(d12); dz = air_wave_sum(dz);
-        if (lane == 0) { float* r = sh_red + wave * 8; r[0] = d00; r[1] = d02; r[2] = d11; r[3] = d12; r[4] = dz; }
-    };
-    auto chains = [&](int ph0, int ph1) {
-        if (is_slot && !corner)
-            for (int ph = ph0; ph < ph1; ++ph) {
-                int start, n;
-                slot_run(ph, sp, sq, start, n);
-                acc = stream_add(acc, sh_T, start, n);
-            }
-    };
-    // the non-corner slots' outputs
-    auto publish = [&]() {
-        if (is_slot && !corner) {
-            const float r = sh_win[sl];
-            const float dgv = (acc * r) * (1.0f - r);        // SigmoidGrad of vae.py:39-41: dy * y * (1 - y)
-            dgen[sl] = dgv;
-            if (dgen16) dgen16[sl] = air_bf16_of(dgv);
-        }
-    };
-    // CARRIED: this thread's slot, taps [PH0, PH1).  short_s: all four of its streams are single chunks -> the reference's
-    // chain (acc); otherwise P_s / R_s carry the scheme above from tap to tap (and from pass to pass on large canvases)
-    float P_s = 0.0f, corr_s = 0.0f, Q_s = 0.0f;
-    bool short_s = true, have_s = false;
-    if (CARRIED && is_slot) {
-#pragma unroll
-        for (int ph = 0; ph < 4; ++ph) { int st, n; slot_run(ph, sp, sq, st, n); short_s = short_s && n <= WB_CHUNK_MIN; }
-    }
-    auto carried_slot = [&](auto ph0c, auto ph1c) __attribute__((always_inline)) {
-        constexpr int PH0 = decltype(ph0c)::value, PH1 = decltype(ph1c)::value;
-        if (!is_slot) return;
-#pragma unroll
-        for (int ph = PH0; ph < PH1; ++ph) {
-            int start, n;
-            slot_run(ph, sp, sq, start, n);
-            n = max(n, 0);
-            if (short_s) { acc = stream_add(acc, sh_T, start, n); continue; }
-            const int cs = wb_chunk_len(n);
-            for (int k0 = 0; k0 < n; k0 += cs) {
-                if (have_s) corr_s += Q_s - P_s;                 // the previous chunk's chain against the prefix behind it (exact)
-                float c = 0.0f, q = P_s;
-                stream_add2(c, q, sh_T, start + k0, min(cs, n - k0));
-                Q_s = q;
-                P_s += c;
-                have_s = true;
-            }
-            acc = Q_s + corr_s;                                  // (final after the last tap)
-        }
-    };
-    auto publish_corner = [&](int c, float du) {
-        const int it = ((c & 2) ? w - 1 : 0) * w + ((c & 1) ? w - 1 : 0);
-        const float r = sh_win[it];
-        const float dgv = (du * r) * (1.0f - r);
-        dgen[it] = dgv;
-        if (dgen16) dgen16[it] = air_bf16_of(dgv);
-    };
-    // theta_recon = [[1/s, 0, -x/s], [0, 1/s, -y/s]] (air_model.py:353-356): truediv_grad .. truediv_3_grad,
-    // summed in AddN_24's order; Neg_grad / Neg_1_grad for x, y.  One wave: lanes 0..4 each combine one quantity over
-    // the waves' partials in wave order; lane 0 collects them by shuffle
-    auto finish_theta = [&]() {
-        float u = 0.0f;
-        if (lane < 5) { u = sh_red[lane]; for (int wv = 1; wv < NW; ++wv) u += sh_red[wv * 8 + lane]; }
-        float t5[5];
-#pragma unroll
-        for (int k = 0; k < 5; ++k) t5[k] = __shfl(u, k, 64);
-        if (lane == 0) {
-            const float n1 = (-1.0f / s) / s;
-            dsx[0] = ((t5[0] * n1 + t5[1] * ((x / s) / s)) + t5[2] * n1) + t5[3] * ((y / s) / s);
-            dsx[1] = -(t5[1] / s);
-            dsx[2] = -(t5[3] / s);
-            dsx[3] = t5[4];
-        }
-    };
-    // waves 0..3 feed one corner each to the atomic pipe; the pixel loop runs beside them on the other twelve
-    constexpr int TH0 = 4 * 64, THN = WB_THREADS - TH0;
-    if (CARRIED && ALLPH) {
-        // [terms of all taps + coordinate gradients] | [waves 0..3: corner c's 4 x 16 chunks, one per lane, then their 64
-        // sums added in stream order || the other slots' streams, one lane each || last wave: the theta / z outputs]
-        using std::integral_constant;
-        AIR_STAMP_WG(1);
-        carried_terms(integral_constant<int, 0>{}, integral_constant<int, 4>{}, integral_constant<bool, true>{});
-        theta_publish();
-        __syncthreads();
-        AIR_STAMP(43);
-        AIR_STAMP_WG(2);
-        if (wave < 4) {
-            // corner `wave`: lane = tap * 16 + chunk.  [C of every chunk] -> [P: their exclusive running sum in stream order]
-            // -> [Q of every chunk from its P] -> [R: the running sum of Q - P in stream order]
-            const int cp = (wave & 2) ? w - 1 : 0, cq = (wave & 1) ? w - 1 : 0;
-            int start, n;
-            slot_run(lane >> 4, cp, cq, start, n);
-            n = max(n, 0);
-            int nmax = n;
-#pragma unroll
-            for (int m = 16; m < 64; m <<= 1) nmax = max(nmax, __shfl_xor(nmax, m, 64));
-            if (nmax <= WB_CHUNK_MIN) {
-                // all four streams are single chunks: the reference's chain (lanes 0, 16, 32, 48 hold the taps' runs)
-                float du = 0.0f;
-#pragma unroll
-                for (int ph = 0; ph < 4; ++ph)
-                    du = stream_add(du, sh_T, __builtin_amdgcn_readlane(start, ph * 16), __builtin_amdgcn_readlane(n, ph * 16));
-                if (lane == 0) publish_corner(wave, du);
-            } else {
-                const int cs = wb_chunk_len(n), off = (lane & 15) * cs, len = min(max(n - off, 0), cs);
-                const float ck = stream_add(0.0f, sh_T, start + off, len);
-                float run = 0.0f, pk = 0.0f;
-#pragma unroll
-                for (int l = 0; l < 64; ++l) {
-                    pk = lane == l ? run : pk;
-                    run += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ck), l));
-                }
-                const float qk = stream_add(pk, sh_T, start + off, len);
-                // Q_last + the corrections Q_k - P_k+1 of the chunks before it, in stream order (empty chunks: nothing)
-                float corr = 0.0f, qprev = 0.0f;
-                bool have = false;
-#pragma unroll
-                for (int l = 0; l < 64; ++l) {
-                    if (__builtin_amdgcn_readlane(len, l) > 0) {             // (uniform)
-                        if (have) corr += qprev - __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pk), l));
-                        qprev = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qk), l));
-                        have = true;
-                    }
-                }
-                if (lane == 0) publish_corner(wave, qprev + corr);
-            }
-        }
-        if (wave == NW - 1) finish_theta();
-        AIR_STAMP(44);
-        AIR_STAMP_WG(3);
-        carried_slot(integral_constant<int, 0>{}, integral_constant<int, 4>{});
-        AIR_STAMP_WG(4);
-        AIR_STAMP_WG_T(5, 4 * 64);
-        publish();
-        AIR_STAMP(47);
-        AIR_STAMP_WG(6);
-        AIR_STAMP_WG_T(7, 15 * 64);
-        return;
-    } else if (CARRIED) {
-        // one tap per pass (large canvases).  Wave 1 holds the four corners' chunks of the pass (lane = corner * 16 + chunk)
-        // and carries the corner accumulators from pass to pass; the coordinate gradients ride in pass 0
-        using std::integral_constant;
-        float cacc[4] = {0.f, 0.f, 0.f, 0.f};
-        // cP = the four corners' prefixes P, cQ / ccorr / chave = the last chain's end, the corrections so far and
-        // whether a chain has run (cacc = cQ + ccorr; a short corner -- all four streams single chunks -- keeps the
-        // reference's chain in cacc)
-        float cP[4] = {0.f, 0.f, 0.f, 0.f}, cQ[4] = {0.f, 0.f, 0.f, 0.f}, ccorr[4] = {0.f, 0.f, 0.f, 0.f};
-        bool cshort[4] = {true, true, true, true}, chave[4] = {false, false, false, false};
-        if (wave == 1) {
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc)
-#pragma unroll
-                for (int ph = 0; ph < 4; ++ph) {
-                    int st, n;
-                    slot_run(ph, (cc & 2) ? w - 1 : 0, (cc & 1) ? w - 1 : 0, st, n);
-                    cshort[cc] = cshort[cc] && n <= WB_CHUNK_MIN;
-                }
-        }
-        auto pass = [&](auto phc) __attribute__((always_inline)) {
-            constexpr int ph = decltype(phc)::value;
-            carried_terms(integral_constant<int, ph>{}, integral_constant<int, ph + 1>{}, integral_constant<bool, ph == 0>{});
-            if (ph == 0) theta_publish();
-            __syncthreads();
-            if (wave == 1) {
-                // lane = corner * 16 + chunk of this pass's tap
-                const int c = lane >> 4;
-                int start, n;
-                slot_run(ph, (c & 2) ? w - 1 : 0, (c & 1) ? w - 1 : 0, start, n);
-                n = max(n, 0);
-                const int cs = wb_chunk_len(n), off = (lane & 15) * cs, len = min(max(n - off, 0), cs);
-                const float ck = stream_add(0.0f, sh_T, start + off, len);
-                float pk = 0.0f;
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) {
-                    float run = cshort[cc] ? cacc[cc] : cP[cc];          // (a short corner continues the reference's chain)
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        pk = lane == cc * 16 + k ? run : pk;
-                        run += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ck), cc * 16 + k));
-                    }
-                    cP[cc] = run;
-                }
-                const float qk = stream_add(pk, sh_T, start + off, len);
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) {
-                    if (cshort[cc]) { cacc[cc] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qk), cc * 16)); continue; }
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        if (__builtin_amdgcn_readlane(len, cc * 16 + k) > 0) {       // (uniform)
-                            if (chave[cc]) ccorr[cc] += cQ[cc] - __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pk), cc * 16 + k));
-                            cQ[cc] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qk), cc * 16 + k));
-                            chave[cc] = true;
-                        }
-                    }
-                    cacc[cc] = cQ[cc] + ccorr[cc];
-                }
-            }
-            if (ph == 0 && wave == NW - 1) finish_theta();
-            carried_slot(integral_constant<int, ph>{}, integral_constant<int, ph + 1>{});
-            if (ph < 3) __syncthreads();
-        };
-        pass(integral_constant<int, 0>{}); pass(integral_constant<int, 1>{});
-        pass(integral_constant<int, 2>{}); pass(integral_constant<int, 3>{});
-        publish();
-        if (wave == 1 && lane < 4) publish_corner(lane, lane == 0 ? cacc[0] : lane == 1 ? cacc[1] : lane == 2 ? cacc[2] : cacc[3]);
-        AIR_STAMP(47);
-        AIR_STAMP_WG(6);
-        return;
-    } else if (ALLPH) {
-        // [terms of all taps] | [short chains + slot outputs on all waves: no LDS atomics in flight, every dependent LDS
-        // read returns at full speed] | [corner accumulation on the LDS || pixel loop on VALU / memory]
-        AIR_STAMP_WG(1);
-        stage_T(0, 4);
-        __syncthreads();
-        AIR_STAMP(43);
-        AIR_STAMP_WG(2);
-        chains(0, 4);
-        AIR_STAMP(49);
-        publish();
-        AIR_STAMP(39);
-        __syncthreads();
-        AIR_STAMP(44);
-        AIR_STAMP_WG(3);
-        if (wave < 4) {
-            if ((pipe_mask >> wave) & 1) feed_corner(wave, 0, 4);
-            else if (ring_ok) ring_corner(wave, 0, 4);
-        } else theta_loop(TH0, THN);
-        AIR_STAMP(48);
-        AIR_STAMP_WG(4);                       // wave 0's own feed is over
-        __syncthreads();
-        AIR_STAMP_WG(5);
-    } else {
-        // one tap per pass: the tap is a compile-time constant of the term loop (its six operand selects fold away)
-        auto stage_one = [&](auto phc) __attribute__((always_inline)) {
-            constexpr int ph = decltype(phc)::value;
-            constexpr bool x1 = ph >> 1, y1 = ph & 1;
-            int i = tid / C, j = tid % C;
-            for (int p = tid; p < CC; p += WB_THREADS) {
-                const Tap tx = sh_tx[j], ty = sh_ty[i];
-                const float gp = z * gsrc[p];
-                const int4 ci = sh_ci[j], ri = sh_ri[i];
-                const float wgt = (x1 ? tx.w1 : tx.w0) * (y1 ? ty.w1 : ty.w0);
-                const int clo = x1 ? ci.z : ci.x, ncols = x1 ? ci.w : ci.y, rlo = y1 ? ri.z : ri.x, nrows = y1 ? ri.w : ri.y;
-                sh_T[rlo * C + nrows * clo + (i - rlo) * ncols + (j - clo)] = wgt * gp;
-                i += di; j += dj;
-                if (j >= C) { j -= C; ++i; }
-            }
-        };
-        // (debug stamps of every workgroup: [1] terms, [2] chains, [3] corner phase summed over the four passes, [4] hardware
-        // id (XCC / SE / CU), [5] pipe mask, [6] end; tools/wb_wg_stamps.py --stress)
-        AIR_STAMP_WG_SET(1, 0); AIR_STAMP_WG_SET(2, 0); AIR_STAMP_WG_SET(3, 0);
-        AIR_STAMP_WG_SET(4, (__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 16) | __builtin_amdgcn_s_getreg(4 | (0 << 6) | (15 << 11)));
-        AIR_STAMP_WG_SET(5, pipe_mask | (sh_cn[0] + sh_cn[1] + sh_cn[2] + sh_cn[3]) << 4);
-        for (int ph = 0; ph < 4; ++ph) {
-            const unsigned long long ta = AIR_NOW();
-            if (ph == 0) stage_one(std::integral_constant<int, 0>{});
-            else if (ph == 1) stage_one(std::integral_constant<int, 1>{});
-            else if (ph == 2) stage_one(std::integral_constant<int, 2>{});
-            else stage_one(std::integral_constant<int, 3>{});
-            __syncthreads();
-            AIR_STAMP(50 + 3 * ph);
-            AIR_STAMP_WG_ADD(1, ta);
-            const unsigned long long tb = AIR_NOW();
-            chains(ph, ph + 1);
-            __syncthreads();
-            AIR_STAMP(51 + 3 * ph);
-            AIR_STAMP_WG_ADD(2, tb);
-            const unsigned long long tc = AIR_NOW();
-            if (wave < 4) {
-                if ((pipe_mask >> wave) & 1) feed_corner(wave, ph, ph + 1);
-                else if (ring_ok) ring_corner(wave, ph, ph + 1);
-            } else if (ph == 0) theta_loop(TH0, THN);
-            __syncthreads();
-            AIR_STAMP(52 + 3 * ph);
-            AIR_STAMP_WG_ADD(3, tc);
-        }
-    }
-    if (!ALLPH) { publish(); __syncthreads(); }
-    AIR_STAMP(45);
-    if (corner) {
-        const float r = sh_win[tid];
-        const float dgv = (sh_acc[(sp ? 2 : 0) + (sq ? 1 : 0)] * r) * (1.0f - r);
-        dgen[tid] = dgv;
-        if (dgen16) dgen16[tid] = air_bf16_of(dgv);
-    }
-    if (tid < 64) finish_theta();
-    AIR_STAMP(47);
-    AIR_STAMP_WG(6);
-}
-
-template <bool ALLPH>
-__global__ __launch_bounds__(WB_THREADS) void write_bwd_graph_kernel(air_write_bwd_t a, int seq_flags)
-{
-    write_bwd_graph_body<ALLPH, false>(a, seq_flags);
-}
-template <bool ALLPH>
-__global__ __launch_bounds__(WB_THREADS) void write_bwd_carried_kernel(air_write_bwd_t a)
-{
-    write_bwd_graph_body<ALLPH, true>(a, 0);
-}
-
 // the canvas is staged in LDS only when one prefetch pass covers it (PF * THREADS floats, see the kernels)
 size_t attend_canvas_floats(int C) { return (size_t)C * C <= 10 * (size_t)THREADS ? (size_t)C * C : 0; }
 size_t attend_smem(int C, int w, int HT) {
@@ -1738,108 +631,6 @@ size_t attend_bwd_smem(int C, int w) {
     return (24 + 8 * w + w + 4 + attend_canvas_floats(C)) * sizeof(float);
 }
 size_t write_smem(int N, int C, int w) { return (16 + 7 * MAX_STEPS + (size_t)N * (8 * C + (size_t)w * w)) * sizeof(float); }
-size_t write_bwd_graph_smem(int C, int w, bool allph) {
-    return (136 + 8 * C + ((C + 3) & ~3) + 8 * C + ((8 * w + 3) & ~3) + (((size_t)w * w + 3) & ~3) +
-            (allph ? 5 : 1) * (((size_t)C * C + 3) & ~3)) * sizeof(float);
-}
-size_t write_bwd_smem(int C, int w) { return (64 + 8 * C + C + 8 * w + (size_t)w * w + (size_t)C * w + (size_t)C * C) * sizeof(float); }
-
-// ---------------------------------------------------------------------------
-// The bit-for-bit reproduction of the reference's UnsortedSegmentSum rests on a property of gfx950 that no manual
-// states: a same-address ds_add_f32 applies the 64 lanes of an instruction in ascending lane order, and a wave's
-// instructions in program order.  It is probed ONCE per process and device on the first eager call that needs it (a
-// known-order sum whose value depends on the order; the probe needs a stream synchronise, so a first call under stream
-// capture takes the register chains -- nothing is assumed -- and says so: capture_graph() warms up eagerly first).  A
-// part that orders differently takes the ring / register-chain fallbacks (same results, slower) instead of silently
-// changing gradients.
-// AIR_LDS_ORDER=0 / 1 forces the answer (tests run both paths against each other).
-// ---------------------------------------------------------------------------
-constexpr int PROBE_N = 8 * 64;
-__device__ float air_probe_vals[PROBE_N];
-__device__ float air_probe_out[4];
-__global__ void lds_order_probe_kernel() {
-    __shared__ float slot[2];
-    if (threadIdx.x < 2) slot[threadIdx.x] = 0.0f;
-    __syncthreads();
-    for (int k = 0; k < PROBE_N / 64; ++k) lds_fadd(&slot[0], air_probe_vals[k * 64 + threadIdx.x]);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) air_probe_out[0] = slot[0];
-    // the lane ring of write_bwd_graph_kernel (ring_corner) on the same stream: the same value if the DPP read of the
-    // previous instruction's result is interlocked and wave_ror:1 hands lane k-1 (63 for lane 0) to lane k
-    float S = 0.0f;
-    for (int k = 0; k < PROBE_N / 64; ++k) {
-        const float r = air_probe_vals[k * 64 + threadIdx.x];
-#pragma unroll
-        for (int i = 0; i < 64; ++i)
-            asm volatile("v_add_f32_dpp %0, %0, %1 wave_ror:1 row_mask:0xf bank_mask:0xf" : "+v"(S) : "v"(r));
-    }
-    if (threadIdx.x == 63) air_probe_out[1] = S;
-}
-
-// bit 0: the LDS atomic pipe is a sequential accumulator on this part; bit 1: so is the lane ring.
-// Remembered PER DEVICE (a node may mix parts).  A first call that arrives while the stream is being captured cannot
-// probe (the probe synchronises): it takes the conservative answer -- neither property, i.e. the register chains, same
-// bits on any part, slower -- says so once, and remembers nothing, so the first eager call still probes.
-int accumulators(hipStream_t s) {
-    constexpr int MAX_DEV = 32;
-    static std::atomic<int> states[MAX_DEV];             // per device: 0 unknown, else 4 | flags
-    static std::atomic<int> warned{0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) dev = 0;
-    std::atomic<int>& state = states[dev];
-    int st = state.load(std::memory_order_acquire);
-    if (st) return st & 3;
-    const char* e0 = getenv("AIR_LDS_ORDER");
-    const char* e1 = getenv("AIR_WB_RING");
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    const bool capturing = hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
-    int probed = 3;
-    if (!(e0 && e1)) {
-        if (capturing) {                                 // cannot synchronise here: nothing assumed, nothing remembered
-            if (!warned.exchange(1))
-                fprintf(stderr, "libair_hip: air_write_bwd / air_transformer_bwd first called under stream capture on device %d: the "
-                                "accumulator probe cannot run, this capture takes the register-chain fallback (same results, slower) -- "
-                                "run the launch once eagerly before capturing\n", dev);
-            return (e0 ? (e0[0] != '0') : 0) | (e1 ? (e1[0] != '0') << 1 : 0);
-        }
-        float vals[PROBE_N];
-        unsigned x = 12345u;
-        float want = 0.0f;
-        for (int i = 0; i < PROBE_N; ++i) {
-            x = x * 1664525u + 1013904223u;
-            // magnitudes over 2^-8 .. 2^23 with mixed signs: every partial sum rounds, so the value pins the order
-            const float mant = 1.0f + (float)((x >> 9) & 0x3fffu) / 16384.0f;
-            const int ex = (int)((x >> 24) & 31u) - 8;
-            vals[i] = ((x >> 31) ? -1.0f : 1.0f) * ldexpf(mant, ex);
-            want = want + vals[i];                           // ascending lane, program order
-        }
-        float got[2] = {0.0f, 0.0f};
-        bool ok = hipMemcpyToSymbolAsync(HIP_SYMBOL(air_probe_vals), vals, sizeof(vals), 0, hipMemcpyHostToDevice, s) == hipSuccess;
-        if (ok) {
-            hipLaunchKernelGGL(lds_order_probe_kernel, dim3(1), dim3(64), 0, s);
-            ok = hipGetLastError() == hipSuccess &&
-                 hipMemcpyFromSymbolAsync(got, HIP_SYMBOL(air_probe_out), sizeof(got), 0, hipMemcpyDeviceToHost, s) == hipSuccess &&
-                 hipStreamSynchronize(s) == hipSuccess;
-        }
-        probed = ((ok && memcmp(&got[0], &want, sizeof(float)) == 0) ? 1 : 0) | ((ok && memcmp(&got[1], &want, sizeof(float)) == 0) ? 2 : 0);
-        if (!(probed & 1) && !e0)
-            fprintf(stderr, "libair_hip: ds_add_f32 lane order differs on this part (probe %.9g, expected %.9g): "
-                            "the sampler backward takes its ring / register-chain fallbacks\n", (double)got[0], (double)want);
-        if (!(probed & 2) && !e1)
-            fprintf(stderr, "libair_hip: the DPP lane ring is not an in-order accumulator on this part (probe %.9g, expected %.9g): "
-                            "the sampler backward keeps every corner stream on the LDS atomic pipe\n", (double)got[1], (double)want);
-    }
-    int flags = probed;
-    if (e0) flags = (flags & 2) | (e0[0] != '0' ? 1 : 0);
-    if (e1) flags = (flags & 1) | (e1[0] != '0' ? 2 : 0);
-    state.store(4 | flags, std::memory_order_release);
-    return flags;
-}
-int lds_ordered(hipStream_t s) { return accumulators(s) & 1; }
-
-template <typename K>
-int ensure_lds(K kernel, size_t bytes) { return air_grant_lds(reinterpret_cast<const void*>(kernel), bytes); }
 
 }  // namespace
 
@@ -1850,18 +641,6 @@ extern "C" int air_transformer_fwd(const float* U, const float* theta, float* ou
     const int blocks = (int)((total + THREADS - 1) / THREADS < 2048 ? (total + THREADS - 1) / THREADS : 2048);
     hipLaunchKernelGGL(transformer_fwd_kernel, dim3(blocks), dim3(THREADS), 0, air_stream(stream),
                        U, theta, out, B, Hi, Wi, Ho, Wo);
-    AIR_CHECK_LAUNCH();
-    return 0;
-}
-
-extern "C" int air_transformer_bwd(const float* U, const float* theta, const float* d_out, float* d_U, float* d_theta,
-                                   int B, int Hi, int Wi, int Ho, int Wo, void* stream) {
-    if (!U || !theta || !d_out || (!d_U && !d_theta) || B <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return AIR_EINVAL;
-    const size_t lds = (40 + 2 * (((size_t)Hi * Wi + 3) & ~3)) * sizeof(float);
-    int rc = ensure_lds(transformer_bwd_kernel, lds);
-    if (rc) return rc;
-    hipLaunchKernelGGL(transformer_bwd_kernel, dim3(B), dim3(THREADS), lds, air_stream(stream),
-                       U, theta, d_out, d_U, d_theta, Hi, Wi, Ho, Wo, d_U ? lds_ordered(air_stream(stream)) : 1);
     AIR_CHECK_LAUNCH();
     return 0;
 }
@@ -1911,55 +690,6 @@ extern "C" int air_write_fwd(const air_write_fwd_t* a, void* stream) {
         if (rc) return rc;
         hipLaunchKernelGGL((write_fwd_kernel<CF_THREADS>), dim3(a->B + extra), dim3(CF_THREADS), lds, air_stream(stream), *a);
     }
-    AIR_CHECK_LAUNCH();
-    return 0;
-}
-
-/* name of the kernel function air_write_bwd dispatches this descriptor to, as rocprofv3 prints it */
-extern "C" int air_write_bwd_kernel_name(const air_write_bwd_t* a, char* buf, int n) {
-    if (!a || !buf || n <= 0 || a->C < 2 || a->w < 2) return AIR_EINVAL;
-    if (a->literal == 2 || a->literal == 4)
-        snprintf(buf, n, "write_bwd_%s_kernel<%s>", a->literal == 4 ? "carried" : "graph",
-                 write_bwd_graph_smem(a->C, a->w, true) <= 80 * 1024 ? "true" : "false");
-    else snprintf(buf, n, "write_bwd_kernel");
-    return 0;
-}
-
-extern "C" int air_write_bwd(const air_write_bwd_t* a, void* stream) {
-    if (!a || !a->d_recon || !a->vrec || !a->att || !a->d_gen_pre || !a->d_sxy_write) return AIR_EINVAL;
-    if (a->B <= 0 || a->N <= 0 || a->C < 2 || a->w < 2) return AIR_EINVAL;
-    if (a->literal != 0 && a->literal != 2 && a->literal != 4) return AIR_EINVAL;     // (1 and 3 were removed with ABI 5)
-    if (a->order && a->literal < 2) return AIR_EINVAL;            // (the ordered form exists in the graph-order kernels only)
-    if (2 * a->w > THREADS) return AIR_ELIMIT;
-    if (a->literal == 4) {
-        // the carried graph order: register chains only -- no LDS-atomic lane order to probe, capture-safe from the first call
-        if (a->w * a->w > WB_THREADS) return AIR_ELIMIT;
-        const bool allph = write_bwd_graph_smem(a->C, a->w, true) <= 80 * 1024;
-        const size_t lds = write_bwd_graph_smem(a->C, a->w, allph);
-        int rc = allph ? ensure_lds(write_bwd_carried_kernel<true>, lds) : ensure_lds(write_bwd_carried_kernel<false>, lds);
-        if (rc) return rc;
-        if (allph) hipLaunchKernelGGL(write_bwd_carried_kernel<true>, dim3(a->B, a->N), dim3(WB_THREADS), lds, air_stream(stream), *a);
-        else hipLaunchKernelGGL(write_bwd_carried_kernel<false>, dim3(a->B, a->N), dim3(WB_THREADS), lds, air_stream(stream), *a);
-        AIR_CHECK_LAUNCH();
-        return 0;
-    }
-    if (a->literal == 2) {
-        if (a->w * a->w > WB_THREADS) return AIR_ELIMIT;
-        // all four taps' terms resident when they fit next to a second workgroup's share of the LDS
-        const bool allph = write_bwd_graph_smem(a->C, a->w, true) <= 80 * 1024;
-        const size_t lds = write_bwd_graph_smem(a->C, a->w, allph);
-        int rc = allph ? ensure_lds(write_bwd_graph_kernel<true>, lds) : ensure_lds(write_bwd_graph_kernel<false>, lds);
-        if (rc) return rc;
-        int flags = accumulators(air_stream(stream));
-        if (allph) hipLaunchKernelGGL(write_bwd_graph_kernel<true>, dim3(a->B, a->N), dim3(WB_THREADS), lds, air_stream(stream), *a, flags);
-        else hipLaunchKernelGGL(write_bwd_graph_kernel<false>, dim3(a->B, a->N), dim3(WB_THREADS), lds, air_stream(stream), *a, flags);
-        AIR_CHECK_LAUNCH();
-        return 0;
-    }
-    const size_t lds = write_bwd_smem(a->C, a->w);
-    int rc = ensure_lds(write_bwd_kernel, lds);
-    if (rc) return rc;
-    hipLaunchKernelGGL(write_bwd_kernel, dim3(a->B, a->N), dim3(WB_THREADS), lds, air_stream(stream), *a);
     AIR_CHECK_LAUNCH();
     return 0;
 }

@@ -14,5 +14,5 @@ python bench.py --steps 20 --warmup 5 > $out/bench_steps20.json 2>> $out/bench.e
 python bench.py --steps 20 --warmup 5 > $out/bench_steps20_b.json 2>> $out/bench.err
 python -c "import __graft_entry__ as g; g.build(); g.smoke()" > $out/smoke.log 2>&1
 timeout 2400 python -m pytest tests -m gpu -q > $out/pytest_gpu.log 2>&1
-(cd tf-attend-infer-repeat_amd && python training.py -r /tmp/full_fp32 -o 1 --print-every 0 --precision fp32 --seed 0 > $out/full_fp32.log 2>&1; cp /tmp/full_fp32/summary/scalars.jsonl $out/full_fp32_scalars.jsonl)
+for p in bf16 fp32; do (cd tf-attend-infer-repeat_amd && python training.py -r /tmp/full_$p -o 1 --print-every 0 --precision $p --seed 0 > $out/full_$p.log 2>&1; cp /tmp/full_$p/summary/scalars.jsonl $out/full_${p}_scalars.jsonl; tail -1 $out/full_$p.log); done; python tools/exp/queue_cost.py 50 2>&1 | grep "ms per step\|us" > $out/queue_cost.txt
 tail -3 $out/smoke.log; tail -4 $out/pytest_gpu.log; tail -1 $out/full_fp32.log; cut -c1-200 $out/bench_steps20.json; head -8 gpurun_out/prof_r06/kernel_stats.txt

@@ -17,7 +17,7 @@ subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared"
 import torch
 from air import _hip as H
 H._LIB = H.load(out)
-for fn in ("air_debug_stamps", "air_debug_stamps_gemm", "air_debug_stamps_gemm_tw", "air_debug_stamps_wgrad"):
+for fn in ("air_debug_stamps", "air_debug_stamps_wb", "air_debug_stamps_gemm", "air_debug_stamps_gemm_tw", "air_debug_stamps_wgrad"):
     getattr(H._LIB, fn).restype = C.c_int
     getattr(H._LIB, fn).argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 from bench import HP, ANNEAL, synthetic_canvases
@@ -45,7 +45,7 @@ for want in names:
             torch.cuda.synchronize()
             base = {"write_bwd": 40, "attend_fwd": 10, "attend_bwd": 20, "compose": 30, "wgrad": 0}.get(want, 56)
             {56: (H._LIB.air_debug_stamps_gemm_tw if "tw_kernel" in op.kernel else H._LIB.air_debug_stamps_gemm),
-             0: H._LIB.air_debug_stamps_wgrad}.get(base, H._LIB.air_debug_stamps)(buf, 64)
+             0: H._LIB.air_debug_stamps_wgrad, 40: H._LIB.air_debug_stamps_wb}.get(base, H._LIB.air_debug_stamps)(buf, 64)
             v = [int(x) for x in buf]
             idx = [i for i in range(base - (1 if base == 40 else 0), base + (8 if base == 56 else 22 if base == 40 else 10)) if v[i]]
             idx.sort(key=lambda i: v[i])
