@@ -22,7 +22,8 @@ __global__ __launch_bounds__(SQ_THREADS) void shuffle_init_kernel(air_shuffle_ba
 // last pick that hits a surviving slot writes it; the `batch` freed slots at the back are refilled from the stream.  Pick
 // for pick the sequential queue (tests/test_shuffle_queue.py: 400 batches x 3 geometries against the numpy model).
 __device__ __forceinline__ void dequeue_batch(int* q, const air_shuffle_batch_t& a, long n, unsigned pos_mod /* stream position mod n_records */,
-                                              int* sh_idx, int32_t* picks_out) {
+                                              int* sh_idx, unsigned* sh_bits /* [capacity / 32 + 1], all zero on entry and on exit */,
+                                              int32_t* picks_out) {
     const int tid = threadIdx.x, cap = a.capacity, batch = a.batch;
     if (tid * 4 < batch) {
         uint32_t c[4] = {(uint32_t)n, (uint32_t)((unsigned long)n >> 32), (uint32_t)tid, 0x53485546u};
@@ -35,21 +36,38 @@ __device__ __forceinline__ void dequeue_batch(int* q, const air_shuffle_batch_t&
     int my = -1, s = 0, sb = 0, emit = 0, moved = 0;
     bool last_writer = true;
     if (batch <= 64) {
-        // the reference's batch: the picks live in the lanes of ONE wave, the walk reads them by v_readlane (no LDS round trip
-        // per step: 64 dependent LDS reads were 6 us of a 7.5 us dequeue)
+        // the reference's batch: the picks live in the lanes of ONE wave.  A pick is touched by the earlier picks of its
+        // batch only through an EVENT: two picks on one slot, or a pick that lands among the last `batch` slots (the backs
+        // that move).  Both are detected exactly -- a bitmap of the picked slots in LDS, one atomic OR per lane -- and a
+        // batch without events (more than half of them at the reference's geometry) needs no walk at all: pick k emits
+        // q[idx_k] and moves q[capacity - 1 - k].  Otherwise the wave walks the picks once, branch-free, reading them by
+        // v_readlane (a walk with per-lane branches was 35 instructions per step: 5 of the 6 us of a dequeue).
         if (tid < 64) {
-            my = k < batch ? sh_idx[k] : -1;
+            const bool live = k < batch;
+            my = live ? sh_idx[k] : -1;
             s = my;                   // -> the original slot whose content pick k emits
             sb = cap - 1 - k;         // -> the original slot whose content pick k moves into idx_k
-            for (int j = batch - 1; j >= 0; --j) {                   // uniform loop: j is a scalar
-                const int ij = __builtin_amdgcn_readlane(my, j), bj = cap - 1 - j;
-                if (j > k) last_writer = last_writer && ij != my;
-                else if (j < k) {
-                    if (ij == s) s = bj;
-                    if (ij == sb) sb = bj;
+            bool event = false;
+            unsigned bit = 0;
+            if (live) {
+                bit = 1u << (my & 31);
+                event = (atomicOr(&sh_bits[my >> 5], bit) & bit) != 0 || my >= cap - batch;
+            }
+            if (__any(event)) {
+#pragma unroll 4
+                for (int j = batch - 1; j >= 0; --j) {               // uniform loop: j is a scalar
+                    const int ij = __builtin_amdgcn_readlane(my, j), bj = cap - 1 - j;
+                    const bool before = j < k;
+                    last_writer = last_writer && !(j > k && ij == my);
+                    s = (before && ij == s) ? bj : s;
+                    sb = (before && ij == sb) ? bj : sb;
                 }
             }
-            if (k < batch) { emit = q[s]; moved = q[sb]; }
+            if (live) {
+                emit = q[s];
+                moved = q[sb];
+                atomicAnd(&sh_bits[my >> 5], ~bit);                  // the bitmap is all zero again
+            }
         }
     } else if (k < batch) {
         my = sh_idx[k];
@@ -73,10 +91,14 @@ __device__ __forceinline__ void dequeue_batch(int* q, const air_shuffle_batch_t&
     __syncthreads();
 }
 
+constexpr int SQ_BITS_WORDS = 48 * 1024 / 4 / 32 + 1;                  // one bit per slot of the largest queue sq_check admits
+
 __global__ __launch_bounds__(SQ_THREADS) void shuffle_dequeue_kernel(air_shuffle_batch_t a) {
     __shared__ int sh_idx[SQ_THREADS];
+    __shared__ unsigned sh_bits[SQ_BITS_WORDS];
+    for (int i = threadIdx.x; i < SQ_BITS_WORDS; i += SQ_THREADS) sh_bits[i] = 0;
     const long pos = a.state[0], n = a.state[1];
-    dequeue_batch(a.queue, a, n, (unsigned)(pos % a.n_records), sh_idx, a.picks);   // on the queue in memory: 2 x batch scattered reads, <= 2 x batch writes
+    dequeue_batch(a.queue, a, n, (unsigned)(pos % a.n_records), sh_idx, sh_bits, a.picks);   // on the queue in memory: 2 x batch scattered reads, <= 2 x batch writes
     if (threadIdx.x == 0) { a.state[0] = pos + a.batch; a.state[1] = n + 1; }
 }
 
@@ -87,13 +109,15 @@ __global__ __launch_bounds__(SQ_THREADS) void shuffle_dequeue_many_kernel(air_sh
     extern __shared__ int sq_lds[];
     int* q = sq_lds;                                                   // [capacity]
     int* sh_idx = sq_lds + a.capacity;                                 // [batch]
+    __shared__ unsigned sh_bits[SQ_BITS_WORDS];
     const int tid = threadIdx.x;
+    for (int i = tid; i < SQ_BITS_WORDS; i += SQ_THREADS) sh_bits[i] = 0;
     const long pos0 = a.state[0], n0 = a.state[1];
     for (int i = tid; i < a.capacity; i += SQ_THREADS) q[i] = a.queue[i];
     __syncthreads();
     unsigned pm = (unsigned)(pos0 % a.n_records);                      // (one 64-bit division per launch, not one per record)
     for (int kb = 0; kb < nb; ++kb) {
-        dequeue_batch(q, a, n0 + kb, pm, sh_idx, picks_out + (size_t)kb * a.batch);
+        dequeue_batch(q, a, n0 + kb, pm, sh_idx, sh_bits, picks_out + (size_t)kb * a.batch);
         pm = (pm + (unsigned)a.batch) % (unsigned)a.n_records;
     }
     for (int i = tid; i < a.capacity; i += SQ_THREADS) a.queue[i] = q[i];
