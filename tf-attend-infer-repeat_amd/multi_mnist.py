@@ -257,9 +257,9 @@ class ShuffleBatchQueue:
     launch that makes the picks of all its `steps` batches into a device table (air_shuffle_batch_dequeue_many, the queue
     staged in LDS once) and holds one more launch per step, the row gather of that step's batch.  The batches are the same
     sequence either way, pick for pick the numpy model of the reference's queue that tests/test_shuffle_queue.py holds.
-    (Measured on one MI355X, 50 steps per replay, ms per train step: no input work 0.1751; gather only 0.1706; the
-    first version's serial dequeue + gather in front of every step 0.1901; a dequeue_many concurrent with the steps -- on
-    a forked branch of the graph or on a second stream -- 0.2085: DESIGN.md section 11.)"""
+    (Measured on one MI355X, 50 steps per replay, ms per train step: no input work 0.1774; a gather per step 0.1801; this
+    form 0.1815; a serial dequeue + gather in front of every step 0.186-0.190; a dequeue_many concurrent with the steps --
+    on a forked branch of the graph or on a second stream -- 0.2085: DESIGN.md section 11.3.)"""
 
     def __init__(self, images, digits, batch_size, out_images, out_digits, seed=0, min_after_dequeue=10000):
         import ctypes as C

@@ -34,7 +34,10 @@ def run(tag, hooks):
 
 run("no input work", lambda: (None, None))
 q1 = ShuffleBatchQueue(images, digits, 64, x, t, seed=1, min_after_dequeue=2000)
-run("row gather only (static picks)", lambda: ((lambda i: q1._gather(q1.picks)), None))
+q1.picks.copy_(torch.arange(64, dtype=torch.int32, device=dev))      # the batch of the line above, gathered again every step
+run("row gather only (the same 64 records every step)", lambda: ((lambda i: q1._gather(q1.picks)), None))
+q0 = ShuffleBatchQueue(images, digits, 64, x, t, seed=1, min_after_dequeue=2000)
+run("row gather only, picks all zero (64 copies of ONE image: not a floor)", lambda: ((lambda i: q0._gather(q0.picks)), None))
 q2 = ShuffleBatchQueue(images, digits, 64, x, t, seed=1, min_after_dequeue=2000)
 run("dequeue + gather in front of every step", lambda: (q2.next_batch, None))
 q3 = ShuffleBatchQueue(images, digits, 64, x, t, seed=1, min_after_dequeue=10000 if len(im) > 11000 else 2000)
