@@ -371,9 +371,9 @@ class AIRModel:
         #   reference's accumulator, so that every add rounds at the reference's magnitude (the order tests call "carried16").
         # "exact": the mathematical adjoint (the fp64-gradient tests; the model does not learn to localise with it).
         # (first, second, N): `first` while global_step < N, `second` from then on -- e.g. ("reference", "reference_carried",
-        #   5000): the reference's own order while the out-of-range residue rules the gradient (the z_pres prior anneals over
-        #   the first 3 000 iterations), the faster carried order for the rest of the run.  The switch is made by training()
-        #   between two steps (launch lists rebuilt, a captured graph captured again); forward outputs are not affected.
+        #   5000): the reference's own order at the start of training, the faster carried order for the rest of the run.  The
+        #   switch is made by training() between two steps (launch lists rebuilt, a captured graph captured again); forward
+        #   outputs are not affected.  Opt-in: no switch iteration passed the learning gate of DESIGN.md section 11.1.
         self._schedule = None
         if isinstance(backward, (tuple, list)):
             if len(backward) != 3 or backward[0] not in self._ORDERS or backward[1] not in self._ORDERS or int(backward[2]) < 0:
@@ -965,7 +965,7 @@ class AIRModel:
         """(first order, second order, switch iteration) or None"""
         return self._schedule
 
-    def _follow_schedule(self):
+    def _follow_schedule(self, recapture=True):
         """AIRModel(backward=(first, second, N)): the order global_step asks for, before a train step is launched.  The host
         follows global_step by counting the steps it launches (one read of the device counter after construction / a
         checkpoint load); with a multi-step graph the switch happens at the first replay that starts at or after N."""
@@ -975,7 +975,7 @@ class AIRModel:
             self._host_step = int(self.store.istate[H.IST_GLOBAL_STEP])
         first, second, n = self._schedule
         args = self._capture_args if self._graph is not None else None
-        if self._set_order(first if self._host_step < n else second) and args is not None:
+        if self._set_order(first if self._host_step < n else second) and args is not None and recapture:
             self.capture_graph(**args)
 
     def use_device_rng(self, seed=None):
@@ -1173,7 +1173,7 @@ class AIRModel:
         if not self.train:
             return self._capture_forward_graph()
         self._capture_args = dict(steps=steps, between_steps=between_steps, after_steps=after_steps)
-        self._follow_schedule()
+        self._follow_schedule(recapture=False)        # (this call is the capture)
         self._optimizer_ops()
         world = self._world()
         if self.store.synced_world != world:
